@@ -1,0 +1,110 @@
+"""Pins the CPU oracle (oracle/) against fixtures generated from the REAL reference
+(tests/golden/make_golden.py).  CPU only."""
+import json
+
+import numpy as np
+import torch
+
+from oracle import losses as OL
+from oracle import nets as ON
+from oracle.state import fill_state
+
+T = torch.from_numpy
+
+
+def test_lovasz_against_reference(golden):
+    g = golden("losses")
+    for tag, tol in (("a", 1e-6), ("b", 1e-6), ("c", 1e-6)):
+        lg = T(g[tag + "_logits"]).requires_grad_()
+        lb = T(g[tag + "_labels"])
+        loss = OL.lovasz_softmax(lg, lb)
+        loss.backward()
+        assert abs(float(loss) - float(g[tag + "_loss"])) < tol
+        np.testing.assert_allclose(lg.grad.numpy(), g[tag + "_grad"], atol=2e-7, rtol=1e-4)
+        assert abs(OL.lovasz_softmax_np(g[tag + "_logits"], g[tag + "_labels"]) - float(g[tag + "_loss"])) < 2e-6
+    np.testing.assert_allclose(OL.lovasz_grad(torch.tensor([1., 0., 1., 0.])).numpy(), g["lovasz_grad_1010"], atol=1e-7)
+    # literals captured in SURVEY.md 8c
+    np.testing.assert_allclose(g["lovasz_grad_1010"], [0.5, 0.1666666, 0.3333334, 0.0], atol=1e-6)
+    assert abs(float(g["c_loss"]) - 0.5170469284) < 1e-6
+    assert abs(float(g["a_loss"]) - 0.9599470496) < 1e-6
+
+
+def test_two_scale_and_ce(golden):
+    g = golden("losses")
+    v = OL.two_scale_lovasz(T(g["t_interm"]), T(g["t_final"]), T(g["t_labels"]))
+    assert abs(float(v) - float(g["t_loss"])) < 1e-6
+    lg = T(g["ce_logits"]).requires_grad_()
+    loss = OL.cross_entropy(lg, T(g["ce_labels"]), 2)
+    loss.backward()
+    assert abs(float(loss) - float(g["ce_loss"])) < 1e-6
+    np.testing.assert_allclose(lg.grad.numpy(), g["ce_grad"], atol=1e-7)
+
+
+def test_metrics(golden):
+    g = golden("metrics")
+    for exp in (1, 2, 3):
+        cm = OL.confusion_matrix(T(g["e%d_logits" % exp]), T(g["e%d_labels" % exp]))
+        assert np.array_equal(cm.numpy(), g["e%d_cm" % exp])
+        np.testing.assert_allclose(OL.mean_ious(cm, exp), g["e%d_miou" % exp], atol=1e-6)
+        np.testing.assert_allclose(OL.pixel_accuracy(cm), g["e%d_pa" % exp], atol=1e-6)
+    np.testing.assert_allclose([OL.lr_multiplier(e) for e in range(50)], g["lr_mult"], rtol=1e-12)
+
+
+def test_ocr_modules(golden):
+    g = golden("ocr_modules")
+    feats = T(g["sg_feats"]).requires_grad_()
+    logits = T(g["sg_logits"]).requires_grad_()
+    ctx = ON.spatial_gather(feats, logits)
+    np.testing.assert_allclose(ctx.detach().numpy(), g["sg_out"], atol=1e-5)
+    (ctx * T(g["sg_w"])).sum().backward()
+    np.testing.assert_allclose(feats.grad.numpy(), g["sg_dfeats"], atol=1e-5)
+    np.testing.assert_allclose(logits.grad.numpy(), g["sg_dlogits"], atol=1e-5)
+    np.testing.assert_allclose(g["sg_kat"].reshape(-1), [1.5, 2.7236e-4, 5.5, 4.000272], rtol=1e-3)
+    spec = json.loads(str(g["ocr_spec"]))
+    S = fill_state(spec, 4)
+    for k, v in S.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_()
+    x = T(g["ocr_x"]).requires_grad_()
+    proxy = T(g["ocr_proxy"]).requires_grad_()
+    c = ON.object_attention(S, "object_context_block", x, proxy, True, key_channels=16)
+    y = torch.relu(ON.bn(S, "conv_bn_dropout.1", ON.conv(S, "conv_bn_dropout.0", torch.cat([c, x], 1)), True))
+    np.testing.assert_allclose(y.detach().numpy(), g["ocr_y"], atol=2e-5)
+    (y * T(g["ocr_w"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["ocr_dx"], atol=2e-4)
+    np.testing.assert_allclose(proxy.grad.numpy(), g["ocr_dproxy"], atol=2e-4)
+    for k in S:
+        if ("ocr_g:" + k) in g.files:
+            np.testing.assert_allclose(S[k].grad.numpy(), g["ocr_g:" + k], atol=3e-4, rtol=1e-3)
+
+
+def _whole(golden, name, fwd, loss_fn, two):
+    g = golden(name)
+    spec = json.loads(str(g["spec"]))
+    S = fill_state(spec, int(g["seed"]))
+    x, lbl = T(g["x"]), T(g["lbl"])
+    with torch.no_grad():
+        out = fwd(S, x, train=False)
+    np.testing.assert_allclose((out[1] if two else out).numpy(), g["eval_final"], atol=2e-4)
+    params = [k for k, v in S.items() if v.dtype.is_floating_point and "running" not in k]
+    for k in params:
+        S[k].requires_grad_()
+    out = fwd(S, x, train=True)
+    np.testing.assert_allclose((out[1] if two else out).detach().numpy(), g["train_final"], atol=2e-4)
+    loss = loss_fn(out, lbl)
+    assert abs(float(loss) - float(g["losses"][0])) < 1e-4
+    loss.backward()
+    names = json.loads(str(g["grad_names"]))
+    norms = np.array([float(S[k].grad.double().norm()) for k in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-2, atol=1e-6)
+    for k in ("backbone.bn1.running_mean", "backbone.layer4.2.bn3.running_var"):
+        np.testing.assert_allclose(S[k].numpy(), g["rs:" + k], atol=1e-5)
+    assert [k for k, _ in spec if not k.endswith("num_batches_tracked") and "running" not in k] == names
+
+
+def test_ocrnet_whole(golden):
+    _whole(golden, "ocrnet_r50_e3_tiny", ON.ocrnet_forward, lambda o, l: OL.two_scale_lovasz(o[0], o[1], l), True)
+
+
+def test_deeplab_whole(golden):
+    _whole(golden, "deeplab_r50_e2_tiny", ON.deeplabv3plus_forward, lambda o, l: OL.cross_entropy(o, l, 2), False)
