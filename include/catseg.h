@@ -1,0 +1,171 @@
+/*
+ * catseg.h — C ABI of libcatseg_hip.so: the MI355X (gfx950) hot path of the
+ * cataract-segmentation trainer.
+ *
+ * The reference (RViMLab/MICCAI2021_Cataract_semantic_segmentation) is 100 % Python and
+ * has no FFI: its hot path is the list of ATen ops dispatched from models/*.py and
+ * losses/*.py.  Each entry point below replaces one such ATen call site (cited as
+ * file:line relative to the reference tree).  The boundary is plain C: raw device
+ * pointers, explicit sizes / strides, a hipStream_t passed as void*, int status.
+ *
+ * Conventions
+ *  - activations are NHWC fp32: pixel p = (b*H + y)*W + x, element (p, c) at base[p*ld + c],
+ *    ld >= C and ld % 4 == 0, base 16-byte aligned ("ld" lets a tensor live inside a
+ *    wider concat buffer without a copy);
+ *  - conv weights are OHWI fp32 (a torch [O,I,kh,kw] tensor in channels_last memory format);
+ *  - every function is asynchronous on `stream`, never allocates, never synchronises;
+ *  - return value: 0 = ok, otherwise a CATSEG_E* code; catseg_last_error() gives a message.
+ */
+#ifndef CATSEG_H
+#define CATSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CATSEG_OK 0
+#define CATSEG_EINVAL 1   /* bad argument (shape / alignment)  */
+#define CATSEG_EHIP 2     /* a HIP runtime call failed          */
+#define CATSEG_EWORKSPACE 3
+
+typedef void* catseg_stream_t; /* hipStream_t */
+
+const char* catseg_last_error(void);
+int catseg_version(void);
+
+/* ---- convolution as implicit GEMM on v_mfma_f32_32x32x2_f32 ------------------------------
+ * replaces F.conv2d behind nn.Conv2d at models/OCR.py:72-97,200-235,308-313 and
+ * models/DeepLabv3Plus.py:92-105,145-156, models/HRNetv2.py:23-33 etc. and every
+ * torchvision ResNet conv (models/OCR.py:58-61). */
+typedef struct {
+  int B, H, W, Cin;        /* input  NHWC dims                                   */
+  int Ho, Wo, Cout;        /* output NHWC dims                                   */
+  int kh, kw, stride, pad, dil;
+  int ldx, ldy;            /* floats per pixel of x / y buffers                  */
+  int stem4;               /* 1: 7x7/2 stem on a 4-channel-padded image, weights packed [O][kh][8][4] */
+} catseg_conv_desc;
+
+/* y[p, o] = sum_{ky,kx,c} x[pix(p,ky,kx), c] * w[o,ky,kx,c] (+ bias[o]); columns
+ * [Cout, zero_to) of y are written as zeros (zero_to <= ldy, 0 = none). */
+int catseg_conv2d_fwd(const catseg_conv_desc* d, const float* x, const float* w, const float* bias,
+                      float* y, int zero_to, catseg_stream_t stream);
+/* dx[q, c] (+)= sum_{ky,kx,o} dy[opix(q,ky,kx), o] * w[o,ky,kx,c]  (autograd of the above) */
+int catseg_conv2d_bwd_data(const catseg_conv_desc* d, const float* dy, const float* w, float* dx,
+                           int accumulate, catseg_stream_t stream);
+/* dw[o,ky,kx,c] = sum_p dy[p, o] * x[pix(p,ky,kx), c]; dbias[o] = sum_p dy[p,o] (may be NULL).
+ * workspace: catseg_conv2d_bwd_weight_workspace() bytes (split-reduction slabs). */
+size_t catseg_conv2d_bwd_weight_workspace(const catseg_conv_desc* d);
+int catseg_conv2d_bwd_weight(const catseg_conv_desc* d, const float* x, const float* dy, float* dw,
+                             float* dbias, void* workspace, size_t workspace_bytes,
+                             catseg_stream_t stream);
+
+/* ---- batched GEMM for the OCR gather / object attention (torch.matmul at
+ * models/OCR.py:167,266,274).  C[z] (M x N, ldc) = op(A[z]) * op(B[z]):
+ *   layout "NT": A is M x K (lda), B is N x K (ldb)      (K contiguous in both)
+ *   layout "NN": A is M x K (lda), B is K x N (ldb)
+ *   layout "TN": A is K x M (lda), B is K x N (ldb)      (reduction over rows) */
+#define CATSEG_GEMM_NT 0
+#define CATSEG_GEMM_NN 1
+#define CATSEG_GEMM_TN 2
+int catseg_gemm_batched(int layout, int batch, int M, int N, int K, const float* A, int lda,
+                        long long strideA, const float* Bm, int ldb, long long strideB, float* C,
+                        int ldc, long long strideC, int zero_to, int accumulate,
+                        catseg_stream_t stream);
+
+/* ---- BatchNorm (+ReLU, +residual) — nn.BatchNorm2d/ReLU at e.g. models/OCR.py:74-75,
+ * torchvision Bottleneck, models/DeepLabv3Plus.py:98-104.  rows = B*H*W pixels. */
+/* batch statistics + running-stat update.  stats_out = [mean(C), invstd(C)] (biased variance),
+ *   scale = gamma*invstd.  running_mean/var may be NULL (no update; unbiased variance, momentum
+ *   as nn.BatchNorm2d).  workspace >= catseg_bn_workspace(rows, C). */
+size_t catseg_bn_workspace(long long rows, int C);
+int catseg_bn_train_stats(const float* y, long long rows, int C, int ldy, const float* gamma, float eps,
+                          float momentum, float* running_mean, float* running_var, float* stats_out,
+                          float* scale, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
+/* eval mode: scale = gamma / sqrt(running_var + eps) (use with mean = running_mean) */
+int catseg_bn_eval_scale(int C, const float* gamma, const float* running_var, float eps, float* scale,
+                         catseg_stream_t stream);
+/* z = act((y - mean) * scale + beta (+ residual)),  act = relu if relu != 0 */
+int catseg_bn_apply(const float* y, int ldy, const float* mean, const float* scale, const float* beta,
+                    const float* residual, int ldr, float* z, int ldz, long long rows, int C, int relu,
+                    catseg_stream_t stream);
+/* backward of the fused op.  g = dz * (z > 0 if relu).  Produces dgamma, dbeta, dy and, when
+ * dres != NULL, the residual-branch gradient (dres (+)= g if dres_accumulate).
+ * workspace >= catseg_bn_workspace(rows, C). */
+int catseg_bn_backward(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                       const float* stats, const float* gamma, long long rows, int C, int relu,
+                       float* dy, int lddy, float* dgamma, float* dbeta, float* dres, int lddres,
+                       int dres_accumulate, void* workspace, size_t workspace_bytes,
+                       catseg_stream_t stream);
+/* eval-mode / frozen-statistics backward is not on the training path and is not provided. */
+
+/* ---- layout / pointwise helpers ---------------------------------------------------------- */
+/* img.float() NCHW (B,3,H,W) -> NHWC with 4 channels (4th = 0) : managers/OCRNet_Manager.py:86 */
+int catseg_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, catseg_stream_t stream);
+/* OIHW-logical/OHWI-physical 7x7x3 stem weight -> packed [O][7][8][4] and back (gradient) */
+int catseg_stem_pack_weight(const float* w_ohwi, float* packed, int O, catseg_stream_t stream);
+int catseg_stem_unpack_grad(const float* packed_grad, float* dw_ohwi, int O, catseg_stream_t stream);
+/* dst[p, c] (+)= alpha * src[p, c] */
+int catseg_axpy2d(const float* src, int lds, float* dst, int ldd, long long rows, int C, float alpha,
+                  int accumulate, catseg_stream_t stream);
+/* nn.MaxPool2d(3, 2, 1) of the torchvision stem; idx = window position of the max (uint8) */
+int catseg_maxpool3x3s2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int B, int H, int W,
+                            int C, int Ho, int Wo, catseg_stream_t stream);
+int catseg_maxpool3x3s2_bwd(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx, int B,
+                            int H, int W, int C, int Ho, int Wo, catseg_stream_t stream);
+/* F.interpolate(mode='bilinear') — models/OCR.py:128-131, DeepLabv3Plus.py:68,123,163,
+ * HRNetv2.py:253-256,504-512.  NHWC, C channels, input ld ldx, output ld ldy. */
+int catseg_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C, int Ho,
+                        int Wo, int align_corners, int accumulate, catseg_stream_t stream);
+/* dx[., c] = sum of dy contributions (deterministic gather form); columns [C, zero_to) of dx zeroed.
+ * workspace >= B*H*Wo*C*4 bytes. */
+int catseg_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int B, int H, int W, int C,
+                        int Ho, int Wo, int align_corners, int zero_to, int accumulate, void* workspace,
+                        size_t workspace_bytes, catseg_stream_t stream);
+/* nn.AdaptiveAvgPool2d(1) (ASPP image pooling, DeepLabv3Plus.py:121) and its backward */
+int catseg_global_avgpool_fwd(const float* x, int ldx, float* y, int B, int HW, int C,
+                              catseg_stream_t stream);
+int catseg_global_avgpool_bwd(const float* dy, float* dx, int lddx, int B, int HW, int C, int accumulate,
+                              catseg_stream_t stream);
+
+/* ---- softmax ------------------------------------------------------------------------------ */
+/* F.softmax(probs.view(B,K,N), dim=2) at models/OCR.py:165, on NHWC logits [B][N][ld]:
+ * per (b, k) over the N pixels.  Columns [K, ld) of the output are zeroed. */
+int catseg_softmax_spatial_fwd(const float* x, float* y, int B, int N, int K, int ld, catseg_stream_t stream);
+int catseg_softmax_spatial_bwd(const float* y, const float* dy, float* dx, int B, int N, int K, int ld,
+                               int accumulate, catseg_stream_t stream);
+/* F.softmax(scale * sim, dim=-1) at models/OCR.py:270-271: per row over K (<= 64) columns */
+int catseg_softmax_rows_fwd(const float* x, float* y, long long rows, int K, int ld, float scale,
+                            catseg_stream_t stream);
+int catseg_softmax_rows_bwd(const float* y, const float* dy, float* dx, long long rows, int K, int ld,
+                            float scale, catseg_stream_t stream);
+
+/* ---- losses ------------------------------------------------------------------------------- */
+/* LovaszSoftmax.forward (losses/LovaszSoftmax.py:19-61, per_image=False, classes 'present',
+ * nothing ignored) fused with its autograd backward.  logits [P][K] (ld = K, compact),
+ * labels int64 [P].  loss_out[0] = loss; dlogits (may be NULL) = weight * dloss/dlogits. */
+size_t catseg_lovasz_workspace(long long P, int K);
+int catseg_lovasz_softmax(const float* logits, const int64_t* labels, long long P, int K, float weight,
+                          float* loss_out, float* dlogits, int accumulate_dlogits, void* workspace,
+                          size_t workspace_bytes, catseg_stream_t stream);
+/* nn.CrossEntropyLoss(ignore_index) (losses/LossWrapper.py:17-24) fused with backward */
+size_t catseg_ce_workspace(long long P);
+int catseg_cross_entropy(const float* logits, const int64_t* labels, long long P, int K, long long ignore_index,
+                         float weight, float* loss_out, float* dlogits, void* workspace,
+                         size_t workspace_bytes, catseg_stream_t stream);
+
+/* ---- metrics / optimiser ------------------------------------------------------------------ */
+/* t_get_confusion_matrix (utils/torch_utils.py:221-241): cm[pred*K + gt] += 1 (int32, K x K),
+ * labels >= K are dropped; cm is accumulated into (zero it first for a fresh matrix). */
+int catseg_confusion_matrix(const float* logits, const int64_t* labels, long long P, int K, int32_t* cm,
+                            catseg_stream_t stream);
+/* torch.optim.Adam(lr) step over a flat parameter buffer (managers/BaseManager.py:441) */
+int catseg_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                     float beta2, float eps, int step, float grad_scale, catseg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CATSEG_H */

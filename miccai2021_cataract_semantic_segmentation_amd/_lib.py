@@ -1,0 +1,86 @@
+"""ctypes binding of libcatseg_hip.so (C ABI declared in include/catseg.h).
+
+There is no CPU fallback: importing this module without the built library raises.
+PyTorch is used only to own device memory and streams; every kernel is launched
+through the C ABI with raw pointers.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcatseg_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libcatseg_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C miccai2021_cataract_semantic_segmentation_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+P, I, L, F, SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, I) for n in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "kh", "kw", "stride", "pad", "dil",
+                                 "ldx", "ldy", "stem4")]
+
+
+_SIGS = {
+    "catseg_last_error": (C.c_char_p, []),
+    "catseg_version": (I, []),
+    "catseg_conv2d_fwd": (I, [P, P, P, P, P, I, P]),
+    "catseg_conv2d_bwd_data": (I, [P, P, P, P, I, P]),
+    "catseg_conv2d_bwd_weight_workspace": (SZ, [P]),
+    "catseg_conv2d_bwd_weight": (I, [P, P, P, P, P, P, SZ, P]),
+    "catseg_gemm_batched": (I, [I, I, I, I, I, P, I, L, P, I, L, P, I, L, I, I, P]),
+    "catseg_bn_workspace": (SZ, [L, I]),
+    "catseg_bn_train_stats": (I, [P, L, I, I, P, F, F, P, P, P, P, P, SZ, P]),
+    "catseg_bn_eval_scale": (I, [I, P, P, F, P, P]),
+    "catseg_bn_apply": (I, [P, I, P, P, P, P, I, P, I, L, I, I, P]),
+    "catseg_bn_backward": (I, [P, I, P, I, P, I, P, P, L, I, I, P, I, P, P, P, I, I, P, SZ, P]),
+    "catseg_nchw3_to_nhwc4": (I, [P, P, I, I, I, P]),
+    "catseg_stem_pack_weight": (I, [P, P, I, P]),
+    "catseg_stem_unpack_grad": (I, [P, P, I, P]),
+    "catseg_axpy2d": (I, [P, I, P, I, L, I, F, I, P]),
+    "catseg_maxpool3x3s2_fwd": (I, [P, I, P, I, P, I, I, I, I, I, I, P]),
+    "catseg_maxpool3x3s2_bwd": (I, [P, I, P, P, I, I, I, I, I, I, I, P]),
+    "catseg_bilinear_fwd": (I, [P, I, P, I, I, I, I, I, I, I, I, I, P]),
+    "catseg_bilinear_bwd": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, P, SZ, P]),
+    "catseg_global_avgpool_fwd": (I, [P, I, P, I, I, I, P]),
+    "catseg_global_avgpool_bwd": (I, [P, P, I, I, I, I, I, P]),
+    "catseg_softmax_spatial_fwd": (I, [P, P, I, I, I, I, P]),
+    "catseg_softmax_spatial_bwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "catseg_softmax_rows_fwd": (I, [P, P, L, I, I, F, P]),
+    "catseg_softmax_rows_bwd": (I, [P, P, P, L, I, I, F, P]),
+    "catseg_lovasz_workspace": (SZ, [L, I]),
+    "catseg_lovasz_softmax": (I, [P, P, L, I, F, P, P, I, P, SZ, P]),
+    "catseg_ce_workspace": (SZ, [L]),
+    "catseg_cross_entropy": (I, [P, P, L, I, L, F, P, P, P, SZ, P]),
+    "catseg_confusion_matrix": (I, [P, P, L, I, P, P]),
+    "catseg_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, F, P]),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header / library mismatch
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTS = tuple(_SIGS)
+
+
+class CatsegError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise CatsegError("libcatseg_hip: error %d: %s" % (rc, lib.catseg_last_error().decode()))
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,540 @@
+// Implicit-GEMM convolution / batched GEMM on the fp32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains, 157 TFLOP/s dense peak).
+//
+// One kernel template, three operand layouts:
+//   L_NT  conv forward / GEMM "NT":  A rows = output pixels (K contiguous), B rows = out-channels (K contiguous)
+//   L_NN  conv backward-data / "NN": A rows = pixels (K contiguous),        B = [k][n] (n contiguous)
+//   L_TN  conv backward-weight/"TN": A = [r][m], B = [r][n], reduction over pixel rows r (split over blocks)
+//
+// Data path: global --(global_load_lds_dwordx4, 16 B per lane, no VGPR round trip)--> LDS
+// (double buffered, one K-step of 16 in flight behind a counted vmcnt) --> ds_read_b128 /
+// ds_read_b32 fragments --> MFMA.  The im2col matrix is never materialised: each lane
+// computes the source address of its 16-byte chunk (out-of-image taps point at a zero page).
+//
+// LDS images (per K-step of BK = 16 floats):
+//   K-contiguous operand: [rows][16] floats, 64-B rows; the four 16-B chunks of a row are stored
+//     at position (chunk ^ ((row >> 2) & 3)) so that the 16 lanes of a ds_read_b128 group hit 16
+//     distinct 4-bank slots (the swizzle is applied to the per-lane SOURCE address, the LDS
+//     destination of a global_load_lds is lane-linear).
+//   K-major operand: [16][cols] floats, read with conflict-free ds_read_b32 (lane = column).
+// MFMA k-mapping: lane half h = lane >> 5 feeds k = 8*jj + 4*h + ii of the K-step to MFMA (jj, ii);
+// A and B use the same mapping, the sum over k is order-insensitive up to fp32 rounding.
+#include "common.h"
+
+namespace {
+
+__device__ __attribute__((aligned(256))) float g_zero_page[64];
+
+enum { L_NT = 0, L_NN = 1, L_TN = 2 };
+
+struct Geo {
+  const float* base;
+  int mode;  // 0 plain rows, 1 conv-forward gather, 2 conv-backward-data gather, 3 stem (chunk = pixel)
+  int rows;  // valid row indices [0, rows)
+  int ld;    // floats per source pixel / row
+  int H, W;  // spatial dims of the source tensor
+  int Ho, Wo;  // spatial dims the row index decodes over
+  int kw, stride, pad, dil;
+};
+
+struct IgemmArgs {
+  Geo g;               // gathered operand (A for L_NT / L_NN, B for L_TN)
+  const float* other;  // L_NT: B[n][ldo]  L_NN: B[k][ldo]  L_TN: A[r][ldo]
+  float* C;
+  const float* bias;
+  int M, N, ldc, ldo, tap_stride;
+  int taps, Cred, Cred_b;
+  int tilesM, tilesN;
+  int zero_to, accumulate;
+  long long g_bs, o_bs, c_bs;
+  // L_TN only
+  int splits, rows_per_split;
+  long long c_split_stride;
+  int c_tap_stride;
+};
+
+__device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void decode_row(const Geo& g, int r, int& b, int& y, int& x) {
+  const int hw = g.Ho * g.Wo;
+  b = r / hw;
+  const int rem = r - b * hw;
+  y = rem / g.Wo;
+  x = rem - y * g.Wo;
+}
+
+// Source address of one 16-byte chunk of the gathered operand (or the zero page).
+// chunk = index of the 4-float chunk inside the tap's reduction range; cvalid = chunk in range.
+__device__ __forceinline__ const float* gather_ptr(const Geo& g, const float* base, bool rvalid, int r, int b,
+                                                   int y, int x, int ky, int kx, int chunk, bool cvalid) {
+  long long pix;
+  bool ok = rvalid && cvalid;
+  if (g.mode == 0) {
+    pix = r;
+  } else if (g.mode == 1) {
+    const int iy = y * g.stride - g.pad + ky * g.dil;
+    const int ix = x * g.stride - g.pad + kx * g.dil;
+    ok = ok && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+    pix = ((long long)b * g.H + iy) * g.W + ix;
+  } else if (g.mode == 2) {
+    const int ty = y + g.pad - ky * g.dil;
+    const int tx = x + g.pad - kx * g.dil;
+    const int oy = ty / g.stride, ox = tx / g.stride;
+    ok = ok && ty >= 0 && tx >= 0 && oy * g.stride == ty && ox * g.stride == tx && oy < g.H && ox < g.W;
+    pix = ((long long)b * g.H + oy) * g.W + ox;
+  } else {  // stem: tap = ky only, the 8 chunks of the K range are 8 consecutive pixels of 4 channels
+    const int iy = y * g.stride - g.pad + ky * g.dil;
+    const int ix = x * g.stride - g.pad + chunk;
+    ok = ok && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+    pix = ((long long)b * g.H + iy) * g.W + ix;
+    chunk = 0;
+  }
+  return ok ? base + pix * g.ld + chunk * 4 : g_zero_page;
+}
+
+template <int LAYOUT, int MI, int NI>
+__global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmArgs p) {
+  constexpr int BM = 64 * MI, BN = 64 * NI;
+  constexpr bool A_KC = (LAYOUT != L_TN);
+  constexpr bool B_KC = (LAYOUT == L_NT);
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 16];
+  float* const sA0 = smem;
+  float* const sB0 = smem + 2 * BM * 16;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
+  // contiguous run of tiles (bijective for any grid size).
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_m = swz / p.tilesN, tile_n = swz - tile_m * p.tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  int zb = blockIdx.z, split = 0;
+  if (LAYOUT == L_TN) {
+    split = zb % p.splits;
+    zb = zb / p.splits;
+  }
+  const float* gbase = p.g.base + zb * p.g_bs;
+  const float* obase = p.other + zb * p.o_bs;
+  float* cbase = p.C + zb * p.c_bs;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- per-thread staging state --------------------------------------------------------
+  // K-contiguous tiles: thread handles chunk position (tid & 3) of row j*64 + (tid >> 2).
+  const int kc_row = tid >> 2;
+  const int kc_chunk = (tid & 3) ^ ((tid >> 4) & 3);  // logical chunk stored at position tid & 3
+  int ab[MI], ay[MI], ax[MI];
+  bool arv[MI];
+  if (A_KC) {
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int r = m0 + j * 64 + kc_row;
+      arv[j] = r < p.g.rows;
+      ab[j] = ay[j] = ax[j] = 0;
+      if (p.g.mode != 0) decode_row(p.g, arv[j] ? r : 0, ab[j], ay[j], ax[j]);
+    }
+  }
+
+  int nks, r_begin = 0, r_end = 0;
+  const int nck = (p.Cred + 15) >> 4;
+  if (LAYOUT == L_TN) {
+    r_begin = split * p.rows_per_split;
+    r_end = min(r_begin + p.rows_per_split, p.g.rows);
+    nks = (max(r_end - r_begin, 0) + 15) >> 4;
+  } else {
+    nks = p.taps * nck;
+  }
+  int tky = 0, tkx = 0, ttap = 0, tck = 0;  // staging cursor (wave-uniform)
+  if (LAYOUT == L_TN) {
+    ttap = blockIdx.y;
+    tky = (p.g.mode == 3) ? ttap : ttap / p.g.kw;
+    tkx = (p.g.mode == 3) ? 0 : ttap - tky * p.g.kw;
+  }
+
+  auto stage = [&](int ks, int buf) {
+    float* sA = sA0 + buf * BM * 16;
+    float* sB = sB0 + buf * BN * 16;
+    if (LAYOUT != L_TN) {
+      // ---- A: gathered pixels, K contiguous
+      const int chunk = tck * 4 + kc_chunk;
+      const bool cv = chunk * 4 < p.Cred;
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        const float* src = gather_ptr(p.g, gbase, arv[j], m0 + j * 64 + kc_row, ab[j], ay[j], ax[j], tky, tkx,
+                                      chunk, cv);
+        glds16(src, sA + (j * 256 + wave * 64) * 4);
+      }
+      if (B_KC) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int n = n0 + j * 64 + kc_row;
+          const bool ok = n < p.N && cv;
+          const float* src = ok ? obase + (long long)n * p.ldo + ttap * p.tap_stride + chunk * 4 : g_zero_page;
+          glds16(src, sB + (j * 256 + wave * 64) * 4);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int q = j * 256 + tid;
+          const int krow = q / (16 * NI), cc = q % (16 * NI);
+          const int k = tck * 16 + krow;
+          const bool ok = k < p.Cred_b && (n0 + cc * 4) < ((p.N + 3) & ~3);
+          const float* src = ok ? obase + (long long)k * p.ldo + ttap * p.tap_stride + n0 + cc * 4 : g_zero_page;
+          glds16(src, sB + (j * 256 + wave * 64) * 4);
+        }
+      }
+      // advance cursor
+      if (++tck == nck) {
+        tck = 0;
+        ++ttap;
+        if (p.g.mode == 3) {
+          ++tky;
+        } else if (++tkx == p.g.kw) {
+          tkx = 0;
+          ++tky;
+        }
+      }
+    } else {
+      const int kbase = r_begin + ks * 16;
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        const int q = j * 256 + tid;
+        const int krow = q / (16 * MI), cc = q % (16 * MI);
+        const int r = kbase + krow;
+        const bool ok = r < r_end && (m0 + cc * 4) < ((p.M + 3) & ~3);
+        const float* src = ok ? obase + (long long)r * p.ldo + m0 + cc * 4 : g_zero_page;
+        glds16(src, sA + (j * 256 + wave * 64) * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int q = j * 256 + tid;
+        const int krow = q / (16 * NI), cc = q % (16 * NI);
+        const int r = kbase + krow;
+        const bool rv = r < r_end;
+        int b = 0, y = 0, x = 0;
+        if (p.g.mode != 0) decode_row(p.g, rv ? r : 0, b, y, x);
+        const int chunk = (n0 >> 2) + cc;
+        const float* src = gather_ptr(p.g, gbase, rv, r, b, y, x, tky, tkx, chunk, chunk * 4 < ((p.N + 3) & ~3));
+        glds16(src, sB + (j * 256 + wave * 64) * 4);
+      }
+    }
+  };
+
+  auto compute = [&](int buf) {
+    const float* sA = sA0 + buf * BM * 16;
+    const float* sB = sB0 + buf * BN * 16;
+    float a[MI][2][4], b[NI][2][4];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int row = wm * 32 * MI + mi * 32 + l31;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        if (A_KC) {
+          const int pos = (2 * jj + h) ^ ((row >> 2) & 3);
+          const f32x4 v = *(const f32x4*)(sA + row * 16 + pos * 4);
+          a[mi][jj][0] = v[0]; a[mi][jj][1] = v[1]; a[mi][jj][2] = v[2]; a[mi][jj][3] = v[3];
+        } else {
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii) a[mi][jj][ii] = sA[(8 * jj + 4 * h + ii) * BM + row];
+        }
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int row = wn * 32 * NI + ni * 32 + l31;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        if (B_KC) {
+          const int pos = (2 * jj + h) ^ ((row >> 2) & 3);
+          const f32x4 v = *(const f32x4*)(sB + row * 16 + pos * 4);
+          b[ni][jj][0] = v[0]; b[ni][jj][1] = v[1]; b[ni][jj][2] = v[2]; b[ni][jj][3] = v[3];
+        } else {
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii) b[ni][jj][ii] = sB[(8 * jj + 4 * h + ii) * BN + row];
+        }
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][jj][ii], b[ni][jj][ii], acc[mi][ni], 0, 0, 0);
+  };
+
+  // ---- main loop: stage(k+1) in flight while computing k ---------------------------------
+  if (nks > 0) {
+    stage(0, 0);
+    for (int ks = 0; ks < nks; ++ks) {
+      const int cur = ks & 1;
+      if (ks + 1 < nks) {
+        stage(ks + 1, cur ^ 1);
+        if (MI + NI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (MI + NI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      compute(cur);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------
+  float* cout = cbase;
+  if (LAYOUT == L_TN) cout += split * p.c_split_stride + (long long)blockIdx.y * p.c_tap_stride;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = n0 + wn * 32 * NI + ni * 32 + l31;
+      const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < p.M) {
+          float* dst = cout + (long long)row * p.ldc + col;
+          if (col < p.N) {
+            float v = acc[mi][ni][r] + bv;
+            if (p.accumulate) v += *dst;
+            *dst = v;
+          } else if (col < p.zero_to) {
+            *dst = 0.f;
+          }
+        }
+      }
+    }
+  }
+}
+
+// out[i] = sum_s slab[s][i]  (deterministic split reduction of backward-weight partials)
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n4,
+                                    int splits, long long stride4) {
+  const f32x4* s = (const f32x4*)slabs;
+  f32x4* o = (f32x4*)out;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 a = s[i];
+    for (int k = 1; k < splits; ++k) a += s[i + k * stride4];
+    o[i] = a;
+  }
+}
+
+// dbias[o] = sum_p dy[p, o]: block = 64 channels x 4 row lanes, rows strided over gridDim.y
+__global__ void colsum_partial_kernel(const float* __restrict__ dy, int ld, long long rows, int C,
+                                      float* __restrict__ part) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (long long r = blockIdx.y * 4 + rl; r < rows; r += (long long)gridDim.y * 4) s += dy[r * ld + c];
+  __shared__ float sh[256];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) part[(long long)blockIdx.y * C + c] = sh[threadIdx.x] + sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int i = 0; i < nparts; ++i) s += part[(long long)i * C + c];
+  out[c] = s;
+}
+
+template <int LAYOUT>
+int launch_igemm(const IgemmArgs& a0, int nbatch, int grid_y, hipStream_t st) {
+  IgemmArgs a = a0;
+  // tile choice: 128x128 by default, narrower tiles for narrow outputs
+  const int ncols = a.zero_to > a.N ? a.zero_to : a.N;  // pad columns to be zero-filled are visited too
+  const int mi = (a.M > 64) ? 2 : 1;
+  const int ni = (ncols > 64) ? 2 : 1;
+  a.tilesM = (a.M + 64 * mi - 1) / (64 * mi);
+  a.tilesN = (ncols + 64 * ni - 1) / (64 * ni);
+  dim3 grid(a.tilesM * a.tilesN, grid_y, nbatch * (LAYOUT == L_TN ? a.splits : 1));
+  if (mi == 2 && ni == 2) hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, 2, 2>), grid, dim3(256), 0, st, a);
+  else if (mi == 2 && ni == 1) hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, 2, 1>), grid, dim3(256), 0, st, a);
+  else if (mi == 1 && ni == 2) hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, 1, 2>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, 1, 1>), grid, dim3(256), 0, st, a);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+int check_desc(const catseg_conv_desc* d) {
+  CS_REQUIRE(d != nullptr, "conv: null descriptor");
+  CS_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0, "conv: bad dims");
+  CS_REQUIRE(d->stride >= 1 && d->dil >= 1 && d->kh >= 1 && d->kw >= 1 && d->pad >= 0, "conv: bad geometry");
+  CS_REQUIRE(d->ldx % 4 == 0 && d->ldy % 4 == 0 && d->ldx >= d->Cin && d->ldy >= d->Cout, "conv: ld must be >= C and a multiple of 4");
+  const int ho = (d->H + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+  const int wo = (d->W + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+  CS_REQUIRE(ho == d->Ho && wo == d->Wo, "conv: Ho/Wo (%d,%d) do not match geometry (%d,%d)", d->Ho, d->Wo, ho, wo);
+  if (d->stem4) CS_REQUIRE(d->Cin == 4 && d->kw == 7 && d->ldx == 4, "conv: stem4 needs Cin == ldx == 4, kw == 7");
+  else CS_REQUIRE(d->Cin % 4 == 0, "conv: Cin must be a multiple of 4 (got %d)", d->Cin);
+  CS_REQUIRE((long long)d->B * d->Ho * d->Wo < (1ll << 31) && (long long)d->B * d->H * d->W < (1ll << 31), "conv: too many pixels");
+  return CATSEG_OK;
+}
+
+Geo fwd_geo(const catseg_conv_desc* d, const float* x) {
+  Geo g;
+  g.base = x; g.mode = d->stem4 ? 3 : 1; g.rows = d->B * d->Ho * d->Wo; g.ld = d->ldx;
+  g.H = d->H; g.W = d->W; g.Ho = d->Ho; g.Wo = d->Wo; g.kw = d->kw; g.stride = d->stride; g.pad = d->pad; g.dil = d->dil;
+  return g;
+}
+
+}  // namespace
+
+extern "C" int catseg_conv2d_fwd(const catseg_conv_desc* d, const float* x, const float* w, const float* bias,
+                                 float* y, int zero_to, catseg_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  CS_REQUIRE(cs_aligned16(x) && cs_aligned16(w) && cs_aligned16(y), "conv fwd: pointers must be 16-byte aligned");
+  CS_REQUIRE(zero_to <= d->ldy, "conv fwd: zero_to > ldy");
+  IgemmArgs a = {};
+  a.g = fwd_geo(d, x);
+  a.other = w; a.C = y; a.bias = bias;
+  a.M = a.g.rows; a.N = d->Cout; a.ldc = d->ldy;
+  if (d->stem4) { a.taps = d->kh; a.Cred = 32; a.ldo = d->kh * 32; a.tap_stride = 32; }
+  else { a.taps = d->kh * d->kw; a.Cred = d->Cin; a.ldo = a.taps * d->Cin; a.tap_stride = d->Cin; }
+  a.Cred_b = a.Cred; a.zero_to = zero_to; a.accumulate = 0;
+  return launch_igemm<L_NT>(a, 1, 1, (hipStream_t)stream);
+}
+
+extern "C" int catseg_conv2d_bwd_data(const catseg_conv_desc* d, const float* dy, const float* w, float* dx,
+                                      int accumulate, catseg_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  CS_REQUIRE(!d->stem4, "conv bwd_data: not defined for the stem (the image needs no gradient)");
+  CS_REQUIRE(cs_aligned16(dy) && cs_aligned16(w) && cs_aligned16(dx), "conv bwd_data: pointers must be 16-byte aligned");
+  IgemmArgs a = {};
+  Geo& g = a.g;
+  g.base = dy; g.mode = 2; g.rows = d->B * d->H * d->W; g.ld = d->ldy;
+  g.H = d->Ho; g.W = d->Wo; g.Ho = d->H; g.Wo = d->W; g.kw = d->kw; g.stride = d->stride; g.pad = d->pad; g.dil = d->dil;
+  a.other = w; a.C = dx; a.bias = nullptr;
+  a.M = g.rows; a.N = d->Cin; a.ldc = d->ldx;
+  a.taps = d->kh * d->kw;
+  a.Cred = (d->Cout + 3) & ~3;  // dy pad columns [Cout, roundup4) must be zero (conv_fwd zero_to / bilinear_bwd zero_to)
+  a.Cred_b = d->Cout;
+  a.ldo = a.taps * d->Cin; a.tap_stride = d->Cin;
+  a.zero_to = 0; a.accumulate = accumulate;
+  return launch_igemm<L_NN>(a, 1, 1, (hipStream_t)stream);
+}
+
+namespace {
+void wgrad_plan(const catseg_conv_desc* d, int& splits, int& rps) {
+  const long long rows = (long long)d->B * d->Ho * d->Wo;
+  const int N = d->stem4 ? 32 : d->Cin;
+  const int taps = d->stem4 ? d->kh : d->kh * d->kw;
+  const int mi = d->Cout > 64 ? 2 : 1, ni = N > 64 ? 2 : 1;
+  const long long tiles = (long long)((d->Cout + 64 * mi - 1) / (64 * mi)) * ((N + 64 * ni - 1) / (64 * ni)) * taps;
+  long long want = (1024 + tiles - 1) / tiles;  // ~4 blocks per CU
+  const long long maxs = (rows + 255) / 256;    // at least 16 K-steps per split
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  rps = (int)(((rows + want - 1) / want + 15) / 16 * 16);
+  splits = (int)((rows + rps - 1) / rps);
+}
+}  // namespace
+
+extern "C" size_t catseg_conv2d_bwd_weight_workspace(const catseg_conv_desc* d) {
+  if (check_desc(d)) return 0;
+  int splits, rps;
+  wgrad_plan(d, splits, rps);
+  const size_t wel = (size_t)d->Cout * (d->stem4 ? d->kh * 32 : d->kh * d->kw * d->Cin);
+  size_t bytes = splits > 1 ? (size_t)splits * wel * 4 : 0;
+  bytes += (size_t)256 * d->Cout * 4;  // bias-gradient partials
+  return cs_align_up(bytes, 256);
+}
+
+extern "C" int catseg_conv2d_bwd_weight(const catseg_conv_desc* d, const float* x, const float* dy, float* dw,
+                                        float* dbias, void* workspace, size_t workspace_bytes,
+                                        catseg_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  CS_REQUIRE(cs_aligned16(dy) && cs_aligned16(x) && cs_aligned16(dw), "conv bwd_weight: pointers must be 16-byte aligned");
+  const size_t need = catseg_conv2d_bwd_weight_workspace(d);
+  if (workspace_bytes < need || (need && !workspace)) {
+    catseg_set_error("conv bwd_weight: workspace %zu < %zu", workspace_bytes, need);
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int splits, rps;
+  wgrad_plan(d, splits, rps);
+  const int taps = d->stem4 ? d->kh : d->kh * d->kw;
+  const int ncol = d->stem4 ? 32 : d->Cin;
+  const size_t wel = (size_t)d->Cout * taps * ncol;
+  IgemmArgs a = {};
+  a.g = fwd_geo(d, x);
+  a.other = dy; a.ldo = d->ldy;
+  a.M = d->Cout; a.N = ncol; a.ldc = taps * ncol; a.c_tap_stride = ncol;
+  a.splits = splits; a.rows_per_split = rps; a.c_split_stride = (long long)wel;
+  a.C = splits > 1 ? (float*)workspace : dw;
+  a.taps = taps; a.Cred = 0; a.Cred_b = 0;
+  if (int e = launch_igemm<L_TN>(a, 1, taps, st)) return e;
+  if (splits > 1) {
+    const long long n4 = (long long)(wel / 4);
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n4, splits, n4);
+    CS_LAUNCH_CHECK();
+  }
+  if (dbias) {
+    float* part = (float*)((char*)workspace + (splits > 1 ? (size_t)splits * wel * 4 : 0));
+    const long long rows = (long long)d->B * d->Ho * d->Wo;
+    const int gy = (int)((rows + 1023) / 1024 < 256 ? (rows + 1023) / 1024 : 256);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((d->Cout + 63) / 64, gy), dim3(256), 0, st, dy, d->ldy, rows, d->Cout, part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d->Cout + 255) / 256), dim3(256), 0, st, (const float*)part, gy, d->Cout, dbias);
+    CS_LAUNCH_CHECK();
+  }
+  return CATSEG_OK;
+}
+
+extern "C" int catseg_gemm_batched(int layout, int batch, int M, int N, int K, const float* A, int lda,
+                                   long long strideA, const float* Bm, int ldb, long long strideB, float* C,
+                                   int ldc, long long strideC, int zero_to, int accumulate,
+                                   catseg_stream_t stream) {
+  CS_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0, "gemm: bad dims");
+  CS_REQUIRE(cs_aligned16(A) && cs_aligned16(Bm) && cs_aligned16(C), "gemm: pointers must be 16-byte aligned");
+  CS_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0, "gemm: lda/ldb/strides must be multiples of 4");
+  CS_REQUIRE(zero_to <= ldc, "gemm: zero_to > ldc");
+  IgemmArgs a = {};
+  Geo& g = a.g;
+  g.mode = 0; g.H = g.W = g.Ho = g.Wo = 1; g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1;
+  a.C = C; a.ldc = ldc; a.c_bs = strideC; a.M = M; a.N = N; a.zero_to = zero_to; a.accumulate = accumulate;
+  a.taps = 1; a.tap_stride = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == CATSEG_GEMM_NT) {
+    CS_REQUIRE(K % 4 == 0 && lda >= K && ldb >= K, "gemm NT: K must be a multiple of 4 and <= lda, ldb");
+    g.base = A; g.rows = M; g.ld = lda; a.g_bs = strideA;
+    a.other = Bm; a.ldo = ldb; a.o_bs = strideB; a.Cred = K; a.Cred_b = K;
+    return launch_igemm<L_NT>(a, batch, 1, st);
+  } else if (layout == CATSEG_GEMM_NN) {
+    CS_REQUIRE(lda >= ((K + 3) & ~3) && ldb >= ((N + 3) & ~3), "gemm NN: lda/ldb too small");
+    g.base = A; g.rows = M; g.ld = lda; a.g_bs = strideA;
+    a.other = Bm; a.ldo = ldb; a.o_bs = strideB; a.Cred = (K + 3) & ~3; a.Cred_b = K;
+    return launch_igemm<L_NN>(a, batch, 1, st);
+  } else if (layout == CATSEG_GEMM_TN) {
+    CS_REQUIRE(lda >= ((M + 3) & ~3) && ldb >= ((N + 3) & ~3), "gemm TN: lda/ldb too small");
+    g.base = Bm; g.rows = K; g.ld = ldb; a.g_bs = strideB;
+    a.other = A; a.ldo = lda; a.o_bs = strideA;
+    a.splits = 1; a.rows_per_split = (K + 15) / 16 * 16; a.c_split_stride = 0; a.c_tap_stride = 0;
+    return launch_igemm<L_TN>(a, batch, 1, st);
+  }
+  catseg_set_error("gemm: unknown layout %d", layout);
+  return CATSEG_EINVAL;
+}

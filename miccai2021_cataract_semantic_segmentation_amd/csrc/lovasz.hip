@@ -1,0 +1,627 @@
+// Lovasz-Softmax (losses/LovaszSoftmax.py:19-120 of the reference), cross entropy and the
+// confusion matrix, as batched-over-classes HBM-bound kernels.
+//
+// Lovasz pipeline for logits [P][K], labels [P] (all classes in one launch, blockIdx.y = class,
+// classes without a foreground pixel exit at once, no host round trip):
+//   label_hist      : fg count per class, number of present classes
+//   prep            : softmax over K per pixel; key[c][p] = 0x3F800000 - bits(|fg - p_c|) (ascending key
+//                     = descending error, 30 significant bits), val[c][p] = p | fg << 31
+//   3 x (upsweep, scan, downsweep): stable LSD radix sort, 10-bit digits; ranking inside a wave by
+//                     ballot match (64-wide), wave->block->grid offsets through LDS
+//   fg block sums + scan, then `grad`: inclusive fg count F_i -> Jaccard gradient in fp32 exactly as
+//                     lovasz_grad() computes it, loss partials, scatter of d loss / d prob to [c][pixel]
+//   finalize        : loss = mean over present classes
+//   backward        : softmax backward per pixel -> dlogits [P][K]
+#include "common.h"
+
+namespace {
+
+constexpr int RBITS = 10;
+constexpr int RADIX = 1 << RBITS;
+constexpr int SORT_BLOCKS = 128;  // blocks per class in upsweep / downsweep
+constexpr int TILE = 4096;        // keys per tile (256 threads x 16)
+constexpr int PIX = 256;          // pixels per block in the per-pixel kernels
+constexpr int MAXK = 64;
+
+struct LvWs {
+  uint32_t* counts;   // [MAXK] fg count per class, [MAXK] = number of present classes
+  uint32_t* keys[2];  // [K][P]
+  uint32_t* vals[2];
+  uint32_t* hist;     // [K][RADIX][SORT_BLOCKS]
+  uint32_t* fgsum;    // [K][ntiles]
+  float* lpart;       // [K][ntiles]
+  float* dprob;       // [K][P]
+  double* lossd;      // [1]
+};
+
+size_t lv_layout(long long P, int K, char* base, LvWs* w) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += cs_align_up(bytes, 256);
+    return p;
+  };
+  const long long ntiles = (P + TILE - 1) / TILE;
+  LvWs t;
+  t.counts = (uint32_t*)take((MAXK + 4) * 4);
+  for (int i = 0; i < 2; ++i) {
+    t.keys[i] = (uint32_t*)take((size_t)K * P * 4);
+    t.vals[i] = (uint32_t*)take((size_t)K * P * 4);
+  }
+  t.hist = (uint32_t*)take((size_t)K * RADIX * SORT_BLOCKS * 4);
+  t.fgsum = (uint32_t*)take((size_t)K * ntiles * 4);
+  t.lpart = (float*)take((size_t)K * ntiles * 4);
+  t.dprob = (float*)take((size_t)K * P * 4);
+  t.lossd = (double*)take(64);
+  if (w) *w = t;
+  return off;
+}
+
+// ---- stage a block of PIX pixels x K logits into LDS (coalesced), row stride KS (odd)
+__device__ __forceinline__ void stage_rows(const float* __restrict__ logits, long long p0, int np, int K, int KS, float* sh) {
+  const int n = np * K;
+  const float* src = logits + p0 * K;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int r = i / K, c = i - r * K;
+    sh[r * KS + c] = src[i];
+  }
+}
+
+__global__ void label_hist_kernel(const int64_t* __restrict__ labels, long long P, int K, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t h[MAXK];
+  if (threadIdx.x < MAXK) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
+    const int64_t l = labels[i];
+    if (l >= 0 && l < K) atomicAdd(&h[(int)l], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < K && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void present_kernel(int K, uint32_t* counts) {
+  if (threadIdx.x == 0) {
+    uint32_t n = 0;
+    for (int c = 0; c < K; ++c) n += counts[c] != 0;
+    counts[MAXK] = n;
+  }
+}
+
+__global__ __launch_bounds__(PIX) void lv_prep_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, long long P,
+                                                      int K, const uint32_t* __restrict__ counts, uint32_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ vals) {
+  extern __shared__ float sh[];
+  const int KS = K | 1;
+  const long long p0 = (long long)blockIdx.x * PIX;
+  const int np = (int)min((long long)PIX, P - p0);
+  stage_rows(logits, p0, np, K, KS, sh);
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t >= np) return;
+  float* row = sh + t * KS;
+  float m = row[0];
+  for (int c = 1; c < K; ++c) m = fmaxf(m, row[c]);
+  float s = 0.f;
+  for (int c = 0; c < K; ++c) {
+    const float e = expf(row[c] - m);
+    row[c] = e;
+    s += e;
+  }
+  const long long p = p0 + t;
+  const int64_t lab = labels[p];
+  for (int c = 0; c < K; ++c) {
+    if (counts[c] == 0) continue;
+    const float pr = row[c] / s;
+    const uint32_t fg = (lab == c) ? 1u : 0u;
+    const float err = fabsf((float)fg - pr);
+    keys[(long long)c * P + p] = 0x3F800000u - __float_as_uint(err);
+    vals[(long long)c * P + p] = (uint32_t)p | (fg << 31);
+  }
+}
+
+// ---- radix sort ---------------------------------------------------------------------------
+__device__ __forceinline__ void block_range(long long P, long long& t0, long long& t1) {
+  const long long ntiles = (P + TILE - 1) / TILE;
+  const long long per = (ntiles + SORT_BLOCKS - 1) / SORT_BLOCKS;
+  t0 = blockIdx.x * per;
+  t1 = min(t0 + per, ntiles);
+}
+
+__global__ __launch_bounds__(256) void radix_upsweep_kernel(const uint32_t* __restrict__ keys, long long P, int shift,
+                                                            const uint32_t* __restrict__ counts, uint32_t* __restrict__ hist) {
+  const int c = blockIdx.y;
+  if (counts[c] == 0) return;
+  __shared__ uint32_t h[RADIX];
+  for (int i = threadIdx.x; i < RADIX; i += 256) h[i] = 0;
+  __syncthreads();
+  long long t0, t1;
+  block_range(P, t0, t1);
+  const uint32_t* k = keys + (long long)c * P;
+  const long long e0 = t0 * TILE, e1 = min(t1 * TILE, P);
+  for (long long i = e0 + threadIdx.x; i < e1; i += 256) atomicAdd(&h[(k[i] >> shift) & (RADIX - 1)], 1u);
+  __syncthreads();
+  uint32_t* o = hist + (long long)c * RADIX * SORT_BLOCKS;
+  for (int d = threadIdx.x; d < RADIX; d += 256) o[d * SORT_BLOCKS + blockIdx.x] = h[d];
+}
+
+// exclusive scan of hist[c][d][b] in (d, b) order; one 1024-thread block per class
+__global__ __launch_bounds__(RADIX) void radix_scan_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ hist) {
+  const int c = blockIdx.x;
+  if (counts[c] == 0) return;
+  uint32_t* row = hist + ((long long)c * RADIX + threadIdx.x) * SORT_BLOCKS;
+  uint32_t tot = 0;
+  for (int b = 0; b < SORT_BLOCKS; ++b) {
+    const uint32_t v = row[b];
+    row[b] = tot;
+    tot += v;
+  }
+  __shared__ uint32_t sh[RADIX];
+  sh[threadIdx.x] = tot;
+  __syncthreads();
+  for (int off = 1; off < RADIX; off <<= 1) {
+    const uint32_t v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += v;
+    __syncthreads();
+  }
+  const uint32_t base = sh[threadIdx.x] - tot;
+  for (int b = 0; b < SORT_BLOCKS; ++b) row[b] += base;
+}
+
+__global__ __launch_bounds__(256) void radix_downsweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                              long long P, int shift, const uint32_t* __restrict__ counts,
+                                                              const uint32_t* __restrict__ hist) {
+  const int c = blockIdx.y;
+  if (counts[c] == 0) return;
+  __shared__ uint32_t whist[4][RADIX];  // per-wave digit counts of the current tile
+  __shared__ uint32_t running[RADIX];   // next global slot per digit for this block
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t* hb = hist + (long long)c * RADIX * SORT_BLOCKS;
+  for (int d = tid; d < RADIX; d += 256) running[d] = hb[d * SORT_BLOCKS + blockIdx.x];
+  const uint32_t* kin = keys_in + (long long)c * P;
+  const uint32_t* vin = vals_in + (long long)c * P;
+  uint32_t* kout = keys_out + (long long)c * P;
+  uint32_t* vout = vals_out + (long long)c * P;
+  long long t0, t1;
+  block_range(P, t0, t1);
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (long long t = t0; t < t1; ++t) {
+    for (int i = tid; i < 4 * RADIX; i += 256) (&whist[0][0])[i] = 0;
+    __syncthreads();
+    const long long base = t * TILE + wave * (TILE / 4);
+    uint32_t key[16], val[16], rank[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long i = base + r * 64 + lane;
+      const bool live = i < P;
+      key[r] = live ? kin[i] : 0xFFFFFFFFu;
+      val[r] = live ? vin[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long i = base + r * 64 + lane;
+      const bool live = i < P;
+      const uint32_t d = (key[r] >> shift) & (RADIX - 1);
+      unsigned long long peers = __ballot(live);
+#pragma unroll
+      for (int b = 0; b < RBITS; ++b) {
+        const unsigned long long bal = __ballot((d >> b) & 1);
+        peers &= ((d >> b) & 1) ? bal : ~bal;
+      }
+      uint32_t old = 0;
+      const int leader = __ffsll((long long)peers) - 1;
+      if (live && lane == leader) {
+        old = whist[wave][d];
+        whist[wave][d] = old + __popcll(peers);
+      }
+      old = __shfl(old, leader < 0 ? 0 : leader, 64);
+      rank[r] = old + __popcll(peers & lt_mask);
+    }
+    __syncthreads();
+    // digit base of each wave inside the tile + advance the running global offsets
+    for (int d = tid; d < RADIX; d += 256) {
+      const uint32_t c0 = whist[0][d], c1 = whist[1][d], c2 = whist[2][d], c3 = whist[3][d];
+      const uint32_t g = running[d];
+      whist[0][d] = g;
+      whist[1][d] = g + c0;
+      whist[2][d] = g + c0 + c1;
+      whist[3][d] = g + c0 + c1 + c2;
+      running[d] = g + c0 + c1 + c2 + c3;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long i = base + r * 64 + lane;
+      if (i < P) {
+        const uint32_t d = (key[r] >> shift) & (RADIX - 1);
+        const uint32_t dst = whist[wave][d] + rank[r];
+        kout[dst] = key[r];
+        vout[dst] = val[r];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- Jaccard gradient over the sorted order -------------------------------------------------
+__global__ __launch_bounds__(256) void lv_fgsum_kernel(const uint32_t* __restrict__ vals, long long P, const uint32_t* __restrict__ counts,
+                                                       uint32_t* __restrict__ fgsum, long long ntiles) {
+  const int c = blockIdx.y;
+  if (counts[c] == 0) return;
+  const uint32_t* v = vals + (long long)c * P;
+  const long long e0 = (long long)blockIdx.x * TILE, e1 = min(e0 + TILE, P);
+  uint32_t n = 0;
+  for (long long i = e0 + threadIdx.x; i < e1; i += 256) n += v[i] >> 31;
+  n = (uint32_t)wave_sum((float)n);  // <= 4096, exact in fp32
+  __shared__ uint32_t sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) fgsum[(long long)c * ntiles + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(1024) void lv_fgscan_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ fgsum, long long ntiles) {
+  const int c = blockIdx.x;
+  if (counts[c] == 0) return;
+  uint32_t* row = fgsum + (long long)c * ntiles;
+  __shared__ uint32_t sh[1024];
+  uint32_t carry = 0;
+  for (long long b0 = 0; b0 < ntiles; b0 += 1024) {
+    const long long i = b0 + threadIdx.x;
+    const uint32_t v = i < ntiles ? row[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const uint32_t a = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += a;
+      __syncthreads();
+    }
+    if (i < ntiles) row[i] = carry + sh[threadIdx.x] - v;  // exclusive
+    carry += sh[1023];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void lv_grad_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, long long P,
+                                                      const uint32_t* __restrict__ counts, const uint32_t* __restrict__ fgsum,
+                                                      long long ntiles, float* __restrict__ lpart, float* __restrict__ dprob) {
+  const int c = blockIdx.y;
+  if (counts[c] == 0) return;
+  const uint32_t* k = keys + (long long)c * P;
+  const uint32_t* v = vals + (long long)c * P;
+  float* dp = dprob ? dprob + (long long)c * P : nullptr;
+  const float G = (float)counts[c];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long e0 = (long long)blockIdx.x * TILE;
+  // thread owns 16 consecutive elements: e0 + tid*16 .. +15
+  uint32_t kk[16], vv[16];
+  uint32_t nfg = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const long long i = e0 + tid * 16 + j;
+    kk[j] = i < P ? k[i] : 0x3F800000u;
+    vv[j] = i < P ? v[i] : 0u;
+    nfg += vv[j] >> 31;
+  }
+  // exclusive scan of nfg over the block
+  uint32_t incl = nfg;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t a = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += a;
+  }
+  __shared__ uint32_t wsum[4];
+  __shared__ float lsum[4];
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t F = fgsum[(long long)c * ntiles + blockIdx.x] + incl - nfg;
+  for (int w = 0; w < wave; ++w) F += wsum[w];
+  float loss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const long long i = e0 + tid * 16 + j;
+    if (i < P) {
+      const uint32_t f = vv[j] >> 31;
+      // J_{i-1} from F (fg count before i), J_i after including i
+      const float Fb = (float)F;
+      const float jprev = (i == 0) ? 0.f : 1.f - (G - Fb) / (G + ((float)i - Fb));
+      F += f;
+      const float Fa = (float)F;
+      const float jcur = 1.f - (G - Fa) / (G + ((float)(i + 1) - Fa));
+      const float g = jcur - jprev;
+      const float err = __uint_as_float(0x3F800000u - kk[j]);
+      loss += err * g;
+      if (dp) dp[vv[j] & 0x7FFFFFFFu] = (err == 0.f) ? 0.f : (f ? -g : g);
+    }
+  }
+  loss = wave_sum(loss);
+  if (lane == 0) lsum[wave] = loss;
+  __syncthreads();
+  if (tid == 0) lpart[(long long)c * ntiles + blockIdx.x] = lsum[0] + lsum[1] + lsum[2] + lsum[3];
+}
+
+__global__ __launch_bounds__(256) void lv_finalize_kernel(const uint32_t* __restrict__ counts, const float* __restrict__ lpart, long long ntiles,
+                                                          int K, float weight, float* __restrict__ loss_out, int accumulate) {
+  __shared__ double sh[256];
+  double tot = 0;
+  for (int c = 0; c < K; ++c) {
+    if (counts[c] == 0) continue;
+    double s = 0;
+    for (long long i = threadIdx.x; i < ntiles; i += 256) s += lpart[(long long)c * ntiles + i];
+    tot += s;
+  }
+  sh[threadIdx.x] = tot;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t n = counts[MAXK];
+    const float l = n ? (float)(sh[0] / (double)n) * weight : 0.f;
+    loss_out[0] = accumulate ? loss_out[0] + l : l;
+  }
+}
+
+__global__ __launch_bounds__(PIX) void lv_backward_kernel(const float* __restrict__ logits, long long P, int K, const uint32_t* __restrict__ counts,
+                                                          const float* __restrict__ dprob, float weight, float* __restrict__ dlogits, int acc) {
+  extern __shared__ float sh[];
+  const int KS = K | 1;
+  const long long p0 = (long long)blockIdx.x * PIX;
+  const int np = (int)min((long long)PIX, P - p0);
+  stage_rows(logits, p0, np, K, KS, sh);
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < np) {
+    float* row = sh + t * KS;
+    float m = row[0];
+    for (int c = 1; c < K; ++c) m = fmaxf(m, row[c]);
+    float s = 0.f;
+    for (int c = 0; c < K; ++c) {
+      const float e = expf(row[c] - m);
+      row[c] = e;
+      s += e;
+    }
+    const uint32_t npres = counts[MAXK];
+    const float w = npres ? weight / (float)npres : 0.f;
+    const long long p = p0 + t;
+    float* grow = sh + PIX * KS + t * KS;  // second LDS image: d loss / d prob of this pixel
+    float dot = 0.f;
+    for (int c = 0; c < K; ++c) {
+      const float pr = row[c] / s;
+      const float g = counts[c] ? dprob[(long long)c * P + p] * w : 0.f;
+      row[c] = pr;
+      grow[c] = g;
+      dot += g * pr;
+    }
+    for (int c = 0; c < K; ++c) row[c] = row[c] * (grow[c] - dot);
+  }
+  __syncthreads();
+  const int n = np * K;
+  float* dst = dlogits + p0 * K;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int r = i / K, c = i - r * K;
+    const float v = sh[r * KS + c];
+    dst[i] = acc ? dst[i] + v : v;
+  }
+}
+
+// ---- cross entropy ----------------------------------------------------------------------------
+__global__ __launch_bounds__(PIX) void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, long long P, int K,
+                                                     long long ignore, float* __restrict__ part) {
+  extern __shared__ float sh[];
+  const int KS = K | 1;
+  const long long p0 = (long long)blockIdx.x * PIX;
+  const int np = (int)min((long long)PIX, P - p0);
+  stage_rows(logits, p0, np, K, KS, sh);
+  __syncthreads();
+  const int t = threadIdx.x;
+  float l = 0.f, cnt = 0.f;
+  if (t < np) {
+    const int64_t lab = labels[p0 + t];
+    if (lab != ignore && lab >= 0 && lab < K) {
+      const float* row = sh + t * KS;
+      float m = row[0];
+      for (int c = 1; c < K; ++c) m = fmaxf(m, row[c]);
+      float s = 0.f;
+      for (int c = 0; c < K; ++c) s += expf(row[c] - m);
+      l = logf(s) + m - row[(int)lab];
+      cnt = 1.f;
+    }
+  }
+  l = wave_sum(l);
+  cnt = wave_sum(cnt);
+  __shared__ float r[8];
+  if ((t & 63) == 0) { r[t >> 6] = l; r[4 + (t >> 6)] = cnt; }
+  __syncthreads();
+  if (t == 0) {
+    part[2 * blockIdx.x] = r[0] + r[1] + r[2] + r[3];
+    part[2 * blockIdx.x + 1] = r[4] + r[5] + r[6] + r[7];
+  }
+}
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ part, long long nb, float weight, float* __restrict__ loss_out,
+                                                          float* __restrict__ inv_count) {
+  __shared__ double s1[256], s2[256];
+  double a = 0, b = 0;
+  for (long long i = threadIdx.x; i < nb; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
+  s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss_out[0] = (float)(s1[0] / s2[0]) * weight;  // 0/0 -> nan, as torch
+    inv_count[0] = s2[0] > 0 ? (float)(1.0 / s2[0]) : 0.f;
+  }
+}
+__global__ __launch_bounds__(PIX) void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, long long P, int K,
+                                                     long long ignore, float weight, const float* __restrict__ inv_count,
+                                                     float* __restrict__ dlogits) {
+  extern __shared__ float sh[];
+  const int KS = K | 1;
+  const long long p0 = (long long)blockIdx.x * PIX;
+  const int np = (int)min((long long)PIX, P - p0);
+  stage_rows(logits, p0, np, K, KS, sh);
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < np) {
+    float* row = sh + t * KS;
+    const int64_t lab = labels[p0 + t];
+    if (lab != ignore && lab >= 0 && lab < K) {
+      float m = row[0];
+      for (int c = 1; c < K; ++c) m = fmaxf(m, row[c]);
+      float s = 0.f;
+      for (int c = 0; c < K; ++c) { const float e = expf(row[c] - m); row[c] = e; s += e; }
+      const float w = weight * inv_count[0];
+      for (int c = 0; c < K; ++c) row[c] = (row[c] / s - (c == (int)lab ? 1.f : 0.f)) * w;
+    } else {
+      for (int c = 0; c < K; ++c) row[c] = 0.f;
+    }
+  }
+  __syncthreads();
+  const int n = np * K;
+  float* dst = dlogits + p0 * K;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int r = i / K, c = i - r * K;
+    dst[i] = sh[r * KS + c];
+  }
+}
+
+// ---- confusion matrix ---------------------------------------------------------------------------
+__global__ __launch_bounds__(PIX) void confusion_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, long long P, int K,
+                                                        int32_t* __restrict__ cm) {
+  extern __shared__ float sh[];
+  const int KS = K | 1;
+  int* hist = (int*)(sh + PIX * KS);
+  for (int i = threadIdx.x; i < K * K; i += blockDim.x) hist[i] = 0;
+  const long long p0 = (long long)blockIdx.x * PIX;
+  const int np = (int)min((long long)PIX, P - p0);
+  stage_rows(logits, p0, np, K, KS, sh);
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < np) {
+    const float* row = sh + t * KS;
+    int best = 0;
+    float bv = row[0];
+    for (int c = 1; c < K; ++c)
+      if (row[c] > bv) { bv = row[c]; best = c; }
+    const int64_t lab = labels[p0 + t];
+    if (lab >= 0 && lab < K) atomicAdd(&hist[best * K + (int)lab], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * K; i += blockDim.x)
+    if (hist[i]) atomicAdd(&cm[i], hist[i]);
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n4,
+                            long long n, float lr, float b1, float b2, float eps, float bc1, float bc2s, float gscale) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4;
+    if (e + 3 < n) {
+      f32x4 gg = *(const f32x4*)(g + e) * gscale;
+      f32x4 mm = *(f32x4*)(m + e) * b1 + gg * (1.f - b1);
+      f32x4 vv = *(f32x4*)(v + e) * b2 + gg * gg * (1.f - b2);
+      f32x4 pp = *(f32x4*)(p + e);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pp[k] -= (lr / bc1) * (mm[k] / (sqrtf(vv[k]) / bc2s + eps));
+      *(f32x4*)(m + e) = mm; *(f32x4*)(v + e) = vv; *(f32x4*)(p + e) = pp;
+    } else {
+      for (long long j = e; j < n; ++j) {
+        const float gg = g[j] * gscale;
+        const float mm = m[j] * b1 + gg * (1.f - b1);
+        const float vv = v[j] * b2 + gg * gg * (1.f - b2);
+        m[j] = mm; v[j] = vv;
+        p[j] -= (lr / bc1) * (mm / (sqrtf(vv) / bc2s + eps));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t catseg_lovasz_workspace(long long P, int K) { return lv_layout(P, K, nullptr, nullptr); }
+
+extern "C" int catseg_lovasz_softmax(const float* logits, const int64_t* labels, long long P, int K, float weight,
+                                     float* loss_out, float* dlogits, int accumulate_dlogits, void* workspace,
+                                     size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(P > 0 && P < (1ll << 31) && K > 0 && K <= MAXK, "lovasz: need 0 < P < 2^31 and K <= %d", MAXK);
+  const size_t need = lv_layout(P, K, nullptr, nullptr);
+  if (workspace_bytes < need || !workspace) {
+    catseg_set_error("lovasz: workspace %zu < %zu", workspace_bytes, need);
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  LvWs w;
+  lv_layout(P, K, (char*)workspace, &w);
+  const long long ntiles = (P + TILE - 1) / TILE;
+  const int nb = (int)((P + PIX - 1) / PIX);
+  const size_t shb = (size_t)PIX * (K | 1) * 4;
+  if (hipMemsetAsync(w.counts, 0, (MAXK + 4) * 4, st) != hipSuccess) { catseg_set_error("lovasz: memset failed"); return CATSEG_EHIP; }
+  hipLaunchKernelGGL(label_hist_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, st, labels, P, K, w.counts);
+  hipLaunchKernelGGL(present_kernel, dim3(1), dim3(64), 0, st, K, w.counts);
+  hipLaunchKernelGGL(lv_prep_kernel, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, (const uint32_t*)w.counts, w.keys[0], w.vals[0]);
+  int cur = 0;
+  for (int pass = 0; pass < 3; ++pass) {
+    const int shift = pass * RBITS;
+    hipLaunchKernelGGL(radix_upsweep_kernel, dim3(SORT_BLOCKS, K), dim3(256), 0, st, (const uint32_t*)w.keys[cur], P, shift, (const uint32_t*)w.counts, w.hist);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(K), dim3(RADIX), 0, st, (const uint32_t*)w.counts, w.hist);
+    hipLaunchKernelGGL(radix_downsweep_kernel, dim3(SORT_BLOCKS, K), dim3(256), 0, st, (const uint32_t*)w.keys[cur], (const uint32_t*)w.vals[cur],
+                       w.keys[cur ^ 1], w.vals[cur ^ 1], P, shift, (const uint32_t*)w.counts, (const uint32_t*)w.hist);
+    cur ^= 1;
+  }
+  hipLaunchKernelGGL(lv_fgsum_kernel, dim3((unsigned)ntiles, K), dim3(256), 0, st, (const uint32_t*)w.vals[cur], P, (const uint32_t*)w.counts, w.fgsum, ntiles);
+  hipLaunchKernelGGL(lv_fgscan_kernel, dim3(K), dim3(1024), 0, st, (const uint32_t*)w.counts, w.fgsum, ntiles);
+  hipLaunchKernelGGL(lv_grad_kernel, dim3((unsigned)ntiles, K), dim3(256), 0, st, (const uint32_t*)w.keys[cur], (const uint32_t*)w.vals[cur], P,
+                     (const uint32_t*)w.counts, (const uint32_t*)w.fgsum, ntiles, w.lpart, dlogits ? w.dprob : nullptr);
+  hipLaunchKernelGGL(lv_finalize_kernel, dim3(1), dim3(256), 0, st, (const uint32_t*)w.counts, (const float*)w.lpart, ntiles, K, weight, loss_out, 0);
+  if (dlogits)
+    hipLaunchKernelGGL(lv_backward_kernel, dim3(nb), dim3(PIX), 2 * shb, st, logits, P, K, (const uint32_t*)w.counts, (const float*)w.dprob, weight, dlogits,
+                       accumulate_dlogits);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+extern "C" size_t catseg_ce_workspace(long long P) { return cs_align_up((size_t)((P + PIX - 1) / PIX) * 8 + 256, 256); }
+
+extern "C" int catseg_cross_entropy(const float* logits, const int64_t* labels, long long P, int K, long long ignore_index,
+                                    float weight, float* loss_out, float* dlogits, void* workspace,
+                                    size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(P > 0 && K > 0 && K <= MAXK, "ce: bad args");
+  if (workspace_bytes < catseg_ce_workspace(P) || !workspace) {
+    catseg_set_error("ce: workspace too small");
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)((P + PIX - 1) / PIX);
+  const size_t shb = (size_t)PIX * (K | 1) * 4;
+  float* inv = (float*)workspace;
+  float* part = inv + 64;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, ignore_index, part);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, (long long)nb, weight, loss_out, inv);
+  if (dlogits) hipLaunchKernelGGL(ce_bwd_kernel, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, ignore_index, weight, (const float*)inv, dlogits);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+extern "C" int catseg_confusion_matrix(const float* logits, const int64_t* labels, long long P, int K, int32_t* cm,
+                                       catseg_stream_t stream) {
+  CS_REQUIRE(P > 0 && K > 0 && K <= MAXK, "confusion: bad args");
+  const int nb = (int)((P + PIX - 1) / PIX);
+  const size_t shb = (size_t)PIX * (K | 1) * 4 + (size_t)K * K * 4;
+  hipLaunchKernelGGL(confusion_kernel, dim3(nb), dim3(PIX), shb, (hipStream_t)stream, logits, labels, P, K, cm);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+extern "C" int catseg_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                                float beta2, float eps, int step, float grad_scale, catseg_stream_t stream) {
+  CS_REQUIRE(n > 0 && step >= 1 && cs_aligned16(p) && cs_aligned16(g) && cs_aligned16(m) && cs_aligned16(v), "adam: bad args");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const long long n4 = (n + 3) / 4;
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, lr, beta1, beta2, eps, (float)bc1,
+                     (float)sqrt(bc2), grad_scale);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}

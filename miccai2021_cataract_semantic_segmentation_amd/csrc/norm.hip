@@ -1,0 +1,290 @@
+// BatchNorm2d (training statistics, eval affine) fused with ReLU and the residual add,
+// forward and backward, on NHWC fp32 activations.  HBM-bound: every pass streams the
+// activation once with 16-byte accesses; per-channel reductions are two-level
+// (per-block shifted sums -> fp64 Chan merge), deterministic (no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxRowBlocks = 1024;
+
+struct RowSplit {
+  int tpr;   // threads per row (float4 channel groups handled side by side)
+  int rpp;   // rows per pass of a 256-thread block
+  int gy;    // channel blocks
+  int nrb;   // row blocks
+  long long rpb;  // rows per block
+};
+
+RowSplit plan_rows(long long rows, int C) {
+  RowSplit s;
+  const int cpt = (C + 3) / 4;
+  s.tpr = cpt < 64 ? cpt : 64;
+  s.rpp = 256 / s.tpr;
+  s.gy = (cpt + s.tpr - 1) / s.tpr;
+  long long rpb = (rows + kMaxRowBlocks - 1) / kMaxRowBlocks;
+  if (rpb < 4 * s.rpp) rpb = 4 * s.rpp;
+  rpb = (rpb + s.rpp - 1) / s.rpp * s.rpp;
+  s.rpb = rpb;
+  s.nrb = (int)((rows + rpb - 1) / rpb);
+  return s;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+
+// per (row block, channel): shift K, s1 = sum(x-K), s2 = sum((x-K)^2)
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ y, int ld, long long rows, int C,
+                                                         RowSplit s, float* __restrict__ part) {
+  const int t = threadIdx.x;
+  const int cg = blockIdx.y * s.tpr + t % s.tpr;
+  const int rl = t / s.tpr;
+  const int c = cg * 4;
+  const long long r0 = (long long)blockIdx.x * s.rpb;
+  const long long r1 = min(r0 + s.rpb, rows);
+  const bool act = (c < C) && (rl < s.rpp);
+  f32x4 K = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  if (act) {
+    K = ld4(y + r0 * ld + c);
+    for (long long r = r0 + rl; r < r1; r += s.rpp) {
+      const f32x4 d = ld4(y + r * ld + c) - K;
+      s1 += d;
+      s2 += d * d;
+    }
+  }
+  __shared__ f32x4 sh1[256], sh2[256];
+  sh1[t] = s1;
+  sh2[t] = s2;
+  __syncthreads();
+  if (act && rl == 0) {
+    for (int k = 1; k < s.rpp; ++k) {
+      s1 += sh1[t + k * s.tpr];
+      s2 += sh2[t + k * s.tpr];
+    }
+    float* o = part + ((long long)blockIdx.x * 3) * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (c + i < C) {
+        o[c + i] = K[i];
+        o[C + c + i] = s1[i];
+        o[2 * C + c + i] = s2[i];
+      }
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nrb, long long rpb, long long rows, int C,
+                                   const float* __restrict__ gamma, float eps, float momentum, float* running_mean,
+                                   float* running_var, float* __restrict__ stats, float* __restrict__ scale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double n = 0, mean = 0, m2 = 0;
+  for (int b = 0; b < nrb; ++b) {
+    const long long r0 = (long long)b * rpb;
+    const double nb = (double)(min(r0 + rpb, rows) - r0);
+    const float* o = part + ((long long)b * 3) * C;
+    const double K = o[c], s1 = o[C + c], s2 = o[2 * C + c];
+    const double mb = K + s1 / nb;
+    const double m2b = s2 - s1 * s1 / nb;
+    const double tot = n + nb;
+    const double delta = mb - mean;
+    mean += delta * nb / tot;
+    m2 += m2b + delta * delta * n * nb / tot;
+    n = tot;
+  }
+  const float var = (float)(m2 / n);
+  const float invstd = 1.0f / sqrtf(var + eps);
+  stats[c] = (float)mean;
+  stats[C + c] = invstd;
+  scale[c] = gamma[c] * invstd;
+  if (running_mean) {
+    const float unb = (float)(m2 / (n > 1 ? n - 1 : 1));
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+  }
+}
+
+__global__ void bn_eval_kernel(int C, const float* gamma, const float* rv, float eps, float* scale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) scale[c] = gamma[c] / sqrtf(rv[c] + eps);
+}
+
+// z = act((y - mean) * scale + beta (+ res))
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ mean,
+                                                       const float* __restrict__ scale, const float* __restrict__ beta,
+                                                       const float* __restrict__ res, int ldr, float* __restrict__ z,
+                                                       int ldz, long long rows, int C, int relu) {
+  const int cpt = C >> 2;
+  const long long total = rows * cpt;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cpt;
+    const int c = (int)(i - r * cpt) * 4;
+    f32x4 v = (ld4(y + r * ldy + c) - ld4(mean + c)) * ld4(scale + c) + ld4(beta + c);
+    if (res) v += ld4(res + r * ldr + c);
+    if (relu) {
+      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    *(f32x4*)(z + r * ldz + c) = v;
+  }
+}
+
+// backward partials: sg = sum g, sgx = sum g * xhat
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z,
+                                                             int ldz, const float* __restrict__ y, int ldy,
+                                                             const float* __restrict__ stats, long long rows, int C, int relu,
+                                                             RowSplit s, float* __restrict__ part) {
+  const int t = threadIdx.x;
+  const int cg = blockIdx.y * s.tpr + t % s.tpr;
+  const int rl = t / s.tpr;
+  const int c = cg * 4;
+  const long long r0 = (long long)blockIdx.x * s.rpb;
+  const long long r1 = min(r0 + s.rpb, rows);
+  const bool act = (c < C) && (rl < s.rpp);
+  f32x4 sg = {0, 0, 0, 0}, sgx = {0, 0, 0, 0};
+  if (act) {
+    const f32x4 mean = ld4(stats + c), inv = ld4(stats + C + c);
+    for (long long r = r0 + rl; r < r1; r += s.rpp) {
+      f32x4 g = ld4(dz + r * lddz + c);
+      if (relu) {
+        const f32x4 zz = ld4(z + r * ldz + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = zz[i] > 0.f ? g[i] : 0.f;
+      }
+      const f32x4 xh = (ld4(y + r * ldy + c) - mean) * inv;
+      sg += g;
+      sgx += g * xh;
+    }
+  }
+  __shared__ f32x4 sh1[256], sh2[256];
+  sh1[t] = sg;
+  sh2[t] = sgx;
+  __syncthreads();
+  if (act && rl == 0) {
+    for (int k = 1; k < s.rpp; ++k) {
+      sg += sh1[t + k * s.tpr];
+      sgx += sh2[t + k * s.tpr];
+    }
+    float* o = part + ((long long)blockIdx.x * 2) * C;
+    *(f32x4*)(o + c) = sg;
+    *(f32x4*)(o + C + c) = sgx;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nrb, long long rows, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sg = 0, sgx = 0;
+  for (int b = 0; b < nrb; ++b) {
+    const float* o = part + ((long long)b * 2) * C;
+    sg += o[c];
+    sgx += o[C + c];
+  }
+  if (dbeta) dbeta[c] = (float)sg;
+  if (dgamma) dgamma[c] = (float)sgx;
+  coef[c] = (float)(sg / (double)rows);
+  coef[C + c] = (float)(sgx / (double)rows);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z,
+                                                           int ldz, const float* __restrict__ y, int ldy,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ coef, long long rows, int C, int relu,
+                                                           float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres,
+                                                           int dres_acc) {
+  const int cpt = C >> 2;
+  const long long total = rows * cpt;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cpt;
+    const int c = (int)(i - r * cpt) * 4;
+    f32x4 g = ld4(dz + r * lddz + c);
+    if (relu) {
+      const f32x4 zz = ld4(z + r * ldz + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
+    }
+    const f32x4 inv = ld4(stats + C + c);
+    const f32x4 xh = (ld4(y + r * ldy + c) - ld4(stats + c)) * inv;
+    const f32x4 o = ld4(gamma + c) * inv * (g - ld4(coef + c) - xh * ld4(coef + C + c));
+    *(f32x4*)(dy + r * lddy + c) = o;
+    if (dres) {
+      f32x4* d = (f32x4*)(dres + r * lddres + c);
+      *d = dres_acc ? (*d + g) : g;
+    }
+  }
+}
+
+int grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" size_t catseg_bn_workspace(long long rows, int C) {
+  (void)rows;
+  return cs_align_up((size_t)(kMaxRowBlocks * 3 + 2) * (size_t)((C + 3) & ~3) * 4, 256);
+}
+
+extern "C" int catseg_bn_train_stats(const float* y, long long rows, int C, int ldy, const float* gamma, float eps,
+                                     float momentum, float* running_mean, float* running_var, float* stats_out,
+                                     float* scale, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && ldy % 4 == 0 && ldy >= C, "bn stats: C and ld must be multiples of 4");
+  CS_REQUIRE(cs_aligned16(y) && cs_aligned16(stats_out) && cs_aligned16(scale), "bn stats: alignment");
+  if (workspace_bytes < catseg_bn_workspace(rows, C) || !workspace) {
+    catseg_set_error("bn stats: workspace too small");
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const RowSplit s = plan_rows(rows, C);
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, y, ldy, rows, C, s, part);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)part, s.nrb, s.rpb, rows, C,
+                     gamma, eps, momentum, running_mean, running_var, stats_out, scale);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+extern "C" int catseg_bn_eval_scale(int C, const float* gamma, const float* running_var, float eps, float* scale,
+                                    catseg_stream_t stream) {
+  CS_REQUIRE(C > 0, "bn eval: C");
+  hipLaunchKernelGGL(bn_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, running_var, eps, scale);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+extern "C" int catseg_bn_apply(const float* y, int ldy, const float* mean, const float* scale, const float* beta,
+                               const float* residual, int ldr, float* z, int ldz, long long rows, int C, int relu,
+                               catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && ldy % 4 == 0 && ldz % 4 == 0 && (residual == nullptr || ldr % 4 == 0),
+             "bn apply: C and ld must be multiples of 4");
+  CS_REQUIRE(cs_aligned16(y) && cs_aligned16(z) && cs_aligned16(mean) && cs_aligned16(scale) && cs_aligned16(beta) &&
+                 cs_aligned16(residual), "bn apply: alignment");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, mean, scale,
+                     beta, residual, ldr, z, ldz, rows, C, relu);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+extern "C" int catseg_bn_backward(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                                  const float* stats, const float* gamma, long long rows, int C, int relu,
+                                  float* dy, int lddy, float* dgamma, float* dbeta, float* dres, int lddres,
+                                  int dres_accumulate, void* workspace, size_t workspace_bytes,
+                                  catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0, "bn bwd: C and ld must be multiples of 4");
+  CS_REQUIRE(!relu || (z != nullptr && ldz % 4 == 0), "bn bwd: relu needs z");
+  CS_REQUIRE(cs_aligned16(dz) && cs_aligned16(y) && cs_aligned16(dy) && cs_aligned16(stats) && cs_aligned16(gamma) &&
+                 cs_aligned16(z) && cs_aligned16(dres), "bn bwd: alignment");
+  if (workspace_bytes < catseg_bn_workspace(rows, C) || !workspace) {
+    catseg_set_error("bn bwd: workspace too small");
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const RowSplit s = plan_rows(rows, C);
+  float* part = (float*)workspace;
+  float* coef = part + (size_t)kMaxRowBlocks * 3 * ((C + 3) & ~3);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, rows, C, relu, s, part);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma,
+                     (const float*)coef, rows, C, relu, dy, lddy, dres, lddres, dres_accumulate);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}

@@ -1,0 +1,458 @@
+// HBM-bound companions of the convolutions: layout transforms, max-pool, bilinear resize,
+// global average pool and the two softmaxes of the OCR head.  All NHWC fp32, all
+// deterministic (backward passes are written as gathers, never atomics).
+#include "common.h"
+
+namespace {
+
+int grid_for(long long total, int per_block = 256) {
+  long long b = (total + per_block - 1) / per_block;
+  return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+// ------------------------------------------------------------------ layout
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int B, long long HW) {
+  const long long total = (long long)B * HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / HW, p = i - b * HW;
+    const float* s = x + b * 3 * HW + p;
+    f32x4 v = {s[0], s[HW], s[2 * HW], 0.f};
+    *(f32x4*)(y + i * 4) = v;
+  }
+}
+
+// w [O][7][7][3] (OHWI) -> packed [O][7][8][4], zero padded
+__global__ void stem_pack_kernel(const float* __restrict__ w, float* __restrict__ pk, int O) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= O * 7 * 8 * 4) return;
+  const int c = i & 3, kx = (i >> 2) & 7, ky = (i >> 5) % 7, o = i / (7 * 32);
+  pk[i] = (c < 3 && kx < 7) ? w[((o * 7 + ky) * 7 + kx) * 3 + c] : 0.f;
+}
+__global__ void stem_unpack_kernel(const float* __restrict__ pk, float* __restrict__ dw, int O) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= O * 147) return;
+  const int c = i % 3, kx = (i / 3) % 7, ky = (i / 21) % 7, o = i / 147;
+  dw[i] = pk[((o * 7 + ky) * 8 + kx) * 4 + c];
+}
+
+__global__ void axpy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, long long rows, int C,
+                              float alpha, int acc) {
+  const int cpt = C >> 2;
+  const long long total = rows * cpt;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cpt;
+    const int c = (int)(i - r * cpt) * 4;
+    f32x4 v = *(const f32x4*)(src + r * lds + c) * alpha;
+    f32x4* d = (f32x4*)(dst + r * ldd + c);
+    *d = acc ? (*d + v) : v;
+  }
+}
+
+// ------------------------------------------------------------------ maxpool 3x3 / 2 / pad 1
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, uint8_t* __restrict__ idx,
+                                   int B, int H, int W, int C, int Ho, int Wo) {
+  const int cpt = C >> 2;
+  const long long total = (long long)B * Ho * Wo * cpt;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / cpt;
+    const int c = (int)(i - p * cpt) * 4;
+    const int ox = (int)(p % Wo);
+    const int oy = (int)((p / Wo) % Ho);
+    const int b = (int)(p / ((long long)Wo * Ho));
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+    bool first[4] = {true, true, true, true};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const f32x4 v = *(const f32x4*)(x + (((long long)b * H + iy) * W + ix) * ldx + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // ATen keeps the FIRST maximum in scan order (val > max, or NaN)
+          if (first[k] || v[k] > best[k] || v[k] != v[k]) {
+            best[k] = v[k];
+            bi[k] = ky * 3 + kx;
+            first[k] = false;
+          }
+        }
+      }
+    }
+    *(f32x4*)(y + p * ldy + c) = best;
+    *(uint32_t*)(idx + p * C + c) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+  }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, int lddy, const uint8_t* __restrict__ idx, float* __restrict__ dx,
+                                   int lddx, int B, int H, int W, int C, int Ho, int Wo) {
+  const int cpt = C >> 2;
+  const long long total = (long long)B * H * W * cpt;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / cpt;
+    const int c = (int)(i - p * cpt) * 4;
+    const int ix = (int)(p % W);
+    const int iy = (int)((p / W) % H);
+    const int b = (int)(p / ((long long)W * H));
+    f32x4 g = {0, 0, 0, 0};
+    // output windows covering (iy, ix): oy in {(iy+1)/2 (ky = iy+1-2oy)}, with ky in 0..2
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ty = iy + 1 - ky;
+      if (ty < 0 || (ty & 1)) continue;
+      const int oy = ty >> 1;
+      if (oy >= Ho) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int tx = ix + 1 - kx;
+        if (tx < 0 || (tx & 1)) continue;
+        const int ox = tx >> 1;
+        if (ox >= Wo) continue;
+        const long long q = ((long long)b * Ho + oy) * Wo + ox;
+        const uint32_t pk = *(const uint32_t*)(idx + q * C + c);
+        const f32x4 d = *(const f32x4*)(dy + q * lddy + c);
+        const uint32_t me = ky * 3 + kx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (((pk >> (8 * k)) & 0xff) == me) g[k] += d[k];
+      }
+    }
+    *(f32x4*)(dx + p * lddx + c) = g;
+  }
+}
+
+// ------------------------------------------------------------------ bilinear
+// ATen's area_pixel_compute_source_index in fp32
+__device__ __forceinline__ float src_index(float scale, int dst, bool align) {
+  if (align) return scale * dst;
+  const float s = scale * (dst + 0.5f) - 0.5f;
+  return s < 0.f ? 0.f : s;
+}
+__device__ __forceinline__ void lerp_setup(float scale, int dst, bool align, int in_size, int& i0, int& i1, float& l0, float& l1) {
+  const float s = src_index(scale, dst, align);
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = s - i0;
+  l0 = 1.f - l1;
+}
+__host__ __device__ inline float resize_scale(int in, int out, bool align) {
+  if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  return (float)in / (float)out;
+}
+
+__global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int B, int H, int W, int C,
+                                    int Ho, int Wo, int align, float sh, float sw, int acc) {
+  // one block per output row (b, oy); threads sweep (ox, c), which is contiguous when ldy == C
+  const int b = blockIdx.x / Ho, oy = blockIdx.x - b * Ho;
+  int y0, y1;
+  float ly0, ly1;
+  lerp_setup(sh, oy, align, H, y0, y1, ly0, ly1);
+  const float* r0 = x + ((long long)b * H + y0) * W * ldx;
+  const float* r1 = x + ((long long)b * H + y1) * W * ldx;
+  float* o = y + ((long long)b * Ho + oy) * Wo * ldy;
+  const int n = Wo * C;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int ox = i / C, c = i - ox * C;
+    int x0, x1;
+    float lx0, lx1;
+    lerp_setup(sw, ox, align, W, x0, x1, lx0, lx1);
+    const float v = ly0 * (lx0 * r0[x0 * ldx + c] + lx1 * r0[x1 * ldx + c]) + ly1 * (lx0 * r1[x0 * ldx + c] + lx1 * r1[x1 * ldx + c]);
+    float* d = o + (long long)ox * ldy + c;
+    *d = acc ? (*d + v) : v;
+  }
+}
+
+// backward pass 1: tmp[b, iy, ox, c] = sum_{oy} wy(oy -> iy) * dy[b, oy, ox, c]
+__global__ void bilinear_bwd_rows_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ tmp, int B, int H, int C, int Ho,
+                                         int Wo, int align, float sh) {
+  const int b = blockIdx.x / H, iy = blockIdx.x - b * H;
+  // candidate output rows: source index in (iy-1, iy+1)
+  int lo, hi;
+  if (sh > 0.f) {
+    lo = align ? (int)floorf((iy - 1) / sh) - 1 : (int)floorf((iy - 0.5f) / sh) - 2;
+    hi = align ? (int)ceilf((iy + 1) / sh) + 1 : (int)ceilf((iy + 1.5f) / sh) + 1;
+  } else {
+    lo = 0; hi = Ho - 1;
+  }
+  if (lo < 0) lo = 0;
+  if (hi > Ho - 1) hi = Ho - 1;
+  const int n = Wo * C;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int ox = i / C, c = i - ox * C;
+    float s = 0.f;
+    for (int oy = lo; oy <= hi; ++oy) {
+      int y0, y1;
+      float l0, l1;
+      lerp_setup(sh, oy, align, H, y0, y1, l0, l1);
+      float w = 0.f;
+      if (y0 == iy) w += l0;
+      if (y1 == iy) w += l1;
+      if (w != 0.f) s += w * dy[(((long long)b * Ho + oy) * Wo + ox) * lddy + c];
+    }
+    tmp[((long long)blockIdx.x * Wo) * C + i] = s;
+  }
+}
+// backward pass 2: dx[b, iy, ix, c] = sum_{ox} wx(ox -> ix) * tmp[b, iy, ox, c]
+__global__ void bilinear_bwd_cols_kernel(const float* __restrict__ tmp, float* __restrict__ dx, int lddx, int W, int C, int Wo, int align,
+                                         float sw, int zero_to, int acc) {
+  const long long row = blockIdx.x;  // (b, iy)
+  const float* t = tmp + row * Wo * C;
+  float* o = dx + row * W * lddx;
+  const int cw = zero_to > C ? zero_to : C;
+  const int n = W * cw;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int ix = i / cw, c = i - ix * cw;
+    float* d = o + (long long)ix * lddx + c;
+    if (c >= C) {
+      *d = 0.f;
+      continue;
+    }
+    int lo, hi;
+    if (sw > 0.f) {
+      lo = align ? (int)floorf((ix - 1) / sw) - 1 : (int)floorf((ix - 0.5f) / sw) - 2;
+      hi = align ? (int)ceilf((ix + 1) / sw) + 1 : (int)ceilf((ix + 1.5f) / sw) + 1;
+    } else {
+      lo = 0; hi = Wo - 1;
+    }
+    if (lo < 0) lo = 0;
+    if (hi > Wo - 1) hi = Wo - 1;
+    float s = 0.f;
+    for (int ox = lo; ox <= hi; ++ox) {
+      int x0, x1;
+      float l0, l1;
+      lerp_setup(sw, ox, align, W, x0, x1, l0, l1);
+      float w = 0.f;
+      if (x0 == ix) w += l0;
+      if (x1 == ix) w += l1;
+      if (w != 0.f) s += w * t[ox * C + c];
+    }
+    *d = acc ? (*d + s) : s;
+  }
+}
+
+// ------------------------------------------------------------------ global average pool
+__global__ void gap_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int HW, int C) {
+  // grid (C/64 ceil, B); block 256 = 64 channels x 4 row lanes
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, b = blockIdx.y;
+  float s = 0.f;
+  if (c < C)
+    for (int p = rl; p < HW; p += 4) s += x[((long long)b * HW + p) * ldx + c];
+  __shared__ float sh[256];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) y[(long long)b * C + c] = (sh[threadIdx.x] + sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192]) / (float)HW;
+}
+__global__ void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int lddx, int B, int HW, int C, int acc) {
+  const int cpt = C >> 2;
+  const long long total = (long long)B * HW * cpt;
+  const float inv = 1.f / (float)HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / cpt;
+    const int c = (int)(i - p * cpt) * 4;
+    const long long b = p / HW;
+    const f32x4 v = *(const f32x4*)(dy + b * C + c) * inv;
+    f32x4* d = (f32x4*)(dx + p * lddx + c);
+    *d = acc ? (*d + v) : v;
+  }
+}
+
+// ------------------------------------------------------------------ softmax over pixels (per batch, per class column)
+// block = 32 columns x 8 row lanes; grid = B.  N ~ 8160, ld = 32: the slab is L2 resident.
+__global__ __launch_bounds__(256) void softmax_spatial_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int K, int ld) {
+  const int b = blockIdx.x;
+  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const float* xb = x + (long long)b * N * ld;
+  float* yb = y + (long long)b * N * ld;
+  __shared__ float sh[8][33];
+  for (int c0 = 0; c0 < ld; c0 += 32) {
+    const int c = c0 + col;
+    const bool live = c < K;
+    float m = -INFINITY;
+    if (live)
+      for (int n = rl; n < N; n += 8) m = fmaxf(m, xb[(long long)n * ld + c]);
+    sh[rl][col] = m;
+    __syncthreads();
+    m = sh[0][col];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) m = fmaxf(m, sh[k][col]);
+    __syncthreads();
+    float s = 0.f;
+    if (live)
+      for (int n = rl; n < N; n += 8) s += expf(xb[(long long)n * ld + c] - m);
+    sh[rl][col] = s;
+    __syncthreads();
+    s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += sh[k][col];
+    __syncthreads();
+    const float inv = 1.f / s;
+    if (c < ld)
+      for (int n = rl; n < N; n += 8) yb[(long long)n * ld + c] = live ? expf(xb[(long long)n * ld + c] - m) * inv : 0.f;
+  }
+}
+// dx = y * (dy - sum_n dy*y)
+__global__ __launch_bounds__(256) void softmax_spatial_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                                  float* __restrict__ dx, int N, int K, int ld, int acc) {
+  const int b = blockIdx.x;
+  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const float* yb = y + (long long)b * N * ld;
+  const float* gb = dy + (long long)b * N * ld;
+  float* ob = dx + (long long)b * N * ld;
+  __shared__ float sh[8][33];
+  for (int c0 = 0; c0 < ld; c0 += 32) {
+    const int c = c0 + col;
+    const bool live = c < K;
+    float s = 0.f;
+    if (live)
+      for (int n = rl; n < N; n += 8) s += gb[(long long)n * ld + c] * yb[(long long)n * ld + c];
+    sh[rl][col] = s;
+    __syncthreads();
+    s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += sh[k][col];
+    __syncthreads();
+    if (c < ld)
+      for (int n = rl; n < N; n += 8) {
+        const long long o = (long long)n * ld + c;
+        const float v = live ? yb[o] * (gb[o] - s) : 0.f;
+        ob[o] = (acc && live) ? ob[o] + v : v;
+      }
+  }
+}
+
+// ------------------------------------------------------------------ softmax over <= 64 columns per row (one wave = one row)
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int K,
+                                                               int ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+  const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long r = wave0; r < rows; r += nw) {
+    const float v = lane < K ? scale * x[r * ld + lane] : -INFINITY;
+    const float m = wave_max(v);
+    const float e = lane < K ? expf(v - m) : 0.f;
+    const float s = wave_sum(e);
+    if (lane < ld) y[r * ld + lane] = e / s;
+  }
+}
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                               float* __restrict__ dx, long long rows, int K, int ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+  const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long r = wave0; r < rows; r += nw) {
+    const float yy = lane < K ? y[r * ld + lane] : 0.f;
+    const float g = lane < K ? dy[r * ld + lane] : 0.f;
+    const float s = wave_sum(yy * g);
+    if (lane < ld) dx[r * ld + lane] = scale * yy * (g - s);
+  }
+}
+
+}  // namespace
+
+extern "C" int catseg_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, catseg_stream_t stream) {
+  CS_REQUIRE(B > 0 && H > 0 && W > 0 && cs_aligned16(y), "nchw3_to_nhwc4: bad args");
+  const long long HW = (long long)H * W;
+  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(grid_for(B * HW)), dim3(256), 0, (hipStream_t)stream, x, y, B, HW);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_stem_pack_weight(const float* w, float* packed, int O, catseg_stream_t stream) {
+  hipLaunchKernelGGL(stem_pack_kernel, dim3((O * 224 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, packed, O);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_stem_unpack_grad(const float* packed_grad, float* dw, int O, catseg_stream_t stream) {
+  hipLaunchKernelGGL(stem_unpack_kernel, dim3((O * 147 + 255) / 256), dim3(256), 0, (hipStream_t)stream, packed_grad, dw, O);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_axpy2d(const float* src, int lds, float* dst, int ldd, long long rows, int C, float alpha,
+                             int accumulate, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && cs_aligned16(src) && cs_aligned16(dst), "axpy2d: C/ld multiples of 4, 16-B aligned");
+  hipLaunchKernelGGL(axpy2d_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, rows, C, alpha, accumulate);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_maxpool3x3s2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int B, int H, int W,
+                                       int C, int Ho, int Wo, catseg_stream_t stream) {
+  CS_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && Ho == (H + 1) / 2 && Wo == (W + 1) / 2 && cs_aligned16(x) && cs_aligned16(y) && cs_aligned16(idx), "maxpool fwd: bad args");
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long long)B * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, idx, B, H, W, C, Ho, Wo);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_maxpool3x3s2_bwd(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx, int B,
+                                       int H, int W, int C, int Ho, int Wo, catseg_stream_t stream) {
+  CS_REQUIRE(C % 4 == 0 && lddx % 4 == 0 && lddy % 4 == 0 && cs_aligned16(dx) && cs_aligned16(dy), "maxpool bwd: bad args");
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, lddy, idx, dx, lddx, B, H, W, C, Ho, Wo);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C, int Ho,
+                                   int Wo, int align_corners, int accumulate, catseg_stream_t stream) {
+  CS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && ldx >= C && ldy >= C, "bilinear fwd: bad args");
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(B * Ho), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, H, W, C, Ho, Wo, align_corners,
+                     resize_scale(H, Ho, align_corners), resize_scale(W, Wo, align_corners), accumulate);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int B, int H, int W, int C,
+                                   int Ho, int Wo, int align_corners, int zero_to, int accumulate, void* workspace,
+                                   size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && lddx >= C && lddy >= C && zero_to <= lddx, "bilinear bwd: bad args");
+  const size_t need = (size_t)B * H * Wo * C * 4;
+  if (workspace_bytes < need || !workspace) {
+    catseg_set_error("bilinear bwd: workspace %zu < %zu", workspace_bytes, need);
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bilinear_bwd_rows_kernel, dim3(B * H), dim3(256), 0, st, dy, lddy, (float*)workspace, B, H, C, Ho, Wo, align_corners,
+                     resize_scale(H, Ho, align_corners));
+  hipLaunchKernelGGL(bilinear_bwd_cols_kernel, dim3(B * H), dim3(256), 0, st, (const float*)workspace, dx, lddx, W, C, Wo, align_corners,
+                     resize_scale(W, Wo, align_corners), zero_to, accumulate);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_global_avgpool_fwd(const float* x, int ldx, float* y, int B, int HW, int C, catseg_stream_t stream) {
+  CS_REQUIRE(B > 0 && HW > 0 && C > 0, "gap fwd: bad args");
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, HW, C);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_global_avgpool_bwd(const float* dy, float* dx, int lddx, int B, int HW, int C, int accumulate,
+                                         catseg_stream_t stream) {
+  CS_REQUIRE(C % 4 == 0 && lddx % 4 == 0 && cs_aligned16(dy) && cs_aligned16(dx), "gap bwd: bad args");
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for((long long)B * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, dx, lddx, B, HW, C, accumulate);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_softmax_spatial_fwd(const float* x, float* y, int B, int N, int K, int ld, catseg_stream_t stream) {
+  CS_REQUIRE(B > 0 && N > 0 && K > 0 && ld >= K, "softmax spatial: bad args");
+  hipLaunchKernelGGL(softmax_spatial_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, y, N, K, ld);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_softmax_spatial_bwd(const float* y, const float* dy, float* dx, int B, int N, int K, int ld,
+                                          int accumulate, catseg_stream_t stream) {
+  CS_REQUIRE(B > 0 && N > 0 && K > 0 && ld >= K, "softmax spatial bwd: bad args");
+  hipLaunchKernelGGL(softmax_spatial_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, y, dy, dx, N, K, ld, accumulate);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_softmax_rows_fwd(const float* x, float* y, long long rows, int K, int ld, float scale,
+                                       catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && K > 0 && K <= 64 && ld <= 64 && ld >= K, "softmax rows: K, ld <= 64");
+  hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, K, ld, scale);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_softmax_rows_bwd(const float* y, const float* dy, float* dx, long long rows, int K, int ld,
+                                       float scale, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && K > 0 && K <= 64 && ld <= 64 && ld >= K, "softmax rows bwd: K, ld <= 64");
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, rows, K, ld, scale);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}

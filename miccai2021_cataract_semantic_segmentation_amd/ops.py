@@ -1,0 +1,273 @@
+"""Tensor-level wrappers over the C ABI (include/catseg.h).
+
+Activations are NHWC fp32 torch tensors of shape [B, H, W, C] whose last dim is
+contiguous and whose pixel stride ``ld = t.stride(2)`` may exceed C (a view into
+a wider concat buffer).  Conv weights are [O, I, kh, kw] tensors in
+channels_last memory format (physical OHWI).  Nothing here touches autograd.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, lib, ptr, stream
+
+_ws = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device (all launches are ordered on one stream)."""
+    key = (device.type, device.index)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def release_workspaces():
+    _ws.clear()
+
+
+def new_act(B, H, W, C, device, ld=None, zero=False):
+    """NHWC activation; ld (pixel stride) defaults to C rounded up to 4."""
+    ld = ld or ((C + 3) // 4 * 4)
+    buf = (torch.zeros if zero else torch.empty)((B, H, W, ld), dtype=torch.float32, device=device)
+    return buf[..., :C] if ld != C else buf
+
+
+def ld_of(t):
+    return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+
+
+def rows_of(t):
+    n = 1
+    for s in t.shape[:-1]:
+        n *= s
+    return n
+
+
+def conv_out_size(n, k, s, p, d):
+    return (n + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def make_desc(xshape, ldx, Cout, ldy, kh, kw, stride, pad, dil, stem4=False):
+    B, H, W, Cin = xshape
+    return ConvDesc(B, H, W, Cin, conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil), Cout,
+                    kh, kw, stride, pad, dil, ldx, ldy, 1 if stem4 else 0)
+
+
+def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False):
+    B, H, W, Cin = x.shape
+    Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
+    if out is None:
+        out = new_act(B, Ho, Wo, Cout, x.device, ld=max(zero_to, (Cout + 3) // 4 * 4))
+    d = make_desc(x.shape, ld_of(x), Cout, ld_of(out), kh, kw, stride, pad, dil, stem4)
+    check(lib.catseg_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_ptr_tensor), ptr(bias), ptr(out), zero_to, stream()))
+    return out
+
+
+def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accumulate=False):
+    B, H, W, Cin = xshape
+    Cout = dy.shape[-1]
+    if out is None:
+        out = new_act(B, H, W, Cin, dy.device)
+        accumulate = False
+    d = make_desc(xshape, ld_of(out), Cout, ld_of(dy), kh, kw, stride, pad, dil)
+    check(lib.catseg_conv2d_bwd_data(ctypes.byref(d), ptr(dy), ptr(w), ptr(out), 1 if accumulate else 0, stream()))
+    return out
+
+
+def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=False):
+    """dw: destination tensor (physical OHWI, or packed [O][7][8][4] for the stem)."""
+    d = make_desc(x.shape, ld_of(x), dy.shape[-1], ld_of(dy), kh, kw, stride, pad, dil, stem4)
+    need = lib.catseg_conv2d_bwd_weight_workspace(ctypes.byref(d))
+    ws = workspace(need, x.device)
+    check(lib.catseg_conv2d_bwd_weight(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), stream()))
+    return dw
+
+
+NT, NN, TN = 0, 1, 2
+
+
+def gemm(layout, batch, M, N, K, A, lda, sA, Bm, ldb, sB, Cm, ldc, sC, zero_to=0, accumulate=False):
+    check(lib.catseg_gemm_batched(layout, batch, M, N, K, ptr(A), lda, sA, ptr(Bm), ldb, sB, ptr(Cm), ldc, sC, zero_to,
+                                  1 if accumulate else 0, stream()))
+    return Cm
+
+
+def bn_train_stats(y, gamma, eps, momentum, running_mean, running_var):
+    C = y.shape[-1]
+    rows = rows_of(y)
+    stats = torch.empty(2 * C, dtype=torch.float32, device=y.device)
+    scale = torch.empty(C, dtype=torch.float32, device=y.device)
+    ws = workspace(lib.catseg_bn_workspace(rows, C), y.device)
+    check(lib.catseg_bn_train_stats(ptr(y), rows, C, ld_of(y), ptr(gamma), eps, momentum, ptr(running_mean),
+                                    ptr(running_var), ptr(stats), ptr(scale), ptr(ws), ws.numel(), stream()))
+    return stats, scale
+
+
+def bn_eval_scale(gamma, running_var, eps):
+    scale = torch.empty_like(gamma)
+    check(lib.catseg_bn_eval_scale(gamma.numel(), ptr(gamma), ptr(running_var), eps, ptr(scale), stream()))
+    return scale
+
+
+def bn_apply(y, mean, scale, beta, residual, relu, out=None):
+    if out is None:
+        out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    check(lib.catseg_bn_apply(ptr(y), ld_of(y), ptr(mean), ptr(scale), ptr(beta), ptr(residual),
+                              ld_of(residual) if residual is not None else 0, ptr(out), ld_of(out), rows_of(y),
+                              y.shape[-1], 1 if relu else 0, stream()))
+    return out
+
+
+def bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres=None, dres_accumulate=False, dy_out=None):
+    C = y.shape[-1]
+    rows = rows_of(y)
+    if dy_out is None:
+        dy_out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    ws = workspace(lib.catseg_bn_workspace(rows, C), y.device)
+    check(lib.catseg_bn_backward(ptr(dz), ld_of(dz), ptr(z), ld_of(z) if z is not None else 0, ptr(y), ld_of(y), ptr(stats),
+                                 ptr(gamma), rows, C, 1 if relu else 0, ptr(dy_out), ld_of(dy_out), ptr(dgamma), ptr(dbeta),
+                                 ptr(dres), ld_of(dres) if dres is not None else 0, 1 if dres_accumulate else 0, ptr(ws),
+                                 ws.numel(), stream()))
+    return dy_out
+
+
+def nchw3_to_nhwc4(x):
+    B, C, H, W = x.shape
+    assert C == 3 and x.is_contiguous() and x.dtype == torch.float32
+    y = torch.empty((B, H, W, 4), dtype=torch.float32, device=x.device)
+    check(lib.catseg_nchw3_to_nhwc4(ptr(x), ptr(y), B, H, W, stream()))
+    return y
+
+
+def stem_pack_weight(w, O):
+    pk = torch.empty((O, 7, 8, 4), dtype=torch.float32, device=w.device)
+    check(lib.catseg_stem_pack_weight(ptr(w), ptr(pk), O, stream()))
+    return pk
+
+
+def stem_unpack_grad(pk, dw, O):
+    check(lib.catseg_stem_unpack_grad(ptr(pk), ptr(dw), O, stream()))
+    return dw
+
+
+def axpy(src, dst, alpha=1.0, accumulate=True):
+    check(lib.catseg_axpy2d(ptr(src), ld_of(src), ptr(dst), ld_of(dst), rows_of(src), src.shape[-1], alpha,
+                            1 if accumulate else 0, stream()))
+    return dst
+
+
+def maxpool_fwd(x):
+    B, H, W, C = x.shape
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    check(lib.catseg_maxpool3x3s2_fwd(ptr(x), ld_of(x), ptr(y), C, ptr(idx), B, H, W, C, Ho, Wo, stream()))
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, xshape):
+    B, H, W, C = xshape
+    dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
+    check(lib.catseg_maxpool3x3s2_bwd(ptr(dy), ld_of(dy), ptr(idx), ptr(dx), C, B, H, W, C, dy.shape[1], dy.shape[2], stream()))
+    return dx
+
+
+def bilinear_fwd(x, Ho, Wo, align_corners, out=None, accumulate=False):
+    B, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    check(lib.catseg_bilinear_fwd(ptr(x), ld_of(x), ptr(out), ld_of(out), B, H, W, C, Ho, Wo, 1 if align_corners else 0,
+                                  1 if accumulate else 0, stream()))
+    return out
+
+
+def bilinear_bwd(dy, xshape, align_corners, out=None, zero_to=0, accumulate=False):
+    B, H, W, C = xshape
+    Ho, Wo = dy.shape[1], dy.shape[2]
+    if out is None:
+        out = new_act(B, H, W, C, dy.device, ld=max(zero_to, (C + 3) // 4 * 4))
+        accumulate = False
+    ws = workspace(B * H * Wo * C * 4, dy.device)
+    check(lib.catseg_bilinear_bwd(ptr(dy), ld_of(dy), ptr(out), ld_of(out), B, H, W, C, Ho, Wo, 1 if align_corners else 0,
+                                  zero_to, 1 if accumulate else 0, ptr(ws), ws.numel(), stream()))
+    return out
+
+
+def global_avgpool_fwd(x):
+    B, H, W, C = x.shape
+    y = torch.empty((B, 1, 1, C), dtype=torch.float32, device=x.device)
+    check(lib.catseg_global_avgpool_fwd(ptr(x), ld_of(x), ptr(y), B, H * W, C, stream()))
+    return y
+
+
+def global_avgpool_bwd(dy, dx, accumulate):
+    B, H, W, C = dx.shape
+    check(lib.catseg_global_avgpool_bwd(ptr(dy), ptr(dx), ld_of(dx), B, H * W, C, 1 if accumulate else 0, stream()))
+    return dx
+
+
+def softmax_spatial_fwd(x, K):
+    """x: [B, N, ld] buffer (logits in columns [0, K)); returns same-shape probabilities, pad columns zero."""
+    B, N, ld = x.shape
+    y = torch.empty_like(x)
+    check(lib.catseg_softmax_spatial_fwd(ptr(x), ptr(y), B, N, K, ld, stream()))
+    return y
+
+
+def softmax_spatial_bwd(y, dy, dx, K, accumulate=False):
+    B, N, ld = y.shape
+    check(lib.catseg_softmax_spatial_bwd(ptr(y), ptr(dy), ptr(dx), B, N, K, ld, 1 if accumulate else 0, stream()))
+    return dx
+
+
+def softmax_rows_fwd(x, K, scale):
+    rows, ld = x.shape
+    y = torch.empty_like(x)
+    check(lib.catseg_softmax_rows_fwd(ptr(x), ptr(y), rows, K, ld, scale, stream()))
+    return y
+
+
+def softmax_rows_bwd(y, dy, K, scale):
+    rows, ld = y.shape
+    dx = torch.empty_like(y)
+    check(lib.catseg_softmax_rows_bwd(ptr(y), ptr(dy), ptr(dx), rows, K, ld, scale, stream()))
+    return dx
+
+
+def lovasz_softmax(logits, labels, weight=1.0, dlogits=None, accumulate=False, loss_out=None):
+    """logits: [P, K] contiguous (NHWC flattened); labels int64 [P]."""
+    Pn, K = logits.shape
+    assert logits.is_contiguous() and labels.dtype == torch.int64 and labels.is_contiguous()
+    if loss_out is None:
+        loss_out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    ws = workspace(lib.catseg_lovasz_workspace(Pn, K), logits.device)
+    check(lib.catseg_lovasz_softmax(ptr(logits), ptr(labels), Pn, K, weight, ptr(loss_out), ptr(dlogits),
+                                    1 if accumulate else 0, ptr(ws), ws.numel(), stream()))
+    return loss_out
+
+
+def cross_entropy(logits, labels, ignore_index, weight=1.0, dlogits=None, loss_out=None):
+    Pn, K = logits.shape
+    assert logits.is_contiguous() and labels.dtype == torch.int64 and labels.is_contiguous()
+    if loss_out is None:
+        loss_out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    ws = workspace(lib.catseg_ce_workspace(Pn), logits.device)
+    check(lib.catseg_cross_entropy(ptr(logits), ptr(labels), Pn, K, ignore_index, weight, ptr(loss_out), ptr(dlogits),
+                                   ptr(ws), ws.numel(), stream()))
+    return loss_out
+
+
+def confusion_matrix(logits, labels, cm=None):
+    Pn, K = logits.shape
+    if cm is None:
+        cm = torch.zeros((K, K), dtype=torch.int32, device=logits.device)
+    check(lib.catseg_confusion_matrix(ptr(logits), ptr(labels), Pn, K, ptr(cm), stream()))
+    return cm
+
+
+def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    check(lib.catseg_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, stream()))

@@ -1,0 +1,405 @@
+"""Parity of every C-ABI kernel (called through ctypes) against fp32 CPU references:
+torch.nn.functional for the float ops, oracle/ for the losses and metrics."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(atol=2e-4, rtol=2e-4)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from miccai2021_cataract_semantic_segmentation_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.cuda()
+
+
+def nhwc(t):  # NCHW cpu -> NHWC gpu contiguous
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):  # NHWC gpu -> NCHW cpu
+    return t.cpu().permute(0, 3, 1, 2)
+
+
+def ohwi(w):  # [O,I,kh,kw] cpu -> channels_last gpu (physical OHWI)
+    return w.cuda().contiguous(memory_format=torch.channels_last)
+
+
+def close(a, b, atol=2e-4, rtol=2e-4):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    scale = b.abs().max().item() + 1e-12
+    assert err <= atol + rtol * scale, "max abs err %g (ref scale %g)" % (err, scale)
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 9, 11, 16, 32, 1, 1, 0, 1),
+    (1, 12, 10, 64, 64, 3, 1, 1, 1),
+    (2, 13, 17, 32, 48, 3, 2, 1, 1),
+    (1, 20, 24, 16, 25, 1, 1, 0, 1),
+    (1, 17, 19, 48, 160, 3, 1, 2, 2),
+    (1, 30, 34, 16, 72, 3, 1, 12, 12),
+    (2, 8, 8, 304, 20, 3, 1, 1, 1),
+    (1, 16, 16, 128, 130, 1, 2, 0, 1),
+    (3, 7, 5, 8, 8, 3, 1, 4, 4),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(ops, case):
+    B, H, W, Cin, Cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.1).requires_grad_()
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    y = F.conv2d(x, w, b, s, p, d)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd, wd, bd = nhwc(x.detach()), ohwi(w.detach()), b.detach().cuda()
+    yd = ops.conv_fwd(xd, wd, bd, Cout, k, k, s, p, d)
+    close(nchw(yd), y)
+    # padded output with zero fill
+    ldp = (Cout + 3) // 4 * 4 + 4
+    yd2 = ops.conv_fwd(xd, wd, None, Cout, k, k, s, p, d, zero_to=ldp)
+    assert yd2.stride(2) == ldp
+    close(nchw(yd2), F.conv2d(x, w, None, s, p, d))
+    full = torch.as_strided(yd2, yd2.shape[:3] + (ldp,), yd2.stride())
+    assert float(full[..., Cout:].abs().max()) == 0.0
+    # backward: dy lives in a zero-padded buffer (ld multiple of 4)
+    gyd = ops.new_act(B, y.shape[2], y.shape[3], Cout, xd.device, zero=True)
+    gyd.copy_(nhwc(gy))
+    dx = ops.conv_bwd_data(gyd, wd, tuple(xd.shape), k, k, s, p, d)
+    close(nchw(dx), x.grad)
+    dx2 = ops.conv_bwd_data(gyd, wd, tuple(xd.shape), k, k, s, p, d, out=dx.clone(), accumulate=True)
+    close(nchw(dx2), 2 * x.grad)
+    dw = torch.empty_like(wd)
+    db = torch.empty(Cout, device="cuda")
+    ops.conv_bwd_weight(xd, gyd, dw, db, k, k, s, p, d)
+    close(dw.cpu(), w.grad, atol=5e-4, rtol=5e-4)
+    close(db, b.grad, atol=5e-4, rtol=5e-4)
+
+
+def test_conv_stem(ops):
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 37, 45, generator=g)
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).requires_grad_()
+    y = F.conv2d(x, w, None, 2, 3)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    x4 = ops.nchw3_to_nhwc4(x.cuda())
+    close(x4[..., :3].cpu(), x.permute(0, 2, 3, 1))
+    assert float(x4[..., 3].abs().max()) == 0
+    wd = ohwi(w.detach())
+    pk = ops.stem_pack_weight(wd, 64)
+    yd = ops.conv_fwd(x4, pk, None, 64, 7, 7, 2, 3, 1, stem4=True)
+    close(nchw(yd), y)
+    dpk = torch.empty_like(pk)
+    ops.conv_bwd_weight(x4, nhwc(gy), dpk, None, 7, 7, 2, 3, 1, stem4=True)
+    dw = torch.empty_like(wd)
+    ops.stem_unpack_grad(dpk, dw, 64)
+    close(dw.cpu(), w.grad, atol=1e-3, rtol=5e-4)
+
+
+def test_conv_large_channels_splits(ops):
+    """wide reduction (K = 9*256) and many pixel rows -> multi-split weight gradient"""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 256, 34, 30, generator=g, requires_grad=True)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).requires_grad_()
+    y = F.conv2d(x, w, None, 1, 2, 2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd, wd = nhwc(x.detach()), ohwi(w.detach())
+    close(nchw(ops.conv_fwd(xd, wd, None, 256, 3, 3, 1, 2, 2)), y)
+    gyd = nhwc(gy)
+    close(nchw(ops.conv_bwd_data(gyd, wd, tuple(xd.shape), 3, 3, 1, 2, 2)), x.grad)
+    dw = torch.empty_like(wd)
+    ops.conv_bwd_weight(xd, gyd, dw, None, 3, 3, 1, 2, 2)
+    close(dw.cpu(), w.grad, atol=2e-3, rtol=5e-4)
+
+
+def test_conv_concat_views(ops):
+    """input read from / output written into channel slices of wider buffers (ld > C)"""
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 32, 6, 7, generator=g)
+    w = torch.randn(16, 32, 1, 1, generator=g) * 0.2
+    big_in = torch.zeros(1, 6, 7, 80, device="cuda")
+    big_in[..., 48:80] = nhwc(x)
+    big_out = torch.full((1, 6, 7, 40), 7.0, device="cuda")
+    ops.conv_fwd(big_in[..., 48:80], ohwi(w), None, 16, 1, 1, out=big_out[..., 8:24])
+    close(nchw(big_out[..., 8:24]), F.conv2d(x, w))
+    assert float((big_out[..., :8] - 7).abs().max()) == 0 and float((big_out[..., 24:] - 7).abs().max()) == 0
+
+
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+def test_gemm_batched(ops, layout):
+    g = torch.Generator().manual_seed(5)
+    Bz, M, N, K = 3, 70, 25, 40
+    if layout == "NT":
+        A, Bm = torch.randn(Bz, M, K, generator=g), torch.randn(Bz, N, K, generator=g)
+        ref = A @ Bm.transpose(1, 2)
+        Ad, Bd = A.cuda(), Bm.cuda()
+        lda, ldb = K, K
+    elif layout == "NN":
+        K = 25  # reduction over a zero-padded 25 -> 28/32 wide operand
+        A, Bm = torch.randn(Bz, M, K, generator=g), torch.randn(Bz, K, 36, generator=g)
+        N = 36
+        ref = A @ Bm
+        Ad = torch.zeros(Bz, M, 32, device="cuda")
+        Ad[..., :K] = A.cuda()
+        Bd = Bm.cuda()
+        lda, ldb = 32, N
+    else:
+        M, N, K = 25, 68, 150
+        A, Bm = torch.randn(Bz, K, M, generator=g), torch.randn(Bz, K, N, generator=g)
+        ref = A.transpose(1, 2) @ Bm
+        Ad = torch.zeros(Bz, K, 32, device="cuda")
+        Ad[..., :M] = A.cuda()
+        Bd = Bm.cuda()
+        lda, ldb = 32, N
+    ldc = (N + 3) // 4 * 4 + 4
+    Cd = torch.full((Bz, M, ldc), 3.0, device="cuda")
+    code = {"NT": ops.NT, "NN": ops.NN, "TN": ops.TN}[layout]
+    ops.gemm(code, Bz, M, N, K, Ad, lda, Ad.stride(0), Bd, ldb, Bd.stride(0), Cd, ldc, Cd.stride(0), zero_to=ldc)
+    close(Cd[..., :N], ref)
+    assert float(Cd[..., N:].abs().max()) == 0
+    ops.gemm(code, Bz, M, N, K, Ad, lda, Ad.stride(0), Bd, ldb, Bd.stride(0), Cd, ldc, Cd.stride(0), accumulate=True)
+    close(Cd[..., :N], 2 * ref)
+
+
+@pytest.mark.parametrize("shape,relu,res", [((2, 9, 11, 64), True, False), ((3, 5, 7, 48), True, True),
+                                            ((2, 25, 1, 256), False, False), ((1, 40, 50, 12), True, True)])
+def test_batchnorm(ops, shape, relu, res):
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(C)
+    y = (torch.randn(B, C, H, W, generator=g) * 2 + 3).requires_grad_()
+    r = torch.randn(B, C, H, W, generator=g).requires_grad_() if res else None
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).requires_grad_()
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_()
+    rm, rv = 0.1 * torch.randn(C, generator=g), 1 + 0.1 * torch.rand(C, generator=g)
+    rm0, rv0 = rm.clone(), rv.clone()
+    z = F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    if res:
+        z = z + r
+    if relu:
+        z = F.relu(z)
+    gz = torch.randn(z.shape, generator=g)
+    z.backward(gz)
+    yd = nhwc(y.detach())
+    rmd, rvd = rm0.cuda(), rv0.cuda()
+    stats, scale = ops.bn_train_stats(yd, gamma.detach().cuda(), 1e-5, 0.1, rmd, rvd)
+    close(rmd, rm, atol=1e-5)
+    close(rvd, rv, atol=1e-5)
+    rd = nhwc(r.detach()) if res else None
+    zd = ops.bn_apply(yd, stats[:C], scale, beta.detach().cuda(), rd, relu)
+    close(nchw(zd), z, atol=1e-4)
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dres = torch.empty_like(yd) if res else None
+    dy = ops.bn_backward(nhwc(gz), zd, yd, stats, gamma.detach().cuda(), relu, dg, db, dres)
+    close(nchw(dy), y.grad, atol=2e-4)
+    close(dg, gamma.grad, atol=1e-3, rtol=1e-3)
+    close(db, beta.grad, atol=1e-3, rtol=1e-3)
+    if res:
+        close(nchw(dres), r.grad)
+    # eval mode
+    ze = F.batch_norm(y.detach(), rm, rv, gamma.detach(), beta.detach(), False, 0.1, 1e-5)
+    sc = ops.bn_eval_scale(gamma.detach().cuda(), rv.cuda(), 1e-5)
+    close(nchw(ops.bn_apply(yd, rm.cuda(), sc, beta.detach().cuda(), None, False)), ze, atol=1e-4)
+
+
+def test_batchnorm_many_rows(ops):
+    g = torch.Generator().manual_seed(1)
+    y = torch.randn(4, 64, 136, 120, generator=g) * 0.5 + 10.0  # large mean / std ratio
+    gamma, beta = torch.ones(64), torch.zeros(64)
+    z = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)
+    yd = nhwc(y)
+    stats, scale = ops.bn_train_stats(yd, gamma.cuda(), 1e-5, 0.1, None, None)
+    close(stats[:64], y.mean((0, 2, 3)), atol=1e-5)
+    close(nchw(ops.bn_apply(yd, stats[:64], scale, beta.cuda(), None, False)), z, atol=2e-4)
+
+
+def test_maxpool(ops):
+    g = torch.Generator().manual_seed(2)
+    x = F.relu(torch.randn(2, 8, 13, 18, generator=g)).requires_grad_()  # many exact ties at 0
+    y = F.max_pool2d(x, 3, 2, 1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    yd, idx = ops.maxpool_fwd(nhwc(x.detach()))
+    close(nchw(yd), y, atol=0, rtol=0)
+    close(nchw(ops.maxpool_bwd(nhwc(gy), idx, (2, 13, 18, 8))), x.grad, atol=1e-6)
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("sizes", [((6, 10), (48, 80)), ((17, 30), (68, 120)), ((5, 7), (5, 7)), ((9, 9), (20, 31))])
+def test_bilinear(ops, align, sizes):
+    (H, W), (Ho, Wo) = sizes
+    g = torch.Generator().manual_seed(H * W)
+    C = 25
+    x = torch.randn(2, C, H, W, generator=g, requires_grad=True)
+    y = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=align)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = ops.new_act(2, H, W, C, torch.device("cuda"), ld=32, zero=True)
+    xd.copy_(nhwc(x.detach()))
+    yd = ops.bilinear_fwd(xd, Ho, Wo, align)
+    close(nchw(yd), y, atol=1e-5)
+    dx = ops.bilinear_bwd(nhwc(gy), (2, H, W, C), align, zero_to=32)
+    close(nchw(dx), x.grad, atol=1e-4)
+    full = torch.as_strided(dx, dx.shape[:3] + (32,), dx.stride())
+    assert float(full[..., C:].abs().max()) == 0
+
+
+def test_global_avgpool(ops):
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 72, 9, 13, generator=g)
+    yd = ops.global_avgpool_fwd(nhwc(x))
+    close(yd.reshape(2, 72), x.mean((2, 3)), atol=1e-6)
+    dx = torch.ones(2, 9, 13, 72, device="cuda")
+    gy = torch.randn(2, 72, generator=g)
+    ops.global_avgpool_bwd(gy.cuda().reshape(2, 1, 1, 72), dx, True)
+    close(nchw(dx), 1 + gy[:, :, None, None].expand(2, 72, 9, 13) / (9 * 13), atol=1e-6)
+
+
+def test_softmaxes(ops):
+    g = torch.Generator().manual_seed(6)
+    B, N, K, ld = 2, 300, 25, 32
+    x = (3 * torch.randn(B, N, K, generator=g)).requires_grad_()
+    y = F.softmax(x, dim=1)  # over the N pixels, per (b, k)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = torch.zeros(B, N, ld, device="cuda")
+    xd[..., :K] = x.detach().cuda()
+    yd = ops.softmax_spatial_fwd(xd, K)
+    close(yd[..., :K], y, atol=1e-6)
+    assert float(yd[..., K:].abs().max()) == 0
+    gyd = torch.zeros(B, N, ld, device="cuda")
+    gyd[..., :K] = gy.cuda()
+    dx = ops.softmax_spatial_bwd(yd, gyd, torch.empty_like(xd), K)
+    close(dx[..., :K], x.grad, atol=1e-6)
+    # rows
+    x2 = torch.randn(B * N, K, generator=g, requires_grad=True)
+    sc = 256 ** -0.5
+    y2 = F.softmax(sc * x2, dim=-1)
+    g2 = torch.randn(y2.shape, generator=g)
+    y2.backward(g2)
+    x2d = torch.zeros(B * N, ld, device="cuda")
+    x2d[:, :K] = x2.detach().cuda()
+    y2d = ops.softmax_rows_fwd(x2d, K, sc)
+    close(y2d[:, :K], y2, atol=1e-6)
+    assert float(y2d[:, K:].abs().max()) == 0
+    g2d = torch.zeros(B * N, ld, device="cuda")
+    g2d[:, :K] = g2.cuda()
+    close(ops.softmax_rows_bwd(y2d, g2d, K, sc)[:, :K], x2.grad, atol=1e-6)
+
+
+def _lovasz_case(ops, logits, labels, tol_loss=2e-6, check_grad=True):
+    from oracle import losses as OL
+    lg = logits.clone().requires_grad_()
+    ref = OL.lovasz_softmax(lg, labels)
+    ref.backward()
+    B, K, H, W = logits.shape
+    ld = logits.permute(0, 2, 3, 1).reshape(-1, K).contiguous().cuda()
+    lb = labels.reshape(-1).cuda()
+    dl = torch.empty_like(ld)
+    loss = ops.lovasz_softmax(ld, lb, 1.0, dl)
+    assert abs(float(loss) - float(ref)) < tol_loss + 1e-5 * abs(float(ref)), (float(loss), float(ref))
+    if check_grad:
+        gref = lg.grad.permute(0, 2, 3, 1).reshape(-1, K)
+        close(dl, gref, atol=1e-7, rtol=1e-3)
+    return float(loss)
+
+
+def test_lovasz_golden(ops, golden):
+    g = golden("losses")
+    for tag in "abc":
+        lg, lb = torch.from_numpy(g[tag + "_logits"]), torch.from_numpy(g[tag + "_labels"])
+        v = _lovasz_case(ops, lg, lb)
+        assert abs(v - float(g[tag + "_loss"])) < 2e-6
+        K = lg.shape[1]
+        ld = lg.permute(0, 2, 3, 1).reshape(-1, K).contiguous().cuda()
+        dl = torch.empty_like(ld)
+        ops.lovasz_softmax(ld, lb.reshape(-1).cuda(), 1.0, dl)
+        close(dl, torch.from_numpy(g[tag + "_grad"]).permute(0, 2, 3, 1).reshape(-1, K), atol=1e-7, rtol=1e-3)
+
+
+def test_lovasz_edge_cases(ops):
+    g = torch.Generator().manual_seed(12)
+    # all pixels ignore-labelled -> no class present -> loss 0, zero gradient
+    lg = torch.randn(1, 25, 8, 8, generator=g)
+    ld = lg.permute(0, 2, 3, 1).reshape(-1, 25).contiguous().cuda()
+    dl = torch.full_like(ld, 5.0)
+    loss = ops.lovasz_softmax(ld, torch.full((64,), 25, dtype=torch.int64).cuda(), 1.0, dl)
+    assert float(loss) == 0.0 and float(dl.abs().max()) == 0.0
+    # single pixel, single class present
+    _lovasz_case(ops, torch.randn(1, 8, 1, 1, generator=g), torch.tensor([[[3]]]))
+    # ragged size (not a multiple of any tile), 17 classes, weight + accumulate
+    lg = 2 * torch.randn(1, 17, 67, 131, generator=g)
+    lb = torch.randint(0, 18, (1, 67, 131), generator=g)
+    v = _lovasz_case(ops, lg, lb)
+    ld = lg.permute(0, 2, 3, 1).reshape(-1, 17).contiguous().cuda()
+    d1, d2 = torch.empty_like(ld), torch.zeros_like(ld)
+    ops.lovasz_softmax(ld, lb.reshape(-1).cuda(), 1.0, d1)
+    l2 = ops.lovasz_softmax(ld, lb.reshape(-1).cuda(), 0.4, d2, accumulate=True)
+    assert abs(float(l2) - 0.4 * v) < 1e-6
+    close(d2, 0.4 * d1, atol=1e-8, rtol=1e-5)
+
+
+def test_lovasz_many_pixels_sorted_property(ops):
+    """P = 2*544*480: size-independent checks against the float64 numpy oracle"""
+    from oracle import losses as OL
+    g = torch.Generator().manual_seed(13)
+    lg = 2 * torch.randn(2, 25, 136, 120, generator=g)
+    lg = F.interpolate(lg, size=(544, 480), mode="bilinear", align_corners=True)
+    lb = torch.randint(0, 26, (2, 17, 15), generator=g)
+    lb = lb.repeat_interleave(32, 1).repeat_interleave(32, 2)
+    lb[lb == 7] = 2
+    ref = OL.lovasz_softmax_np(lg.numpy(), lb.numpy())
+    ld = lg.permute(0, 2, 3, 1).reshape(-1, 25).contiguous().cuda()
+    dl = torch.empty_like(ld)
+    loss = ops.lovasz_softmax(ld, lb.reshape(-1).cuda(), 1.0, dl)
+    assert abs(float(loss) - ref) < 5e-6, (float(loss), ref)
+    # gradient of a softmax-composed loss sums to zero over classes at every pixel
+    assert float(dl.sum(1).abs().max()) < 1e-9 + 1e-4 * float(dl.abs().max())
+    assert torch.isfinite(dl).all()
+
+
+def test_cross_entropy(ops, golden):
+    g = golden("losses")
+    lg, lb = torch.from_numpy(g["ce_logits"]), torch.from_numpy(g["ce_labels"])
+    ld = lg.permute(0, 2, 3, 1).reshape(-1, 17).contiguous().cuda()
+    dl = torch.empty_like(ld)
+    loss = ops.cross_entropy(ld, lb.reshape(-1).cuda(), 17, 1.0, dl)
+    assert abs(float(loss) - float(g["ce_loss"])) < 1e-6
+    close(dl, torch.from_numpy(g["ce_grad"]).permute(0, 2, 3, 1).reshape(-1, 17), atol=1e-8, rtol=1e-4)
+
+
+def test_confusion_matrix(ops, golden):
+    g = golden("metrics")
+    for exp, K in ((1, 8), (2, 17), (3, 25)):
+        lg, lb = torch.from_numpy(g["e%d_logits" % exp]), torch.from_numpy(g["e%d_labels" % exp])
+        ld = lg.permute(0, 2, 3, 1).reshape(-1, K).contiguous().cuda()
+        cm = ops.confusion_matrix(ld, lb.reshape(-1).cuda())
+        assert np.array_equal(cm.cpu().numpy(), g["e%d_cm" % exp])
+
+
+def test_adam(ops):
+    from oracle import losses as OL
+    g = torch.Generator().manual_seed(21)
+    n = 1003
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, md, vd = p.cuda(), m.cuda(), v.cuda()
+    for step in (1, 2, 3):
+        OL.adam_step(p, gr, m, v, step, 1e-3)
+        ops.adam_step(pd, gr.cuda(), md, vd, 1e-3, step)
+    close(pd, p, atol=1e-6)
+    close(vd, v, atol=1e-7)
