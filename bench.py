@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training frames/s of OCRNet (ResNet50, output stride 8, 25 classes) with the
+TwoScale Lovasz-Softmax loss and Adam, batch 8 per GPU at 3x544x960 (a 540x960 frame after the
+reference's 'pad' transform), synthetic data, random-init weights, fp32.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def synth_batch(B, H, W, K, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(B, 3, H, W, generator=g)
+    # blob-structured labels: 32x32 patches, a few classes absent, some ignore-labelled patches
+    lbl = torch.randint(0, K + 1, (B, H // 32, W // 32), generator=g)
+    lbl[lbl == 5] = 0
+    lbl[lbl == 11] = 4
+    lbl[lbl == 19] = 4
+    lbl = lbl.repeat_interleave(32, 1).repeat_interleave(32, 2).contiguous()
+    return img.to(device), lbl.to(device)
+
+
+def cpu_baseline(H, W, K):
+    """the CPU oracle (port of the reference path) on this box's host cores: 1 train step, batch 1"""
+    from oracle import nets as ON, losses as OL
+    from oracle.state import fill_state, spec_of
+    from miccai2021_cataract_semantic_segmentation_amd.models import OCRNet
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))   # beyond ~32 threads the sort / BN phases of this step stop scaling
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    spec = spec_of(OCRNet({"backbone": "resnet50", "out_stride": 8, "pretrained": False}, 3).state_dict())
+    S = fill_state(spec, 0)
+    params = [k for k, v in S.items() if v.dtype.is_floating_point and "running" not in k]
+    for k in params:
+        S[k].requires_grad_()
+    img, lbl = synth_batch(1, H, W, K, 0, "cpu")
+    m = {k: torch.zeros_like(S[k]) for k in params}
+    v = {k: torch.zeros_like(S[k]) for k in params}
+    t0 = time.perf_counter()
+    oi, of = ON.ocrnet_forward(S, img, train=True)
+    loss = OL.two_scale_lovasz(oi, of, lbl)
+    loss.backward()
+    with torch.no_grad():
+        for k in params:
+            OL.adam_step(S[k], S[k].grad, m[k], v[k], 1, 1e-4)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 train step (fwd + TwoScale-Lovasz + bwd + Adam) of the CPU oracle, batch 1, 3x%dx%d, K=%d, fp32, "
+                      "%.1f s wall" % (H, W, K, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU")
+    ap.add_argument("--height", type=int, default=544)
+    ap.add_argument("--width", type=int, default=960)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from miccai2021_cataract_semantic_segmentation_amd import dist as D
+    rank, local, world = D.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import torch.distributed as dist
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from miccai2021_cataract_semantic_segmentation_amd import ops
+    from miccai2021_cataract_semantic_segmentation_amd.models import OCRNet
+    from miccai2021_cataract_semantic_segmentation_amd.losses import TwoScaleLoss
+    from miccai2021_cataract_semantic_segmentation_amd.optim import FusedAdam
+
+    K, B, H, W = 25, args.batch, args.height, args.width
+    torch.manual_seed(0)
+    model = OCRNet({"backbone": "resnet50", "out_stride": 8, "pretrained": False}, 3).to(dev).train()
+    crit = TwoScaleLoss({"experiment": 3, "interm": {"name": "LovaszSoftmax", "args": [], "weight": 0.4},
+                         "final": {"name": "LovaszSoftmax", "args": [], "weight": 1.0}})
+    gscale = 1.0
+    if world > 1:
+        D.broadcast_parameters(model)
+        gscale = D.attach(model)
+    opt = FusedAdam(model, lr=1e-4, grad_scale=gscale)
+    img, lbl = synth_batch(B, H, W, K, 1000 + rank, dev)
+
+    def step():
+        opt.zero_grad()
+        interm, final = model(img)
+        loss = crit(interm, final, lbl)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss.detach())
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        # per-launch HIP-event timing of the implicit-GEMM kernels on the launch stream (2 extra steps)
+        ops.PROFILE = []
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        agg = {}
+        for kind, flops, e0, e1 in prof:
+            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        dom = max(agg, key=lambda k: agg[k][1])
+        fl, sec, n = agg[dom]
+        peak = 157.3
+        roof = {"bound": "mfma", "kernel": "igemm_f32_kernel<%s>" % dom, "achieved": fl / sec / 1e12, "peak": peak,
+                "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak, "traffic": None, "launches_per_step": n // 2,
+                "avg_launch_ms": sec / n * 1e3, "algorithmic_gflop_per_launch": fl / n / 1e9,
+                "all_igemm": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / 2 * 1e3, "launches_per_step": v[2] // 2}
+                              for k, v in agg.items()}}
+    cpu = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        cpu = cpu_baseline(H, W, K)
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        out = {
+            "metric": "train frames/sec @540x960 (3x544x960 after pad), OCRNet, fwd+TwoScale-Lovasz+bwd+Adam",
+            "value": world * B * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "OCRNet-ResNet50-OS8, 25-class (task 3), bs=%d/GPU @3x%dx%d, TwoScale Lovasz-Softmax, "
+                                   "Adam lr 1e-4 (reference configs/OCRNet_rf_lvsz.json; the reference has no HRNet-W48 OCRNet)"
+                                   % (B, H, W),
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": final_loss},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

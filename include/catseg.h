@@ -110,6 +110,8 @@ int catseg_stem_unpack_grad(const float* packed_grad, float* dw_ohwi, int O, cat
 /* dst[p, c] (+)= alpha * src[p, c] */
 int catseg_axpy2d(const float* src, int lds, float* dst, int ldd, long long rows, int C, float alpha,
                   int accumulate, catseg_stream_t stream);
+/* x[i] *= s[0], s on the device (applies an upstream loss gradient without a host sync) */
+int catseg_scale_by_device_scalar(float* x, long long n, const float* s, catseg_stream_t stream);
 /* nn.MaxPool2d(3, 2, 1) of the torchvision stem; idx = window position of the max (uint8) */
 int catseg_maxpool3x3s2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int B, int H, int W,
                             int C, int Ho, int Wo, catseg_stream_t stream);

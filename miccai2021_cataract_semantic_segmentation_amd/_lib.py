@@ -44,6 +44,7 @@ _SIGS = {
     "catseg_stem_pack_weight": (I, [P, P, I, P]),
     "catseg_stem_unpack_grad": (I, [P, P, I, P]),
     "catseg_axpy2d": (I, [P, I, P, I, L, I, F, I, P]),
+    "catseg_scale_by_device_scalar": (I, [P, L, P, P]),
     "catseg_maxpool3x3s2_fwd": (I, [P, I, P, I, P, I, I, I, I, I, I, P]),
     "catseg_maxpool3x3s2_bwd": (I, [P, I, P, P, I, I, I, I, I, I, I, P]),
     "catseg_bilinear_fwd": (I, [P, I, P, I, I, I, I, I, I, I, I, I, P]),

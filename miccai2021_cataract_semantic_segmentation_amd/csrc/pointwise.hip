@@ -48,6 +48,17 @@ __global__ void axpy2d_kernel(const float* __restrict__ src, int lds, float* __r
   }
 }
 
+// x *= s[0]  (s lives on the device: the upstream gradient of a loss, no host sync)
+__global__ void scale_dev_kernel(float* __restrict__ x, long long n, const float* __restrict__ s) {
+  const float a = s[0];
+  const long long n4 = n >> 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4* p = (f32x4*)x + i;
+    *p = *p * a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) x[(n4 << 2) + threadIdx.x] *= a;
+}
+
 // ------------------------------------------------------------------ maxpool 3x3 / 2 / pad 1
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, uint8_t* __restrict__ idx,
                                    int B, int H, int W, int C, int Ho, int Wo) {
@@ -374,6 +385,12 @@ extern "C" int catseg_axpy2d(const float* src, int lds, float* dst, int ldd, lon
                              int accumulate, catseg_stream_t stream) {
   CS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && cs_aligned16(src) && cs_aligned16(dst), "axpy2d: C/ld multiples of 4, 16-B aligned");
   hipLaunchKernelGGL(axpy2d_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, rows, C, alpha, accumulate);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_scale_by_device_scalar(float* x, long long n, const float* s, catseg_stream_t stream) {
+  CS_REQUIRE(n > 0 && cs_aligned16(x) && s != nullptr, "scale: bad args");
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, n, s);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

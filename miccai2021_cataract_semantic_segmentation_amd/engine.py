@@ -1,0 +1,405 @@
+"""Execution engine: explicit tape of native kernels (no tracing compiler, no torch ops in the
+hot path).  A forward pass records one backward closure per fused layer; the backward pass
+walks the tape in reverse, writing parameter gradients straight into one flat fp32 buffer
+(so the optimiser is a single kernel and data-parallel all-reduce works on contiguous buckets).
+
+torch.autograd sees exactly one node per network (``NetFunction``) and one per loss, which keeps
+the reference's ``loss.backward(); optimiser.step()`` calling convention working.
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+
+# --------------------------------------------------------------------------- parameter containers
+class Conv2d(nn.Conv2d):
+    """Parameter container with nn.Conv2d's init / state-dict behaviour; runs on the HIP engine."""
+    stem = False
+
+    def forward(self, x):  # pragma: no cover
+        raise RuntimeError("engine Conv2d is executed by the owning network, not called directly")
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._pending_batches = 0  # num_batches_tracked is flushed lazily (no per-step kernel)
+
+    def forward(self, x):  # pragma: no cover
+        raise RuntimeError("engine BatchNorm2d is executed by the owning network, not called directly")
+
+
+def flush_bn_counters(module):
+    for m in module.modules():
+        if isinstance(m, BatchNorm2d) and m._pending_batches:
+            m.num_batches_tracked += m._pending_batches
+            m._pending_batches = 0
+
+
+# --------------------------------------------------------------------------- flat parameter storage
+class FlatParams:
+    """All parameters of a network as views into one flat buffer (conv weights physically OHWI),
+    gradients likewise.  Rebuilt automatically if the module was moved (.to / .cuda)."""
+    ALIGN = 64  # floats
+
+    def __init__(self, module):
+        self.module = module
+        self.params = [p for p in module.parameters()]
+        self.device = None
+        self.flat = self.grad = None
+        self.offsets = {}
+
+    def _stale(self):
+        if self.flat is None:
+            return True
+        p0, pn = self.params[0], self.params[-1]
+        return (p0.device != self.flat.device or p0.data_ptr() != self.flat.data_ptr() + 4 * self.offsets[id(p0)]
+                or pn.data_ptr() != self.flat.data_ptr() + 4 * self.offsets[id(pn)])
+
+    def ensure(self):
+        if not self._stale():
+            return self
+        dev = self.params[0].device
+        off = 0
+        offs = {}
+        for p in self.params:
+            offs[id(p)] = off
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p in self.params:
+            o, n = offs[id(p)], p.numel()
+            pv, gv = self._view(flat, o, p), self._view(grad, o, p)
+            pv.copy_(p.data)
+            p.data = pv
+            p.grad = gv
+        self.flat, self.grad, self.offsets, self.device, self.numel = flat, grad, offs, dev, off
+        return self
+
+    @staticmethod
+    def _view(buf, o, p):
+        if p.dim() == 4:
+            O, I, kh, kw = p.shape
+            return buf[o:o + p.numel()].view(O, kh, kw, I).permute(0, 3, 1, 2)
+        return buf[o:o + p.numel()].view(p.shape)
+
+    def bind_grads(self):
+        """(re)attach .grad views (optimizer.zero_grad(set_to_none=True) detaches them)"""
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * self.offsets[id(p)]:
+                p.grad = self._view(self.grad, self.offsets[id(p)], p)
+
+
+# --------------------------------------------------------------------------- tape
+class Ctx:
+    def __init__(self, train, record, on_param_grad=None):
+        self.train = train
+        self.record = record
+        self.tape = []
+        self.grads = {}
+        self.on_param_grad = on_param_grad
+
+    def push(self, fn):
+        if self.record:
+            self.tape.append(fn)
+
+    def take(self, t):
+        return self.grads.pop(id(t), None)
+
+    def give(self, t, g):
+        cur = self.grads.get(id(t))
+        if cur is None:
+            self.grads[id(t)] = g
+        else:
+            ops.axpy(g, cur, 1.0, True)
+
+    def dest(self, t):
+        """buffer the gradient of activation t must be written to: (buffer, accumulate?)"""
+        cur = self.grads.get(id(t))
+        if cur is not None:
+            return cur, True
+        C = t.shape[-1]
+        ld = ops.ld_of(t) if t.dim() == 4 else C
+        if t.dim() == 4 and ld != C and ld <= 64:   # small padded rows (class logits): keep the zero pad
+            buf = ops.new_act(t.shape[0], t.shape[1], t.shape[2], C, t.device, ld=ld, zero=True)
+        else:
+            buf = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+        self.grads[id(t)] = buf
+        return buf, False
+
+    def pgrad(self, p):
+        return p.grad
+
+    def done(self, *params):
+        if self.on_param_grad is not None:
+            for p in params:
+                if p is not None:
+                    self.on_param_grad(p)
+
+    def backward(self):
+        tape = self.tape
+        while tape:
+            tape.pop()()
+        self.grads.clear()
+
+
+# --------------------------------------------------------------------------- fused layers
+def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=True):
+    """conv -> BatchNorm (batch stats in training) -> (+residual) -> (ReLU).  x NHWC (or the raw
+    NCHW image for the stem).  Returns z (NHWC)."""
+    w = conv.weight
+    Cout = w.shape[0]
+    kh, kw = conv.kernel_size
+    s, p, d = conv.stride[0], conv.padding[0], conv.dilation[0]
+    if conv.stem:
+        x_in = ops.nchw3_to_nhwc4(x)
+        wk = ops.stem_pack_weight(w.data, Cout)
+    else:
+        x_in, wk = x, w.data
+    bias = conv.bias.data if conv.bias is not None else None
+    y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem)
+    if cx.train:
+        stats, scale = ops.bn_train_stats(y, bn.weight.data, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        bn._pending_batches += 1
+        mean = stats[:Cout]
+    else:
+        stats = None
+        mean = bn.running_mean
+        scale = ops.bn_eval_scale(bn.weight.data, bn.running_var, bn.eps)
+    z = ops.bn_apply(y, mean, scale, bn.bias.data, residual, relu, out=out)
+    if cx.record:
+        if not cx.train:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not on the training path")
+
+        def bwd():
+            dz = cx.take(z)
+            if dz is None:
+                return
+            dres, acc = (None, False)
+            if residual is not None:
+                dres, acc = cx.dest(residual)
+            dy = ops.bn_backward(dz, z, y, stats, bn.weight.data, relu, cx.pgrad(bn.weight), cx.pgrad(bn.bias), dres, acc)
+            del dz
+            dbias = cx.pgrad(conv.bias) if conv.bias is not None else None
+            if conv.stem:
+                dpk = torch.empty_like(wk)
+                ops.conv_bwd_weight(x_in, dy, dpk, dbias, kh, kw, s, p, d, stem4=True)
+                ops.stem_unpack_grad(dpk, cx.pgrad(w), Cout)
+            else:
+                ops.conv_bwd_weight(x_in, dy, cx.pgrad(w), dbias, kh, kw, s, p, d)
+                if need_dx:
+                    dx, accx = cx.dest(x)
+                    ops.conv_bwd_data(dy, w.data, tuple(x.shape), kh, kw, s, p, d, out=dx, accumulate=accx)
+            cx.done(bn.weight, bn.bias, w, conv.bias)
+        cx.push(bwd)
+    return z
+
+
+def conv_bias(cx, x, conv, pad_to=32):
+    """plain conv (+bias), used for the K-class classifier heads.  The output keeps a zero-padded
+    row stride (pad_to floats) so that it can feed 16-byte-granular kernels."""
+    w = conv.weight
+    Cout = w.shape[0]
+    kh, kw = conv.kernel_size
+    s, p, d = conv.stride[0], conv.padding[0], conv.dilation[0]
+    ld = max(pad_to, (Cout + 3) // 4 * 4)
+    bias = conv.bias.data if conv.bias is not None else None
+    y = ops.conv_fwd(x, w.data, bias, Cout, kh, kw, s, p, d, zero_to=ld)
+    if cx.record:
+        def bwd():
+            dy = cx.take(y)
+            if dy is None:
+                return
+            ops.conv_bwd_weight(x, dy, cx.pgrad(w), cx.pgrad(conv.bias) if conv.bias is not None else None, kh, kw, s, p, d)
+            dx, acc = cx.dest(x)
+            ops.conv_bwd_data(dy, w.data, tuple(x.shape), kh, kw, s, p, d, out=dx, accumulate=acc)
+            cx.done(w, conv.bias)
+        cx.push(bwd)
+    return y
+
+
+def maxpool(cx, x):
+    y, idx = ops.maxpool_fwd(x)
+    if cx.record:
+        def bwd():
+            dy = cx.take(y)
+            if dy is not None:
+                cx.give(x, ops.maxpool_bwd(dy, idx, tuple(x.shape)))
+        cx.push(bwd)
+    return y
+
+
+def bilinear(cx, x, Ho, Wo, align_corners, out=None):
+    y = ops.bilinear_fwd(x, Ho, Wo, align_corners, out=out)
+    if cx.record:
+        def bwd():
+            dy = cx.take(y)
+            if dy is None:
+                return
+            dx, acc = cx.dest(x)
+            C = x.shape[-1]
+            ops.bilinear_bwd(dy, tuple(x.shape), align_corners, out=dx, zero_to=(ops.ld_of(dx) if ops.ld_of(dx) != C else 0),
+                             accumulate=acc)
+        cx.push(bwd)
+    return y
+
+
+def global_avgpool(cx, x):
+    y = ops.global_avgpool_fwd(x)
+    if cx.record:
+        def bwd():
+            dy = cx.take(y)
+            if dy is None:
+                return
+            dx, acc = cx.dest(x)
+            ops.global_avgpool_bwd(dy, dx, acc)
+        cx.push(bwd)
+    return y
+
+
+def concat_views(cx, cat, parts):
+    """parts: [(tensor written as a channel slice of `cat`, c0, c1)] — backward hands out slices."""
+    if cx.record:
+        def bwd():
+            dcat = cx.take(cat)
+            if dcat is None:
+                return
+            for t, c0, c1 in parts:
+                cx.give(t, dcat[..., c0:c1])
+        cx.push(bwd)
+    return cat
+
+
+def spatial_gather(cx, feats, logits, K):
+    """models/OCR.py:158-170: proxy[b, k, :] = sum_n softmax_n(logits[b, n, k]) * feats[b, n, :]"""
+    B, H, W, C = feats.shape
+    N = H * W
+    ldl = ops.ld_of(logits)
+    lbuf = torch.as_strided(logits, (B, N, ldl), (N * ldl, ldl, 1))
+    probs = ops.softmax_spatial_fwd(lbuf, K)
+    proxy = torch.empty((B, K, 1, C), dtype=torch.float32, device=feats.device)
+    ldf = ops.ld_of(feats)
+    ops.gemm(ops.TN, B, K, C, N, probs, ldl, N * ldl, feats, ldf, N * ldf, proxy, C, K * C)
+    if cx.record:
+        def bwd():
+            dproxy = cx.take(proxy)
+            if dproxy is None:
+                return
+            dfe, acc = cx.dest(feats)
+            ops.gemm(ops.NN, B, N, C, K, probs, ldl, N * ldl, dproxy, C, K * C, dfe, ops.ld_of(dfe), N * ops.ld_of(dfe),
+                     accumulate=acc)
+            dprobs = torch.empty_like(probs)
+            ops.gemm(ops.NT, B, N, K, C, feats, ldf, N * ldf, dproxy, C, K * C, dprobs, ldl, N * ldl, zero_to=ldl)
+            dlg, accl = cx.dest(logits)
+            dbuf = torch.as_strided(dlg, (B, N, ldl), (N * ldl, ldl, 1))
+            ops.softmax_spatial_bwd(probs, dprobs, dbuf, K, accumulate=accl)
+        cx.push(bwd)
+    return proxy
+
+
+def object_attention_core(cx, q, key, val, K, key_channels):
+    """models/OCR.py:266-274: softmax_k(C^-0.5 q.key) . val   (q [B,H,W,Ck]; key, val [B,K,1,Ck])"""
+    B, H, W, Ck = q.shape
+    N = H * W
+    ld = 32 if K <= 32 else 64
+    scale = float(key_channels) ** -0.5
+    sim = torch.empty((B, N, ld), dtype=torch.float32, device=q.device)
+    ops.gemm(ops.NT, B, N, K, Ck, q, Ck, N * Ck, key, Ck, K * Ck, sim, ld, N * ld, zero_to=ld)
+    p = ops.softmax_rows_fwd(sim.view(B * N, ld), K, scale)
+    del sim
+    ctx = torch.empty((B, H, W, Ck), dtype=torch.float32, device=q.device)
+    ops.gemm(ops.NN, B, N, Ck, K, p, ld, N * ld, val, Ck, K * Ck, ctx, Ck, N * Ck)
+    if cx.record:
+        def bwd():
+            dctx = cx.take(ctx)
+            if dctx is None:
+                return
+            dp = torch.empty_like(p)
+            ops.gemm(ops.NT, B, N, K, Ck, dctx, Ck, N * Ck, val, Ck, K * Ck, dp, ld, N * ld, zero_to=ld)
+            dv, accv = cx.dest(val)
+            ops.gemm(ops.TN, B, K, Ck, N, p, ld, N * ld, dctx, Ck, N * Ck, dv, Ck, K * Ck, accumulate=accv)
+            dsim = ops.softmax_rows_bwd(p, dp, K, scale)
+            dq, accq = cx.dest(q)
+            ops.gemm(ops.NN, B, N, Ck, K, dsim, ld, N * ld, key, Ck, K * Ck, dq, Ck, N * Ck, accumulate=accq)
+            dk, acck = cx.dest(key)
+            ops.gemm(ops.TN, B, K, Ck, N, dsim, ld, N * ld, q, Ck, N * Ck, dk, Ck, K * Ck, accumulate=acck)
+        cx.push(bwd)
+    return ctx
+
+
+# --------------------------------------------------------------------------- autograd bridge
+class NetFunction(torch.autograd.Function):
+    """One autograd node for a whole network.  Parameter gradients are written directly into the
+    flat gradient buffer by the tape; autograd only carries the output gradients in."""
+
+    @staticmethod
+    def forward(ctx, net, x, anchor):
+        cx, outs = net._run(x, record=True)
+        ctx.cx = cx
+        ctx.net = net
+        ctx.outs_nhwc = outs
+        res = tuple(o.permute(0, 3, 1, 2) for o in outs)
+        ctx.mark_non_differentiable()
+        return res if len(res) > 1 else res[0]
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        cx = ctx.cx
+        for o, g in zip(ctx.outs_nhwc, gouts):
+            if g is None:
+                continue
+            gn = g.permute(0, 2, 3, 1)
+            if not gn.is_contiguous():
+                gn = gn.contiguous()
+            cx.give(o, gn)
+        ctx.net._begin_backward(cx)
+        cx.backward()
+        ctx.net._end_backward(cx)
+        return None, None, None
+
+
+class EngineNet(nn.Module):
+    """Base class of the HIP-engine networks (keeps the reference's ``Model(config, experiment)``
+    / ``model(x)`` surface).  Subclasses implement ``_body(cx, x_nchw) -> [NHWC outputs]``."""
+
+    def __init__(self):
+        super().__init__()
+        self._flatp = None
+        self._grad_sync = None  # optional data-parallel gradient reducer
+
+    def flat(self):
+        if self._flatp is None:
+            self._flatp = FlatParams(self)
+        return self._flatp.ensure()
+
+    def state_dict(self, *a, **k):
+        flush_bn_counters(self)
+        return super().state_dict(*a, **k)
+
+    def _run(self, x, record):
+        cx = Ctx(self.training, record, None)
+        outs = self._body(cx, x)
+        return cx, outs
+
+    def _begin_backward(self, cx):
+        fp = self.flat()
+        fp.bind_grads()
+        if self._grad_sync is not None:
+            cx.on_param_grad = self._grad_sync.param_ready
+            self._grad_sync.begin(fp)
+
+    def _end_backward(self, cx):
+        if self._grad_sync is not None:
+            self._grad_sync.finish()
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("the HIP engine only runs on an MI355X device tensor (no CPU fallback)")
+        fp = self.flat()
+        x = x.contiguous().float()
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in fp.params):
+            return NetFunction.apply(self, x, fp.params[0])
+        _, outs = self._run(x, record=False)
+        res = tuple(o.permute(0, 3, 1, 2) for o in outs)
+        return res if len(res) > 1 else res[0]

@@ -1,0 +1,110 @@
+"""OCRNet on the HIP engine — same constructor / forward contract and state-dict keys as the
+reference's models/OCR.py:10-138 (OCRNet, SpatialGatherModule :146-170, ObjectAttentionBlock2D
+:173-284, SpatialOCR_Module :287-321)."""
+import torch
+from torch import nn
+
+from .. import ops
+from ..engine import (BatchNorm2d, Conv2d, EngineNet, bilinear, concat_views, conv_bias, conv_bn_act,
+                      object_attention_core, spatial_gather)
+from ..utils import num_classes
+from .backbone import ResNetBackbone
+
+
+class ObjectAttentionBlock2D(nn.Module):
+    def __init__(self, in_channels, key_channels, scale=1):
+        super().__init__()
+        if scale != 1:
+            raise NotImplementedError("scale > 1 is unused by the reference configs")
+        self.scale, self.in_channels, self.key_channels = scale, in_channels, key_channels
+        self.pool = nn.MaxPool2d(kernel_size=(scale, scale))
+        self.relu = nn.ReLU(inplace=True)
+
+        def cbr(cin, cout):
+            return [Conv2d(cin, cout, 1, bias=False), BatchNorm2d(cout), self.relu]
+        self.f_pixel = nn.Sequential(*cbr(in_channels, key_channels), *cbr(key_channels, key_channels))
+        self.f_object = nn.Sequential(*cbr(in_channels, key_channels), *cbr(key_channels, key_channels))
+        self.f_down = nn.Sequential(*cbr(in_channels, key_channels))
+        self.f_up = nn.Sequential(*cbr(key_channels, in_channels))
+
+    def run(self, cx, x, proxy, K, out):
+        q = conv_bn_act(cx, conv_bn_act(cx, x, self.f_pixel[0], self.f_pixel[1]), self.f_pixel[3], self.f_pixel[4])
+        k = conv_bn_act(cx, conv_bn_act(cx, proxy, self.f_object[0], self.f_object[1]), self.f_object[3], self.f_object[4])
+        v = conv_bn_act(cx, proxy, self.f_down[0], self.f_down[1])
+        ctx = object_attention_core(cx, q, k, v, K, self.key_channels)
+        return conv_bn_act(cx, ctx, self.f_up[0], self.f_up[1], out=out)
+
+
+class SpatialOCR_Module(nn.Module):
+    def __init__(self, in_channels, key_channels, out_channels, scale=1, dropout=0.0):
+        super().__init__()
+        self.relu = nn.ReLU(inplace=True)
+        self.object_context_block = ObjectAttentionBlock2D(in_channels, key_channels, scale)
+        self.conv_bn_dropout = nn.Sequential(Conv2d(2 * in_channels, out_channels, 1, padding=0, bias=False),
+                                             BatchNorm2d(out_channels), self.relu, nn.Dropout2d(dropout))
+        self.in_channels = in_channels
+
+    def run(self, cx, cat, feats, proxy, K):
+        """cat: [B,H,W,2C] buffer whose upper half already holds feats (torch.cat([context, feats], 1))"""
+        C = self.in_channels
+        context = self.object_context_block.run(cx, feats, proxy, K, out=cat[..., :C])
+        concat_views(cx, cat, [(context, 0, C), (feats, C, 2 * C)])
+        return conv_bn_act(cx, cat, self.conv_bn_dropout[0], self.conv_bn_dropout[1])
+
+
+class SpatialGatherModule(nn.Module):
+    def __init__(self, cls_num=0, scale=1):
+        super().__init__()
+        self.cls_num, self.scale = cls_num, scale
+
+
+class OCRNet(EngineNet):
+    eligible_backbones = ["resnet50", "resnet101"]  # resnet18/34 are broken in the reference
+
+    def __init__(self, config, experiment):
+        super().__init__()
+        self.config = config
+        self.backbone_name = config["backbone"] if "backbone" in config else "resnet101"
+        assert self.backbone_name in self.eligible_backbones, "backbone must be in {}".format(self.eligible_backbones)
+        self.out_stride = config["out_stride"] if "out_stride" in config else 8
+        assert self.out_stride in [8, 16, 32]
+        self.align_corners = True
+        self.dropout = config["dropout"] if "dropout" in config else 0.0
+        if self.dropout != 0.0:
+            raise NotImplementedError("Dropout2d(p>0) is not used by the shipped configs")
+        self.num_classes = num_classes(experiment)
+        self.get_intermediate = True
+        self.relu = nn.ReLU(inplace=True)
+        strides = {8: [False, True, True], 16: [False, False, True], 32: [False, False, False]}[self.out_stride]
+        self.backbone_cutoff = {"layer3": "low", "layer4": "high"}
+        self.backbone = ResNetBackbone(self.backbone_name, strides, self.backbone_cutoff)
+        self.high_out_channels = self.backbone.out_channels("layer4")
+        self.low_level_channels = self.backbone.out_channels("layer3")
+        self.conv_high_map = nn.Sequential(Conv2d(self.high_out_channels, 512, 3, 1, 1), BatchNorm2d(512), self.relu)
+        self.interm_prediction_head = nn.Sequential(
+            Conv2d(self.low_level_channels, 512, 3, 1, 1), BatchNorm2d(512), self.relu, nn.Dropout2d(self.dropout),
+            Conv2d(512, self.num_classes, 1, 1, 0, bias=True))
+        self.spatial_gather = SpatialGatherModule(self.num_classes)
+        self.spatial_ocr_head = SpatialOCR_Module(512, 256, 512, 1, self.dropout)
+        self.conv_out = Conv2d(512, self.num_classes, 1, 1, bias=True)
+        if "projector" in config:
+            raise NotImplementedError("the contrastive projector is outside the accelerated path")
+        self.projector_model = None
+
+    def _body(self, cx, x):
+        H, W = x.shape[-2:]
+        K = self.num_classes
+        f = self.backbone.run(cx, x)
+        low, high = f["low"], f["high"]
+        hd = self.interm_prediction_head
+        interm = conv_bias(cx, conv_bn_act(cx, low, hd[0], hd[1]), hd[4])
+        B, h, w, _ = high.shape
+        cat = torch.empty((B, h, w, 1024), dtype=torch.float32, device=x.device)
+        feats = conv_bn_act(cx, high, self.conv_high_map[0], self.conv_high_map[1], out=cat[..., 512:])
+        proxy = spatial_gather(cx, feats, interm, K)
+        o = self.spatial_ocr_head.run(cx, cat, feats, proxy, K)
+        logits = conv_bias(cx, o, self.conv_out)
+        up = bilinear(cx, logits, H, W, True)
+        if self.get_intermediate:
+            return [bilinear(cx, interm, H, W, True), up]
+        return [up]

@@ -57,13 +57,35 @@ def make_desc(xshape, ldx, Cout, ldy, kh, kw, stride, pad, dil, stem4=False):
                     kh, kw, stride, pad, dil, ldx, ldy, 1 if stem4 else 0)
 
 
+PROFILE = None  # bench.py sets this to a list: every implicit-GEMM launch is bracketed by HIP events
+
+
+class _Timed:
+    """HIP events on the launch stream around one C-ABI call (algorithmic FLOPs = 2*M*N*K)."""
+
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+
+
 def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False):
     B, H, W, Cin = x.shape
     Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
     if out is None:
         out = new_act(B, Ho, Wo, Cout, x.device, ld=max(zero_to, (Cout + 3) // 4 * 4))
     d = make_desc(x.shape, ld_of(x), Cout, ld_of(out), kh, kw, stride, pad, dil, stem4)
-    check(lib.catseg_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_ptr_tensor), ptr(bias), ptr(out), zero_to, stream()))
+    with _Timed("fwd", 2.0 * B * Ho * Wo * Cout * (3 if stem4 else Cin) * kh * kw):
+        check(lib.catseg_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_ptr_tensor), ptr(bias), ptr(out), zero_to, stream()))
     return out
 
 
@@ -74,7 +96,8 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
         out = new_act(B, H, W, Cin, dy.device)
         accumulate = False
     d = make_desc(xshape, ld_of(out), Cout, ld_of(dy), kh, kw, stride, pad, dil)
-    check(lib.catseg_conv2d_bwd_data(ctypes.byref(d), ptr(dy), ptr(w), ptr(out), 1 if accumulate else 0, stream()))
+    with _Timed("dgrad", 2.0 * rows_of(dy) * Cout * Cin * kh * kw):
+        check(lib.catseg_conv2d_bwd_data(ctypes.byref(d), ptr(dy), ptr(w), ptr(out), 1 if accumulate else 0, stream()))
     return out
 
 
@@ -83,7 +106,8 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
     d = make_desc(x.shape, ld_of(x), dy.shape[-1], ld_of(dy), kh, kw, stride, pad, dil, stem4)
     need = lib.catseg_conv2d_bwd_weight_workspace(ctypes.byref(d))
     ws = workspace(need, x.device)
-    check(lib.catseg_conv2d_bwd_weight(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), stream()))
+    with _Timed("wgrad", 2.0 * rows_of(dy) * dy.shape[-1] * (3 if stem4 else x.shape[-1]) * kh * kw):
+        check(lib.catseg_conv2d_bwd_weight(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), stream()))
     return dw
 
 
@@ -158,6 +182,13 @@ def axpy(src, dst, alpha=1.0, accumulate=True):
     check(lib.catseg_axpy2d(ptr(src), ld_of(src), ptr(dst), ld_of(dst), rows_of(src), src.shape[-1], alpha,
                             1 if accumulate else 0, stream()))
     return dst
+
+
+def scale_by_device_scalar(x, s):
+    """x *= s (s: 0-dim / 1-element device tensor), in place"""
+    assert x.is_contiguous() and s.numel() == 1 and s.dtype == torch.float32
+    check(lib.catseg_scale_by_device_scalar(ptr(x), x.numel(), ptr(s), stream()))
+    return x
 
 
 def maxpool_fwd(x):

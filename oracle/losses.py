@@ -28,7 +28,7 @@ def lovasz_softmax(logits, target):
     lbl = target.reshape(-1)
     losses = []
     for c in range(C):
-        fg = (lbl == c).float()
+        fg = (lbl == c).to(prob.dtype)
         if fg.sum() == 0:
             continue
         err = (fg - prob[:, c]).abs()
