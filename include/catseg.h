@@ -75,6 +75,9 @@ int catseg_gemm_batched(int layout, int batch, int M, int N, int K, const float*
                         int ldc, long long strideC, int zero_to, int accumulate,
                         catseg_stream_t stream);
 
+/* tuning hook: force the igemm block tile to (64*mi) x (64*ni); mi = 0 restores the heuristic */
+int catseg_debug_set_tile(int mi, int ni);
+
 /* ---- BatchNorm (+ReLU, +residual) — nn.BatchNorm2d/ReLU at e.g. models/OCR.py:74-75,
  * torchvision Bottleneck, models/DeepLabv3Plus.py:98-104.  rows = B*H*W pixels. */
 /* batch statistics + running-stat update.  stats_out = [mean(C), invstd(C)] (biased variance),
@@ -110,6 +113,15 @@ int catseg_stem_unpack_grad(const float* packed_grad, float* dw_ohwi, int O, cat
 /* dst[p, c] (+)= alpha * src[p, c] */
 int catseg_axpy2d(const float* src, int lds, float* dst, int ldd, long long rows, int C, float alpha,
                   int accumulate, catseg_stream_t stream);
+/* out = act(in_0 + ... + in_{n-1}), n <= 4 (HRNet fuse sum, models/HRNetv2.py:237-261); g = dz * (z > 0) */
+int catseg_add_n_act(const float* const* in, const int* ld, int n, float* out, int ldo, long long rows, int C,
+                     int relu, catseg_stream_t stream);
+int catseg_relu_bwd(const float* dz, int lddz, const float* z, int ldz, float* g, int ldg, long long rows, int C,
+                    catseg_stream_t stream);
+/* conv weight [O][taps][cin] -> zero-padded [O][taps][cpad] (unpad = 0) or back (unpad = 1): lets a
+ * 3-channel 3x3 stem (models/HRNetv2.py:311) run on the 4-channel NHWC image */
+int catseg_weight_pad_cin(const float* w, float* out, int O, int taps, int cin, int cpad, int unpad,
+                          catseg_stream_t stream);
 /* x[i] *= s[0], s on the device (applies an upstream loss gradient without a host sync) */
 int catseg_scale_by_device_scalar(float* x, long long n, const float* s, catseg_stream_t stream);
 /* nn.MaxPool2d(3, 2, 1) of the torchvision stem; idx = window position of the max (uint8) */

@@ -35,6 +35,7 @@ _SIGS = {
     "catseg_conv2d_bwd_weight_workspace": (SZ, [P]),
     "catseg_conv2d_bwd_weight": (I, [P, P, P, P, P, P, SZ, P]),
     "catseg_gemm_batched": (I, [I, I, I, I, I, P, I, L, P, I, L, P, I, L, I, I, P]),
+    "catseg_debug_set_tile": (I, [I, I]),
     "catseg_bn_workspace": (SZ, [L, I]),
     "catseg_bn_train_stats": (I, [P, L, I, I, P, F, F, P, P, P, P, P, SZ, P]),
     "catseg_bn_eval_scale": (I, [I, P, P, F, P, P]),
@@ -44,6 +45,9 @@ _SIGS = {
     "catseg_stem_pack_weight": (I, [P, P, I, P]),
     "catseg_stem_unpack_grad": (I, [P, P, I, P]),
     "catseg_axpy2d": (I, [P, I, P, I, L, I, F, I, P]),
+    "catseg_add_n_act": (I, [P, P, I, P, I, L, I, I, P]),
+    "catseg_relu_bwd": (I, [P, I, P, I, P, I, L, I, P]),
+    "catseg_weight_pad_cin": (I, [P, P, I, I, I, I, I, P]),
     "catseg_scale_by_device_scalar": (I, [P, L, P, P]),
     "catseg_maxpool3x3s2_fwd": (I, [P, I, P, I, P, I, I, I, I, I, I, P]),
     "catseg_maxpool3x3s2_bwd": (I, [P, I, P, P, I, I, I, I, I, I, I, P]),

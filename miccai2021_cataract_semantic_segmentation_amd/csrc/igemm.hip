@@ -95,8 +95,11 @@ __device__ __forceinline__ const float* gather_ptr(const Geo& g, const float* ba
   return ok ? base + pix * g.ld + chunk * 4 : g_zero_page;
 }
 
-template <int LAYOUT, int MI, int NI>
-__global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmArgs p) {
+// FAST: the gathered operand is a plain / stride-any forward conv gather (mode 1) or a stride-1
+// backward-data gather (mode 2) with <= 32 taps: the per-K-step address generation is branch-free
+// straight-line code that the scheduler interleaves with the MFMAs.
+template <int LAYOUT, int MI, int NI, bool FAST>
+__global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(const IgemmArgs p) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
   constexpr bool A_KC = (LAYOUT != L_TN);
   constexpr bool B_KC = (LAYOUT == L_NT);
@@ -139,15 +142,36 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmArgs p) {
   // K-contiguous tiles: thread handles chunk position (tid & 3) of row j*64 + (tid >> 2).
   const int kc_row = tid >> 2;
   const int kc_chunk = (tid & 3) ^ ((tid >> 4) & 3);  // logical chunk stored at position tid & 3
+  // Fast gather: per row, the pixel offset of tap (0,0) and a bit mask of the taps that fall inside
+  // the image are computed once; per K-step the address is base + row offset + (uniform) tap offset.
+  constexpr bool fast = FAST;
   int ab[MI], ay[MI], ax[MI];
   bool arv[MI];
+  long long aoff[MI];
+  unsigned amask[MI];
   if (A_KC) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
       const int r = m0 + j * 64 + kc_row;
       arv[j] = r < p.g.rows;
       ab[j] = ay[j] = ax[j] = 0;
+      aoff[j] = 0;
+      amask[j] = 0;
       if (p.g.mode != 0) decode_row(p.g, arv[j] ? r : 0, ab[j], ay[j], ax[j]);
+      if (fast && arv[j]) {
+        {
+          const int sgn = p.g.mode == 1 ? 1 : -1;
+          const int y0 = p.g.mode == 1 ? ay[j] * p.g.stride - p.g.pad : ay[j] + p.g.pad;
+          const int x0 = p.g.mode == 1 ? ax[j] * p.g.stride - p.g.pad : ax[j] + p.g.pad;
+          aoff[j] = (((long long)ab[j] * p.g.H + y0) * p.g.W + x0) * p.g.ld;
+          int t = 0;
+          for (int ky = 0; ky * p.g.kw < p.taps; ++ky)
+            for (int kx = 0; kx < p.g.kw; ++kx, ++t) {
+              const int yy = y0 + sgn * ky * p.g.dil, xx = x0 + sgn * kx * p.g.dil;
+              if ((unsigned)yy < (unsigned)p.g.H && (unsigned)xx < (unsigned)p.g.W) amask[j] |= 1u << t;
+            }
+        }
+      }
     }
   }
 
@@ -160,33 +184,36 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmArgs p) {
   } else {
     nks = p.taps * nck;
   }
-  int tky = 0, tkx = 0, ttap = 0, tck = 0;  // staging cursor (wave-uniform)
+  int tky = 0, tkx = 0, ttap = 0, tck = 0, tks = 0;  // staging cursor (wave-uniform)
   if (LAYOUT == L_TN) {
     ttap = blockIdx.y;
     tky = (p.g.mode == 3) ? ttap : ttap / p.g.kw;
     tkx = (p.g.mode == 3) ? 0 : ttap - tky * p.g.kw;
   }
+  const long long tap_sign = p.g.mode == 2 ? -1 : 1;
 
-  auto stage = [&](int ks, int buf) {
-    float* sA = sA0 + buf * BM * 16;
-    float* sB = sB0 + buf * BN * 16;
+  const float* pa[MI];
+  const float* pb[NI];
+
+  // source addresses of the next K-step (pure VALU/SALU work: overlaps the MFMAs of the current one)
+  auto prep = [&]() {
     if (LAYOUT != L_TN) {
-      // ---- A: gathered pixels, K contiguous
       const int chunk = tck * 4 + kc_chunk;
       const bool cv = chunk * 4 < p.Cred;
+      if (fast) {
+        const long long toff = tap_sign * ((long long)tky * p.g.dil * p.g.W + tkx * p.g.dil) * p.g.ld + chunk * 4;
 #pragma unroll
-      for (int j = 0; j < MI; ++j) {
-        const float* src = gather_ptr(p.g, gbase, arv[j], m0 + j * 64 + kc_row, ab[j], ay[j], ax[j], tky, tkx,
-                                      chunk, cv);
-        glds16(src, sA + (j * 256 + wave * 64) * 4);
+        for (int j = 0; j < MI; ++j) pa[j] = (cv && ((amask[j] >> ttap) & 1u)) ? gbase + aoff[j] + toff : g_zero_page;
+      } else {
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+          pa[j] = gather_ptr(p.g, gbase, arv[j], m0 + j * 64 + kc_row, ab[j], ay[j], ax[j], tky, tkx, chunk, cv);
       }
       if (B_KC) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int n = n0 + j * 64 + kc_row;
-          const bool ok = n < p.N && cv;
-          const float* src = ok ? obase + (long long)n * p.ldo + ttap * p.tap_stride + chunk * 4 : g_zero_page;
-          glds16(src, sB + (j * 256 + wave * 64) * 4);
+          pb[j] = (n < p.N && cv) ? obase + (long long)n * p.ldo + ttap * p.tap_stride + chunk * 4 : g_zero_page;
         }
       } else {
 #pragma unroll
@@ -195,12 +222,17 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmArgs p) {
           const int krow = q / (16 * NI), cc = q % (16 * NI);
           const int k = tck * 16 + krow;
           const bool ok = k < p.Cred_b && (n0 + cc * 4) < ((p.N + 3) & ~3);
-          const float* src = ok ? obase + (long long)k * p.ldo + ttap * p.tap_stride + n0 + cc * 4 : g_zero_page;
-          glds16(src, sB + (j * 256 + wave * 64) * 4);
+          pb[j] = ok ? obase + (long long)k * p.ldo + ttap * p.tap_stride + n0 + cc * 4 : g_zero_page;
         }
       }
-      // advance cursor
-      if (++tck == nck) {
+      if (FAST) {  // branch-free cursor advance
+        const int nt = tck + 1, nx = tkx + 1;
+        const bool wrap = nt == nck, wrapx = wrap && (nx == p.g.kw);
+        tck = wrap ? 0 : nt;
+        ttap += wrap ? 1 : 0;
+        tkx = wrap ? (wrapx ? 0 : nx) : tkx;
+        tky += wrapx ? 1 : 0;
+      } else if (++tck == nck) {
         tck = 0;
         ++ttap;
         if (p.g.mode == 3) {
@@ -211,15 +243,15 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmArgs p) {
         }
       }
     } else {
-      const int kbase = r_begin + ks * 16;
+      const int kbase = r_begin + tks * 16;
+      ++tks;
 #pragma unroll
       for (int j = 0; j < MI; ++j) {
         const int q = j * 256 + tid;
         const int krow = q / (16 * MI), cc = q % (16 * MI);
         const int r = kbase + krow;
         const bool ok = r < r_end && (m0 + cc * 4) < ((p.M + 3) & ~3);
-        const float* src = ok ? obase + (long long)r * p.ldo + m0 + cc * 4 : g_zero_page;
-        glds16(src, sA + (j * 256 + wave * 64) * 4);
+        pa[j] = ok ? obase + (long long)r * p.ldo + m0 + cc * 4 : g_zero_page;
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
@@ -228,75 +260,89 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmArgs p) {
         const int r = kbase + krow;
         const bool rv = r < r_end;
         int b = 0, y = 0, x = 0;
-        if (p.g.mode != 0) decode_row(p.g, rv ? r : 0, b, y, x);
         const int chunk = (n0 >> 2) + cc;
-        const float* src = gather_ptr(p.g, gbase, rv, r, b, y, x, tky, tkx, chunk, chunk * 4 < ((p.N + 3) & ~3));
-        glds16(src, sB + (j * 256 + wave * 64) * 4);
+        const bool cvv = chunk * 4 < ((p.N + 3) & ~3);
+        if (FAST) {  // forward-conv gather (plain GEMM rows are passed as a degenerate 1-wide image)
+          decode_row(p.g, rv ? r : 0, b, y, x);
+          const int iy = y * p.g.stride - p.g.pad + tky * p.g.dil;
+          const int ix = x * p.g.stride - p.g.pad + tkx * p.g.dil;
+          const bool ok = rv && cvv && (unsigned)iy < (unsigned)p.g.H && (unsigned)ix < (unsigned)p.g.W;
+          pb[j] = ok ? gbase + (((long long)b * p.g.H + iy) * p.g.W + ix) * p.g.ld + chunk * 4 : g_zero_page;
+        } else {
+          if (p.g.mode != 0) decode_row(p.g, rv ? r : 0, b, y, x);
+          pb[j] = gather_ptr(p.g, gbase, rv, r, b, y, x, tky, tkx, chunk, cvv);
+        }
       }
     }
   };
 
-  auto compute = [&](int buf) {
+  auto issue = [&](int buf) {
+    float* sA = sA0 + buf * BM * 16;
+    float* sB = sB0 + buf * BN * 16;
+#pragma unroll
+    for (int j = 0; j < MI; ++j) glds16(pa[j], sA + (j * 256 + wave * 64) * 4);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) glds16(pb[j], sB + (j * 256 + wave * 64) * 4);
+  };
+
+  auto compute = [&](int buf, bool more) {
     const float* sA = sA0 + buf * BM * 16;
     const float* sB = sB0 + buf * BN * 16;
-    float a[MI][2][4], b[NI][2][4];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int row = wm * 32 * MI + mi * 32 + l31;
+    for (int jj = 0; jj < 2; ++jj) {
+      float a[MI][4], b[NI][4];
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * 32 * MI + mi * 32 + l31;
         if (A_KC) {
           const int pos = (2 * jj + h) ^ ((row >> 2) & 3);
           const f32x4 v = *(const f32x4*)(sA + row * 16 + pos * 4);
-          a[mi][jj][0] = v[0]; a[mi][jj][1] = v[1]; a[mi][jj][2] = v[2]; a[mi][jj][3] = v[3];
+          a[mi][0] = v[0]; a[mi][1] = v[1]; a[mi][2] = v[2]; a[mi][3] = v[3];
         } else {
 #pragma unroll
-          for (int ii = 0; ii < 4; ++ii) a[mi][jj][ii] = sA[(8 * jj + 4 * h + ii) * BM + row];
+          for (int ii = 0; ii < 4; ++ii) a[mi][ii] = sA[(8 * jj + 4 * h + ii) * BM + row];
         }
       }
-    }
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int row = wn * 32 * NI + ni * 32 + l31;
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
+      for (int ni = 0; ni < NI; ++ni) {
+        const int row = wn * 32 * NI + ni * 32 + l31;
         if (B_KC) {
           const int pos = (2 * jj + h) ^ ((row >> 2) & 3);
           const f32x4 v = *(const f32x4*)(sB + row * 16 + pos * 4);
-          b[ni][jj][0] = v[0]; b[ni][jj][1] = v[1]; b[ni][jj][2] = v[2]; b[ni][jj][3] = v[3];
+          b[ni][0] = v[0]; b[ni][1] = v[1]; b[ni][2] = v[2]; b[ni][3] = v[3];
         } else {
 #pragma unroll
-          for (int ii = 0; ii < 4; ++ii) b[ni][jj][ii] = sB[(8 * jj + 4 * h + ii) * BN + row];
+          for (int ii = 0; ii < 4; ++ii) b[ni][ii] = sB[(8 * jj + 4 * h + ii) * BN + row];
         }
       }
-    }
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
+      if (jj == 0 && (FAST || more)) prep();  // address math for the K-step after next rides under the MFMAs
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][jj][ii], b[ni][jj][ii], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][ii], b[ni][ii], acc[mi][ni], 0, 0, 0);
+    }
   };
 
-  // ---- main loop: stage(k+1) in flight while computing k ---------------------------------
+  // ---- main loop: K-step k+1 is in flight (LDS-DMA) while k is computed; addresses of k+2 are
+  // prepared inside the MFMA region ------------------------------------------------------------
   if (nks > 0) {
-    stage(0, 0);
+    prep();
+    issue(0);
+    if (nks > 1) prep();
     for (int ks = 0; ks < nks; ++ks) {
       const int cur = ks & 1;
       if (ks + 1 < nks) {
-        stage(ks + 1, cur ^ 1);
-        if (MI + NI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (MI + NI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        issue(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(MI + NI) : "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      compute(cur);
+      compute(cur, ks + 2 < nks);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -362,20 +408,37 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, 
   out[c] = s;
 }
 
-template <int LAYOUT>
-int launch_igemm(const IgemmArgs& a0, int nbatch, int grid_y, hipStream_t st) {
+int g_force_mi = 0, g_force_ni = 0;  // tuning hook (catseg_debug_set_tile)
+
+template <int LAYOUT, int MI, int NI>
+void launch_one(const IgemmArgs& a0, int ncols, int nbatch, int grid_y, hipStream_t st) {
   IgemmArgs a = a0;
-  // tile choice: 128x128 by default, narrower tiles for narrow outputs
-  const int ncols = a.zero_to > a.N ? a.zero_to : a.N;  // pad columns to be zero-filled are visited too
-  const int mi = (a.M > 64) ? 2 : 1;
-  const int ni = (ncols > 64) ? 2 : 1;
-  a.tilesM = (a.M + 64 * mi - 1) / (64 * mi);
-  a.tilesN = (ncols + 64 * ni - 1) / (64 * ni);
+  a.tilesM = (a.M + 64 * MI - 1) / (64 * MI);
+  a.tilesN = (ncols + 64 * NI - 1) / (64 * NI);
   dim3 grid(a.tilesM * a.tilesN, grid_y, nbatch * (LAYOUT == L_TN ? a.splits : 1));
-  if (mi == 2 && ni == 2) hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, 2, 2>), grid, dim3(256), 0, st, a);
-  else if (mi == 2 && ni == 1) hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, 2, 1>), grid, dim3(256), 0, st, a);
-  else if (mi == 1 && ni == 2) hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, 1, 2>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, 1, 1>), grid, dim3(256), 0, st, a);
+  const bool fast = LAYOUT == L_TN ? a.g.mode == 1
+                                   : (a.taps <= 32 && (a.g.mode == 1 || (a.g.mode == 2 && a.g.stride == 1)));
+  if (fast) hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, MI, NI, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, MI, NI, false>), grid, dim3(256), 0, st, a);
+}
+
+template <int LAYOUT>
+int launch_igemm(const IgemmArgs& a, int nbatch, int grid_y, hipStream_t st) {
+  const int ncols = a.zero_to > a.N ? a.zero_to : a.N;  // pad columns to be zero-filled are visited too
+  int mi = (a.M > 64) ? 2 : 1;
+  int ni = (ncols > 64) ? 2 : 1;
+  if (LAYOUT != L_TN) {
+    // big problems: 256-row tiles (less L2->LDS traffic per FLOP) as long as the grid still fills the chip
+    const long long t22 = (long long)((a.M + 127) / 128) * ((ncols + 127) / 128) * nbatch;
+    if (mi == 2 && ni == 2 && a.M >= 4096 && t22 >= 2048) mi = 4;
+  }
+  if (g_force_mi > 0) { mi = g_force_mi; ni = g_force_ni; }
+#define CS_TILE(M_, N_) if (mi == M_ && ni == N_) launch_one<LAYOUT, M_, N_>(a, ncols, nbatch, grid_y, st); else
+  CS_TILE(1, 1) CS_TILE(1, 2) CS_TILE(2, 1) CS_TILE(2, 2) CS_TILE(4, 2) CS_TILE(2, 4) CS_TILE(4, 4) {
+    catseg_set_error("igemm: unsupported tile %dx%d", mi, ni);
+    return CATSEG_EINVAL;
+  }
+#undef CS_TILE
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
@@ -402,6 +465,12 @@ Geo fwd_geo(const catseg_conv_desc* d, const float* x) {
 }
 
 }  // namespace
+
+extern "C" int catseg_debug_set_tile(int mi, int ni) {
+  g_force_mi = mi;
+  g_force_ni = ni;
+  return CATSEG_OK;
+}
 
 extern "C" int catseg_conv2d_fwd(const catseg_conv_desc* d, const float* x, const float* w, const float* bias,
                                  float* y, int zero_to, catseg_stream_t stream) {
@@ -442,7 +511,8 @@ void wgrad_plan(const catseg_conv_desc* d, int& splits, int& rps) {
   const long long rows = (long long)d->B * d->Ho * d->Wo;
   const int N = d->stem4 ? 32 : d->Cin;
   const int taps = d->stem4 ? d->kh : d->kh * d->kw;
-  const int mi = d->Cout > 64 ? 2 : 1, ni = N > 64 ? 2 : 1;
+  int mi = d->Cout > 64 ? 2 : 1, ni = N > 64 ? 2 : 1;
+  if (g_force_mi > 0) { mi = g_force_mi; ni = g_force_ni; }
   const long long tiles = (long long)((d->Cout + 64 * mi - 1) / (64 * mi)) * ((N + 64 * ni - 1) / (64 * ni)) * taps;
   long long want = (1024 + tiles - 1) / tiles;  // ~4 blocks per CU
   const long long maxs = (rows + 255) / 256;    // at least 16 K-steps per split
@@ -514,23 +584,23 @@ extern "C" int catseg_gemm_batched(int layout, int batch, int M, int N, int K, c
   CS_REQUIRE(zero_to <= ldc, "gemm: zero_to > ldc");
   IgemmArgs a = {};
   Geo& g = a.g;
-  g.mode = 0; g.H = g.W = g.Ho = g.Wo = 1; g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1;
+  g.mode = 1; g.W = g.Wo = 1; g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1;  // rows = a 1-pixel-wide image
   a.C = C; a.ldc = ldc; a.c_bs = strideC; a.M = M; a.N = N; a.zero_to = zero_to; a.accumulate = accumulate;
   a.taps = 1; a.tap_stride = 0;
   hipStream_t st = (hipStream_t)stream;
   if (layout == CATSEG_GEMM_NT) {
     CS_REQUIRE(K % 4 == 0 && lda >= K && ldb >= K, "gemm NT: K must be a multiple of 4 and <= lda, ldb");
-    g.base = A; g.rows = M; g.ld = lda; a.g_bs = strideA;
+    g.base = A; g.rows = M; g.H = g.Ho = M; g.ld = lda; a.g_bs = strideA;
     a.other = Bm; a.ldo = ldb; a.o_bs = strideB; a.Cred = K; a.Cred_b = K;
     return launch_igemm<L_NT>(a, batch, 1, st);
   } else if (layout == CATSEG_GEMM_NN) {
     CS_REQUIRE(lda >= ((K + 3) & ~3) && ldb >= ((N + 3) & ~3), "gemm NN: lda/ldb too small");
-    g.base = A; g.rows = M; g.ld = lda; a.g_bs = strideA;
+    g.base = A; g.rows = M; g.H = g.Ho = M; g.ld = lda; a.g_bs = strideA;
     a.other = Bm; a.ldo = ldb; a.o_bs = strideB; a.Cred = (K + 3) & ~3; a.Cred_b = K;
     return launch_igemm<L_NN>(a, batch, 1, st);
   } else if (layout == CATSEG_GEMM_TN) {
     CS_REQUIRE(lda >= ((M + 3) & ~3) && ldb >= ((N + 3) & ~3), "gemm TN: lda/ldb too small");
-    g.base = Bm; g.rows = K; g.ld = ldb; a.g_bs = strideB;
+    g.base = Bm; g.rows = K; g.H = g.Ho = K; g.ld = ldb; a.g_bs = strideB;
     a.other = A; a.ldo = lda; a.o_bs = strideA;
     a.splits = 1; a.rows_per_split = (K + 15) / 16 * 16; a.c_split_stride = 0; a.c_tap_stride = 0;
     return launch_igemm<L_TN>(a, batch, 1, st);

@@ -22,7 +22,10 @@ RowSplit plan_rows(long long rows, int C) {
   s.tpr = cpt < 64 ? cpt : 64;
   s.rpp = 256 / s.tpr;
   s.gy = (cpt + s.tpr - 1) / s.tpr;
-  long long rpb = (rows + kMaxRowBlocks - 1) / kMaxRowBlocks;
+  int want = 2048 / s.gy;  // ~2048 blocks in total fill the chip; fewer partials = cheaper merge
+  if (want > kMaxRowBlocks) want = kMaxRowBlocks;
+  if (want < 64) want = 64;
+  long long rpb = (rows + want - 1) / want;
   if (rpb < 4 * s.rpp) rpb = 4 * s.rpp;
   rpb = (rpb + s.rpp - 1) / s.rpp * s.rpp;
   s.rpb = rpb;
@@ -71,23 +74,39 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nrb, long long rpb, long long rows, int C,
-                                   const float* __restrict__ gamma, float eps, float momentum, float* running_mean,
-                                   float* running_var, float* __restrict__ stats, float* __restrict__ scale) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// merge of the per-row-block partials: block = 64 channels (lanes, coalesced) x 16 row-block lanes,
+// fp64 Chan updates, then a 16-way combine through LDS
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nrb, long long rpb, long long rows, int C,
+                                                           const float* __restrict__ gamma, float eps, float momentum, float* running_mean,
+                                                           float* running_var, float* __restrict__ stats, float* __restrict__ scale) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double n = 0, mean = 0, m2 = 0;
-  for (int b = 0; b < nrb; ++b) {
-    const long long r0 = (long long)b * rpb;
-    const double nb = (double)(min(r0 + rpb, rows) - r0);
-    const float* o = part + ((long long)b * 3) * C;
-    const double K = o[c], s1 = o[C + c], s2 = o[2 * C + c];
-    const double mb = K + s1 / nb;
-    const double m2b = s2 - s1 * s1 / nb;
-    const double tot = n + nb;
-    const double delta = mb - mean;
+  if (c < C) {
+    for (int b = rl; b < nrb; b += 16) {
+      const long long r0 = (long long)b * rpb;
+      const double nb = (double)(min(r0 + rpb, rows) - r0);
+      const float* o = part + ((long long)b * 3) * C;
+      const double K = o[c], s1 = o[C + c], s2 = o[2 * C + c];
+      const double mb = K + s1 / nb;
+      const double m2b = s2 - s1 * s1 / nb;
+      const double tot = n + nb;
+      const double delta = mb - mean;
+      mean += delta * nb / tot;
+      m2 += m2b + delta * delta * n * nb / tot;
+      n = tot;
+    }
+  }
+  __shared__ double sn[16][64], sm[16][64], s2[16][64];
+  sn[rl][cl] = n; sm[rl][cl] = mean; s2[rl][cl] = m2;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  for (int k = 1; k < 16; ++k) {
+    const double nb = sn[k][cl];
+    if (nb == 0) continue;
+    const double tot = n + nb, delta = sm[k][cl] - mean;
     mean += delta * nb / tot;
-    m2 += m2b + delta * delta * n * nb / tot;
+    m2 += s2[k][cl] + delta * delta * n * nb / tot;
     n = tot;
   }
   const float var = (float)(m2 / n);
@@ -168,16 +187,22 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nrb, long long rows, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nrb, long long rows, int C,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double sg = 0, sgx = 0;
-  for (int b = 0; b < nrb; ++b) {
-    const float* o = part + ((long long)b * 2) * C;
-    sg += o[c];
-    sgx += o[C + c];
-  }
+  if (c < C)
+    for (int b = rl; b < nrb; b += 16) {
+      const float* o = part + ((long long)b * 2) * C;
+      sg += o[c];
+      sgx += o[C + c];
+    }
+  __shared__ double s1[16][64], s2[16][64];
+  s1[rl][cl] = sg; s2[rl][cl] = sgx;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  for (int k = 1; k < 16; ++k) { sg += s1[k][cl]; sgx += s2[k][cl]; }
   if (dbeta) dbeta[c] = (float)sg;
   if (dgamma) dgamma[c] = (float)sgx;
   coef[c] = (float)(sg / (double)rows);
@@ -237,7 +262,7 @@ extern "C" int catseg_bn_train_stats(const float* y, long long rows, int C, int 
   const RowSplit s = plan_rows(rows, C);
   float* part = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, y, ldy, rows, C, s, part);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)part, s.nrb, s.rpb, rows, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, (const float*)part, s.nrb, s.rpb, rows, C,
                      gamma, eps, momentum, running_mean, running_var, stats_out, scale);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
@@ -282,7 +307,7 @@ extern "C" int catseg_bn_backward(const float* dz, int lddz, const float* z, int
   float* part = (float*)workspace;
   float* coef = part + (size_t)kMaxRowBlocks * 3 * ((C + 3) & ~3);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, rows, C, relu, s, part);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma,
                      (const float*)coef, rows, C, relu, dy, lddy, dres, lddres, dres_accumulate);
   CS_LAUNCH_CHECK();

@@ -59,6 +59,52 @@ __global__ void scale_dev_kernel(float* __restrict__ x, long long n, const float
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) x[(n4 << 2) + threadIdx.x] *= a;
 }
 
+// out = act(sum_i in_i)  (HRNet fuse: up to 4 same-resolution terms), all [rows][ld_i]
+struct AddArgs {
+  const float* in[4];
+  int ld[4];
+  int n;
+};
+__global__ void add_n_act_kernel(AddArgs a, float* __restrict__ out, int ldo, long long rows, int C, int relu) {
+  const int cpt = C >> 2;
+  const long long total = rows * cpt;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cpt;
+    const int c = (int)(i - r * cpt) * 4;
+    f32x4 v = *(const f32x4*)(a.in[0] + r * a.ld[0] + c);
+    for (int k = 1; k < a.n; ++k) v += *(const f32x4*)(a.in[k] + r * a.ld[k] + c);
+    if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    *(f32x4*)(out + r * ldo + c) = v;
+  }
+}
+// g = dz * (z > 0)
+__global__ void relu_bwd_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz, float* __restrict__ g, int ldg,
+                                long long rows, int C) {
+  const int cpt = C >> 2;
+  const long long total = rows * cpt;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cpt;
+    const int c = (int)(i - r * cpt) * 4;
+    f32x4 d = *(const f32x4*)(dz + r * lddz + c);
+    const f32x4 zz = *(const f32x4*)(z + r * ldz + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = zz[k] > 0.f ? d[k] : 0.f;
+    *(f32x4*)(g + r * ldg + c) = d;
+  }
+}
+// conv weight [O][T][cin] <-> zero-padded [O][T][cpad]
+__global__ void weight_pad_kernel(const float* __restrict__ w, float* __restrict__ pk, int n, int cin, int cpad, int unpad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (!unpad) {
+    const int c = i % cpad, ot = i / cpad;
+    pk[i] = c < cin ? w[ot * cin + c] : 0.f;
+  } else {
+    const int c = i % cin, ot = i / cin;
+    pk[i] = w[ot * cpad + c];
+  }
+}
+
 // ------------------------------------------------------------------ maxpool 3x3 / 2 / pad 1
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, uint8_t* __restrict__ idx,
                                    int B, int H, int W, int C, int Ho, int Wo) {
@@ -385,6 +431,35 @@ extern "C" int catseg_axpy2d(const float* src, int lds, float* dst, int ldd, lon
                              int accumulate, catseg_stream_t stream) {
   CS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && cs_aligned16(src) && cs_aligned16(dst), "axpy2d: C/ld multiples of 4, 16-B aligned");
   hipLaunchKernelGGL(axpy2d_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, rows, C, alpha, accumulate);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_add_n_act(const float* const* in, const int* ld, int n, float* out, int ldo, long long rows, int C, int relu,
+                                catseg_stream_t stream) {
+  CS_REQUIRE(n >= 1 && n <= 4 && rows > 0 && C > 0 && C % 4 == 0 && ldo % 4 == 0 && cs_aligned16(out), "add_n: bad args");
+  AddArgs a;
+  a.n = n;
+  for (int i = 0; i < 4; ++i) {
+    a.in[i] = i < n ? in[i] : nullptr;
+    a.ld[i] = i < n ? ld[i] : 0;
+    if (i < n) CS_REQUIRE(cs_aligned16(in[i]) && ld[i] % 4 == 0, "add_n: input %d misaligned", i);
+  }
+  hipLaunchKernelGGL(add_n_act_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, out, ldo, rows, C, relu);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_relu_bwd(const float* dz, int lddz, const float* z, int ldz, float* g, int ldg, long long rows, int C,
+                               catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && lddz % 4 == 0 && ldz % 4 == 0 && ldg % 4 == 0 && cs_aligned16(dz) && cs_aligned16(z) && cs_aligned16(g),
+             "relu_bwd: bad args");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz, g, ldg, rows, C);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+extern "C" int catseg_weight_pad_cin(const float* w, float* out, int O, int taps, int cin, int cpad, int unpad, catseg_stream_t stream) {
+  CS_REQUIRE(O > 0 && taps > 0 && cin > 0 && cpad >= cin, "weight_pad: bad args");
+  const int n = O * taps * (unpad ? cin : cpad);
+  hipLaunchKernelGGL(weight_pad_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, out, n, cin, cpad, unpad);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

@@ -98,6 +98,7 @@ class Ctx:
         self.record = record
         self.tape = []
         self.grads = {}
+        self.shared = set()
         self.on_param_grad = on_param_grad
 
     def push(self, fn):
@@ -105,20 +106,33 @@ class Ctx:
             self.tape.append(fn)
 
     def take(self, t):
+        self.shared.discard(id(t))
         return self.grads.pop(id(t), None)
 
-    def give(self, t, g):
-        cur = self.grads.get(id(t))
-        if cur is None:
+    def _own(self, t):
+        """a gradient buffer that several activations share (fan-out of an add) is copied before
+        anything is accumulated into it"""
+        k = id(t)
+        if k in self.shared:
+            self.shared.discard(k)
+            src = self.grads[k]
+            own = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+            ops.axpy(src, own, 1.0, False)
+            self.grads[k] = own
+        return self.grads[k]
+
+    def give(self, t, g, shared=False):
+        if id(t) not in self.grads:
             self.grads[id(t)] = g
+            if shared:
+                self.shared.add(id(t))
         else:
-            ops.axpy(g, cur, 1.0, True)
+            ops.axpy(g, self._own(t), 1.0, True)
 
     def dest(self, t):
         """buffer the gradient of activation t must be written to: (buffer, accumulate?)"""
-        cur = self.grads.get(id(t))
-        if cur is not None:
-            return cur, True
+        if id(t) in self.grads:
+            return self._own(t), True
         C = t.shape[-1]
         ld = ops.ld_of(t) if t.dim() == 4 else C
         if t.dim() == 4 and ld != C and ld <= 64:   # small padded rows (class logits): keep the zero pad
@@ -142,6 +156,7 @@ class Ctx:
         while tape:
             tape.pop()()
         self.grads.clear()
+        self.shared.clear()
 
 
 # --------------------------------------------------------------------------- fused layers
@@ -152,9 +167,13 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
     Cout = w.shape[0]
     kh, kw = conv.kernel_size
     s, p, d = conv.stride[0], conv.padding[0], conv.dilation[0]
+    pad3 = (not conv.stem) and w.shape[1] == 3       # 3-channel image into a generic conv (HRNet 3x3/2 stem)
     if conv.stem:
         x_in = ops.nchw3_to_nhwc4(x)
         wk = ops.stem_pack_weight(w.data, Cout)
+    elif pad3:
+        x_in = ops.nchw3_to_nhwc4(x)
+        wk = ops.weight_pad_cin(w.data, Cout, kh * kw, 3, 4)
     else:
         x_in, wk = x, w.data
     bias = conv.bias.data if conv.bias is not None else None
@@ -186,6 +205,10 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
                 dpk = torch.empty_like(wk)
                 ops.conv_bwd_weight(x_in, dy, dpk, dbias, kh, kw, s, p, d, stem4=True)
                 ops.stem_unpack_grad(dpk, cx.pgrad(w), Cout)
+            elif pad3:
+                dpk = torch.empty_like(wk)
+                ops.conv_bwd_weight(x_in, dy, dpk, dbias, kh, kw, s, p, d)
+                ops.weight_unpad_cin(dpk, cx.pgrad(w), Cout, kh * kw, 3, 4)
             else:
                 ops.conv_bwd_weight(x_in, dy, cx.pgrad(w), dbias, kh, kw, s, p, d)
                 if need_dx:
@@ -215,6 +238,21 @@ def conv_bias(cx, x, conv, pad_to=32):
             dx, acc = cx.dest(x)
             ops.conv_bwd_data(dy, w.data, tuple(x.shape), kh, kw, s, p, d, out=dx, accumulate=acc)
             cx.done(w, conv.bias)
+        cx.push(bwd)
+    return y
+
+
+def add_n(cx, terms, relu=True):
+    """y = act(sum(terms)) — the HRNet fuse (models/HRNetv2.py:237-261); terms share one shape"""
+    y = ops.add_n_act(terms, relu)
+    if cx.record:
+        def bwd():
+            dy = cx.take(y)
+            if dy is None:
+                return
+            g = ops.relu_bwd(dy, y) if relu else dy
+            for t in terms:
+                cx.give(t, g, shared=len(terms) > 1)
         cx.push(bwd)
     return y
 

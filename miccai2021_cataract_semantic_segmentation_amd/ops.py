@@ -302,3 +302,32 @@ def confusion_matrix(logits, labels, cm=None):
 
 def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     check(lib.catseg_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, stream()))
+
+
+def add_n_act(terms, relu, out=None):
+    """out = act(sum(terms)); terms: up to 4 NHWC tensors of one shape (row strides may differ)"""
+    t0 = terms[0]
+    if out is None:
+        out = torch.empty(t0.shape, dtype=torch.float32, device=t0.device)
+    n = len(terms)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in terms])
+    lds = (ctypes.c_int * n)(*[ld_of(t) for t in terms])
+    check(lib.catseg_add_n_act(ptrs, lds, n, ptr(out), ld_of(out), rows_of(t0), t0.shape[-1], 1 if relu else 0, stream()))
+    return out
+
+
+def relu_bwd(dz, z):
+    g = torch.empty(z.shape, dtype=torch.float32, device=z.device)
+    check(lib.catseg_relu_bwd(ptr(dz), ld_of(dz), ptr(z), ld_of(z), ptr(g), ld_of(g), rows_of(z), z.shape[-1], stream()))
+    return g
+
+
+def weight_pad_cin(w, O, taps, cin, cpad):
+    out = torch.empty((O, taps, cpad), dtype=torch.float32, device=w.device)
+    check(lib.catseg_weight_pad_cin(ptr(w), ptr(out), O, taps, cin, cpad, 0, stream()))
+    return out
+
+
+def weight_unpad_cin(pk, dw, O, taps, cin, cpad):
+    check(lib.catseg_weight_pad_cin(ptr(pk), ptr(dw), O, taps, cin, cpad, 1, stream()))
+    return dw

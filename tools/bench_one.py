@@ -1,0 +1,20 @@
+"""Run one conv shape repeatedly (for rocprofv3 --pmc passes).  usage: bench_one.py [fwd|dgrad|wgrad] [n]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from miccai2021_cataract_semantic_segmentation_amd import ops
+kind = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+dev = torch.device("cuda")
+B, H, W, Ci, Co, k, s, p, d = 8, 68, 120, 512, 512, 3, 1, 4, 4
+x = torch.randn(B, H, W, Ci, device=dev)
+w = (torch.randn(Co, Ci, k, k, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+y = ops.conv_fwd(x, w, None, Co, k, k, s, p, d)
+dy = torch.randn_like(y); dx = torch.empty_like(x); dw = torch.empty_like(w)
+torch.cuda.synchronize()
+for _ in range(n):
+    if kind == "fwd": ops.conv_fwd(x, w, None, Co, k, k, s, p, d, out=y)
+    elif kind == "dgrad": ops.conv_bwd_data(dy, w, tuple(x.shape), k, k, s, p, d, out=dx)
+    else: ops.conv_bwd_weight(x, dy, dw, None, k, k, s, p, d)
+torch.cuda.synchronize()
+print("done", kind, 2.0 * y.numel() * Ci * k * k / 1e9, "GF per launch")
