@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Headline benchmark: training frames/s of OCRNet (ResNet50, output stride 8, 25 classes) with the
-TwoScale Lovasz-Softmax loss and Adam, batch 8 per GPU at 3x544x960 (a 540x960 frame after the
-reference's 'pad' transform), synthetic data, random-init weights, fp32.
+"""Headline benchmark: training frames/s of OCRNet (25 classes) with the TwoScale Lovasz-Softmax loss and
+Adam, batch 8 per GPU at 3x544x960 (a 540x960 frame after the reference's 'pad' transform), synthetic
+data, random-init weights, fp32.  --model ocrnet_hrnet48 (default; the configuration BASELINE.json's
+metric names: HRNetV2-W48 trunk + the reference's OCR heads) or ocrnet_r50 (the OCRNet the reference ships,
+configs/OCRNet_rf_lvsz.json: ResNet50, output stride 8).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -33,7 +35,13 @@ def synth_batch(B, H, W, K, seed, device):
     return img.to(device), lbl.to(device)
 
 
-def cpu_baseline(H, W, K):
+MODELS = {
+    "ocrnet_hrnet48": ({"backbone": "hrnet48", "pretrained": False}, "OCRNet-HRNetV2-W48 (stride-4 720-ch concat + OCR heads)"),
+    "ocrnet_r50": ({"backbone": "resnet50", "out_stride": 8, "pretrained": False}, "OCRNet-ResNet50-OS8"),
+}
+
+
+def cpu_baseline(H, W, K, model_name):
     """the CPU oracle (port of the reference path) on this box's host cores: 1 train step, batch 1"""
     from oracle import nets as ON, losses as OL
     from oracle.state import fill_state, spec_of
@@ -45,7 +53,8 @@ def cpu_baseline(H, W, K):
     cores = max(1, min(avail, 32))   # beyond ~32 threads the sort / BN phases of this step stop scaling
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    spec = spec_of(OCRNet({"backbone": "resnet50", "out_stride": 8, "pretrained": False}, 3).state_dict())
+    spec = spec_of(OCRNet(dict(MODELS[model_name][0]), 3).state_dict())
+    fwd = ON.ocrnet_hrnet_forward if "hrnet" in model_name else ON.ocrnet_forward
     S = fill_state(spec, 0)
     params = [k for k, v in S.items() if v.dtype.is_floating_point and "running" not in k]
     for k in params:
@@ -54,7 +63,7 @@ def cpu_baseline(H, W, K):
     m = {k: torch.zeros_like(S[k]) for k in params}
     v = {k: torch.zeros_like(S[k]) for k in params}
     t0 = time.perf_counter()
-    oi, of = ON.ocrnet_forward(S, img, train=True)
+    oi, of = fwd(S, img, train=True)
     loss = OL.two_scale_lovasz(oi, of, lbl)
     loss.backward()
     with torch.no_grad():
@@ -74,6 +83,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU")
     ap.add_argument("--height", type=int, default=544)
     ap.add_argument("--width", type=int, default=960)
+    ap.add_argument("--model", default="ocrnet_hrnet48", choices=sorted(MODELS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -93,7 +103,7 @@ def main():
 
     K, B, H, W = 25, args.batch, args.height, args.width
     torch.manual_seed(0)
-    model = OCRNet({"backbone": "resnet50", "out_stride": 8, "pretrained": False}, 3).to(dev).train()
+    model = OCRNet(dict(MODELS[args.model][0]), 3).to(dev).train()
     crit = TwoScaleLoss({"experiment": 3, "interm": {"name": "LovaszSoftmax", "args": [], "weight": 0.4},
                          "final": {"name": "LovaszSoftmax", "args": [], "weight": 1.0}})
     gscale = 1.0
@@ -155,7 +165,7 @@ def main():
                               for k, v in agg.items()}}
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
-        cpu = cpu_baseline(H, W, K)
+        cpu = cpu_baseline(H, W, K, args.model)
     if world > 1:
         dist.barrier()
 
@@ -165,9 +175,9 @@ def main():
             "value": world * B * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "OCRNet-ResNet50-OS8, 25-class (task 3), bs=%d/GPU @3x%dx%d, TwoScale Lovasz-Softmax, "
-                                   "Adam lr 1e-4 (reference configs/OCRNet_rf_lvsz.json; the reference has no HRNet-W48 OCRNet)"
-                                   % (B, H, W),
+            "config": {"workload": "%s, 25-class (task 3), bs=%d/GPU @3x%dx%d, TwoScale Lovasz-Softmax (0.4 interm + 1.0 final), "
+                                   "Adam lr 1e-4, loss/optimiser of reference configs/OCRNet_rf_lvsz.json" % (MODELS[args.model][1], B, H, W),
+                       "model": args.model,
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": final_loss},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -422,17 +422,49 @@ void launch_one(const IgemmArgs& a0, int ncols, int nbatch, int grid_y, hipStrea
   else hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, MI, NI, false>), grid, dim3(256), 0, st, a);
 }
 
-template <int LAYOUT>
-int launch_igemm(const IgemmArgs& a, int nbatch, int grid_y, hipStream_t st) {
-  const int ncols = a.zero_to > a.N ? a.zero_to : a.N;  // pad columns to be zero-filled are visited too
-  int mi = (a.M > 64) ? 2 : 1;
-  int ni = (ncols > 64) ? 2 : 1;
-  if (LAYOUT != L_TN) {
-    // big problems: 256-row tiles (less L2->LDS traffic per FLOP) as long as the grid still fills the chip
-    const long long t22 = (long long)((a.M + 127) / 128) * ((ncols + 127) / 128) * nbatch;
-    if (mi == 2 && ni == 2 && a.M >= 4096 && t22 >= 2048) mi = 4;
+// Tile / split planner.  score = (intrinsic efficiency of the tile) x (useful fraction of the padded
+// tiles) x (wave-quantisation efficiency of the grid on 256 CUs x resident blocks per CU).
+struct TilePlan { int mi, ni, splits, rps; };
+struct TileInfo { int mi, ni, occ; float eff; };
+const TileInfo kTiles[] = {{1, 1, 8, 0.80f}, {2, 1, 6, 0.88f}, {1, 2, 6, 0.86f}, {2, 2, 3, 0.96f}, {4, 2, 2, 1.00f}, {2, 4, 2, 0.97f}};
+
+TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, long long red_rows) {
+  TilePlan best = {2, 2, 1, 0};
+  double best_score = -1;
+  for (const TileInfo& t : kTiles) {
+    if (g_force_mi > 0 && (t.mi != g_force_mi || t.ni != g_force_ni)) continue;
+    const long long tm = (M + 64 * t.mi - 1) / (64 * t.mi), tn = (ncols + 64 * t.ni - 1) / (64 * t.ni);
+    const double pad = (double)(M * ncols) / (double)(tm * 64 * t.mi * tn * 64 * t.ni);
+    const double slots = 256.0 * t.occ;
+    long long maxs = 1;
+    if (layout == L_TN) {
+      maxs = red_rows / 512;  // at least 32 K-steps per split
+      if (maxs > 96) maxs = 96;
+      if (maxs < 1) maxs = 1;
+    }
+    for (long long sp = 1; sp <= maxs; ++sp) {
+      const double rounds = (double)(tm * tn * extra * sp) / slots;
+      const double q = rounds / (double)(long long)(rounds + 0.999999);
+      const double score = t.eff * pad * q * (1.0 - 0.002 * (double)(sp - 1));
+      if (score > best_score) {
+        best_score = score;
+        best = {t.mi, t.ni, (int)sp, 0};
+      }
+    }
   }
-  if (g_force_mi > 0) { mi = g_force_mi; ni = g_force_ni; }
+  if (g_force_mi > 0 && best_score < 0) best = {g_force_mi, g_force_ni, 1, 0};
+  if (layout == L_TN) {
+    best.rps = (int)(((red_rows + best.splits - 1) / best.splits + 15) / 16 * 16);
+    best.splits = (int)((red_rows + best.rps - 1) / best.rps);
+  }
+  return best;
+}
+
+template <int LAYOUT>
+int launch_igemm(const IgemmArgs& a, int nbatch, int grid_y, hipStream_t st, const TilePlan* given = nullptr) {
+  const int ncols = a.zero_to > a.N ? a.zero_to : a.N;  // pad columns to be zero-filled are visited too
+  const TilePlan pl = given ? *given : plan_tiles(LAYOUT, a.M, ncols, (long long)grid_y * nbatch, a.g.rows);
+  const int mi = pl.mi, ni = pl.ni;
 #define CS_TILE(M_, N_) if (mi == M_ && ni == N_) launch_one<LAYOUT, M_, N_>(a, ncols, nbatch, grid_y, st); else
   CS_TILE(1, 1) CS_TILE(1, 2) CS_TILE(2, 1) CS_TILE(2, 2) CS_TILE(4, 2) CS_TILE(2, 4) CS_TILE(4, 4) {
     catseg_set_error("igemm: unsupported tile %dx%d", mi, ni);
@@ -507,26 +539,17 @@ extern "C" int catseg_conv2d_bwd_data(const catseg_conv_desc* d, const float* dy
 }
 
 namespace {
-void wgrad_plan(const catseg_conv_desc* d, int& splits, int& rps) {
+TilePlan wgrad_plan(const catseg_conv_desc* d) {
   const long long rows = (long long)d->B * d->Ho * d->Wo;
   const int N = d->stem4 ? 32 : d->Cin;
   const int taps = d->stem4 ? d->kh : d->kh * d->kw;
-  int mi = d->Cout > 64 ? 2 : 1, ni = N > 64 ? 2 : 1;
-  if (g_force_mi > 0) { mi = g_force_mi; ni = g_force_ni; }
-  const long long tiles = (long long)((d->Cout + 64 * mi - 1) / (64 * mi)) * ((N + 64 * ni - 1) / (64 * ni)) * taps;
-  long long want = (1024 + tiles - 1) / tiles;  // ~4 blocks per CU
-  const long long maxs = (rows + 255) / 256;    // at least 16 K-steps per split
-  if (want > maxs) want = maxs;
-  if (want < 1) want = 1;
-  rps = (int)(((rows + want - 1) / want + 15) / 16 * 16);
-  splits = (int)((rows + rps - 1) / rps);
+  return plan_tiles(L_TN, d->Cout, N, taps, rows);
 }
 }  // namespace
 
 extern "C" size_t catseg_conv2d_bwd_weight_workspace(const catseg_conv_desc* d) {
   if (check_desc(d)) return 0;
-  int splits, rps;
-  wgrad_plan(d, splits, rps);
+  const int splits = wgrad_plan(d).splits;
   const size_t wel = (size_t)d->Cout * (d->stem4 ? d->kh * 32 : d->kh * d->kw * d->Cin);
   size_t bytes = splits > 1 ? (size_t)splits * wel * 4 : 0;
   bytes += (size_t)256 * d->Cout * 4;  // bias-gradient partials
@@ -544,8 +567,8 @@ extern "C" int catseg_conv2d_bwd_weight(const catseg_conv_desc* d, const float* 
     return CATSEG_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  int splits, rps;
-  wgrad_plan(d, splits, rps);
+  const TilePlan pl = wgrad_plan(d);
+  const int splits = pl.splits, rps = pl.rps;
   const int taps = d->stem4 ? d->kh : d->kh * d->kw;
   const int ncol = d->stem4 ? 32 : d->Cin;
   const size_t wel = (size_t)d->Cout * taps * ncol;
@@ -556,7 +579,7 @@ extern "C" int catseg_conv2d_bwd_weight(const catseg_conv_desc* d, const float* 
   a.splits = splits; a.rows_per_split = rps; a.c_split_stride = (long long)wel;
   a.C = splits > 1 ? (float*)workspace : dw;
   a.taps = taps; a.Cred = 0; a.Cred_b = 0;
-  if (int e = launch_igemm<L_TN>(a, 1, taps, st)) return e;
+  if (int e = launch_igemm<L_TN>(a, 1, taps, st, &pl)) return e;
   if (splits > 1) {
     const long long n4 = (long long)(wel / 4);
     const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
@@ -603,7 +626,9 @@ extern "C" int catseg_gemm_batched(int layout, int batch, int M, int N, int K, c
     g.base = Bm; g.rows = K; g.H = g.Ho = K; g.ld = ldb; a.g_bs = strideB;
     a.other = A; a.ldo = lda; a.o_bs = strideA;
     a.splits = 1; a.rows_per_split = (K + 15) / 16 * 16; a.c_split_stride = 0; a.c_tap_stride = 0;
-    return launch_igemm<L_TN>(a, batch, 1, st);
+    TilePlan pl = plan_tiles(L_NT, M, zero_to > N ? zero_to : N, batch, K);  // no split-K for the batched form
+    pl.splits = 1;
+    return launch_igemm<L_TN>(a, batch, 1, st, &pl);
   }
   catseg_set_error("gemm: unknown layout %d", layout);
   return CATSEG_EINVAL;

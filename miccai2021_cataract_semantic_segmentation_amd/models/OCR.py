@@ -9,6 +9,7 @@ from ..engine import (BatchNorm2d, Conv2d, EngineNet, bilinear, concat_views, co
                       object_attention_core, spatial_gather)
 from ..utils import num_classes
 from .backbone import ResNetBackbone
+from .HRNetv2 import build_hrnet_trunk, concat_branches, run_hrnet_trunk
 
 
 class ObjectAttentionBlock2D(nn.Module):
@@ -58,8 +59,22 @@ class SpatialGatherModule(nn.Module):
         self.cls_num, self.scale = cls_num, scale
 
 
+class HRNetFeatures(nn.Module):
+    """HRNetv2 trunk (models/HRNetv2.py blocks) as an OCRNet backbone: returns the stride-4 concat of the
+    four branches (15*width channels).  The reference's OCRNet raises NotImplementedError for HRNet
+    (models/OCR.py:68-69); this is the build-side assembly SURVEY.md 8a/A2 describes."""
+
+    def __init__(self, width=48, stage1_width=64, modules=(1, 4, 3)):
+        super().__init__()
+        self.out_channels = int(sum(build_hrnet_trunk(self, width, stage1_width, tuple(modules))))
+
+    def run(self, cx, x):
+        return concat_branches(cx, run_hrnet_trunk(self, cx, x))
+
+
 class OCRNet(EngineNet):
-    eligible_backbones = ["resnet50", "resnet101"]  # resnet18/34 are broken in the reference
+    # resnet18/34 are broken in the reference (SURVEY F7); 'hrnet48' / 'hrnet32' are build-side additions
+    eligible_backbones = ["resnet50", "resnet101", "hrnet48", "hrnet32", "hrnet18"]
 
     def __init__(self, config, experiment):
         super().__init__()
@@ -75,11 +90,19 @@ class OCRNet(EngineNet):
         self.num_classes = num_classes(experiment)
         self.get_intermediate = True
         self.relu = nn.ReLU(inplace=True)
-        strides = {8: [False, True, True], 16: [False, False, True], 32: [False, False, False]}[self.out_stride]
-        self.backbone_cutoff = {"layer3": "low", "layer4": "high"}
-        self.backbone = ResNetBackbone(self.backbone_name, strides, self.backbone_cutoff)
-        self.high_out_channels = self.backbone.out_channels("layer4")
-        self.low_level_channels = self.backbone.out_channels("layer3")
+        if "resnet" in self.backbone_name:
+            strides = {8: [False, True, True], 16: [False, False, True], 32: [False, False, False]}[self.out_stride]
+            self.backbone_cutoff = {"layer3": "low", "layer4": "high"}
+            self.backbone = ResNetBackbone(self.backbone_name, strides, self.backbone_cutoff)
+            self.high_out_channels = self.backbone.out_channels("layer4")
+            self.low_level_channels = self.backbone.out_channels("layer3")
+        else:
+            w = int(self.backbone_name[5:])
+            hcfg = config.get("hrnet", {})
+            self.backbone = HRNetFeatures(hcfg.get("width", w), hcfg.get("stage1_width", 64),
+                                          hcfg.get("modules", (1, 4, 3)))
+            self.out_stride = 4
+            self.high_out_channels = self.low_level_channels = self.backbone.out_channels
         self.conv_high_map = nn.Sequential(Conv2d(self.high_out_channels, 512, 3, 1, 1), BatchNorm2d(512), self.relu)
         self.interm_prediction_head = nn.Sequential(
             Conv2d(self.low_level_channels, 512, 3, 1, 1), BatchNorm2d(512), self.relu, nn.Dropout2d(self.dropout),
@@ -94,8 +117,11 @@ class OCRNet(EngineNet):
     def _body(self, cx, x):
         H, W = x.shape[-2:]
         K = self.num_classes
-        f = self.backbone.run(cx, x)
-        low, high = f["low"], f["high"]
+        if isinstance(self.backbone, HRNetFeatures):
+            low = high = self.backbone.run(cx, x)
+        else:
+            f = self.backbone.run(cx, x)
+            low, high = f["low"], f["high"]
         hd = self.interm_prediction_head
         interm = conv_bias(cx, conv_bn_act(cx, low, hd[0], hd[1]), hd[4])
         B, h, w, _ = high.shape

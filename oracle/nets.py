@@ -147,3 +147,22 @@ def deeplabv3plus_forward(S, x, backbone="resnet50", out_stride=8, train=True):
     a = aspp(S, "aspp.", f[4], 1 if out_stride >= 16 else 2, train)
     logits = deeplab_decoder(S, "decoder.", f[1], a, train)
     return F.interpolate(logits, size=size, mode="bilinear", align_corners=True)
+
+
+def ocrnet_hrnet_forward(S, x, train=True):
+    """Build-side assembly (the reference has no HRNet OCRNet, models/OCR.py:68-69): HRNetv2 trunk
+    (oracle/hrnet.py, keys under 'backbone.') -> stride-4 concat -> the reference's OCR heads
+    (models/OCR.py:107-138) with low = high = the concat."""
+    from .hrnet import hrnet_branches, hrnet_concat
+    size = x.shape[-2:]
+    f = hrnet_concat(hrnet_branches(S, x, train, prefix="backbone."))
+    h = F.relu(bn(S, "interm_prediction_head.1", conv(S, "interm_prediction_head.0", f, 1, 1), train))
+    interm = conv(S, "interm_prediction_head.4", h)
+    xh = F.relu(bn(S, "conv_high_map.1", conv(S, "conv_high_map.0", f, 1, 1), train))
+    proxy = spatial_gather(xh, interm)
+    ctx = object_attention(S, "spatial_ocr_head.object_context_block", xh, proxy, train)
+    o = torch.cat([ctx, xh], 1)
+    o = F.relu(bn(S, "spatial_ocr_head.conv_bn_dropout.1", conv(S, "spatial_ocr_head.conv_bn_dropout.0", o), train))
+    logits = conv(S, "conv_out", o)
+    return (F.interpolate(interm, size=size, mode="bilinear", align_corners=True),
+            F.interpolate(logits, size=size, mode="bilinear", align_corners=True))
