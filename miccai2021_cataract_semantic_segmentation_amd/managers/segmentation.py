@@ -1,0 +1,57 @@
+"""Per-model managers (names as main.py:46 resolves them: config['manager'] + 'Manager') and a synthetic
+CaDIS-like dataset for smoke runs and benchmarks."""
+import torch
+from torch.utils.data import Dataset
+
+from ..losses import LossWrapper
+from .base import BaseManager
+
+
+class OCRNetManager(BaseManager):
+    """managers/OCRNet_Manager.py:12-245: the model returns (interm, final); TwoScaleLoss takes both."""
+
+    def forward_loss(self, img, lbl):
+        interm, out = self.model(img.float())
+        if isinstance(self.loss, LossWrapper):
+            return self.loss(None, out, lbl.long(), interm_prediction=interm), out
+        return self.loss(interm, out, lbl.long()), out
+
+    def final_output(self, out):
+        return out[1] if isinstance(out, tuple) else out
+
+
+class DeepLabv3PlusManager(BaseManager):
+    """managers/DeepLabv3Plus_Manager.py:65-237: single output; LossWrapper-style or plain two-argument losses."""
+
+    def forward_loss(self, img, lbl):
+        out = self.model(img.float())
+        if isinstance(self.loss, LossWrapper):
+            return self.loss(None, out, lbl.long()), out
+        return self.loss(out, lbl.long()), out
+
+
+class HRNetv2Manager(DeepLabv3PlusManager):
+    pass
+
+
+class SyntheticCataractDataset(Dataset):
+    """Seeded synthetic frames with blob-structured label maps (piecewise-constant patches, a few classes
+    absent, optional ignore label) — the shape of data SURVEY.md 8d asks the measurements to use."""
+
+    def __init__(self, n, height, width, num_classes, ignore=True, seed=0, patch=16):
+        self.n, self.h, self.w, self.k, self.ignore, self.seed, self.patch = n, height, width, num_classes, ignore, seed, patch
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 100003 + i)
+        p = self.patch
+        lbl = torch.randint(0, self.k + (1 if self.ignore else 0), ((self.h + p - 1) // p, (self.w + p - 1) // p), generator=g)
+        lbl[lbl == 3] = 0
+        lbl = lbl.repeat_interleave(p, 0).repeat_interleave(p, 1)[: self.h, : self.w].contiguous()
+        # image correlated with the labels so that a few optimisation steps can reduce the loss
+        img = torch.rand(3, self.h, self.w, generator=g) * 0.5
+        img[0] += (lbl.float() / (self.k + 1)) * 0.5
+        img[1] += ((lbl * 7) % (self.k + 1)).float() / (self.k + 1) * 0.5
+        return img, lbl, {"index": i}
