@@ -46,6 +46,8 @@ typedef struct {
   int kh, kw, stride, pad, dil;
   int ldx, ldy;            /* floats per pixel of x / y buffers                  */
   int stem4;               /* 1: 7x7/2 stem on a 4-channel-padded image, weights packed [O][kh][8][4] */
+  int groups;              /* 0 or 1 = dense; g > 1 = grouped (forward only: ResNeXt inference, models/ResNeXt.py:46-60);
+                              weights [Cout][kh][kw][Cin/g], Cin/g a multiple of 4 */
 } catseg_conv_desc;
 
 /* y[p, o] = sum_{ky,kx,c} x[pix(p,ky,kx), c] * w[o,ky,kx,c] (+ bias[o]); columns
@@ -143,6 +145,12 @@ int catseg_global_avgpool_fwd(const float* x, int ldx, float* y, int B, int HW, 
                               catseg_stream_t stream);
 int catseg_global_avgpool_bwd(const float* dy, float* dx, int lddx, int B, int HW, int C, int accumulate,
                               catseg_stream_t stream);
+
+/* nn.AdaptiveAvgPool2d(S) (UPerNet pyramid pooling, models/UPerNet.py:25-33); y is [B][S][S][C] compact */
+int catseg_adaptive_avgpool_fwd(const float* x, int ldx, float* y, int B, int H, int W, int C, int S,
+                                catseg_stream_t stream);
+int catseg_adaptive_avgpool_bwd(const float* dy, float* dx, int lddx, int B, int H, int W, int C, int S,
+                                int accumulate, catseg_stream_t stream);
 
 /* ---- softmax ------------------------------------------------------------------------------ */
 /* F.softmax(probs.view(B,K,N), dim=2) at models/OCR.py:165, on NHWC logits [B][N][ld]:

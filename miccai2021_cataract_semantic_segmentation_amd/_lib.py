@@ -24,7 +24,7 @@ P, I, L, F, SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, I) for n in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "kh", "kw", "stride", "pad", "dil",
-                                 "ldx", "ldy", "stem4")]
+                                 "ldx", "ldy", "stem4", "groups")]
 
 
 _SIGS = {
@@ -55,6 +55,8 @@ _SIGS = {
     "catseg_bilinear_bwd": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, P, SZ, P]),
     "catseg_global_avgpool_fwd": (I, [P, I, P, I, I, I, P]),
     "catseg_global_avgpool_bwd": (I, [P, P, I, I, I, I, I, P]),
+    "catseg_adaptive_avgpool_fwd": (I, [P, I, P, I, I, I, I, I, P]),
+    "catseg_adaptive_avgpool_bwd": (I, [P, P, I, I, I, I, I, I, I, P]),
     "catseg_softmax_spatial_fwd": (I, [P, P, I, I, I, I, P]),
     "catseg_softmax_spatial_bwd": (I, [P, P, P, I, I, I, I, I, P]),
     "catseg_softmax_rows_fwd": (I, [P, P, L, I, I, F, P]),

@@ -485,6 +485,9 @@ int check_desc(const catseg_conv_desc* d) {
   CS_REQUIRE(ho == d->Ho && wo == d->Wo, "conv: Ho/Wo (%d,%d) do not match geometry (%d,%d)", d->Ho, d->Wo, ho, wo);
   if (d->stem4) CS_REQUIRE(d->Cin == 4 && d->kw == 7 && d->ldx == 4, "conv: stem4 needs Cin == ldx == 4, kw == 7");
   else CS_REQUIRE(d->Cin % 4 == 0, "conv: Cin must be a multiple of 4 (got %d)", d->Cin);
+  if (d->groups > 1)
+    CS_REQUIRE(!d->stem4 && d->Cin % d->groups == 0 && d->Cout % d->groups == 0 && (d->Cin / d->groups) % 4 == 0,
+               "conv: groups must divide Cin and Cout, Cin/groups a multiple of 4");
   CS_REQUIRE((long long)d->B * d->Ho * d->Wo < (1ll << 31) && (long long)d->B * d->H * d->W < (1ll << 31), "conv: too many pixels");
   return CATSEG_OK;
 }
@@ -516,6 +519,14 @@ extern "C" int catseg_conv2d_fwd(const catseg_conv_desc* d, const float* x, cons
   if (d->stem4) { a.taps = d->kh; a.Cred = 32; a.ldo = d->kh * 32; a.tap_stride = 32; }
   else { a.taps = d->kh * d->kw; a.Cred = d->Cin; a.ldo = a.taps * d->Cin; a.tap_stride = d->Cin; }
   a.Cred_b = a.Cred; a.zero_to = zero_to; a.accumulate = 0;
+  if (d->groups > 1) {  // one GEMM per group: batch strides walk the channel groups of x, w and y
+    CS_REQUIRE(zero_to == 0, "conv fwd: zero_to is not supported with groups");
+    const int cig = d->Cin / d->groups, cog = d->Cout / d->groups;
+    a.N = cog; a.Cred = a.Cred_b = cig; a.ldo = a.taps * cig; a.tap_stride = cig;
+    a.g_bs = cig; a.o_bs = (long long)cog * a.taps * cig; a.c_bs = cog;
+    if (bias) { catseg_set_error("conv fwd: bias is not supported with groups"); return CATSEG_EINVAL; }
+    return launch_igemm<L_NT>(a, d->groups, 1, (hipStream_t)stream);
+  }
   return launch_igemm<L_NT>(a, 1, 1, (hipStream_t)stream);
 }
 
@@ -523,6 +534,7 @@ extern "C" int catseg_conv2d_bwd_data(const catseg_conv_desc* d, const float* dy
                                       int accumulate, catseg_stream_t stream) {
   if (int e = check_desc(d)) return e;
   CS_REQUIRE(!d->stem4, "conv bwd_data: not defined for the stem (the image needs no gradient)");
+  CS_REQUIRE(d->groups <= 1, "conv bwd_data: grouped convolution is forward-only");
   CS_REQUIRE(cs_aligned16(dy) && cs_aligned16(w) && cs_aligned16(dx), "conv bwd_data: pointers must be 16-byte aligned");
   IgemmArgs a = {};
   Geo& g = a.g;
@@ -561,6 +573,7 @@ extern "C" int catseg_conv2d_bwd_weight(const catseg_conv_desc* d, const float* 
                                         catseg_stream_t stream) {
   if (int e = check_desc(d)) return e;
   CS_REQUIRE(cs_aligned16(dy) && cs_aligned16(x) && cs_aligned16(dw), "conv bwd_weight: pointers must be 16-byte aligned");
+  CS_REQUIRE(d->groups <= 1, "conv bwd_weight: grouped convolution is forward-only");
   const size_t need = catseg_conv2d_bwd_weight_workspace(d);
   if (workspace_bytes < need || (need && !workspace)) {
     catseg_set_error("conv bwd_weight: workspace %zu < %zu", workspace_bytes, need);

@@ -177,7 +177,9 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
     else:
         x_in, wk = x, w.data
     bias = conv.bias.data if conv.bias is not None else None
-    y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem)
+    if conv.groups > 1 and cx.record:
+        raise NotImplementedError("grouped convolution (ResNeXt) is inference-only on the HIP path")
+    y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups)
     if cx.train:
         stats, scale = ops.bn_train_stats(y, bn.weight.data, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
         bn._pending_batches += 1
@@ -281,6 +283,32 @@ def bilinear(cx, x, Ho, Wo, align_corners, out=None):
                              accumulate=acc)
         cx.push(bwd)
     return y
+
+
+def adaptive_avgpool(cx, x, S):
+    """nn.AdaptiveAvgPool2d(S) -> [B, S, S, C]"""
+    y = ops.adaptive_avgpool_fwd(x, S)
+    if cx.record:
+        def bwd():
+            dy = cx.take(y)
+            if dy is None:
+                return
+            dx, acc = cx.dest(x)
+            ops.adaptive_avgpool_bwd(dy, dx, S, acc)
+        cx.push(bwd)
+    return y
+
+
+def copy_into(cx, src, dst):
+    """dst (a channel slice of a concat buffer) = src; the gradient of dst flows back to src"""
+    ops.axpy(src, dst, 1.0, False)
+    if cx.record:
+        def bwd():
+            g = cx.take(dst)
+            if g is not None:
+                cx.give(src, g)
+        cx.push(bwd)
+    return dst
 
 
 def global_avgpool(cx, x):

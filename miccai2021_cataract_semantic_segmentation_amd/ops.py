@@ -51,10 +51,10 @@ def conv_out_size(n, k, s, p, d):
     return (n + 2 * p - d * (k - 1) - 1) // s + 1
 
 
-def make_desc(xshape, ldx, Cout, ldy, kh, kw, stride, pad, dil, stem4=False):
+def make_desc(xshape, ldx, Cout, ldy, kh, kw, stride, pad, dil, stem4=False, groups=1):
     B, H, W, Cin = xshape
     return ConvDesc(B, H, W, Cin, conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil), Cout,
-                    kh, kw, stride, pad, dil, ldx, ldy, 1 if stem4 else 0)
+                    kh, kw, stride, pad, dil, ldx, ldy, 1 if stem4 else 0, groups)
 
 
 PROFILE = None  # bench.py sets this to a list: every implicit-GEMM launch is bracketed by HIP events
@@ -78,13 +78,13 @@ class _Timed:
             PROFILE.append((self.kind, self.flops, self.e0, self.e1))
 
 
-def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False):
+def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False, groups=1):
     B, H, W, Cin = x.shape
     Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
     if out is None:
         out = new_act(B, Ho, Wo, Cout, x.device, ld=max(zero_to, (Cout + 3) // 4 * 4))
-    d = make_desc(x.shape, ld_of(x), Cout, ld_of(out), kh, kw, stride, pad, dil, stem4)
-    with _Timed("fwd", 2.0 * B * Ho * Wo * Cout * (3 if stem4 else Cin) * kh * kw):
+    d = make_desc(x.shape, ld_of(x), Cout, ld_of(out), kh, kw, stride, pad, dil, stem4, groups)
+    with _Timed("fwd", 2.0 * B * Ho * Wo * Cout * (3 if stem4 else Cin // groups) * kh * kw):
         check(lib.catseg_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_ptr_tensor), ptr(bias), ptr(out), zero_to, stream()))
     return out
 
@@ -331,3 +331,16 @@ def weight_pad_cin(w, O, taps, cin, cpad):
 def weight_unpad_cin(pk, dw, O, taps, cin, cpad):
     check(lib.catseg_weight_pad_cin(ptr(pk), ptr(dw), O, taps, cin, cpad, 1, stream()))
     return dw
+
+
+def adaptive_avgpool_fwd(x, S):
+    B, H, W, C = x.shape
+    y = torch.empty((B, S, S, C), dtype=torch.float32, device=x.device)
+    check(lib.catseg_adaptive_avgpool_fwd(ptr(x), ld_of(x), ptr(y), B, H, W, C, S, stream()))
+    return y
+
+
+def adaptive_avgpool_bwd(dy, dx, S, accumulate):
+    B, H, W, C = dx.shape
+    check(lib.catseg_adaptive_avgpool_bwd(ptr(dy), ptr(dx), ld_of(dx), B, H, W, C, S, 1 if accumulate else 0, stream()))
+    return dx
