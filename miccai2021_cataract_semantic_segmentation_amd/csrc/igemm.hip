@@ -51,6 +51,7 @@ struct IgemmArgs {
   int splits, rows_per_split;
   long long c_split_stride;
   int c_tap_stride;
+  int tap_cin;  // L_TN, FAST: > 0 = the N dimension is taps x tap_cin (tap of a column = col / tap_cin), grid.y = 1
 };
 
 __device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
@@ -263,11 +264,15 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(
         const int chunk = (n0 >> 2) + cc;
         const bool cvv = chunk * 4 < ((p.N + 3) & ~3);
         if (FAST) {  // forward-conv gather (plain GEMM rows are passed as a degenerate 1-wide image)
+          // the column block of this lane fixes its filter tap: columns are (tap, channel) pairs
+          const int col = chunk * 4;
+          const int tap = col / p.tap_cin, ch = col - tap * p.tap_cin;
+          const int ky = tap / p.g.kw, kx = tap - ky * p.g.kw;
           decode_row(p.g, rv ? r : 0, b, y, x);
-          const int iy = y * p.g.stride - p.g.pad + tky * p.g.dil;
-          const int ix = x * p.g.stride - p.g.pad + tkx * p.g.dil;
+          const int iy = y * p.g.stride - p.g.pad + ky * p.g.dil;
+          const int ix = x * p.g.stride - p.g.pad + kx * p.g.dil;
           const bool ok = rv && cvv && (unsigned)iy < (unsigned)p.g.H && (unsigned)ix < (unsigned)p.g.W;
-          pb[j] = ok ? gbase + (((long long)b * p.g.H + iy) * p.g.W + ix) * p.g.ld + chunk * 4 : g_zero_page;
+          pb[j] = ok ? gbase + (((long long)b * p.g.H + iy) * p.g.W + ix) * p.g.ld + ch : g_zero_page;
         } else {
           if (p.g.mode != 0) decode_row(p.g, rv ? r : 0, b, y, x);
           pb[j] = gather_ptr(p.g, gbase, rv, r, b, y, x, tky, tkx, chunk, cvv);
@@ -553,9 +558,8 @@ extern "C" int catseg_conv2d_bwd_data(const catseg_conv_desc* d, const float* dy
 namespace {
 TilePlan wgrad_plan(const catseg_conv_desc* d) {
   const long long rows = (long long)d->B * d->Ho * d->Wo;
-  const int N = d->stem4 ? 32 : d->Cin;
-  const int taps = d->stem4 ? d->kh : d->kh * d->kw;
-  return plan_tiles(L_TN, d->Cout, N, taps, rows);
+  if (d->stem4) return plan_tiles(L_TN, d->Cout, 32, d->kh, rows);
+  return plan_tiles(L_TN, d->Cout, (long long)d->kh * d->kw * d->Cin, 1, rows);
 }
 }  // namespace
 
@@ -588,11 +592,14 @@ extern "C" int catseg_conv2d_bwd_weight(const catseg_conv_desc* d, const float* 
   IgemmArgs a = {};
   a.g = fwd_geo(d, x);
   a.other = dy; a.ldo = d->ldy;
-  a.M = d->Cout; a.N = ncol; a.ldc = taps * ncol; a.c_tap_stride = ncol;
+  a.M = d->Cout; a.ldc = taps * ncol;
   a.splits = splits; a.rows_per_split = rps; a.c_split_stride = (long long)wel;
   a.C = splits > 1 ? (float*)workspace : dw;
   a.taps = taps; a.Cred = 0; a.Cred_b = 0;
-  if (int e = launch_igemm<L_TN>(a, 1, taps, st, &pl)) return e;
+  const int grid_y = d->stem4 ? taps : 1;
+  if (d->stem4) { a.N = ncol; a.c_tap_stride = ncol; a.tap_cin = 0; }
+  else { a.N = taps * ncol; a.c_tap_stride = 0; a.tap_cin = ncol; }   // all taps side by side in the N dimension
+  if (int e = launch_igemm<L_TN>(a, 1, grid_y, st, &pl)) return e;
   if (splits > 1) {
     const long long n4 = (long long)(wel / 4);
     const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
@@ -639,6 +646,7 @@ extern "C" int catseg_gemm_batched(int layout, int batch, int M, int N, int K, c
     g.base = Bm; g.rows = K; g.H = g.Ho = K; g.ld = ldb; a.g_bs = strideB;
     a.other = A; a.ldo = lda; a.o_bs = strideA;
     a.splits = 1; a.rows_per_split = (K + 15) / 16 * 16; a.c_split_stride = 0; a.c_tap_stride = 0;
+    a.tap_cin = (N + 3) & ~3;
     TilePlan pl = plan_tiles(L_NT, M, zero_to > N ? zero_to : N, batch, K);  // no split-K for the batched form
     pl.splits = 1;
     return launch_igemm<L_TN>(a, batch, 1, st, &pl);

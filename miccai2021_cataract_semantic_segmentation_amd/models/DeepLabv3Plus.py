@@ -98,3 +98,33 @@ class DeepLabv3Plus(EngineNet):
         a = self.aspp.run(cx, f["high"])
         logits = self.decoder.run(cx, f["low"], a)
         return [bilinear(cx, logits, H, W, True)]
+
+
+class DeepLabv3(EngineNet):
+    """models/DeepLabv3.py:11-71 of the reference: backbone 'out' = layer4 -> the same ASPP -> 1x1 classifier ->
+    bilinear (align_corners=True) to the input size."""
+    eligible_backbones = ["resnet50", "resnet101"]
+
+    def __init__(self, config, experiment):
+        super().__init__()
+        self.backbone_name = config["backbone"] if "backbone" in config else "resnet50"
+        self.c_aspp = config["aspp"]["channels"] if "aspp" in config else 256
+        self.out_stride = config["out_stride"] if "out_stride" in config else 16
+        self.config = config
+        assert self.out_stride in [8, 16, 32]
+        striding = {8: [False, True, True], 16: [False, False, True], 32: [True, True, True]}[self.out_stride]
+        assert self.backbone_name in self.eligible_backbones, "backbone must be in {}".format(self.eligible_backbones)
+        self.num_classes = num_classes(experiment)
+        self.backbone_cutoff = {"layer4": "out"}
+        self.backbone = ResNetBackbone(self.backbone_name, striding, self.backbone_cutoff)
+        self.backbone_out_channels = self.backbone.out_channels("layer4")
+        self.aspp = ASPP(self.backbone_out_channels, self.c_aspp, 1 if self.out_stride >= 16 else 2)
+        self.conv_out = Conv2d(self.c_aspp, self.num_classes, 1, 1)
+        if "projector" in config:
+            raise NotImplementedError("the contrastive projector is outside the accelerated path")
+        self.projector_model = None
+
+    def _body(self, cx, x):
+        H, W = x.shape[-2:]
+        a = self.aspp.run(cx, self.backbone.run(cx, x)["out"])
+        return [bilinear(cx, conv_bias(cx, a, self.conv_out), H, W, True)]

@@ -166,3 +166,11 @@ def ocrnet_hrnet_forward(S, x, train=True):
     logits = conv(S, "conv_out", o)
     return (F.interpolate(interm, size=size, mode="bilinear", align_corners=True),
             F.interpolate(logits, size=size, mode="bilinear", align_corners=True))
+
+
+def deeplabv3_forward(S, x, backbone="resnet50", out_stride=8, train=True):
+    """models/DeepLabv3.py:58-71"""
+    size = x.shape[-2:]
+    f = resnet_features(S, x, backbone, rswd_for(out_stride), train)
+    logits = conv(S, "conv_out", aspp(S, "aspp.", f[4], 1 if out_stride >= 16 else 2, train))
+    return F.interpolate(logits, size=size, mode="bilinear", align_corners=True)
