@@ -154,10 +154,12 @@ int catseg_adaptive_avgpool_bwd(const float* dy, float* dx, int lddx, int B, int
 
 /* ---- softmax ------------------------------------------------------------------------------ */
 /* F.softmax(probs.view(B,K,N), dim=2) at models/OCR.py:165, on NHWC logits [B][N][ld]:
- * per (b, k) over the N pixels.  Columns [K, ld) of the output are zeroed. */
-int catseg_softmax_spatial_fwd(const float* x, float* y, int B, int N, int K, int ld, catseg_stream_t stream);
+ * per (b, k) over the N pixels, K <= 32.  Columns [K, ld) of the output are zeroed. */
+size_t catseg_softmax_spatial_workspace(int B, int N);
+int catseg_softmax_spatial_fwd(const float* x, float* y, int B, int N, int K, int ld, void* workspace,
+                               size_t workspace_bytes, catseg_stream_t stream);
 int catseg_softmax_spatial_bwd(const float* y, const float* dy, float* dx, int B, int N, int K, int ld,
-                               int accumulate, catseg_stream_t stream);
+                               int accumulate, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
 /* F.softmax(scale * sim, dim=-1) at models/OCR.py:270-271: per row over K (<= 64) columns */
 int catseg_softmax_rows_fwd(const float* x, float* y, long long rows, int K, int ld, float scale,
                             catseg_stream_t stream);

@@ -57,8 +57,9 @@ _SIGS = {
     "catseg_global_avgpool_bwd": (I, [P, P, I, I, I, I, I, P]),
     "catseg_adaptive_avgpool_fwd": (I, [P, I, P, I, I, I, I, I, P]),
     "catseg_adaptive_avgpool_bwd": (I, [P, P, I, I, I, I, I, I, I, P]),
-    "catseg_softmax_spatial_fwd": (I, [P, P, I, I, I, I, P]),
-    "catseg_softmax_spatial_bwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "catseg_softmax_spatial_workspace": (SZ, [I, I]),
+    "catseg_softmax_spatial_fwd": (I, [P, P, I, I, I, I, P, SZ, P]),
+    "catseg_softmax_spatial_bwd": (I, [P, P, P, I, I, I, I, I, P, SZ, P]),
     "catseg_softmax_rows_fwd": (I, [P, P, L, I, I, F, P]),
     "catseg_softmax_rows_bwd": (I, [P, P, P, L, I, I, F, P]),
     "catseg_lovasz_workspace": (SZ, [L, I]),

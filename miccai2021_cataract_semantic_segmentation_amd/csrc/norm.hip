@@ -22,8 +22,8 @@ RowSplit plan_rows(long long rows, int C) {
   s.tpr = cpt < 64 ? cpt : 64;
   s.rpp = 256 / s.tpr;
   s.gy = (cpt + s.tpr - 1) / s.tpr;
-  int want = 2048 / s.gy;  // ~2048 blocks in total fill the chip; fewer partials = cheaper merge
-  if (want > kMaxRowBlocks) want = kMaxRowBlocks;
+  int want = 1024 / s.gy;  // ~1024 blocks in total fill the chip; fewer partials = cheaper merge
+  if (want > 512) want = 512;
   if (want < 64) want = 64;
   long long rpb = (rows + want - 1) / want;
   if (rpb < 4 * s.rpp) rpb = 4 * s.rpp;
@@ -74,41 +74,58 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-// merge of the per-row-block partials: block = 64 channels (lanes, coalesced) x 16 row-block lanes,
-// fp64 Chan updates, then a 16-way combine through LDS
+// merge of the per-row-block partials: block = 64 channels (lanes, coalesced) x 16 row-block lanes.
+// Two passes over the (L2-resident) partials, no division inside the loops:
+//   mean = sum_b n_b * mean_b / n ;  M2 = sum_b [ M2_b + n_b * (mean_b - mean)^2 ]     (fp64)
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nrb, long long rpb, long long rows, int C,
                                                            const float* __restrict__ gamma, float eps, float momentum, float* running_mean,
                                                            float* running_var, float* __restrict__ stats, float* __restrict__ scale) {
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  double n = 0, mean = 0, m2 = 0;
-  if (c < C) {
+  const bool live = c < C;
+  const double n_full = (double)rpb, inv_full = 1.0 / n_full;
+  const double n_last = (double)(rows - (long long)(nrb - 1) * rpb), inv_last = 1.0 / n_last;
+  __shared__ double sh[16][64];
+  __shared__ double smean[64];
+  double acc = 0;
+  if (live) {
+#pragma unroll 4
     for (int b = rl; b < nrb; b += 16) {
-      const long long r0 = (long long)b * rpb;
-      const double nb = (double)(min(r0 + rpb, rows) - r0);
       const float* o = part + ((long long)b * 3) * C;
-      const double K = o[c], s1 = o[C + c], s2 = o[2 * C + c];
-      const double mb = K + s1 / nb;
-      const double m2b = s2 - s1 * s1 / nb;
-      const double tot = n + nb;
-      const double delta = mb - mean;
-      mean += delta * nb / tot;
-      m2 += m2b + delta * delta * n * nb / tot;
-      n = tot;
+      const double nb = b == nrb - 1 ? n_last : n_full;
+      acc += nb * (double)o[c] + (double)o[C + c];   // n_b * mean_b = n_b * K + s1
     }
   }
-  __shared__ double sn[16][64], sm[16][64], s2[16][64];
-  sn[rl][cl] = n; sm[rl][cl] = mean; s2[rl][cl] = m2;
+  sh[rl][cl] = acc;
   __syncthreads();
-  if (rl != 0 || c >= C) return;
-  for (int k = 1; k < 16; ++k) {
-    const double nb = sn[k][cl];
-    if (nb == 0) continue;
-    const double tot = n + nb, delta = sm[k][cl] - mean;
-    mean += delta * nb / tot;
-    m2 += s2[k][cl] + delta * delta * n * nb / tot;
-    n = tot;
+  if (rl == 0) {
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][cl];
+    smean[cl] = t / (double)rows;
   }
+  __syncthreads();
+  const double mean = smean[cl];
+  acc = 0;
+  if (live) {
+#pragma unroll 4
+    for (int b = rl; b < nrb; b += 16) {
+      const float* o = part + ((long long)b * 3) * C;
+      const bool last = b == nrb - 1;
+      const double nb = last ? n_last : n_full, inv = last ? inv_last : inv_full;
+      const double K = o[c], s1 = o[C + c], s2 = o[2 * C + c];
+      const double d = K + s1 * inv - mean;
+      acc += (s2 - s1 * s1 * inv) + nb * d * d;
+    }
+  }
+  __syncthreads();
+  sh[rl][cl] = acc;
+  __syncthreads();
+  if (rl != 0 || !live) return;
+  double m2 = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m2 += sh[k][cl];
+  const double n = (double)rows;
   const float var = (float)(m2 / n);
   const float invstd = 1.0f / sqrtf(var + eps);
   stats[c] = (float)mean;
@@ -193,6 +210,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   const int c = blockIdx.x * 64 + cl;
   double sg = 0, sgx = 0;
   if (c < C)
+#pragma unroll 4
     for (int b = rl; b < nrb; b += 16) {
       const float* o = part + ((long long)b * 2) * C;
       sg += o[c];

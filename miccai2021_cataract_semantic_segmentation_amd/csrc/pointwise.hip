@@ -318,66 +318,105 @@ __global__ void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__
 }
 
 // ------------------------------------------------------------------ softmax over pixels (per batch, per class column)
-// block = 32 columns x 8 row lanes; grid = B.  N ~ 8160, ld = 32: the slab is L2 resident.
-__global__ __launch_bounds__(256) void softmax_spatial_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int K, int ld) {
-  const int b = blockIdx.x;
-  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const float* xb = x + (long long)b * N * ld;
-  float* yb = y + (long long)b * N * ld;
-  __shared__ float sh[8][33];
-  for (int c0 = 0; c0 < ld; c0 += 32) {
-    const int c = c0 + col;
-    const bool live = c < K;
-    float m = -INFINITY;
-    if (live)
-      for (int n = rl; n < N; n += 8) m = fmaxf(m, xb[(long long)n * ld + c]);
-    sh[rl][col] = m;
-    __syncthreads();
-    m = sh[0][col];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) m = fmaxf(m, sh[k][col]);
-    __syncthreads();
-    float s = 0.f;
-    if (live)
-      for (int n = rl; n < N; n += 8) s += expf(xb[(long long)n * ld + c] - m);
-    sh[rl][col] = s;
-    __syncthreads();
-    s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += sh[k][col];
-    __syncthreads();
-    const float inv = 1.f / s;
-    if (c < ld)
-      for (int n = rl; n < N; n += 8) yb[(long long)n * ld + c] = live ? expf(xb[(long long)n * ld + c] - m) * inv : 0.f;
+// [B][N][ld] logits, softmax along N for each of the K (<= 32) columns.  Three launches, all multi-block:
+//   partial: per (batch, chunk of N) online (max, sum exp) per column -> ws[b][chunk][2][32]
+//   (the merge of the chunk partials is recomputed by every block of the apply pass: tiny, L2 resident)
+//   apply  : y = exp(x - m) / s
+constexpr int SP_CHUNK = 512;  // pixels per block
+__device__ __forceinline__ void sp_merge(const float* __restrict__ ws, int nch, int col, float& m, float& s) {
+  m = -INFINITY;
+  s = 0.f;
+  for (int k = 0; k < nch; ++k) {
+    const float mk = ws[(k * 2) * 32 + col], sk = ws[(k * 2 + 1) * 32 + col];
+    const float mn = fmaxf(m, mk);
+    s = s * expf(m - mn) + sk * expf(mk - mn);
+    m = mn;
   }
 }
-// dx = y * (dy - sum_n dy*y)
-__global__ __launch_bounds__(256) void softmax_spatial_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
-                                                                  float* __restrict__ dx, int N, int K, int ld, int acc) {
-  const int b = blockIdx.x;
+__global__ __launch_bounds__(256) void softmax_spatial_partial_kernel(const float* __restrict__ x, float* __restrict__ ws, int N, int K, int ld,
+                                                                      int nch) {
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const float* xb = x + (long long)b * N * ld;
+  const int n0 = ch * SP_CHUNK, n1 = min(n0 + SP_CHUNK, N);
+  __shared__ float shm[8][33], shs[8][33];
+  float m = -INFINITY, s = 0.f;
+  if (col < K) {
+    for (int n = n0 + rl; n < n1; n += 8) m = fmaxf(m, xb[(long long)n * ld + col]);
+    for (int n = n0 + rl; n < n1; n += 8) s += expf(xb[(long long)n * ld + col] - m);
+  }
+  shm[rl][col] = m;
+  shs[rl][col] = s;
+  __syncthreads();
+  if (rl == 0) {
+    float M = shm[0][col];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) M = fmaxf(M, shm[k][col]);
+    float S = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) S += shm[k][col] == -INFINITY ? 0.f : shs[k][col] * expf(shm[k][col] - M);
+    float* o = ws + ((long long)b * nch + ch) * 64;
+    o[col] = M;
+    o[32 + col] = S;
+  }
+}
+__global__ __launch_bounds__(256) void softmax_spatial_apply_kernel(const float* __restrict__ x, const float* __restrict__ ws, float* __restrict__ y,
+                                                                    int N, int K, int ld, int nch) {
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  float m = 0.f, s = 1.f;
+  if (col < K) sp_merge(ws + (long long)b * nch * 64, nch, col, m, s);
+  const float inv = 1.f / s;
+  const float* xb = x + (long long)b * N * ld;
+  float* yb = y + (long long)b * N * ld;
+  const int n0 = ch * SP_CHUNK, n1 = min(n0 + SP_CHUNK, N);
+  for (int c0 = 0; c0 < ld; c0 += 32) {
+    const int c = c0 + col;
+    if (c >= ld) continue;
+    for (int n = n0 + rl; n < n1; n += 8) yb[(long long)n * ld + c] = (c < K) ? expf(xb[(long long)n * ld + c] - m) * inv : 0.f;
+  }
+}
+// backward: dot[b][k] = sum_n dy*y (partials per chunk), dx = y * (dy - dot)
+__global__ __launch_bounds__(256) void softmax_spatial_bwd_partial_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                                          float* __restrict__ ws, int N, int K, int ld, int nch) {
+  const int b = blockIdx.y, ch = blockIdx.x;
   const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const float* yb = y + (long long)b * N * ld;
   const float* gb = dy + (long long)b * N * ld;
-  float* ob = dx + (long long)b * N * ld;
+  const int n0 = ch * SP_CHUNK, n1 = min(n0 + SP_CHUNK, N);
   __shared__ float sh[8][33];
+  float s = 0.f;
+  if (col < K)
+    for (int n = n0 + rl; n < n1; n += 8) s += gb[(long long)n * ld + col] * yb[(long long)n * ld + col];
+  sh[rl][col] = s;
+  __syncthreads();
+  if (rl == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sh[k][col];
+    ws[((long long)b * nch + ch) * 32 + col] = t;
+  }
+}
+__global__ __launch_bounds__(256) void softmax_spatial_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                                        const float* __restrict__ ws, float* __restrict__ dx, int N, int K,
+                                                                        int ld, int nch, int acc) {
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  float dot = 0.f;
+  if (col < K)
+    for (int k = 0; k < nch; ++k) dot += ws[((long long)b * nch + k) * 32 + col];
+  const float* yb = y + (long long)b * N * ld;
+  const float* gb = dy + (long long)b * N * ld;
+  float* ob = dx + (long long)b * N * ld;
+  const int n0 = ch * SP_CHUNK, n1 = min(n0 + SP_CHUNK, N);
   for (int c0 = 0; c0 < ld; c0 += 32) {
     const int c = c0 + col;
-    const bool live = c < K;
-    float s = 0.f;
-    if (live)
-      for (int n = rl; n < N; n += 8) s += gb[(long long)n * ld + c] * yb[(long long)n * ld + c];
-    sh[rl][col] = s;
-    __syncthreads();
-    s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += sh[k][col];
-    __syncthreads();
-    if (c < ld)
-      for (int n = rl; n < N; n += 8) {
-        const long long o = (long long)n * ld + c;
-        const float v = live ? yb[o] * (gb[o] - s) : 0.f;
-        ob[o] = (acc && live) ? ob[o] + v : v;
-      }
+    if (c >= ld) continue;
+    for (int n = n0 + rl; n < n1; n += 8) {
+      const long long o = (long long)n * ld + c;
+      const float v = (c < K) ? yb[o] * (gb[o] - dot) : 0.f;
+      ob[o] = (acc && c < K) ? ob[o] + v : v;
+    }
   }
 }
 
@@ -521,16 +560,24 @@ extern "C" int catseg_global_avgpool_bwd(const float* dy, float* dx, int lddx, i
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
-extern "C" int catseg_softmax_spatial_fwd(const float* x, float* y, int B, int N, int K, int ld, catseg_stream_t stream) {
-  CS_REQUIRE(B > 0 && N > 0 && K > 0 && ld >= K, "softmax spatial: bad args");
-  hipLaunchKernelGGL(softmax_spatial_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, y, N, K, ld);
+extern "C" size_t catseg_softmax_spatial_workspace(int B, int N) { return (size_t)B * ((N + SP_CHUNK - 1) / SP_CHUNK) * 64 * 4 + 256; }
+extern "C" int catseg_softmax_spatial_fwd(const float* x, float* y, int B, int N, int K, int ld, void* workspace, size_t workspace_bytes,
+                                          catseg_stream_t stream) {
+  CS_REQUIRE(B > 0 && N > 0 && K > 0 && K <= 32 && ld >= K && workspace != nullptr, "softmax spatial: bad args (K <= 32, workspace required)");
+  const int nch = (N + SP_CHUNK - 1) / SP_CHUNK;
+  CS_REQUIRE(workspace_bytes >= (size_t)B * nch * 64 * 4, "softmax spatial: workspace too small");
+  hipLaunchKernelGGL(softmax_spatial_partial_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)stream, x, (float*)workspace, N, K, ld, nch);
+  hipLaunchKernelGGL(softmax_spatial_apply_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)stream, x, (const float*)workspace, y, N, K, ld, nch);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
 extern "C" int catseg_softmax_spatial_bwd(const float* y, const float* dy, float* dx, int B, int N, int K, int ld,
-                                          int accumulate, catseg_stream_t stream) {
-  CS_REQUIRE(B > 0 && N > 0 && K > 0 && ld >= K, "softmax spatial bwd: bad args");
-  hipLaunchKernelGGL(softmax_spatial_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, y, dy, dx, N, K, ld, accumulate);
+                                          int accumulate, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(B > 0 && N > 0 && K > 0 && K <= 32 && ld >= K && workspace != nullptr, "softmax spatial bwd: bad args (K <= 32, workspace required)");
+  const int nch = (N + SP_CHUNK - 1) / SP_CHUNK;
+  CS_REQUIRE(workspace_bytes >= (size_t)B * nch * 64 * 4, "softmax spatial bwd: workspace too small");
+  hipLaunchKernelGGL(softmax_spatial_bwd_partial_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)stream, y, dy, (float*)workspace, N, K, ld, nch);
+  hipLaunchKernelGGL(softmax_spatial_bwd_apply_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)stream, y, dy, (const float*)workspace, dx, N, K, ld, nch, accumulate);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

@@ -245,13 +245,15 @@ def softmax_spatial_fwd(x, K):
     """x: [B, N, ld] buffer (logits in columns [0, K)); returns same-shape probabilities, pad columns zero."""
     B, N, ld = x.shape
     y = torch.empty_like(x)
-    check(lib.catseg_softmax_spatial_fwd(ptr(x), ptr(y), B, N, K, ld, stream()))
+    ws = workspace(lib.catseg_softmax_spatial_workspace(B, N), x.device)
+    check(lib.catseg_softmax_spatial_fwd(ptr(x), ptr(y), B, N, K, ld, ptr(ws), ws.numel(), stream()))
     return y
 
 
 def softmax_spatial_bwd(y, dy, dx, K, accumulate=False):
     B, N, ld = y.shape
-    check(lib.catseg_softmax_spatial_bwd(ptr(y), ptr(dy), ptr(dx), B, N, K, ld, 1 if accumulate else 0, stream()))
+    ws = workspace(lib.catseg_softmax_spatial_workspace(B, N), y.device)
+    check(lib.catseg_softmax_spatial_bwd(ptr(y), ptr(dy), ptr(dx), B, N, K, ld, 1 if accumulate else 0, ptr(ws), ws.numel(), stream()))
     return dx
 
 

@@ -1,0 +1,32 @@
+"""igemm tile comparison on the small-channel HRNet shapes."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from miccai2021_cataract_semantic_segmentation_amd import ops, _lib
+dev = torch.device("cuda")
+SHAPES = [("hr 3x3 48>48", 8, 136, 240, 48, 48, 3, 1, 1, 1), ("hr 3x3 96>96", 8, 68, 120, 96, 96, 3, 1, 1, 1),
+          ("hr 3x3 192>192", 8, 34, 60, 192, 192, 3, 1, 1, 1), ("hr 3x3 384>384", 8, 17, 30, 384, 384, 3, 1, 1, 1),
+          ("head 3x3 720>512", 8, 136, 240, 720, 512, 3, 1, 1, 1)]
+TILES = [(0, 0), (1, 1), (2, 1), (1, 2), (2, 2), (4, 2), (2, 4)]
+def timeit(fn, n=4):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+for name, B, H, W, Ci, Co, k, s, p, d in SHAPES:
+    x = torch.randn(B, H, W, Ci, device=dev)
+    w = (torch.randn(Co, Ci, k, k, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    y = ops.conv_fwd(x, w, None, Co, k, k, s, p, d)
+    dy = torch.randn_like(y); dx = torch.empty_like(x); dw = torch.empty_like(w)
+    fl = 2.0 * y.numel() * Ci * k * k
+    line = "%-18s" % name
+    for (mi, ni) in TILES:
+        _lib.lib.catseg_debug_set_tile(mi, ni)
+        tf = timeit(lambda: ops.conv_fwd(x, w, None, Co, k, k, s, p, d, out=y))
+        td = timeit(lambda: ops.conv_bwd_data(dy, w, tuple(x.shape), k, k, s, p, d, out=dx))
+        tw = timeit(lambda: ops.conv_bwd_weight(x, dy, dw, None, k, k, s, p, d))
+        line += " | %dx%d f%5.1f d%5.1f w%5.1f" % (mi, ni, fl / tf / 1e9, fl / td / 1e9, fl / tw / 1e9)
+    _lib.lib.catseg_debug_set_tile(0, 0)
+    print(line, flush=True)
