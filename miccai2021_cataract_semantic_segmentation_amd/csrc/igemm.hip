@@ -104,9 +104,11 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(
   constexpr int BM = 64 * MI, BN = 64 * NI;
   constexpr bool A_KC = (LAYOUT != L_TN);
   constexpr bool B_KC = (LAYOUT == L_NT);
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 16];
-  float* const sA0 = smem;
-  float* const sB0 = smem + 2 * BM * 16;
+  // K sub-steps (of 16) per barrier interval.  Measured: > 1 on the small tiles costs more in occupancy
+  // (LDS per block) than it saves in barriers (48-channel 3x3: 67 -> 56 TFLOP/s with 4), so it stays 1.
+  constexpr int KSUB = 1;
+  constexpr int SLAB = (BM + BN) * 16;  // floats of one (A, B) sub-step image
+  __shared__ __attribute__((aligned(16))) float smem[2 * KSUB * SLAB];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -193,28 +195,31 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(
   }
   const long long tap_sign = p.g.mode == 2 ? -1 : 1;
 
-  const float* pa[MI];
-  const float* pb[NI];
+  const float* pa[KSUB][MI];
+  const float* pb[KSUB][NI];
 
-  // source addresses of the next K-step (pure VALU/SALU work: overlaps the MFMAs of the current one)
-  auto prep = [&]() {
+  // source addresses of a future K sub-step (pure VALU/SALU work: overlaps the MFMAs of the current one)
+  auto prep = [&](const int sub) {
+    const bool live = tks < nks;  // sub-steps past the end of the reduction load zeros
     if (LAYOUT != L_TN) {
+      ++tks;
       const int chunk = tck * 4 + kc_chunk;
-      const bool cv = chunk * 4 < p.Cred;
+      const bool cv = live && chunk * 4 < p.Cred;
       if (fast) {
         const long long toff = tap_sign * ((long long)tky * p.g.dil * p.g.W + tkx * p.g.dil) * p.g.ld + chunk * 4;
 #pragma unroll
-        for (int j = 0; j < MI; ++j) pa[j] = (cv && ((amask[j] >> ttap) & 1u)) ? gbase + aoff[j] + toff : g_zero_page;
+        for (int j = 0; j < MI; ++j)
+          pa[sub][j] = (cv && ((amask[j] >> (ttap & 31)) & 1u)) ? gbase + aoff[j] + toff : g_zero_page;
       } else {
 #pragma unroll
         for (int j = 0; j < MI; ++j)
-          pa[j] = gather_ptr(p.g, gbase, arv[j], m0 + j * 64 + kc_row, ab[j], ay[j], ax[j], tky, tkx, chunk, cv);
+          pa[sub][j] = gather_ptr(p.g, gbase, arv[j], m0 + j * 64 + kc_row, ab[j], ay[j], ax[j], tky, tkx, chunk, cv);
       }
       if (B_KC) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int n = n0 + j * 64 + kc_row;
-          pb[j] = (n < p.N && cv) ? obase + (long long)n * p.ldo + ttap * p.tap_stride + chunk * 4 : g_zero_page;
+          pb[sub][j] = (n < p.N && cv) ? obase + (long long)n * p.ldo + ttap * p.tap_stride + chunk * 4 : g_zero_page;
         }
       } else {
 #pragma unroll
@@ -222,8 +227,8 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(
           const int q = j * 256 + tid;
           const int krow = q / (16 * NI), cc = q % (16 * NI);
           const int k = tck * 16 + krow;
-          const bool ok = k < p.Cred_b && (n0 + cc * 4) < ((p.N + 3) & ~3);
-          pb[j] = ok ? obase + (long long)k * p.ldo + ttap * p.tap_stride + n0 + cc * 4 : g_zero_page;
+          const bool ok = live && k < p.Cred_b && (n0 + cc * 4) < ((p.N + 3) & ~3);
+          pb[sub][j] = ok ? obase + (long long)k * p.ldo + ttap * p.tap_stride + n0 + cc * 4 : g_zero_page;
         }
       }
       if (FAST) {  // branch-free cursor advance
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(
         const int krow = q / (16 * MI), cc = q % (16 * MI);
         const int r = kbase + krow;
         const bool ok = r < r_end && (m0 + cc * 4) < ((p.M + 3) & ~3);
-        pa[j] = ok ? obase + (long long)r * p.ldo + m0 + cc * 4 : g_zero_page;
+        pa[sub][j] = ok ? obase + (long long)r * p.ldo + m0 + cc * 4 : g_zero_page;
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
@@ -272,27 +277,27 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(
           const int iy = y * p.g.stride - p.g.pad + ky * p.g.dil;
           const int ix = x * p.g.stride - p.g.pad + kx * p.g.dil;
           const bool ok = rv && cvv && (unsigned)iy < (unsigned)p.g.H && (unsigned)ix < (unsigned)p.g.W;
-          pb[j] = ok ? gbase + (((long long)b * p.g.H + iy) * p.g.W + ix) * p.g.ld + ch : g_zero_page;
+          pb[sub][j] = ok ? gbase + (((long long)b * p.g.H + iy) * p.g.W + ix) * p.g.ld + ch : g_zero_page;
         } else {
           if (p.g.mode != 0) decode_row(p.g, rv ? r : 0, b, y, x);
-          pb[j] = gather_ptr(p.g, gbase, rv, r, b, y, x, tky, tkx, chunk, cvv);
+          pb[sub][j] = gather_ptr(p.g, gbase, rv, r, b, y, x, tky, tkx, chunk, cvv);
         }
       }
     }
   };
 
-  auto issue = [&](int buf) {
-    float* sA = sA0 + buf * BM * 16;
-    float* sB = sB0 + buf * BN * 16;
+  auto issue = [&](const int buf, const int sub) {
+    float* sA = smem + (buf * KSUB + sub) * SLAB;
+    float* sB = sA + BM * 16;
 #pragma unroll
-    for (int j = 0; j < MI; ++j) glds16(pa[j], sA + (j * 256 + wave * 64) * 4);
+    for (int j = 0; j < MI; ++j) glds16(pa[sub][j], sA + (j * 256 + wave * 64) * 4);
 #pragma unroll
-    for (int j = 0; j < NI; ++j) glds16(pb[j], sB + (j * 256 + wave * 64) * 4);
+    for (int j = 0; j < NI; ++j) glds16(pb[sub][j], sB + (j * 256 + wave * 64) * 4);
   };
 
-  auto compute = [&](int buf, bool more) {
-    const float* sA = sA0 + buf * BM * 16;
-    const float* sB = sB0 + buf * BN * 16;
+  auto compute = [&](const int buf, const int sub, const bool more) {
+    const float* sA = smem + (buf * KSUB + sub) * SLAB;
+    const float* sB = sA + BM * 16;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       float a[MI][4], b[NI][4];
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(
           for (int ii = 0; ii < 4; ++ii) b[ni][ii] = sB[(8 * jj + 4 * h + ii) * BN + row];
         }
       }
-      if (jj == 0 && (FAST || more)) prep();  // address math for the K-step after next rides under the MFMAs
+      if (jj == 0 && (FAST || more)) prep(sub);  // address math for the interval after next rides under the MFMAs
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
@@ -334,20 +339,27 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(
   // ---- main loop: K-step k+1 is in flight (LDS-DMA) while k is computed; addresses of k+2 are
   // prepared inside the MFMA region ------------------------------------------------------------
   if (nks > 0) {
-    prep();
-    issue(0);
-    if (nks > 1) prep();
-    for (int ks = 0; ks < nks; ++ks) {
-      const int cur = ks & 1;
-      if (ks + 1 < nks) {
-        issue(cur ^ 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(MI + NI) : "memory");
+    const int nss = (nks + KSUB - 1) / KSUB;  // barrier intervals
+#pragma unroll
+    for (int sub = 0; sub < KSUB; ++sub) {
+      prep(sub);
+      issue(0, sub);
+    }
+#pragma unroll
+    for (int sub = 0; sub < KSUB; ++sub) prep(sub);
+    for (int ss = 0; ss < nss; ++ss) {
+      const int cur = ss & 1;
+      if (ss + 1 < nss) {
+#pragma unroll
+        for (int sub = 0; sub < KSUB; ++sub) issue(cur ^ 1, sub);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(KSUB * (MI + NI)) : "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      compute(cur, ks + 2 < nks);
+#pragma unroll
+      for (int sub = 0; sub < KSUB; ++sub) compute(cur, sub, ss + 2 < nss);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -431,6 +443,8 @@ void launch_one(const IgemmArgs& a0, int ncols, int nbatch, int grid_y, hipStrea
 // tiles) x (wave-quantisation efficiency of the grid on 256 CUs x resident blocks per CU).
 struct TilePlan { int mi, ni, splits, rps; };
 struct TileInfo { int mi, ni, occ; float eff; };
+// eff: measured relative MFMA efficiency of each tile on large problems (tools/bench_tiles*.py); 256x64 /
+// 64x256 tiles exist in the dispatcher but never won a measurement and are not candidates.
 const TileInfo kTiles[] = {{1, 1, 8, 0.80f}, {2, 1, 6, 0.88f}, {1, 2, 6, 0.86f}, {2, 2, 3, 0.96f}, {4, 2, 2, 1.00f}, {2, 4, 2, 0.97f}};
 
 TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, long long red_rows) {
@@ -471,7 +485,7 @@ int launch_igemm(const IgemmArgs& a, int nbatch, int grid_y, hipStream_t st, con
   const TilePlan pl = given ? *given : plan_tiles(LAYOUT, a.M, ncols, (long long)grid_y * nbatch, a.g.rows);
   const int mi = pl.mi, ni = pl.ni;
 #define CS_TILE(M_, N_) if (mi == M_ && ni == N_) launch_one<LAYOUT, M_, N_>(a, ncols, nbatch, grid_y, st); else
-  CS_TILE(1, 1) CS_TILE(1, 2) CS_TILE(2, 1) CS_TILE(2, 2) CS_TILE(4, 2) CS_TILE(2, 4) CS_TILE(4, 4) {
+  CS_TILE(1, 1) CS_TILE(1, 2) CS_TILE(2, 1) CS_TILE(4, 1) CS_TILE(1, 4) CS_TILE(2, 2) CS_TILE(4, 2) CS_TILE(2, 4) CS_TILE(4, 4) {
     catseg_set_error("igemm: unsupported tile %dx%d", mi, ni);
     return CATSEG_EINVAL;
   }
