@@ -52,6 +52,15 @@ struct IgemmArgs {
   long long c_split_stride;
   int c_tap_stride;
   int tap_cin;  // L_TN, FAST: > 0 = the N dimension is taps x tap_cin (tap of a column = col / tap_cin), grid.y = 1
+  // FAST gather of L_NT / L_NN: the taps form an nky x nkx grid (i, j); source pixel of (row (b, y, x), tap (i, j)) =
+  //   (y * row_s + row_o + dy0 + i * ddy, x * row_s + row_o + dx0 + j * ddx); its weights sit at filter tap
+  //   (wy0 + i * wys) * kw + (wx0 + j * wxs).  All affine: no table loads in the K loop (scalar loads share
+  //   lgkmcnt with the LDS reads and would stall them).  row_s > 0 marks the parameters as valid.
+  int row_s, row_o;
+  int nky, nkx, dy0, ddy, dx0, ddx, wy0, wys, wx0, wxs;
+  // output row remap (strided backward-data, one launch per input-pixel parity class):
+  //   GEMM row (b, a, c) over (g.Ho, g.Wo) -> pixel ((b * out_H + a * out_s + out_py) * out_W + c * out_s + out_px)
+  int remap, out_s, out_py, out_px, out_H, out_W;
 };
 
 __device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
@@ -160,20 +169,16 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(
       ab[j] = ay[j] = ax[j] = 0;
       aoff[j] = 0;
       amask[j] = 0;
-      if (p.g.mode != 0) decode_row(p.g, arv[j] ? r : 0, ab[j], ay[j], ax[j]);
+      if (fast || p.g.mode != 0) decode_row(p.g, arv[j] ? r : 0, ab[j], ay[j], ax[j]);
       if (fast && arv[j]) {
-        {
-          const int sgn = p.g.mode == 1 ? 1 : -1;
-          const int y0 = p.g.mode == 1 ? ay[j] * p.g.stride - p.g.pad : ay[j] + p.g.pad;
-          const int x0 = p.g.mode == 1 ? ax[j] * p.g.stride - p.g.pad : ax[j] + p.g.pad;
-          aoff[j] = (((long long)ab[j] * p.g.H + y0) * p.g.W + x0) * p.g.ld;
-          int t = 0;
-          for (int ky = 0; ky * p.g.kw < p.taps; ++ky)
-            for (int kx = 0; kx < p.g.kw; ++kx, ++t) {
-              const int yy = y0 + sgn * ky * p.g.dil, xx = x0 + sgn * kx * p.g.dil;
-              if ((unsigned)yy < (unsigned)p.g.H && (unsigned)xx < (unsigned)p.g.W) amask[j] |= 1u << t;
-            }
-        }
+        const int y0 = ay[j] * p.row_s + p.row_o, x0 = ax[j] * p.row_s + p.row_o;
+        aoff[j] = (((long long)ab[j] * p.g.H + y0) * p.g.W + x0) * p.g.ld;
+        int t = 0;
+        for (int i = 0; i < p.nky; ++i)
+          for (int jx = 0; jx < p.nkx; ++jx, ++t) {
+            const int yy = y0 + p.dy0 + i * p.ddy, xx = x0 + p.dx0 + jx * p.ddx;
+            if ((unsigned)yy < (unsigned)p.g.H && (unsigned)xx < (unsigned)p.g.W) amask[j] |= 1u << t;
+          }
       }
     }
   }
@@ -193,7 +198,6 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(
     tky = (p.g.mode == 3) ? ttap : ttap / p.g.kw;
     tkx = (p.g.mode == 3) ? 0 : ttap - tky * p.g.kw;
   }
-  const long long tap_sign = p.g.mode == 2 ? -1 : 1;
 
   const float* pa[KSUB][MI];
   const float* pb[KSUB][NI];
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(
       const int chunk = tck * 4 + kc_chunk;
       const bool cv = live && chunk * 4 < p.Cred;
       if (fast) {
-        const long long toff = tap_sign * ((long long)tky * p.g.dil * p.g.W + tkx * p.g.dil) * p.g.ld + chunk * 4;
+        const long long toff = ((long long)(p.dy0 + tky * p.ddy) * p.g.W + (p.dx0 + tkx * p.ddx)) * p.g.ld + chunk * 4;
 #pragma unroll
         for (int j = 0; j < MI; ++j)
           pa[sub][j] = (cv && ((amask[j] >> (ttap & 31)) & 1u)) ? gbase + aoff[j] + toff : g_zero_page;
@@ -219,7 +223,8 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int n = n0 + j * 64 + kc_row;
-          pb[sub][j] = (n < p.N && cv) ? obase + (long long)n * p.ldo + ttap * p.tap_stride + chunk * 4 : g_zero_page;
+          const int wt = FAST ? (p.wy0 + tky * p.wys) * p.g.kw + p.wx0 + tkx * p.wxs : ttap;
+          pb[sub][j] = (n < p.N && cv) ? obase + (long long)n * p.ldo + wt * p.tap_stride + chunk * 4 : g_zero_page;
         }
       } else {
 #pragma unroll
@@ -228,12 +233,13 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(
           const int krow = q / (16 * NI), cc = q % (16 * NI);
           const int k = tck * 16 + krow;
           const bool ok = live && k < p.Cred_b && (n0 + cc * 4) < ((p.N + 3) & ~3);
-          pb[sub][j] = ok ? obase + (long long)k * p.ldo + ttap * p.tap_stride + n0 + cc * 4 : g_zero_page;
+          const int wt = FAST ? (p.wy0 + tky * p.wys) * p.g.kw + p.wx0 + tkx * p.wxs : ttap;
+          pb[sub][j] = ok ? obase + (long long)k * p.ldo + wt * p.tap_stride + n0 + cc * 4 : g_zero_page;
         }
       }
       if (FAST) {  // branch-free cursor advance
         const int nt = tck + 1, nx = tkx + 1;
-        const bool wrap = nt == nck, wrapx = wrap && (nx == p.g.kw);
+        const bool wrap = nt == nck, wrapx = wrap && (nx == p.nkx);
         tck = wrap ? 0 : nt;
         ttap += wrap ? 1 : 0;
         tkx = wrap ? (wrapx ? 0 : nx) : tkx;
@@ -378,7 +384,13 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < p.M) {
-          float* dst = cout + (long long)row * p.ldc + col;
+          long long orow = row;
+          if (LAYOUT != L_TN && p.remap) {
+            int b, a, c;
+            decode_row(p.g, row, b, a, c);
+            orow = ((long long)b * p.out_H + a * p.out_s + p.out_py) * p.out_W + c * p.out_s + p.out_px;
+          }
+          float* dst = cout + orow * p.ldc + col;
           if (col < p.N) {
             float v = acc[mi][ni][r] + bv;
             if (p.accumulate) v += *dst;
@@ -433,8 +445,7 @@ void launch_one(const IgemmArgs& a0, int ncols, int nbatch, int grid_y, hipStrea
   a.tilesM = (a.M + 64 * MI - 1) / (64 * MI);
   a.tilesN = (ncols + 64 * NI - 1) / (64 * NI);
   dim3 grid(a.tilesM * a.tilesN, grid_y, nbatch * (LAYOUT == L_TN ? a.splits : 1));
-  const bool fast = LAYOUT == L_TN ? a.g.mode == 1
-                                   : (a.taps <= 32 && (a.g.mode == 1 || (a.g.mode == 2 && a.g.stride == 1)));
+  const bool fast = LAYOUT == L_TN ? a.g.mode == 1 : (a.taps <= 32 && a.row_s > 0);   // row_s > 0 <=> tap tables are filled
   if (fast) hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, MI, NI, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, MI, NI, false>), grid, dim3(256), 0, st, a);
 }
@@ -511,6 +522,17 @@ int check_desc(const catseg_conv_desc* d) {
   return CATSEG_OK;
 }
 
+// affine tap parameters of a forward conv gather (sign = +1) or a stride-1 backward-data gather (sign = -1)
+void fill_taps(IgemmArgs& a, int kh, int kw, int dil, int sign, int row_s, int row_o) {
+  a.row_s = 0;
+  if (kh * kw > 32) return;
+  a.nky = kh; a.nkx = kw;
+  a.dy0 = a.dx0 = 0; a.ddy = a.ddx = sign * dil;
+  a.wy0 = a.wx0 = 0; a.wys = a.wxs = 1;
+  a.row_s = row_s;
+  a.row_o = row_o;
+}
+
 Geo fwd_geo(const catseg_conv_desc* d, const float* x) {
   Geo g;
   g.base = x; g.mode = d->stem4 ? 3 : 1; g.rows = d->B * d->Ho * d->Wo; g.ld = d->ldx;
@@ -538,6 +560,7 @@ extern "C" int catseg_conv2d_fwd(const catseg_conv_desc* d, const float* x, cons
   if (d->stem4) { a.taps = d->kh; a.Cred = 32; a.ldo = d->kh * 32; a.tap_stride = 32; }
   else { a.taps = d->kh * d->kw; a.Cred = d->Cin; a.ldo = a.taps * d->Cin; a.tap_stride = d->Cin; }
   a.Cred_b = a.Cred; a.zero_to = zero_to; a.accumulate = 0;
+  if (!d->stem4) fill_taps(a, d->kh, d->kw, d->dil, +1, d->stride, -d->pad);
   if (d->groups > 1) {  // one GEMM per group: batch strides walk the channel groups of x, w and y
     CS_REQUIRE(zero_to == 0, "conv fwd: zero_to is not supported with groups");
     const int cig = d->Cin / d->groups, cog = d->Cout / d->groups;
@@ -566,7 +589,41 @@ extern "C" int catseg_conv2d_bwd_data(const catseg_conv_desc* d, const float* dy
   a.Cred_b = d->Cout;
   a.ldo = a.taps * d->Cin; a.tap_stride = d->Cin;
   a.zero_to = 0; a.accumulate = accumulate;
-  return launch_igemm<L_NN>(a, 1, 1, (hipStream_t)stream);
+  if (d->stride == 1) {
+    fill_taps(a, d->kh, d->kw, d->dil, -1, 1, d->pad);
+    return launch_igemm<L_NN>(a, 1, 1, (hipStream_t)stream);
+  }
+  // stride s > 1: one dense launch per parity class (py, px) of the input pixels.  Input row iy = a*s + py only
+  // receives taps ky with (py + pad - ky*dil) % s == 0, from output row a + (py + pad - ky*dil) / s: no wasted MACs.
+  const int sdv = d->stride;
+  if (d->kh * d->kw > 32) return launch_igemm<L_NN>(a, 1, 1, (hipStream_t)stream);   // generic (slow) path
+  for (int py = 0; py < sdv; ++py)
+    for (int px = 0; px < sdv; ++px) {
+      const int Hs = (d->H - py + sdv - 1) / sdv, Ws = (d->W - px + sdv - 1) / sdv;
+      if (Hs <= 0 || Ws <= 0) continue;
+      IgemmArgs q = a;
+      q.g.Ho = Hs; q.g.Wo = Ws; q.g.rows = d->B * Hs * Ws; q.M = q.g.rows;
+      q.row_s = 1; q.row_o = 0;
+      // valid filter rows for this parity: ky = ky0 + i * kstep (kstep = s / gcd(s, dil)), i < nky
+      auto gcd = [](int u, int v) { while (v) { const int w = u % v; u = v; v = w; } return u; };
+      const int kstep = sdv / gcd(sdv, d->dil);
+      int ky0 = -1, kx0 = -1;
+      for (int k = 0; k < kstep && k < d->kh; ++k) if ((((py + d->pad - k * d->dil) % sdv) + sdv) % sdv == 0) { ky0 = k; break; }
+      for (int k = 0; k < kstep && k < d->kw; ++k) if ((((px + d->pad - k * d->dil) % sdv) + sdv) % sdv == 0) { kx0 = k; break; }
+      q.nky = ky0 < 0 ? 0 : (d->kh - ky0 + kstep - 1) / kstep;
+      q.nkx = kx0 < 0 ? 0 : (d->kw - kx0 + kstep - 1) / kstep;
+      if (q.nky > 0 && q.nkx > 0) {
+        q.dy0 = (py + d->pad - ky0 * d->dil) / sdv; q.ddy = -(kstep * d->dil) / sdv;
+        q.dx0 = (px + d->pad - kx0 * d->dil) / sdv; q.ddx = -(kstep * d->dil) / sdv;
+        q.wy0 = ky0; q.wys = kstep; q.wx0 = kx0; q.wxs = kstep;
+      } else {
+        q.nky = q.nkx = 0;   // no tap reaches this parity class: the launch only writes zeros
+      }
+      q.taps = q.nky * q.nkx;
+      q.remap = 1; q.out_s = sdv; q.out_py = py; q.out_px = px; q.out_H = d->H; q.out_W = d->W;
+      if (int e = launch_igemm<L_NN>(q, 1, 1, (hipStream_t)stream)) return e;
+    }
+  return CATSEG_OK;
 }
 
 namespace {
@@ -644,6 +701,7 @@ extern "C" int catseg_gemm_batched(int layout, int batch, int M, int N, int K, c
   g.mode = 1; g.W = g.Wo = 1; g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1;  // rows = a 1-pixel-wide image
   a.C = C; a.ldc = ldc; a.c_bs = strideC; a.M = M; a.N = N; a.zero_to = zero_to; a.accumulate = accumulate;
   a.taps = 1; a.tap_stride = 0;
+  a.row_s = 1; a.row_o = 0; a.nky = a.nkx = 1; a.dy0 = a.ddy = a.dx0 = a.ddx = 0; a.wy0 = a.wx0 = 0; a.wys = a.wxs = 1;
   hipStream_t st = (hipStream_t)stream;
   if (layout == CATSEG_GEMM_NT) {
     CS_REQUIRE(K % 4 == 0 && lda >= K && ldb >= K, "gemm NT: K must be a multiple of 4 and <= lda, ldb");

@@ -238,7 +238,7 @@ __global__ void bilinear_bwd_rows_kernel(const float* __restrict__ dy, int lddy,
   if (lo < 0) lo = 0;
   if (hi > Ho - 1) hi = Ho - 1;
   const int n = Wo * C;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
     const int ox = i / C, c = i - ox * C;
     float s = 0.f;
     for (int oy = lo; oy <= hi; ++oy) {
@@ -261,7 +261,7 @@ __global__ void bilinear_bwd_cols_kernel(const float* __restrict__ tmp, float* _
   float* o = dx + row * W * lddx;
   const int cw = zero_to > C ? zero_to : C;
   const int n = W * cw;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
     const int ix = i / cw, c = i - ix * cw;
     float* d = o + (long long)ix * lddx + c;
     if (c >= C) {
@@ -540,9 +540,14 @@ extern "C" int catseg_bilinear_bwd(const float* dy, int lddy, float* dx, int ldd
     return CATSEG_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bilinear_bwd_rows_kernel, dim3(B * H), dim3(256), 0, st, dy, lddy, (float*)workspace, B, H, C, Ho, Wo, align_corners,
+  // few, long input rows at low resolution: split each row's sweep so that the grid still fills the chip
+  const int ysplit_r = (int)((2048 + (long long)B * H - 1) / ((long long)B * H)) < (Wo * C + 255) / 256
+                           ? (int)((2048 + (long long)B * H - 1) / ((long long)B * H)) : (Wo * C + 255) / 256;
+  const int ysplit_c = (int)((2048 + (long long)B * H - 1) / ((long long)B * H)) < (W * C + 255) / 256
+                           ? (int)((2048 + (long long)B * H - 1) / ((long long)B * H)) : (W * C + 255) / 256;
+  hipLaunchKernelGGL(bilinear_bwd_rows_kernel, dim3(B * H, ysplit_r < 1 ? 1 : ysplit_r), dim3(256), 0, st, dy, lddy, (float*)workspace, B, H, C, Ho, Wo, align_corners,
                      resize_scale(H, Ho, align_corners));
-  hipLaunchKernelGGL(bilinear_bwd_cols_kernel, dim3(B * H), dim3(256), 0, st, (const float*)workspace, dx, lddx, W, C, Wo, align_corners,
+  hipLaunchKernelGGL(bilinear_bwd_cols_kernel, dim3(B * H, ysplit_c < 1 ? 1 : ysplit_c), dim3(256), 0, st, (const float*)workspace, dx, lddx, W, C, Wo, align_corners,
                      resize_scale(W, Wo, align_corners), zero_to, accumulate);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
