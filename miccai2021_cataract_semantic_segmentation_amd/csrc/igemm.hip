@@ -109,7 +109,7 @@ __device__ __forceinline__ const float* gather_ptr(const Geo& g, const float* ba
 // backward-data gather (mode 2) with <= 32 taps: the per-K-step address generation is branch-free
 // straight-line code that the scheduler interleaves with the MFMAs.
 template <int LAYOUT, int MI, int NI, bool FAST>
-__global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : 1) void igemm_f32_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI * NI == 4) ? 4 : 1)) void igemm_f32_kernel(const IgemmArgs p) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
   constexpr bool A_KC = (LAYOUT != L_TN);
   constexpr bool B_KC = (LAYOUT == L_NT);
@@ -456,7 +456,7 @@ struct TilePlan { int mi, ni, splits, rps; };
 struct TileInfo { int mi, ni, occ; float eff; };
 // eff: measured relative MFMA efficiency of each tile on large problems (tools/bench_tiles*.py); 256x64 /
 // 64x256 tiles exist in the dispatcher but never won a measurement and are not candidates.
-const TileInfo kTiles[] = {{1, 1, 8, 0.80f}, {2, 1, 6, 0.88f}, {1, 2, 6, 0.86f}, {2, 2, 3, 0.96f}, {4, 2, 2, 1.00f}, {2, 4, 2, 0.97f}};
+const TileInfo kTiles[] = {{1, 1, 8, 0.80f}, {2, 1, 6, 0.88f}, {1, 2, 6, 0.86f}, {2, 2, 4, 1.00f}, {4, 2, 2, 0.97f}, {2, 4, 2, 0.96f}};
 
 TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, long long red_rows) {
   TilePlan best = {2, 2, 1, 0};
@@ -475,7 +475,9 @@ TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, l
     for (long long sp = 1; sp <= maxs; ++sp) {
       const double rounds = (double)(tm * tn * extra * sp) / slots;
       const double q = rounds / (double)(long long)(rounds + 0.999999);
-      const double score = t.eff * pad * q * (1.0 - 0.002 * (double)(sp - 1));
+      // backward-weight (K-major operands) prefers the 256x128 tile: measured 118 vs 113 TFLOP/s
+      const double eff = (layout == L_TN && t.mi == 4) ? 1.03 : t.eff;
+      const double score = eff * pad * q * (1.0 - 0.002 * (double)(sp - 1));
       if (score > best_score) {
         best_score = score;
         best = {t.mi, t.ni, (int)sp, 0};
