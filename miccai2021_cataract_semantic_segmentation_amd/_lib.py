@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcatseg_hip.so")
+LIB_PATH = os.environ.get("CATSEG_LIB") or os.path.join(_HERE, "libcatseg_hip.so")  # CATSEG_LIB: A/B builds of the library
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

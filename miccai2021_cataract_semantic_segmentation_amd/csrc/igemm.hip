@@ -21,6 +21,12 @@
 // A and B use the same mapping, the sum over k is order-insensitive up to fp32 rounding.
 #include "common.h"
 
+// LDS ring depth of the 128x128 and larger tiles.  A/B on one MI355X (tools/bench_conv.py, same process order):
+// 3 slots / one barrier per K-step = 124 TFLOP/s forward, 2 slots / two barriers but 4 blocks per CU = 128.
+#ifndef CATSEG_NBUF_BIG
+#define CATSEG_NBUF_BIG 2
+#endif
+
 namespace {
 
 __device__ __attribute__((aligned(256))) float g_zero_page[64];
@@ -109,15 +115,18 @@ __device__ __forceinline__ const float* gather_ptr(const Geo& g, const float* ba
 // backward-data gather (mode 2) with <= 32 taps: the per-K-step address generation is branch-free
 // straight-line code that the scheduler interleaves with the MFMAs.
 template <int LAYOUT, int MI, int NI, bool FAST>
-__global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI * NI == 4) ? 4 : 1)) void igemm_f32_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4 : 1)) void igemm_f32_kernel(const IgemmArgs p) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
   constexpr bool A_KC = (LAYOUT != L_TN);
   constexpr bool B_KC = (LAYOUT == L_NT);
   // K sub-steps (of 16) per barrier interval.  Measured: > 1 on the small tiles costs more in occupancy
   // (LDS per block) than it saves in barriers (48-channel 3x3: 67 -> 56 TFLOP/s with 4), so it stays 1.
   constexpr int KSUB = 1;
+  // LDS ring: 3 slots = ONE barrier per K-step (the slot refilled after the barrier of step k was last read in
+  // step k-1, which every wave has left); 2 slots = two barriers.  Small tiles keep 2 (occupancy).
+  constexpr int NBUF = CATSEG_NBUF_BIG > 2 && (MI * NI >= 4) ? 3 : 2;
   constexpr int SLAB = (BM + BN) * 16;  // floats of one (A, B) sub-step image
-  __shared__ __attribute__((aligned(16))) float smem[2 * KSUB * SLAB];
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * KSUB * SLAB];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI * NI == 4) ? 4 : 1))
 
   // ---- main loop: K-step k+1 is in flight (LDS-DMA) while k is computed; addresses of k+2 are
   // prepared inside the MFMA region ------------------------------------------------------------
-  if (nks > 0) {
+  if (nks > 0 && NBUF == 2) {
     const int nss = (nks + KSUB - 1) / KSUB;  // barrier intervals
 #pragma unroll
     for (int sub = 0; sub < KSUB; ++sub) {
@@ -368,6 +377,24 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI * NI == 4) ? 4 : 1))
       for (int sub = 0; sub < KSUB; ++sub) compute(cur, sub, ss + 2 < nss);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+    }
+  } else if (nks > 0) {
+    // three-slot ring, one barrier per K-step: steps k+1 and k+2 are in flight while k is computed
+    prep(0);
+    issue(0, 0);
+    prep(0);
+    if (nks > 1) issue(1, 0);
+    prep(0);  // addresses of step 2
+    int cur = 0, fill = 2;
+    for (int ks = 0; ks < nks; ++ks) {
+      if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(MI + NI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (ks + 2 < nks) issue(fill, 0);
+      compute(cur, 0, ks + 3 < nks);
+      cur = cur == 2 ? 0 : cur + 1;
+      fill = fill == 2 ? 0 : fill + 1;
     }
   }
 
