@@ -75,6 +75,59 @@ def cpu_baseline(H, W, K, model_name):
                       "%.1f s wall" % (H, W, K, dt)}
 
 
+def infer_bench(args):
+    """config 5: frames sharded over ranks, no exchange in the timed region (confusion matrices are summed once at
+    the end of a real run); eval-mode BatchNorm, argmax + confusion matrix included in the step"""
+    from miccai2021_cataract_semantic_segmentation_amd import dist as D
+    rank, local, world = D.init_from_env()
+    import torch.distributed as dist
+    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
+    from miccai2021_cataract_semantic_segmentation_amd.models import EncDec
+    from miccai2021_cataract_semantic_segmentation_amd.utils.metrics import t_get_confusion_matrix
+    B = 4 if args.batch == 8 else args.batch
+    H, W = (1080, 1920) if (args.height, args.width) == (544, 960) else (args.height, args.width)
+    H = (H + 31) // 32 * 32   # the encoder strides by 32; 1080 -> 1088 rows (the reference pads as well)
+    torch.manual_seed(0)
+    model = EncDec({"encoder": {"model": "ResNeXt101", "pretrained": False}, "decoder": {"model": "UPerNet"}}, 3).to(dev).eval()
+    model.get_features = False
+    img, lbl = synth_batch(B, H, W, 25, 2000 + rank, dev)
+    cm = torch.zeros((25, 25), dtype=torch.int32, device=dev)
+
+    def step():
+        with torch.no_grad():
+            t_get_confusion_matrix(model(img), lbl, cm)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    if rank == 0:
+        print(json.dumps({"metric": "inference frames/sec @1080x1920 UPerNet-ResNeXt101", "value": world * B * args.steps / dt,
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "EncDec(ResNeXt101_32x8d + UPerNet), 25-class, bs=%d/GPU @3x%dx%d, eval-mode forward + "
+                                                 "argmax + confusion matrix (BASELINE config 5)" % (B, H, W),
+                                     "global_batch": world * B, "parallelism": "dp%d (frame sharded)" % world},
+                          "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,16 +137,20 @@ def main():
     ap.add_argument("--height", type=int, default=544)
     ap.add_argument("--width", type=int, default=960)
     ap.add_argument("--model", default="ocrnet_hrnet48", choices=sorted(MODELS))
+    ap.add_argument("--infer", action="store_true",
+                    help="BASELINE config 5 instead: EncDec(ResNeXt101_32x8d + UPerNet) inference at 3x1080x1920, 4 frames per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.infer:
+        return infer_bench(args)
     from miccai2021_cataract_semantic_segmentation_amd import dist as D
     rank, local, world = D.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import torch.distributed as dist
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))   # (gloo smoke runs may share one GPU)
     torch.cuda.set_device(dev)
 
     from miccai2021_cataract_semantic_segmentation_amd import ops
@@ -142,12 +199,14 @@ def main():
     final_loss = float(loss.detach())
 
     roof = None
-    if not args.no_roofline and rank == 0:
-        # per-launch HIP-event timing of the implicit-GEMM kernels on the launch stream (2 extra steps)
-        ops.PROFILE = []
+    if not args.no_roofline:
+        # per-launch HIP-event timing of the implicit-GEMM kernels on the launch stream (2 extra steps, run by
+        # EVERY rank because a step contains the gradient all-reduce; only rank 0 records)
+        ops.PROFILE = [] if rank == 0 else None
         for _ in range(2):
             step()
         torch.cuda.synchronize()
+    if not args.no_roofline and rank == 0:
         prof, ops.PROFILE = ops.PROFILE, None
         agg = {}
         for kind, flops, e0, e1 in prof:
@@ -175,7 +234,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "train frames/sec @540x960 (3x544x960 after pad), OCRNet, fwd+TwoScale-Lovasz+bwd+Adam",
+            "metric": "train frames/sec @540x960 %s" % ("OCRNet-HRNetw48" if args.model == "ocrnet_hrnet48" else "OCRNet-ResNet50"),
             "value": world * B * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -11,6 +11,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the HIP library is a build artefact (git-ignored): compile it on first use (hipcc cross-compiles without a GPU)
+    lib = os.path.join(ROOT, "miccai2021_cataract_semantic_segmentation_amd", "libcatseg_hip.so")
+    if not os.path.exists(lib):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
