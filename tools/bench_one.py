@@ -7,6 +7,8 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda")
 B, H, W, Ci, Co, k, s, p, d = 8, 68, 120, 512, 512, 3, 1, 4, 4
+if len(sys.argv) > 3:
+    B, H, W, Ci, Co, k, s, p, d = [int(v) for v in sys.argv[3].split(",")]
 x = torch.randn(B, H, W, Ci, device=dev)
 w = (torch.randn(Co, Ci, k, k, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
 y = ops.conv_fwd(x, w, None, Co, k, k, s, p, d)
