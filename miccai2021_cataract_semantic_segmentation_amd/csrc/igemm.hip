@@ -67,6 +67,7 @@ struct IgemmArgs {
   // output row remap (strided backward-data, one launch per input-pixel parity class):
   //   GEMM row (b, a, c) over (g.Ho, g.Wo) -> pixel ((b * out_H + a * out_s + out_py) * out_W + c * out_s + out_px)
   int remap, out_s, out_py, out_px, out_H, out_W;
+  const float* zero;  // 256-byte zero page (kernel argument: no GOT load / lgkmcnt wait inside the K loop)
 };
 
 __device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
@@ -114,6 +115,13 @@ __device__ __forceinline__ const float* gather_ptr(const Geo& g, const float* ba
 // FAST: the gathered operand is a plain / stride-any forward conv gather (mode 1) or a stride-1
 // backward-data gather (mode 2) with <= 32 taps: the per-K-step address generation is branch-free
 // straight-line code that the scheduler interleaves with the MFMAs.
+// branch-free "address or zero page": all element offsets are 32-bit (tensors < 2^31 floats, checked on the host)
+__device__ __forceinline__ const float* sel_ptr(bool ok, const float* base, int off, const float* zero) {
+  const float* b = ok ? base : zero;
+  const unsigned o = ok ? (unsigned)off : 0u;
+  return b + o;
+}
+
 template <int LAYOUT, int MI, int NI, bool FAST>
 __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4 : 1)) void igemm_f32_kernel(const IgemmArgs p) {
   constexpr int BM = 64 * MI, BN = 64 * NI;
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
   constexpr bool fast = FAST;
   int ab[MI], ay[MI], ax[MI];
   bool arv[MI];
-  long long aoff[MI];
+  int aoff[MI];
   unsigned amask[MI];
   if (A_KC) {
 #pragma unroll
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
       if (fast || p.g.mode != 0) decode_row(p.g, arv[j] ? r : 0, ab[j], ay[j], ax[j]);
       if (fast && arv[j]) {
         const int y0 = ay[j] * p.row_s + p.row_o, x0 = ax[j] * p.row_s + p.row_o;
-        aoff[j] = (((long long)ab[j] * p.g.H + y0) * p.g.W + x0) * p.g.ld;
+        aoff[j] = ((ab[j] * p.g.H + y0) * p.g.W + x0) * p.g.ld;
         int t = 0;
         for (int i = 0; i < p.nky; ++i)
           for (int jx = 0; jx < p.nkx; ++jx, ++t) {
@@ -218,32 +226,33 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
       ++tks;
       const int chunk = tck * 4 + kc_chunk;
       const bool cv = live && chunk * 4 < p.Cred;
+      const int wt = FAST ? (p.wy0 + tky * p.wys) * p.g.kw + p.wx0 + tkx * p.wxs : ttap;
       if (fast) {
-        const long long toff = ((long long)(p.dy0 + tky * p.ddy) * p.g.W + (p.dx0 + tkx * p.ddx)) * p.g.ld + chunk * 4;
+        const int toff = ((p.dy0 + tky * p.ddy) * p.g.W + (p.dx0 + tkx * p.ddx)) * p.g.ld + chunk * 4;
 #pragma unroll
         for (int j = 0; j < MI; ++j)
-          pa[sub][j] = (cv && ((amask[j] >> (ttap & 31)) & 1u)) ? gbase + aoff[j] + toff : g_zero_page;
+          pa[sub][j] = sel_ptr(cv && ((amask[j] >> (ttap & 31)) & 1u), gbase, aoff[j] + toff, p.zero);
       } else {
 #pragma unroll
         for (int j = 0; j < MI; ++j)
           pa[sub][j] = gather_ptr(p.g, gbase, arv[j], m0 + j * 64 + kc_row, ab[j], ay[j], ax[j], tky, tkx, chunk, cv);
       }
       if (B_KC) {
+        const int boff = wt * p.tap_stride + chunk * 4;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int n = n0 + j * 64 + kc_row;
-          const int wt = FAST ? (p.wy0 + tky * p.wys) * p.g.kw + p.wx0 + tkx * p.wxs : ttap;
-          pb[sub][j] = (n < p.N && cv) ? obase + (long long)n * p.ldo + wt * p.tap_stride + chunk * 4 : g_zero_page;
+          pb[sub][j] = sel_ptr(n < p.N && cv, obase, n * p.ldo + boff, p.zero);
         }
       } else {
+        const int boff = wt * p.tap_stride + n0;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int q = j * 256 + tid;
           const int krow = q / (16 * NI), cc = q % (16 * NI);
           const int k = tck * 16 + krow;
           const bool ok = live && k < p.Cred_b && (n0 + cc * 4) < ((p.N + 3) & ~3);
-          const int wt = FAST ? (p.wy0 + tky * p.wys) * p.g.kw + p.wx0 + tkx * p.wxs : ttap;
-          pb[sub][j] = ok ? obase + (long long)k * p.ldo + wt * p.tap_stride + n0 + cc * 4 : g_zero_page;
+          pb[sub][j] = sel_ptr(ok, obase, k * p.ldo + boff + cc * 4, p.zero);
         }
       }
       if (FAST) {  // branch-free cursor advance
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
         const int krow = q / (16 * MI), cc = q % (16 * MI);
         const int r = kbase + krow;
         const bool ok = r < r_end && (m0 + cc * 4) < ((p.M + 3) & ~3);
-        pa[sub][j] = ok ? obase + (long long)r * p.ldo + m0 + cc * 4 : g_zero_page;
+        pa[sub][j] = sel_ptr(ok, obase, r * p.ldo + m0 + cc * 4, p.zero);
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
         const int chunk = (n0 >> 2) + cc;
         const bool cvv = chunk * 4 < ((p.N + 3) & ~3);
         if (FAST) {  // forward-conv gather (plain GEMM rows are passed as a degenerate 1-wide image)
-          // the column block of this lane fixes its filter tap: columns are (tap, channel) pairs
+          // the column block of this lane fixes its filter tap: columns are (tap, channel) pairs (loop invariant)
           const int col = chunk * 4;
           const int tap = col / p.tap_cin, ch = col - tap * p.tap_cin;
           const int ky = tap / p.g.kw, kx = tap - ky * p.g.kw;
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
           const int iy = y * p.g.stride - p.g.pad + ky * p.g.dil;
           const int ix = x * p.g.stride - p.g.pad + kx * p.g.dil;
           const bool ok = rv && cvv && (unsigned)iy < (unsigned)p.g.H && (unsigned)ix < (unsigned)p.g.W;
-          pb[sub][j] = ok ? gbase + (((long long)b * p.g.H + iy) * p.g.W + ix) * p.g.ld + ch : g_zero_page;
+          pb[sub][j] = sel_ptr(ok, gbase, ((b * p.g.H + iy) * p.g.W + ix) * p.g.ld + ch, p.zero);
         } else {
           if (p.g.mode != 0) decode_row(p.g, rv ? r : 0, b, y, x);
           pb[sub][j] = gather_ptr(p.g, gbase, rv, r, b, y, x, tky, tkx, chunk, cvv);
@@ -466,9 +475,19 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, 
 
 int g_force_mi = 0, g_force_ni = 0;  // tuning hook (catseg_debug_set_tile)
 
+const float* zero_page_ptr() {
+  static const float* z = nullptr;
+  if (!z) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_page)) == hipSuccess) z = (const float*)q;
+  }
+  return z;
+}
+
 template <int LAYOUT, int MI, int NI>
 void launch_one(const IgemmArgs& a0, int ncols, int nbatch, int grid_y, hipStream_t st) {
   IgemmArgs a = a0;
+  a.zero = zero_page_ptr();
   a.tilesM = (a.M + 64 * MI - 1) / (64 * MI);
   a.tilesN = (ncols + 64 * NI - 1) / (64 * NI);
   dim3 grid(a.tilesM * a.tilesN, grid_y, nbatch * (LAYOUT == L_TN ? a.splits : 1));
@@ -547,7 +566,9 @@ int check_desc(const catseg_conv_desc* d) {
   if (d->groups > 1)
     CS_REQUIRE(!d->stem4 && d->Cin % d->groups == 0 && d->Cout % d->groups == 0 && (d->Cin / d->groups) % 4 == 0,
                "conv: groups must divide Cin and Cout, Cin/groups a multiple of 4");
-  CS_REQUIRE((long long)d->B * d->Ho * d->Wo < (1ll << 31) && (long long)d->B * d->H * d->W < (1ll << 31), "conv: too many pixels");
+  CS_REQUIRE((long long)d->B * d->Ho * d->Wo * d->ldy < (1ll << 31) && (long long)d->B * d->H * d->W * d->ldx < (1ll << 31) &&
+                 (long long)d->Cout * d->kh * d->kw * d->Cin < (1ll << 31),
+             "conv: tensors must have fewer than 2^31 elements (32-bit element offsets)");
   return CATSEG_OK;
 }
 
@@ -725,6 +746,8 @@ extern "C" int catseg_gemm_batched(int layout, int batch, int M, int N, int K, c
   CS_REQUIRE(cs_aligned16(A) && cs_aligned16(Bm) && cs_aligned16(C), "gemm: pointers must be 16-byte aligned");
   CS_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0, "gemm: lda/ldb/strides must be multiples of 4");
   CS_REQUIRE(zero_to <= ldc, "gemm: zero_to > ldc");
+  CS_REQUIRE((long long)M * lda < (1ll << 31) && (long long)N * ldb < (1ll << 31) && (long long)K * (lda > ldb ? lda : ldb) < (1ll << 31),
+             "gemm: operands must have fewer than 2^31 elements per batch item");
   IgemmArgs a = {};
   Geo& g = a.g;
   g.mode = 1; g.W = g.Wo = 1; g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1;  // rows = a 1-pixel-wide image

@@ -74,23 +74,23 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-// merge of the per-row-block partials: block = 64 channels (lanes, coalesced) x 16 row-block lanes.
-// Two passes over the (L2-resident) partials, no division inside the loops:
+// merge of the per-row-block partials: block = 16 channels x 64 row-block lanes (short dependent-load chains:
+// <= 8 partials per thread), two passes over the L2-resident partials, no division inside the loops:
 //   mean = sum_b n_b * mean_b / n ;  M2 = sum_b [ M2_b + n_b * (mean_b - mean)^2 ]     (fp64)
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nrb, long long rpb, long long rows, int C,
                                                            const float* __restrict__ gamma, float eps, float momentum, float* running_mean,
                                                            float* running_var, float* __restrict__ stats, float* __restrict__ scale) {
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   const bool live = c < C;
   const double n_full = (double)rpb, inv_full = 1.0 / n_full;
   const double n_last = (double)(rows - (long long)(nrb - 1) * rpb), inv_last = 1.0 / n_last;
-  __shared__ double sh[16][64];
-  __shared__ double smean[64];
+  __shared__ double sh[64][17];
+  __shared__ double smean[16];
   double acc = 0;
   if (live) {
 #pragma unroll 4
-    for (int b = rl; b < nrb; b += 16) {
+    for (int b = rl; b < nrb; b += 64) {
       const float* o = part + ((long long)b * 3) * C;
       const double nb = b == nrb - 1 ? n_last : n_full;
       acc += nb * (double)o[c] + (double)o[C + c];   // n_b * mean_b = n_b * K + s1
@@ -100,8 +100,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   __syncthreads();
   if (rl == 0) {
     double t = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += sh[k][cl];
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) t += sh[k][cl];
     smean[cl] = t / (double)rows;
   }
   __syncthreads();
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   acc = 0;
   if (live) {
 #pragma unroll 4
-    for (int b = rl; b < nrb; b += 16) {
+    for (int b = rl; b < nrb; b += 64) {
       const float* o = part + ((long long)b * 3) * C;
       const bool last = b == nrb - 1;
       const double nb = last ? n_last : n_full, inv = last ? inv_last : inv_full;
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   __syncthreads();
   if (rl != 0 || !live) return;
   double m2 = 0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) m2 += sh[k][cl];
+#pragma unroll 8
+  for (int k = 0; k < 64; ++k) m2 += sh[k][cl];
   const double n = (double)rows;
   const float var = (float)(m2 / n);
   const float invstd = 1.0f / sqrtf(var + eps);
@@ -280,7 +280,7 @@ extern "C" int catseg_bn_train_stats(const float* y, long long rows, int C, int 
   const RowSplit s = plan_rows(rows, C);
   float* part = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, y, ldy, rows, C, s, part);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, (const float*)part, s.nrb, s.rpb, rows, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, (const float*)part, s.nrb, s.rpb, rows, C,
                      gamma, eps, momentum, running_mean, running_var, stats_out, scale);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
