@@ -79,6 +79,8 @@ int catseg_gemm_batched(int layout, int batch, int M, int N, int K, const float*
 
 /* tuning hook: force the igemm block tile to (64*mi) x (64*ni); mi = 0 restores the heuristic */
 int catseg_debug_set_tile(int mi, int ni);
+/* tuning hook: force the backward-weight split count (0 restores the planner) */
+int catseg_debug_set_splits(int splits);
 
 /* ---- BatchNorm (+ReLU, +residual) — nn.BatchNorm2d/ReLU at e.g. models/OCR.py:74-75,
  * torchvision Bottleneck, models/DeepLabv3Plus.py:98-104.  rows = B*H*W pixels. */

@@ -67,6 +67,7 @@ struct IgemmArgs {
   // output row remap (strided backward-data, one launch per input-pixel parity class):
   //   GEMM row (b, a, c) over (g.Ho, g.Wo) -> pixel ((b * out_H + a * out_s + out_py) * out_W + c * out_s + out_px)
   int remap, out_s, out_py, out_px, out_H, out_W;
+  int step_qy, step_rx;  // L_TN FAST: 16 rows ahead = step_qy image rows + step_rx pixels (no division in the K loop)
   const float* zero;  // 256-byte zero page (kernel argument: no GOT load / lgkmcnt wait inside the K loop)
 };
 
@@ -219,6 +220,26 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
   const float* pa[KSUB][MI];
   const float* pb[KSUB][NI];
 
+  // L_TN FAST: per staged B row the pixel (b, y, x) is decoded once and then advanced by 16 rows per K-step;
+  // the filter tap / channel of the lane's column block is loop invariant
+  int tb[NI], ty[NI], tx[NI], tr[NI], tky_l[NI], tkx_l[NI], tch[NI];
+  bool tcv[NI];
+  if (LAYOUT == L_TN && FAST) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int q = j * 256 + tid;
+      const int krow = q / (16 * NI), cc = q % (16 * NI);
+      tr[j] = r_begin + krow;
+      decode_row(p.g, tr[j] < p.g.rows ? tr[j] : 0, tb[j], ty[j], tx[j]);
+      const int col = ((n0 >> 2) + cc) * 4;
+      const int tap = col / p.tap_cin;
+      tch[j] = col - tap * p.tap_cin;
+      tky_l[j] = tap / p.g.kw;
+      tkx_l[j] = tap - tky_l[j] * p.g.kw;
+      tcv[j] = col < ((p.N + 3) & ~3);
+    }
+  }
+
   // source addresses of a future K sub-step (pure VALU/SALU work: overlaps the MFMAs of the current one)
   auto prep = [&](const int sub) {
     const bool live = tks < nks;  // sub-steps past the end of the reduction load zeros
@@ -293,15 +314,20 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
         const int chunk = (n0 >> 2) + cc;
         const bool cvv = chunk * 4 < ((p.N + 3) & ~3);
         if (FAST) {  // forward-conv gather (plain GEMM rows are passed as a degenerate 1-wide image)
-          // the column block of this lane fixes its filter tap: columns are (tap, channel) pairs (loop invariant)
-          const int col = chunk * 4;
-          const int tap = col / p.tap_cin, ch = col - tap * p.tap_cin;
-          const int ky = tap / p.g.kw, kx = tap - ky * p.g.kw;
-          decode_row(p.g, rv ? r : 0, b, y, x);
-          const int iy = y * p.g.stride - p.g.pad + ky * p.g.dil;
-          const int ix = x * p.g.stride - p.g.pad + kx * p.g.dil;
-          const bool ok = rv && cvv && (unsigned)iy < (unsigned)p.g.H && (unsigned)ix < (unsigned)p.g.W;
-          pb[sub][j] = sel_ptr(ok, gbase, ((b * p.g.H + iy) * p.g.W + ix) * p.g.ld + ch, p.zero);
+          const int iy = ty[j] * p.g.stride - p.g.pad + tky_l[j] * p.g.dil;
+          const int ix = tx[j] * p.g.stride - p.g.pad + tkx_l[j] * p.g.dil;
+          const bool ok = tr[j] < r_end && tcv[j] && (unsigned)iy < (unsigned)p.g.H && (unsigned)ix < (unsigned)p.g.W;
+          pb[sub][j] = sel_ptr(ok, gbase, ((tb[j] * p.g.H + iy) * p.g.W + ix) * p.g.ld + tch[j], p.zero);
+          // advance this row by 16 pixels
+          tr[j] += 16;
+          tx[j] += p.step_rx;
+          ty[j] += p.step_qy;
+          const bool cx = tx[j] >= p.g.Wo;
+          tx[j] -= cx ? p.g.Wo : 0;
+          ty[j] += cx ? 1 : 0;
+          const bool cy = ty[j] >= p.g.Ho;
+          ty[j] -= cy ? p.g.Ho : 0;
+          tb[j] += cy ? 1 : 0;
         } else {
           if (p.g.mode != 0) decode_row(p.g, rv ? r : 0, b, y, x);
           pb[sub][j] = gather_ptr(p.g, gbase, rv, r, b, y, x, tky, tkx, chunk, cvv);
@@ -473,7 +499,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, 
   out[c] = s;
 }
 
-int g_force_mi = 0, g_force_ni = 0;  // tuning hook (catseg_debug_set_tile)
+int g_force_mi = 0, g_force_ni = 0, g_force_splits = 0;  // tuning hooks (catseg_debug_set_tile / _splits)
 
 const float* zero_page_ptr() {
   static const float* z = nullptr;
@@ -491,7 +517,10 @@ void launch_one(const IgemmArgs& a0, int ncols, int nbatch, int grid_y, hipStrea
   a.tilesM = (a.M + 64 * MI - 1) / (64 * MI);
   a.tilesN = (ncols + 64 * NI - 1) / (64 * NI);
   dim3 grid(a.tilesM * a.tilesN, grid_y, nbatch * (LAYOUT == L_TN ? a.splits : 1));
-  const bool fast = LAYOUT == L_TN ? a.g.mode == 1 : (a.taps <= 32 && a.row_s > 0);   // row_s > 0 <=> tap tables are filled
+  a.step_qy = 16 / a.g.Wo;
+  a.step_rx = 16 % a.g.Wo;
+  // TN fast path: forward-conv gather whose rows can be advanced incrementally (a 16-row step wraps at most one image)
+  const bool fast = LAYOUT == L_TN ? (a.g.mode == 1 && a.g.Ho >= a.step_qy + 1) : (a.taps <= 32 && a.row_s > 0);
   if (fast) hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, MI, NI, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, MI, NI, false>), grid, dim3(256), 0, st, a);
 }
@@ -531,6 +560,7 @@ TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, l
     }
   }
   if (g_force_mi > 0 && best_score < 0) best = {g_force_mi, g_force_ni, 1, 0};
+  if (g_force_splits > 0 && layout == L_TN) best.splits = g_force_splits;
   if (layout == L_TN) {
     best.rps = (int)(((red_rows + best.splits - 1) / best.splits + 15) / 16 * 16);
     best.splits = (int)((red_rows + best.rps - 1) / best.rps);
@@ -544,7 +574,8 @@ int launch_igemm(const IgemmArgs& a, int nbatch, int grid_y, hipStream_t st, con
   const TilePlan pl = given ? *given : plan_tiles(LAYOUT, a.M, ncols, (long long)grid_y * nbatch, a.g.rows);
   const int mi = pl.mi, ni = pl.ni;
 #define CS_TILE(M_, N_) if (mi == M_ && ni == N_) launch_one<LAYOUT, M_, N_>(a, ncols, nbatch, grid_y, st); else
-  CS_TILE(1, 1) CS_TILE(1, 2) CS_TILE(2, 1) CS_TILE(4, 1) CS_TILE(1, 4) CS_TILE(2, 2) CS_TILE(4, 2) CS_TILE(2, 4) CS_TILE(4, 4) {
+  // (256x64, 64x256, 64x448, 128x448 and 256x256 tiles were measured and never won: not instantiated)
+  CS_TILE(1, 1) CS_TILE(1, 2) CS_TILE(2, 1) CS_TILE(2, 2) CS_TILE(4, 2) CS_TILE(2, 4) {
     catseg_set_error("igemm: unsupported tile %dx%d", mi, ni);
     return CATSEG_EINVAL;
   }
@@ -595,6 +626,10 @@ Geo fwd_geo(const catseg_conv_desc* d, const float* x) {
 extern "C" int catseg_debug_set_tile(int mi, int ni) {
   g_force_mi = mi;
   g_force_ni = ni;
+  return CATSEG_OK;
+}
+extern "C" int catseg_debug_set_splits(int splits) {
+  g_force_splits = splits;
   return CATSEG_OK;
 }
 
