@@ -54,6 +54,15 @@ typedef struct {
  * [Cout, zero_to) of y are written as zeros (zero_to <= ldy, 0 = none). */
 int catseg_conv2d_fwd(const catseg_conv_desc* d, const float* x, const float* w, const float* bias,
                       float* y, int zero_to, catseg_stream_t stream);
+/* inference: y = act(conv(x, w) + bias (+ residual)), act = relu if relu != 0, in one kernel.  With
+ * catseg_fold_bn this is Conv2d + eval-mode BatchNorm2d + residual add + ReLU of a ResNet / UPerNet block. */
+int catseg_conv2d_fwd_fused(const catseg_conv_desc* d, const float* x, const float* w, const float* bias,
+                            const float* residual, int ldr, int relu, float* y, catseg_stream_t stream);
+/* w'[o,:] = w[o,:] * gamma[o]/sqrt(rv[o]+eps), b'[o] = beta[o] + (b[o] - rm[o]) * gamma[o]/sqrt(rv[o]+eps);
+ * per_out = floats per output channel of w (kh*kw*Cin, or 7*32 for the packed stem) */
+int catseg_fold_bn(const float* w, const float* bias, const float* gamma, const float* beta, const float* running_mean,
+                   const float* running_var, float eps, int O, int per_out, float* w_folded, float* bias_folded,
+                   catseg_stream_t stream);
 /* dx[q, c] (+)= sum_{ky,kx,o} dy[opix(q,ky,kx), o] * w[o,ky,kx,c]  (autograd of the above) */
 int catseg_conv2d_bwd_data(const catseg_conv_desc* d, const float* dy, const float* w, float* dx,
                            int accumulate, catseg_stream_t stream);

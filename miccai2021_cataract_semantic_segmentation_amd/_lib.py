@@ -31,6 +31,8 @@ _SIGS = {
     "catseg_last_error": (C.c_char_p, []),
     "catseg_version": (I, []),
     "catseg_conv2d_fwd": (I, [P, P, P, P, P, I, P]),
+    "catseg_conv2d_fwd_fused": (I, [P, P, P, P, P, I, I, P, P]),
+    "catseg_fold_bn": (I, [P, P, P, P, P, P, F, I, I, P, P, P]),
     "catseg_conv2d_bwd_data": (I, [P, P, P, P, I, P]),
     "catseg_conv2d_bwd_weight_workspace": (SZ, [P]),
     "catseg_conv2d_bwd_weight": (I, [P, P, P, P, P, P, SZ, P]),
@@ -76,6 +78,26 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.argtypes = _args
 
 EXPORTS = tuple(_SIGS)
+
+if os.environ.get("CATSEG_SYNC"):  # debugging aid: synchronise after every entry point so a device fault names its launch
+    class _SyncLib:
+        def __init__(self, inner):
+            self._inner = inner
+
+        def __getattr__(self, name):
+            fn = getattr(self._inner, name)
+            if name in ("catseg_last_error", "catseg_version") or name.endswith("_workspace"):
+                return fn
+
+            def call(*a):
+                desc = [[getattr(x._obj, f) for f, _ in x._obj._fields_] for x in a if isinstance(getattr(x, "_obj", None), ConvDesc)]
+                print("[catseg]", name, desc, [x for x in a if isinstance(x, (int, float))], flush=True)
+                rc = fn(*a)
+                torch.cuda.synchronize()
+                return rc
+            return call
+
+    lib = _SyncLib(lib)
 
 
 class CatsegError(RuntimeError):

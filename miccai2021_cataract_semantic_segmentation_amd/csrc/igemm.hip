@@ -48,6 +48,7 @@ struct IgemmArgs {
   const float* other;  // L_NT: B[n][ldo]  L_NN: B[k][ldo]  L_TN: A[r][ldo]
   float* C;
   const float* bias;
+  int bias_bs;  // bias elements per batch item (grouped conv: Cout / groups)
   int M, N, ldc, ldo, tap_stride;
   int taps, Cred, Cred_b;
   int tilesM, tilesN;
@@ -67,7 +68,10 @@ struct IgemmArgs {
   // output row remap (strided backward-data, one launch per input-pixel parity class):
   //   GEMM row (b, a, c) over (g.Ho, g.Wo) -> pixel ((b * out_H + a * out_s + out_py) * out_W + c * out_s + out_px)
   int remap, out_s, out_py, out_px, out_H, out_W;
-  int step_qy, step_rx;  // L_TN FAST: 16 rows ahead = step_qy image rows + step_rx pixels (no division in the K loop)
+  int step_b, step_qy, step_rx;  // L_TN FAST: 16 rows ahead = step_b images + step_qy image rows + step_rx pixels (no division in the K loop)
+  // fused inference epilogue (eval-mode BatchNorm folded into w / bias on the host side): v = act(v + residual)
+  const float* residual;
+  int ldr, relu;
   const float* zero;  // 256-byte zero page (kernel argument: no GOT load / lgkmcnt wait inside the K loop)
 };
 
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
           ty[j] += cx ? 1 : 0;
           const bool cy = ty[j] >= p.g.Ho;
           ty[j] -= cy ? p.g.Ho : 0;
-          tb[j] += cy ? 1 : 0;
+          tb[j] += p.step_b + (cy ? 1 : 0);
         } else {
           if (p.g.mode != 0) decode_row(p.g, rv ? r : 0, b, y, x);
           pb[sub][j] = gather_ptr(p.g, gbase, rv, r, b, y, x, tky, tkx, chunk, cvv);
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int col = n0 + wn * 32 * NI + ni * 32 + l31;
-      const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+      const float bv = (p.bias != nullptr && col < p.N) ? p.bias[zb * p.bias_bs + col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -456,6 +460,10 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
           if (col < p.N) {
             float v = acc[mi][ni][r] + bv;
             if (p.accumulate) v += *dst;
+            if (LAYOUT == L_NT) {
+              if (p.residual) v += p.residual[orow * p.ldr + col];
+              if (p.relu) v = fmaxf(v, 0.f);
+            }
             *dst = v;
           } else if (col < p.zero_to) {
             *dst = 0.f;
@@ -517,10 +525,13 @@ void launch_one(const IgemmArgs& a0, int ncols, int nbatch, int grid_y, hipStrea
   a.tilesM = (a.M + 64 * MI - 1) / (64 * MI);
   a.tilesN = (ncols + 64 * NI - 1) / (64 * NI);
   dim3 grid(a.tilesM * a.tilesN, grid_y, nbatch * (LAYOUT == L_TN ? a.splits : 1));
-  a.step_qy = 16 / a.g.Wo;
-  a.step_rx = 16 % a.g.Wo;
-  // TN fast path: forward-conv gather whose rows can be advanced incrementally (a 16-row step wraps at most one image)
-  const bool fast = LAYOUT == L_TN ? (a.g.mode == 1 && a.g.Ho >= a.step_qy + 1) : (a.taps <= 32 && a.row_s > 0);
+  // 16 rows = step_b images + step_qy image rows + step_rx pixels (step_qy < Ho, step_rx < Wo: one carry each per step)
+  const int img = a.g.Ho * a.g.Wo > 0 ? a.g.Ho * a.g.Wo : 1, wo = a.g.Wo > 0 ? a.g.Wo : 1;
+  a.step_b = 16 / img;
+  a.step_qy = (16 % img) / wo;
+  a.step_rx = (16 % img) % wo;
+  // TN fast path: every forward-conv gather (mode 1); rows are advanced incrementally in the K loop
+  const bool fast = LAYOUT == L_TN ? (a.g.mode == 1) : (a.taps <= 32 && a.row_s > 0);
   if (fast) hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, MI, NI, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, MI, NI, false>), grid, dim3(256), 0, st, a);
 }
@@ -652,6 +663,32 @@ extern "C" int catseg_conv2d_fwd(const catseg_conv_desc* d, const float* x, cons
     a.N = cog; a.Cred = a.Cred_b = cig; a.ldo = a.taps * cig; a.tap_stride = cig;
     a.g_bs = cig; a.o_bs = (long long)cog * a.taps * cig; a.c_bs = cog;
     if (bias) { catseg_set_error("conv fwd: bias is not supported with groups"); return CATSEG_EINVAL; }
+    return launch_igemm<L_NT>(a, d->groups, 1, (hipStream_t)stream);
+  }
+  return launch_igemm<L_NT>(a, 1, 1, (hipStream_t)stream);
+}
+
+// Inference: y = act(conv(x, w) + bias (+ residual)) in ONE kernel — Conv2d + eval-mode BatchNorm2d (folded into
+// w / bias by catseg_fold_bn) + residual add + ReLU of a ResNet / ResNeXt / UPerNet block.
+extern "C" int catseg_conv2d_fwd_fused(const catseg_conv_desc* d, const float* x, const float* w, const float* bias,
+                                       const float* residual, int ldr, int relu, float* y, catseg_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  CS_REQUIRE(cs_aligned16(x) && cs_aligned16(w) && cs_aligned16(y), "conv fwd fused: pointers must be 16-byte aligned");
+  IgemmArgs a = {};
+  a.g = fwd_geo(d, x);
+  a.other = w; a.C = y; a.bias = bias;
+  a.M = a.g.rows; a.N = d->Cout; a.ldc = d->ldy;
+  if (d->stem4) { a.taps = d->kh; a.Cred = 32; a.ldo = d->kh * 32; a.tap_stride = 32; }
+  else { a.taps = d->kh * d->kw; a.Cred = d->Cin; a.ldo = a.taps * d->Cin; a.tap_stride = d->Cin; }
+  a.Cred_b = a.Cred;
+  a.residual = residual; a.ldr = ldr; a.relu = relu;
+  if (!d->stem4) fill_taps(a, d->kh, d->kw, d->dil, +1, d->stride, -d->pad);
+  if (d->groups > 1) {
+    CS_REQUIRE(residual == nullptr, "conv fwd fused: residual is not supported with groups");
+    const int cig = d->Cin / d->groups, cog = d->Cout / d->groups;
+    a.N = cog; a.Cred = a.Cred_b = cig; a.ldo = a.taps * cig; a.tap_stride = cig;
+    a.g_bs = cig; a.o_bs = (long long)cog * a.taps * cig; a.c_bs = cog;
+    a.bias_bs = cog;
     return launch_igemm<L_NT>(a, d->groups, 1, (hipStream_t)stream);
   }
   return launch_igemm<L_NT>(a, 1, 1, (hipStream_t)stream);

@@ -262,6 +262,29 @@ int grid_for(long long total) {
 
 }  // namespace
 
+// eval-mode BatchNorm folded into the preceding convolution: w'[o,:] = w[o,:] * g[o]/sqrt(rv[o]+eps),
+// b'[o] = beta[o] + (b[o] - rm[o]) * g[o]/sqrt(rv[o]+eps)
+__global__ void fold_bn_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                               int O, int per_out, float* __restrict__ wf, float* __restrict__ bf) {
+  const int o = blockIdx.x;
+  // the scale is formed in fp64 so that each folded weight / bias carries ONE fp32 rounding (a per-channel error of the
+  // scale would be systematic over the whole reduction)
+  const double sc = (double)gamma[o] / sqrt((double)rv[o] + (double)eps);
+  for (int i = threadIdx.x; i < per_out; i += blockDim.x)
+    wf[(long long)o * per_out + i] = (float)((double)w[(long long)o * per_out + i] * sc);
+  if (threadIdx.x == 0) bf[o] = (float)((double)beta[o] + ((double)(b ? b[o] : 0.f) - (double)rm[o]) * sc);
+}
+extern "C" int catseg_fold_bn(const float* w, const float* bias, const float* gamma, const float* beta, const float* running_mean,
+                              const float* running_var, float eps, int O, int per_out, float* w_folded, float* bias_folded,
+                              catseg_stream_t stream) {
+  CS_REQUIRE(O > 0 && per_out > 0, "fold_bn: bad args");
+  hipLaunchKernelGGL(fold_bn_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, w, bias, gamma, beta, running_mean, running_var, eps, O,
+                     per_out, w_folded, bias_folded);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
 extern "C" size_t catseg_bn_workspace(long long rows, int C) {
   (void)rows;
   return cs_align_up((size_t)(kMaxRowBlocks * 3 + 2) * (size_t)((C + 3) & ~3) * 4, 256);

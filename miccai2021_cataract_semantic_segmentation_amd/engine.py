@@ -160,6 +160,9 @@ class Ctx:
 
 
 # --------------------------------------------------------------------------- fused layers
+FUSE_EVAL_BN = True   # eval-mode forward: fold BatchNorm into the conv and fuse bias/residual/ReLU into its epilogue
+
+
 def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=True):
     """conv -> BatchNorm (batch stats in training) -> (+residual) -> (ReLU).  x NHWC (or the raw
     NCHW image for the stem).  Returns z (NHWC)."""
@@ -179,6 +182,12 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
     bias = conv.bias.data if conv.bias is not None else None
     if conv.groups > 1 and cx.record:
         raise NotImplementedError("grouped convolution (ResNeXt) is inference-only on the HIP path")
+    if not cx.train and not cx.record and FUSE_EVAL_BN:
+        # inference fast path: eval-mode BatchNorm folded into the weights, bias + residual + ReLU applied in
+        # the convolution epilogue — one kernel per layer, no separate normalisation pass over HBM
+        per_out = wk.numel() // Cout
+        wf, bf = ops.fold_bn(wk, bias, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps, Cout, per_out)
+        return ops.conv_fwd_fused(x_in, wf, bf, residual, relu, Cout, kh, kw, s, p, d, out=out, stem4=conv.stem, groups=conv.groups)
     y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups)
     if cx.train:
         stats, scale = ops.bn_train_stats(y, bn.weight.data, bn.eps, bn.momentum, bn.running_mean, bn.running_var)

@@ -37,7 +37,16 @@ def new_act(B, H, W, C, device, ld=None, zero=False):
 
 
 def ld_of(t):
-    return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+    """pixel stride of an NHWC tensor; the stride torch reports for a size-1 dimension is arbitrary, so it is
+    taken from the innermost pixel dimension that has more than one entry"""
+    if t.dim() < 2:
+        return t.shape[-1]
+    inner = 1
+    for dim in range(t.dim() - 2, -1, -1):
+        if t.shape[dim] > 1:
+            return t.stride(dim) // inner
+        inner *= t.shape[dim]
+    return (t.shape[-1] + 3) // 4 * 4
 
 
 def rows_of(t):
@@ -346,3 +355,23 @@ def adaptive_avgpool_bwd(dy, dx, S, accumulate):
     B, H, W, C = dx.shape
     check(lib.catseg_adaptive_avgpool_bwd(ptr(dy), ptr(dx), ld_of(dx), B, H, W, C, S, 1 if accumulate else 0, stream()))
     return dx
+
+
+def fold_bn(w, bias, gamma, beta, rm, rv, eps, O, per_out):
+    """conv weight / bias with an eval-mode BatchNorm folded in (inference fast path)"""
+    wf = torch.empty(O * per_out, dtype=torch.float32, device=w.device)
+    bf = torch.empty(O, dtype=torch.float32, device=w.device)
+    check(lib.catseg_fold_bn(ptr(w), ptr(bias), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), eps, O, per_out, ptr(wf), ptr(bf), stream()))
+    return wf, bf
+
+
+def conv_fwd_fused(x, w, bias, residual, relu, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, stem4=False, groups=1):
+    B, H, W, Cin = x.shape
+    Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
+    if out is None:
+        out = new_act(B, Ho, Wo, Cout, x.device)
+    d = make_desc(x.shape, ld_of(x), Cout, ld_of(out), kh, kw, stride, pad, dil, stem4, groups)
+    with _Timed("fwd", 2.0 * B * Ho * Wo * Cout * (3 if stem4 else Cin // groups) * kh * kw):
+        check(lib.catseg_conv2d_fwd_fused(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual),
+                                          ld_of(residual) if residual is not None else 0, 1 if relu else 0, ptr(out), stream()))
+    return out
