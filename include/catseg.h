@@ -190,6 +190,13 @@ size_t catseg_ce_workspace(long long P);
 int catseg_cross_entropy(const float* logits, const int64_t* labels, long long P, int K, long long ignore_index,
                          float weight, float* loss_out, float* dlogits, void* workspace,
                          size_t workspace_bytes, catseg_stream_t stream);
+/* OhemCrossEntropy.forward (losses/OhemCrossEntropy.py:22-39) fused with backward: mean CE over the non-ignored
+ * pixels whose target-class probability is < max(thresh, k-th smallest probability), k = min(min_kept, n - 1).
+ * The k-th order statistic is found by a 3-pass radix select on device (no sort, no host sync). */
+size_t catseg_ohem_workspace(long long P);
+int catseg_ohem_cross_entropy(const float* logits, const int64_t* labels, long long P, int K, long long ignore_index,
+                              float thresh, long long min_kept, float weight, float* loss_out, float* dlogits,
+                              void* workspace, size_t workspace_bytes, catseg_stream_t stream);
 
 /* ---- metrics / optimiser ------------------------------------------------------------------ */
 /* t_get_confusion_matrix (utils/torch_utils.py:221-241): cm[pred*K + gt] += 1 (int32, K x K),

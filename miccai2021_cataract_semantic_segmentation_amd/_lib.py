@@ -69,6 +69,8 @@ _SIGS = {
     "catseg_lovasz_softmax": (I, [P, P, L, I, F, P, P, I, P, SZ, P]),
     "catseg_ce_workspace": (SZ, [L]),
     "catseg_cross_entropy": (I, [P, P, L, I, L, F, P, P, P, SZ, P]),
+    "catseg_ohem_workspace": (SZ, [L]),
+    "catseg_ohem_cross_entropy": (I, [P, P, L, I, L, F, L, F, P, P, P, SZ, P]),
     "catseg_confusion_matrix": (I, [P, P, L, I, P, P]),
     "catseg_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, F, P]),
 }

@@ -536,41 +536,57 @@ void launch_one(const IgemmArgs& a0, int ncols, int nbatch, int grid_y, hipStrea
   else hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, MI, NI, false>), grid, dim3(256), 0, st, a);
 }
 
-// Tile / split planner.  score = (intrinsic efficiency of the tile) x (useful fraction of the padded
-// tiles) x (wave-quantisation efficiency of the grid on 256 CUs x resident blocks per CU).
+// Tile / split planner: minimise a time model
+//   t = padded FLOPs / (R x tile efficiency x CU-level quantisation) [+ slab reduction for split backward-weight].
+// Quantisation is counted in tiles per CU, not per resident-block slot: blocks that share a CU share its MFMA pipes, so
+// a grid that gives every CU the same number of tiles is "full" whatever the residency (measured, tools/bench_tiles_small.py:
+// the machine rate of a tile is within 10 % for 1 ... 6 resident blocks per CU).
 struct TilePlan { int mi, ni, splits, rps; };
 struct TileInfo { int mi, ni, occ; float eff; };
-// eff: measured relative MFMA efficiency of each tile on large problems (tools/bench_tiles*.py); 256x64 /
-// 64x256 tiles exist in the dispatcher but never won a measurement and are not candidates.
-const TileInfo kTiles[] = {{1, 1, 8, 0.80f}, {2, 1, 6, 0.88f}, {1, 2, 6, 0.86f}, {2, 2, 4, 1.00f}, {4, 2, 2, 0.97f}, {2, 4, 2, 0.96f}};
+// eff: measured relative MFMA efficiency of each tile (tools/bench_tiles*.py); 256x64 / 64x256 tiles exist in the
+// dispatcher but never won a measurement and are not candidates.
+const TileInfo kTiles[] = {{1, 1, 8, 0.80f}, {2, 1, 6, 0.90f}, {1, 2, 6, 0.88f}, {2, 2, 4, 1.00f}, {4, 2, 2, 0.98f}, {2, 4, 2, 0.96f}};
+
+inline double cu_quant(double tiles) {
+  const double c = tiles / 256.0;
+  if (c <= 1.0) return c;
+  return c / (double)(long long)(c + 0.999999);
+}
 
 TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, long long red_rows) {
   TilePlan best = {2, 2, 1, 0};
-  double best_score = -1;
+  double best_t = 1e300;
+  const double R = 115e12;
   for (const TileInfo& t : kTiles) {
     if (g_force_mi > 0 && (t.mi != g_force_mi || t.ni != g_force_ni)) continue;
     const long long tm = (M + 64 * t.mi - 1) / (64 * t.mi), tn = (ncols + 64 * t.ni - 1) / (64 * t.ni);
-    const double pad = (double)(M * ncols) / (double)(tm * 64 * t.mi * tn * 64 * t.ni);
-    const double slots = 256.0 * t.occ;
-    long long maxs = 1;
-    if (layout == L_TN) {
-      maxs = red_rows / 512;  // at least 32 K-steps per split
-      if (maxs > 96) maxs = 96;
-      if (maxs < 1) maxs = 1;
+    const double padded = 2.0 * (double)(tm * 64 * t.mi) * (double)(tn * 64 * t.ni) * (double)extra * (double)red_rows;
+    if (layout != L_TN) {
+      const double tt = padded / (R * t.eff * cu_quant((double)(tm * tn * extra)));
+      if (tt < best_t) {
+        best_t = tt;
+        best = {t.mi, t.ni, 1, 0};
+      }
+      continue;
     }
+    // backward-weight: the K-major operand path is latency-bound per block, so here residency matters: the grid is
+    // quantised in resident-block slots and the split count fills them (measured: the CU-level model costs 5-20 %)
+    long long maxs = red_rows / 512;  // at least 32 K-steps per split
+    if (maxs > 96) maxs = 96;
+    if (maxs < 1) maxs = 1;
+    const double slots = 256.0 * t.occ;
+    const double eff = t.mi == 4 ? 1.03 : t.eff;  // prefers the 256x128 tile: measured 118 vs 113 TFLOP/s
     for (long long sp = 1; sp <= maxs; ++sp) {
       const double rounds = (double)(tm * tn * extra * sp) / slots;
       const double q = rounds / (double)(long long)(rounds + 0.999999);
-      // backward-weight (K-major operands) prefers the 256x128 tile: measured 118 vs 113 TFLOP/s
-      const double eff = (layout == L_TN && t.mi == 4) ? 1.03 : t.eff;
-      const double score = eff * pad * q * (1.0 - 0.002 * (double)(sp - 1));
-      if (score > best_score) {
-        best_score = score;
+      const double tt = padded / (R * eff * q * (1.0 - 0.002 * (double)(sp - 1)));
+      if (tt < best_t) {
+        best_t = tt;
         best = {t.mi, t.ni, (int)sp, 0};
       }
     }
   }
-  if (g_force_mi > 0 && best_score < 0) best = {g_force_mi, g_force_ni, 1, 0};
+  if (g_force_mi > 0 && best_t >= 1e300) best = {g_force_mi, g_force_ni, 1, 0};
   if (g_force_splits > 0 && layout == L_TN) best.splits = g_force_splits;
   if (layout == L_TN) {
     best.rps = (int)(((red_rows + best.splits - 1) / best.splits + 15) / 16 * 16);

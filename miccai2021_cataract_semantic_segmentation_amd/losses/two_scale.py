@@ -4,8 +4,9 @@ from torch import nn
 from ..utils import IGNORE_LABEL
 from .cross_entropy import CrossEntropyLoss
 from .lovasz import LovaszSoftmax
+from .ohem import OhemCrossEntropy
 
-_REGISTRY = {"LovaszSoftmax": LovaszSoftmax, "CrossEntropyLoss": CrossEntropyLoss}
+_REGISTRY = {"LovaszSoftmax": LovaszSoftmax, "CrossEntropyLoss": CrossEntropyLoss, "OhemCrossEntropy": OhemCrossEntropy}
 
 
 class TwoScaleLoss(nn.Module):

@@ -6,6 +6,7 @@ from torch import nn
 from ..utils import ce_ignore_index
 from .cross_entropy import CrossEntropyLoss
 from .lovasz import LovaszSoftmax
+from .ohem import OhemCrossEntropy
 from .two_scale import TwoScaleLoss
 
 
@@ -25,6 +26,8 @@ class LossWrapper(nn.Module):
                 fct = LovaszSoftmax(config)
             elif name == "TwoScaleLoss":
                 fct = TwoScaleLoss(config)
+            elif name == "OhemCrossEntropy":
+                fct = OhemCrossEntropy(config)
             else:
                 raise NotImplementedError("loss '{}' is outside the accelerated path".format(name))
             self.loss_classes[name] = fct

@@ -303,6 +303,17 @@ def cross_entropy(logits, labels, ignore_index, weight=1.0, dlogits=None, loss_o
     return loss_out
 
 
+def ohem_cross_entropy(logits, labels, ignore_index, thresh, min_kept, weight=1.0, dlogits=None, loss_out=None):
+    Pn, K = logits.shape
+    assert logits.is_contiguous() and labels.dtype == torch.int64 and labels.is_contiguous()
+    if loss_out is None:
+        loss_out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    ws = workspace(lib.catseg_ohem_workspace(Pn), logits.device)
+    check(lib.catseg_ohem_cross_entropy(ptr(logits), ptr(labels), Pn, K, ignore_index, thresh, min_kept, weight, ptr(loss_out),
+                                        ptr(dlogits), ptr(ws), ws.numel(), stream()))
+    return loss_out
+
+
 def confusion_matrix(logits, labels, cm=None):
     Pn, K = logits.shape
     if cm is None:

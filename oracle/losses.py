@@ -74,6 +74,22 @@ def cross_entropy(logits, target, experiment):
     return F.cross_entropy(logits, target, ignore_index=IGNORE_LABEL[experiment])
 
 
+def ohem_cross_entropy(score, target, experiment=None, thresh=0.7, min_kept=100000):
+    """losses/OhemCrossEntropy.py:22-39 (score already at label resolution)"""
+    ignore = IGNORE_LABEL[experiment] if experiment in (2, 3) else -100
+    pred = F.softmax(score, dim=1)
+    pixel_losses = F.cross_entropy(score, target, ignore_index=ignore, reduction="none").reshape(-1)
+    mask = target.reshape(-1) != ignore
+    tmp = target.clone()
+    tmp[tmp == ignore] = 0
+    pred = pred.gather(1, tmp.unsqueeze(1)).reshape(-1)[mask]
+    pred, ind = pred.sort()
+    min_value = pred[min(max(1, min_kept), pred.numel() - 1)]
+    threshold = max(float(min_value), thresh)
+    pixel_losses = pixel_losses[mask][ind]
+    return pixel_losses[pred < threshold].mean()
+
+
 def confusion_matrix(logits, target):
     """utils/torch_utils.py:221-241: rows = prediction, cols = ground truth, int32;
     for C in {17, 25} label == C (ignore) is dropped."""

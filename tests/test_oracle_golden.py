@@ -108,3 +108,21 @@ def test_ocrnet_whole(golden):
 
 def test_deeplab_whole(golden):
     _whole(golden, "deeplab_r50_e2_tiny", ON.deeplabv3plus_forward, lambda o, l: OL.cross_entropy(o, l, 2), False)
+
+
+def test_ohem_cross_entropy_matches_reference(golden):
+    """oracle/losses.ohem_cross_entropy == losses/OhemCrossEntropy.py of the reference (loss and gradient)"""
+    from oracle import losses as OL
+    g = golden("ohem")
+    for name in "abcd":
+        exp, mk, th = g[name + "_cfg"]
+        kw = {}
+        if mk >= 0:
+            kw["min_kept"] = int(mk)
+        if th >= 0:
+            kw["thresh"] = float(th)
+        x = torch.from_numpy(g[name + "_logits"]).requires_grad_()
+        loss = OL.ohem_cross_entropy(x, torch.from_numpy(g[name + "_target"]), int(exp), **kw)
+        loss.backward()
+        assert abs(float(loss) - float(g[name + "_loss"])) < 1e-6
+        np.testing.assert_allclose(x.grad.numpy(), g[name + "_grad"], atol=1e-8)

@@ -7,7 +7,7 @@ dev = torch.device("cuda")
 SHAPES = [("hr 3x3 48>48", 8, 136, 240, 48, 48, 3, 1, 1, 1), ("hr 3x3 96>96", 8, 68, 120, 96, 96, 3, 1, 1, 1),
           ("hr 3x3 192>192", 8, 34, 60, 192, 192, 3, 1, 1, 1), ("hr 3x3 384>384", 8, 17, 30, 384, 384, 3, 1, 1, 1),
           ("head 3x3 720>512", 8, 136, 240, 720, 512, 3, 1, 1, 1)]
-TILES = [(0, 0), (1, 1), (2, 1), (1, 2), (4, 1), (1, 4), (2, 2)]
+TILES = [(0, 0), (1, 1), (2, 1), (1, 2), (2, 2), (4, 2)]
 def timeit(fn, n=4):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
