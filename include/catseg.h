@@ -198,6 +198,29 @@ int catseg_ohem_cross_entropy(const float* logits, const int64_t* labels, long l
                               float thresh, long long min_kept, float weight, float* loss_out, float* dlogits,
                               void* workspace, size_t workspace_bytes, catseg_stream_t stream);
 
+/* ---- input side -------------------------------------------------------------- */
+/* Dataset_from_df.__getitem__ + its deterministic transforms (datasets/Dataset_from_df.py:31-69;
+ * remap_mask utils/utils.py:23-47; FlipNP / PadNP utils/transforms.py:222-240, 8-20; ToTensor / Normalize
+ * utils/utils.py:440-447) for a whole batch on device.
+ *   img u8 [B][H][W][3] RGB, lbl u8 [B][H][W] raw ids; lut u8[256] (NULL = identity);
+ *   flips int32 [B] (NULL = none): bit 0 = horizontal, bit 1 = vertical, applied before the padding;
+ *   rows are reflect-padded (np.pad 'reflect') by pad_top / pad_bottom; x = u8 / 255, then (x - mean) / std if given.
+ *   Outputs: x_nchw f32 [B][3][H'][W] and / or x_nhwc4 f32 [B][H'][W][4] (4th channel 0: the stem layout),
+ *   labels int64 [B][H'][W], H' = H + pad_top + pad_bottom.  Either side (image / label) may be NULL. */
+int catseg_ingest_u8(const uint8_t* img, const uint8_t* lbl, int B, int H, int W, const uint8_t* lut, const int32_t* flips,
+                     int pad_top, int pad_bottom, const float* mean, const float* stdv, float* x_nchw, float* x_nhwc4,
+                     int64_t* labels, catseg_stream_t stream);
+
+/* Test-time augmentation plumbing (managers/BaseManager.py:652-660 wraps the model in ttach
+ * HorizontalFlip x Scale(0.75, 1, 1.5, 1.75, 2), merge 'mean'; ttach is an un-vendored dependency: its Scale is
+ * F.interpolate(mode='nearest', size=(int(h*s), int(w*s)))).  NHWC nearest resize:
+ *   dst[b][y][x][:] (+)= src[b][sy][sx][:], sy = min(floor(y * (float)Hi / Ho), Hi - 1), sx likewise;
+ *   flip 1: the source is flipped horizontally first (image augmentation), flip 2: the result is flipped
+ *   (mask de-augmentation); accumulate: add into dst; divide_by != 0: the stored value is divided by it
+ *   (the 'mean' merge on the last accumulation). */
+int catseg_resize_nearest(const float* src, int lds, float* dst, int ldd, int B, int Hi, int Wi, int Ho, int Wo, int C, int flip,
+                          int accumulate, float divide_by, catseg_stream_t stream);
+
 /* ---- metrics / optimiser ------------------------------------------------------------------ */
 /* t_get_confusion_matrix (utils/torch_utils.py:221-241): cm[pred*K + gt] += 1 (int32, K x K),
  * labels >= K are dropped; cm is accumulated into (zero it first for a fresh matrix). */

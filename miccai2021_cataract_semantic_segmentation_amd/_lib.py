@@ -71,6 +71,8 @@ _SIGS = {
     "catseg_cross_entropy": (I, [P, P, L, I, L, F, P, P, P, SZ, P]),
     "catseg_ohem_workspace": (SZ, [L]),
     "catseg_ohem_cross_entropy": (I, [P, P, L, I, L, F, L, F, P, P, P, SZ, P]),
+    "catseg_ingest_u8": (I, [P, P, I, I, I, P, P, I, I, P, P, P, P, P, P]),
+    "catseg_resize_nearest": (I, [P, I, P, I, I, I, I, I, I, I, I, I, F, P]),
     "catseg_confusion_matrix": (I, [P, P, L, I, P, P]),
     "catseg_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, F, P]),
 }

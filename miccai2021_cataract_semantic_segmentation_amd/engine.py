@@ -160,6 +160,15 @@ class Ctx:
 
 
 # --------------------------------------------------------------------------- fused layers
+def is_nhwc4(x):
+    """network input already in the stem layout [B, H, W, 4] (utils.GpuIngest(..., nhwc4=True)) instead of NCHW [B, 3, H, W]"""
+    return x.dim() == 4 and x.shape[-1] == 4 and x.shape[1] != 3
+
+
+def image_hw(x):
+    return tuple(x.shape[1:3]) if is_nhwc4(x) else tuple(x.shape[-2:])
+
+
 FUSE_EVAL_BN = True   # eval-mode forward: fold BatchNorm into the conv and fuse bias/residual/ReLU into its epilogue
 
 
@@ -172,10 +181,10 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
     s, p, d = conv.stride[0], conv.padding[0], conv.dilation[0]
     pad3 = (not conv.stem) and w.shape[1] == 3       # 3-channel image into a generic conv (HRNet 3x3/2 stem)
     if conv.stem:
-        x_in = ops.nchw3_to_nhwc4(x)
+        x_in = x if is_nhwc4(x) else ops.nchw3_to_nhwc4(x)
         wk = ops.stem_pack_weight(w.data, Cout)
     elif pad3:
-        x_in = ops.nchw3_to_nhwc4(x)
+        x_in = x if is_nhwc4(x) else ops.nchw3_to_nhwc4(x)
         wk = ops.weight_pad_cin(w.data, Cout, kh * kw, 3, 4)
     else:
         x_in, wk = x, w.data

@@ -214,9 +214,19 @@ class BaseManager:
         self.model.eval()
         if hasattr(self.model, "get_intermediate"):
             self.model.get_intermediate = False
+        if hasattr(self.model, "get_features"):
+            self.model.get_features = False
         self.load_checkpoint("best")
         loader = DataLoader(self.valid_set, batch_size=1, shuffle=False)
-        cm, _ = self._eval_pass(loader, with_loss=False)
+        net = self.model
+        if self.config["tta"]:                       # BaseManager.py:652-660: hflip x 5 scales, mean-merged
+            from ..utils.tta import SegmentationTTA
+            self.model = SegmentationTTA(net)
+            self.model.num_classes = net.num_classes
+        try:
+            cm, _ = self._eval_pass(loader, with_loss=False)
+        finally:
+            self.model = net
         m = t_get_mean_iou(cm, self.experiment, True, rare=True)
         return tuple(float(v) for v in m)
 

@@ -3,7 +3,7 @@ reference's models/DeepLabv3Plus.py:10-175 (DeepLabv3Plus, ASPP :82-129, Decoder
 import torch
 from torch import nn
 
-from ..engine import (BatchNorm2d, Conv2d, EngineNet, bilinear, concat_views, conv_bias, conv_bn_act, global_avgpool)
+from ..engine import (BatchNorm2d, Conv2d, EngineNet, bilinear, image_hw, concat_views, conv_bias, conv_bn_act, global_avgpool)
 from ..utils import num_classes
 from .backbone import ResNetBackbone
 
@@ -93,7 +93,7 @@ class DeepLabv3Plus(EngineNet):
         self.projector_model = None
 
     def _body(self, cx, x):
-        H, W = x.shape[-2:]
+        H, W = image_hw(x)
         f = self.backbone.run(cx, x)
         a = self.aspp.run(cx, f["high"])
         logits = self.decoder.run(cx, f["low"], a)
@@ -125,6 +125,6 @@ class DeepLabv3(EngineNet):
         self.projector_model = None
 
     def _body(self, cx, x):
-        H, W = x.shape[-2:]
+        H, W = image_hw(x)
         a = self.aspp.run(cx, self.backbone.run(cx, x)["out"])
         return [bilinear(cx, conv_bias(cx, a, self.conv_out), H, W, True)]

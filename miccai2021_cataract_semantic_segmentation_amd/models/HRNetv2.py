@@ -7,7 +7,7 @@ BatchNorm momentum 0.01 (:19), bilinear resizes with align_corners=False (:253-2
 import torch
 from torch import nn
 
-from ..engine import BatchNorm2d, Conv2d, EngineNet, add_n, bilinear, concat_views, conv_bias, conv_bn_act
+from ..engine import BatchNorm2d, Conv2d, EngineNet, add_n, bilinear, image_hw, concat_views, conv_bias, conv_bn_act
 from ..utils import num_classes
 
 BN_MOMENTUM = 0.01
@@ -305,7 +305,7 @@ class HRNetv2(EngineNet):
         self.projector_model = None
 
     def _body(self, cx, x):
-        H, W = x.shape[-2:]
+        H, W = image_hw(x)
         ys = run_hrnet_trunk(self, cx, x)
         cat = concat_branches(cx, ys)
         y = conv_bn_act(cx, cat, self.last_layer[0], self.last_layer[1])

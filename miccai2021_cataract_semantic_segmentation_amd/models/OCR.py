@@ -5,7 +5,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..engine import (BatchNorm2d, Conv2d, EngineNet, bilinear, concat_views, conv_bias, conv_bn_act,
+from ..engine import (BatchNorm2d, Conv2d, EngineNet, bilinear, image_hw, concat_views, conv_bias, conv_bn_act,
                       object_attention_core, spatial_gather)
 from ..utils import num_classes
 from .backbone import ResNetBackbone
@@ -115,7 +115,7 @@ class OCRNet(EngineNet):
         self.projector_model = None
 
     def _body(self, cx, x):
-        H, W = x.shape[-2:]
+        H, W = image_hw(x)
         K = self.num_classes
         if isinstance(self.backbone, HRNetFeatures):
             low = high = self.backbone.run(cx, x)

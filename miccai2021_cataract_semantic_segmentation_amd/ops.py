@@ -314,6 +314,40 @@ def ohem_cross_entropy(logits, labels, ignore_index, thresh, min_kept, weight=1.
     return loss_out
 
 
+def ingest_u8(img, lbl, lut=None, flips=None, pad_top=0, pad_bottom=0, mean=None, std=None, nhwc4=False):
+    """img uint8 [B,H,W,3] and / or lbl uint8 [B,H,W] -> (x float32 [B,3,H',W] (or NHWC-4 [B,H',W,4]), labels int64 [B,H',W])"""
+    ref = img if img is not None else lbl
+    B, H, W = ref.shape[:3]
+    Ho = H + pad_top + pad_bottom
+    for t in (img, lbl, lut):
+        assert t is None or (t.dtype == torch.uint8 and t.is_contiguous() and t.is_cuda)
+    assert flips is None or (flips.dtype == torch.int32 and flips.numel() == B)
+    x = x4 = labels = None
+    if img is not None:
+        assert img.shape == (B, H, W, 3)
+        if nhwc4:
+            x4 = torch.empty((B, Ho, W, 4), dtype=torch.float32, device=ref.device)
+        else:
+            x = torch.empty((B, 3, Ho, W), dtype=torch.float32, device=ref.device)
+    if lbl is not None:
+        assert lbl.shape == (B, H, W)
+        labels = torch.empty((B, Ho, W), dtype=torch.int64, device=ref.device)
+    check(lib.catseg_ingest_u8(ptr(img), ptr(lbl), B, H, W, ptr(lut), ptr(flips), pad_top, pad_bottom, ptr(mean), ptr(std),
+                               ptr(x), ptr(x4), ptr(labels), stream()))
+    return (x4 if nhwc4 else x), labels
+
+
+def resize_nearest(src, Ho, Wo, flip=0, out=None, accumulate=False, divide_by=0.0):
+    """NHWC nearest resize (F.interpolate(mode='nearest', size=(Ho, Wo))); flip 1 = flip the source, 2 = flip the result"""
+    B, Hi, Wi, C = src.shape
+    if out is None:
+        out = new_act(B, Ho, Wo, C, src.device)
+        accumulate = False
+    check(lib.catseg_resize_nearest(ptr(src), ld_of(src), ptr(out), ld_of(out), B, Hi, Wi, Ho, Wo, C, flip, 1 if accumulate else 0,
+                                    divide_by, stream()))
+    return out
+
+
 def confusion_matrix(logits, labels, cm=None):
     Pn, K = logits.shape
     if cm is None:
