@@ -90,6 +90,9 @@ int catseg_gemm_batched(int layout, int batch, int M, int N, int K, const float*
 int catseg_debug_set_tile(int mi, int ni);
 /* tuning hook: force the backward-weight split count (0 restores the planner) */
 int catseg_debug_set_splits(int splits);
+/* measurement hook: 0 = sort every pixel of every present class in catseg_lovasz_softmax (the data-independent worst case);
+ * 1 (default) = sort only the elements that can precede the last foreground pixel (bit-identical result) */
+int catseg_debug_set_lovasz_prune(int on);
 
 /* ---- BatchNorm (+ReLU, +residual) — nn.BatchNorm2d/ReLU at e.g. models/OCR.py:74-75,
  * torchvision Bottleneck, models/DeepLabv3Plus.py:98-104.  rows = B*H*W pixels. */

@@ -32,6 +32,9 @@ struct LvWs {
   float* lpart;       // [K][ntiles]
   float* dprob;       // [K][P]
   double* lossd;      // [1]
+  uint32_t* minfg;    // [MAXK] bits of the smallest foreground error per class
+  uint32_t* nact;     // [MAXK] length of the sorted sequence per class (P, or the active prefix when pruning)
+  uint32_t* blkcnt;   // [K][nblk] active elements per 256-pixel block -> exclusive offsets
 };
 
 size_t lv_layout(long long P, int K, char* base, LvWs* w) {
@@ -53,6 +56,9 @@ size_t lv_layout(long long P, int K, char* base, LvWs* w) {
   t.lpart = (float*)take((size_t)K * ntiles * 4);
   t.dprob = (float*)take((size_t)K * P * 4);
   t.lossd = (double*)take(64);
+  t.minfg = (uint32_t*)take(MAXK * 4);
+  t.nact = (uint32_t*)take(MAXK * 4);
+  t.blkcnt = (uint32_t*)take((size_t)K * ((P + PIX - 1) / PIX) * 4);
   if (w) *w = t;
   return off;
 }
@@ -118,6 +124,135 @@ __global__ __launch_bounds__(PIX) void lv_prep_kernel(const float* __restrict__ 
   }
 }
 
+// ---- active-set pruning ----------------------------------------------------------------------
+// In the sorted order every element behind the LAST foreground pixel has Jaccard gradient exactly 0 (intersection is
+// exhausted: J_i = J_{i-1} = 1), so it contributes +0 to the loss and 0 to d loss / d prob.  Only elements with
+// err >= min over foreground pixels of err can precede that pixel: the rest never enters the sort.  The kept elements
+// are compacted in pixel order (deterministic two-pass compaction), so the stable sort places them exactly where the
+// full sort would: loss and gradient are bit-identical to the unpruned path.
+__device__ __forceinline__ void softmax_row(float* row, int K, float& s) {
+  float m = row[0];
+  for (int c = 1; c < K; ++c) m = fmaxf(m, row[c]);
+  s = 0.f;
+  for (int c = 0; c < K; ++c) {
+    const float e = expf(row[c] - m);
+    row[c] = e;
+    s += e;
+  }
+}
+
+__global__ __launch_bounds__(PIX) void lv_minfg_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, long long P, int K,
+                                                       uint32_t* __restrict__ minfg) {
+  extern __shared__ float sh[];
+  __shared__ uint32_t mn[MAXK];
+  const int KS = K | 1;
+  const long long p0 = (long long)blockIdx.x * PIX;
+  const int np = (int)min((long long)PIX, P - p0);
+  if (threadIdx.x < MAXK) mn[threadIdx.x] = 0x7F7F7F7Fu;
+  stage_rows(logits, p0, np, K, KS, sh);
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < np) {
+    const int64_t lab = labels[p0 + t];
+    if (lab >= 0 && lab < K) {
+      float* row = sh + t * KS;
+      float s;
+      softmax_row(row, K, s);
+      const float err = fabsf(1.f - row[(int)lab] / s);
+      atomicMin(&mn[(int)lab], __float_as_uint(err));  // err >= 0: unsigned order of the bits = order of the floats
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < K && mn[threadIdx.x] != 0x7F7F7F7Fu) atomicMin(&minfg[threadIdx.x], mn[threadIdx.x]);
+}
+
+// WRITE = false: count the active elements of each (class, 256-pixel block); WRITE = true: write them compacted
+template <bool WRITE>
+__global__ __launch_bounds__(PIX) void lv_compact_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, long long P, int K,
+                                                         const uint32_t* __restrict__ counts, const uint32_t* __restrict__ minfg,
+                                                         uint32_t* __restrict__ blkcnt, long long nblk, uint32_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ vals) {
+  extern __shared__ float sh[];
+  __shared__ uint32_t wcnt[4][MAXK];
+  const int KS = K | 1;
+  const long long p0 = (long long)blockIdx.x * PIX;
+  const int np = (int)min((long long)PIX, P - p0);
+  stage_rows(logits, p0, np, K, KS, sh);
+  __syncthreads();
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool live = t < np;
+  float* row = sh + t * KS;
+  float s = 1.f;
+  int64_t lab = -1;
+  if (live) {
+    softmax_row(row, K, s);
+    lab = labels[p0 + t];
+  }
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint32_t act_bits = 0, act_bits_hi = 0;  // K <= 64: two words of "class c keeps this pixel"
+  // pass 1: per-wave counts
+  for (int c = 0; c < K; ++c) {
+    bool a = false;
+    if (live && counts[c] != 0) {
+      const uint32_t fg = (lab == c) ? 1u : 0u;
+      const float err = fabsf((float)fg - row[c] / s);
+      a = fg || __float_as_uint(err) >= minfg[c];
+    }
+    const unsigned long long bal = __ballot(a);
+    if (lane == 0) wcnt[wave][c] = (uint32_t)__popcll(bal);
+    if (a) { if (c < 32) act_bits |= 1u << c; else act_bits_hi |= 1u << (c - 32); }
+  }
+  __syncthreads();
+  if (!WRITE) {
+    if (t < K) blkcnt[(long long)t * nblk + blockIdx.x] = wcnt[0][t] + wcnt[1][t] + wcnt[2][t] + wcnt[3][t];
+    return;
+  }
+  const long long p = p0 + t;
+  for (int c = 0; c < K; ++c) {
+    const bool a = c < 32 ? (act_bits >> c) & 1u : (act_bits_hi >> (c - 32)) & 1u;
+    const unsigned long long bal = __ballot(a);
+    if (a) {
+      uint32_t off = blkcnt[(long long)c * nblk + blockIdx.x];
+      for (int w2 = 0; w2 < wave; ++w2) off += wcnt[w2][c];
+      off += (uint32_t)__popcll(bal & lt_mask);
+      const uint32_t fg = (lab == c) ? 1u : 0u;
+      const float err = fabsf((float)fg - row[c] / s);
+      keys[(long long)c * P + off] = 0x3F800000u - __float_as_uint(err);
+      vals[(long long)c * P + off] = (uint32_t)p | (fg << 31);
+    }
+  }
+}
+
+// exclusive scan of blkcnt[c][0..nblk) per class; the total is the length of the class's sort
+__global__ __launch_bounds__(1024) void lv_blkscan_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ blkcnt, long long nblk,
+                                                          uint32_t* __restrict__ nact) {
+  const int c = blockIdx.x;
+  if (counts[c] == 0) { if (threadIdx.x == 0) nact[c] = 0; return; }
+  uint32_t* row = blkcnt + (long long)c * nblk;
+  __shared__ uint32_t sh[1024];
+  uint32_t carry = 0;
+  for (long long b0 = 0; b0 < nblk; b0 += 1024) {
+    const long long i = b0 + threadIdx.x;
+    const uint32_t v = i < nblk ? row[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const uint32_t a = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += a;
+      __syncthreads();
+    }
+    if (i < nblk) row[i] = carry + sh[threadIdx.x] - v;
+    carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) nact[c] = carry;
+}
+
+__global__ void lv_fill_nact_kernel(uint32_t* nact, uint32_t P) {
+  if (threadIdx.x < MAXK) nact[threadIdx.x] = P;
+}
+
 // ---- radix sort ---------------------------------------------------------------------------
 __device__ __forceinline__ void block_range(long long P, long long& t0, long long& t1) {
   const long long ntiles = (P + TILE - 1) / TILE;
@@ -127,16 +262,18 @@ __device__ __forceinline__ void block_range(long long P, long long& t0, long lon
 }
 
 __global__ __launch_bounds__(256) void radix_upsweep_kernel(const uint32_t* __restrict__ keys, long long P, int shift,
-                                                            const uint32_t* __restrict__ counts, uint32_t* __restrict__ hist) {
+                                                            const uint32_t* __restrict__ counts, const uint32_t* __restrict__ nact,
+                                                            uint32_t* __restrict__ hist) {
   const int c = blockIdx.y;
   if (counts[c] == 0) return;
+  const long long n = nact[c];  // elements of this class that take part in the sort (<= P)
   __shared__ uint32_t h[RADIX];
   for (int i = threadIdx.x; i < RADIX; i += 256) h[i] = 0;
   __syncthreads();
   long long t0, t1;
-  block_range(P, t0, t1);
+  block_range(n, t0, t1);
   const uint32_t* k = keys + (long long)c * P;
-  const long long e0 = t0 * TILE, e1 = min(t1 * TILE, P);
+  const long long e0 = t0 * TILE, e1 = min(t1 * TILE, n);
   for (long long i = e0 + threadIdx.x; i < e1; i += 256) atomicAdd(&h[(k[i] >> shift) & (RADIX - 1)], 1u);
   __syncthreads();
   uint32_t* o = hist + (long long)c * RADIX * SORT_BLOCKS;
@@ -170,9 +307,10 @@ __global__ __launch_bounds__(RADIX) void radix_scan_kernel(const uint32_t* __res
 __global__ __launch_bounds__(256) void radix_downsweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                               uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                               long long P, int shift, const uint32_t* __restrict__ counts,
-                                                              const uint32_t* __restrict__ hist) {
+                                                              const uint32_t* __restrict__ nact, const uint32_t* __restrict__ hist) {
   const int c = blockIdx.y;
   if (counts[c] == 0) return;
+  const long long n = nact[c];
   __shared__ uint32_t whist[4][RADIX];  // per-wave digit counts of the current tile
   __shared__ uint32_t running[RADIX];   // next global slot per digit for this block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -183,7 +321,7 @@ __global__ __launch_bounds__(256) void radix_downsweep_kernel(const uint32_t* __
   uint32_t* kout = keys_out + (long long)c * P;
   uint32_t* vout = vals_out + (long long)c * P;
   long long t0, t1;
-  block_range(P, t0, t1);
+  block_range(n, t0, t1);
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (long long t = t0; t < t1; ++t) {
     for (int i = tid; i < 4 * RADIX; i += 256) (&whist[0][0])[i] = 0;
@@ -193,14 +331,14 @@ __global__ __launch_bounds__(256) void radix_downsweep_kernel(const uint32_t* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const long long i = base + r * 64 + lane;
-      const bool live = i < P;
+      const bool live = i < n;
       key[r] = live ? kin[i] : 0xFFFFFFFFu;
       val[r] = live ? vin[i] : 0u;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const long long i = base + r * 64 + lane;
-      const bool live = i < P;
+      const bool live = i < n;
       const uint32_t d = (key[r] >> shift) & (RADIX - 1);
       unsigned long long peers = __ballot(live);
 #pragma unroll
@@ -232,7 +370,7 @@ __global__ __launch_bounds__(256) void radix_downsweep_kernel(const uint32_t* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const long long i = base + r * 64 + lane;
-      if (i < P) {
+      if (i < n) {
         const uint32_t d = (key[r] >> shift) & (RADIX - 1);
         const uint32_t dst = whist[wave][d] + rank[r];
         kout[dst] = key[r];
@@ -245,11 +383,11 @@ __global__ __launch_bounds__(256) void radix_downsweep_kernel(const uint32_t* __
 
 // ---- Jaccard gradient over the sorted order -------------------------------------------------
 __global__ __launch_bounds__(256) void lv_fgsum_kernel(const uint32_t* __restrict__ vals, long long P, const uint32_t* __restrict__ counts,
-                                                       uint32_t* __restrict__ fgsum, long long ntiles) {
+                                                       const uint32_t* __restrict__ nact, uint32_t* __restrict__ fgsum, long long ntiles) {
   const int c = blockIdx.y;
   if (counts[c] == 0) return;
   const uint32_t* v = vals + (long long)c * P;
-  const long long e0 = (long long)blockIdx.x * TILE, e1 = min(e0 + TILE, P);
+  const long long e0 = (long long)blockIdx.x * TILE, e1 = min(e0 + TILE, (long long)nact[c]);
   uint32_t n = 0;
   for (long long i = e0 + threadIdx.x; i < e1; i += 256) n += v[i] >> 31;
   n = (uint32_t)wave_sum((float)n);  // <= 4096, exact in fp32
@@ -282,10 +420,16 @@ __global__ __launch_bounds__(1024) void lv_fgscan_kernel(const uint32_t* __restr
 }
 
 __global__ __launch_bounds__(256) void lv_grad_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, long long P,
-                                                      const uint32_t* __restrict__ counts, const uint32_t* __restrict__ fgsum,
-                                                      long long ntiles, float* __restrict__ lpart, float* __restrict__ dprob) {
+                                                      const uint32_t* __restrict__ counts, const uint32_t* __restrict__ nact,
+                                                      const uint32_t* __restrict__ fgsum, long long ntiles, float* __restrict__ lpart,
+                                                      float* __restrict__ dprob) {
   const int c = blockIdx.y;
   if (counts[c] == 0) return;
+  const long long n = nact[c];
+  if ((long long)blockIdx.x * TILE >= n) {  // behind the active prefix: nothing but an exact +0 to the loss
+    if (threadIdx.x == 0) lpart[(long long)c * ntiles + blockIdx.x] = 0.f;
+    return;
+  }
   const uint32_t* k = keys + (long long)c * P;
   const uint32_t* v = vals + (long long)c * P;
   float* dp = dprob ? dprob + (long long)c * P : nullptr;
@@ -298,8 +442,8 @@ __global__ __launch_bounds__(256) void lv_grad_kernel(const uint32_t* __restrict
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const long long i = e0 + tid * 16 + j;
-    kk[j] = i < P ? k[i] : 0x3F800000u;
-    vv[j] = i < P ? v[i] : 0u;
+    kk[j] = i < n ? k[i] : 0x3F800000u;
+    vv[j] = i < n ? v[i] : 0u;
     nfg += vv[j] >> 31;
   }
   // exclusive scan of nfg over the block
@@ -319,7 +463,7 @@ __global__ __launch_bounds__(256) void lv_grad_kernel(const uint32_t* __restrict
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const long long i = e0 + tid * 16 + j;
-    if (i < P) {
+    if (i < n) {
       const uint32_t f = vv[j] >> 31;
       // J_{i-1} from F (fg count before i), J_i after including i
       const float Fb = (float)F;
@@ -537,7 +681,14 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+int g_prune = 1;
+
 }  // namespace
+
+extern "C" int catseg_debug_set_lovasz_prune(int on) {
+  g_prune = on ? 1 : 0;
+  return CATSEG_OK;
+}
 
 extern "C" size_t catseg_lovasz_workspace(long long P, int K) { return lv_layout(P, K, nullptr, nullptr); }
 
@@ -559,20 +710,34 @@ extern "C" int catseg_lovasz_softmax(const float* logits, const int64_t* labels,
   if (hipMemsetAsync(w.counts, 0, (MAXK + 4) * 4, st) != hipSuccess) { catseg_set_error("lovasz: memset failed"); return CATSEG_EHIP; }
   hipLaunchKernelGGL(label_hist_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, st, labels, P, K, w.counts);
   hipLaunchKernelGGL(present_kernel, dim3(1), dim3(64), 0, st, K, w.counts);
-  hipLaunchKernelGGL(lv_prep_kernel, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, (const uint32_t*)w.counts, w.keys[0], w.vals[0]);
+  if (g_prune) {
+    // active-set pruning: min foreground error per class -> count -> scan -> ordered compaction (3 passes over the logits)
+    if (hipMemsetAsync(w.minfg, 0x7F, MAXK * 4, st) != hipSuccess) { catseg_set_error("lovasz: memset failed"); return CATSEG_EHIP; }
+    hipLaunchKernelGGL(lv_minfg_kernel, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, w.minfg);
+    hipLaunchKernelGGL(lv_compact_kernel<false>, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, (const uint32_t*)w.counts,
+                       (const uint32_t*)w.minfg, w.blkcnt, (long long)nb, w.keys[0], w.vals[0]);
+    hipLaunchKernelGGL(lv_blkscan_kernel, dim3(K), dim3(1024), 0, st, (const uint32_t*)w.counts, w.blkcnt, (long long)nb, w.nact);
+    hipLaunchKernelGGL(lv_compact_kernel<true>, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, (const uint32_t*)w.counts,
+                       (const uint32_t*)w.minfg, w.blkcnt, (long long)nb, w.keys[0], w.vals[0]);
+    if (dlogits && hipMemsetAsync(w.dprob, 0, (size_t)K * P * 4, st) != hipSuccess) { catseg_set_error("lovasz: memset failed"); return CATSEG_EHIP; }
+  } else {
+    hipLaunchKernelGGL(lv_fill_nact_kernel, dim3(1), dim3(64), 0, st, w.nact, (uint32_t)P);
+    hipLaunchKernelGGL(lv_prep_kernel, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, (const uint32_t*)w.counts, w.keys[0], w.vals[0]);
+  }
+  const uint32_t* nact = (const uint32_t*)w.nact;
   int cur = 0;
   for (int pass = 0; pass < 3; ++pass) {
     const int shift = pass * RBITS;
-    hipLaunchKernelGGL(radix_upsweep_kernel, dim3(SORT_BLOCKS, K), dim3(256), 0, st, (const uint32_t*)w.keys[cur], P, shift, (const uint32_t*)w.counts, w.hist);
+    hipLaunchKernelGGL(radix_upsweep_kernel, dim3(SORT_BLOCKS, K), dim3(256), 0, st, (const uint32_t*)w.keys[cur], P, shift, (const uint32_t*)w.counts, nact, w.hist);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(K), dim3(RADIX), 0, st, (const uint32_t*)w.counts, w.hist);
     hipLaunchKernelGGL(radix_downsweep_kernel, dim3(SORT_BLOCKS, K), dim3(256), 0, st, (const uint32_t*)w.keys[cur], (const uint32_t*)w.vals[cur],
-                       w.keys[cur ^ 1], w.vals[cur ^ 1], P, shift, (const uint32_t*)w.counts, (const uint32_t*)w.hist);
+                       w.keys[cur ^ 1], w.vals[cur ^ 1], P, shift, (const uint32_t*)w.counts, nact, (const uint32_t*)w.hist);
     cur ^= 1;
   }
-  hipLaunchKernelGGL(lv_fgsum_kernel, dim3((unsigned)ntiles, K), dim3(256), 0, st, (const uint32_t*)w.vals[cur], P, (const uint32_t*)w.counts, w.fgsum, ntiles);
+  hipLaunchKernelGGL(lv_fgsum_kernel, dim3((unsigned)ntiles, K), dim3(256), 0, st, (const uint32_t*)w.vals[cur], P, (const uint32_t*)w.counts, nact, w.fgsum, ntiles);
   hipLaunchKernelGGL(lv_fgscan_kernel, dim3(K), dim3(1024), 0, st, (const uint32_t*)w.counts, w.fgsum, ntiles);
   hipLaunchKernelGGL(lv_grad_kernel, dim3((unsigned)ntiles, K), dim3(256), 0, st, (const uint32_t*)w.keys[cur], (const uint32_t*)w.vals[cur], P,
-                     (const uint32_t*)w.counts, (const uint32_t*)w.fgsum, ntiles, w.lpart, dlogits ? w.dprob : nullptr);
+                     (const uint32_t*)w.counts, nact, (const uint32_t*)w.fgsum, ntiles, w.lpart, dlogits ? w.dprob : nullptr);
   hipLaunchKernelGGL(lv_finalize_kernel, dim3(1), dim3(256), 0, st, (const uint32_t*)w.counts, (const float*)w.lpart, ntiles, K, weight, loss_out, 0);
   if (dlogits)
     hipLaunchKernelGGL(lv_backward_kernel, dim3(nb), dim3(PIX), 2 * shb, st, logits, P, K, (const uint32_t*)w.counts, (const float*)w.dprob, weight, dlogits,
