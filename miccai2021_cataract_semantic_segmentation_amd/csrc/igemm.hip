@@ -127,9 +127,23 @@ __device__ __forceinline__ const float* sel_ptr(bool ok, const float* base, int 
   return b + o;
 }
 
-template <int LAYOUT, int MI, int NI, bool FAST>
-__global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4 : 1)) void igemm_f32_kernel(const IgemmArgs p) {
-  constexpr int BM = 64 * MI, BN = 64 * NI;
+// NARROW selects the wave arrangement / matrix instruction of the block:
+//   0: 2 x 2 waves, v_mfma_f32_32x32x2_f32, block tile (64 MI) x (64 NI)
+//   1: 4 x 1 waves, v_mfma_f32_16x16x4_f32, block tile (64 MI) x (48 NI): N = 48 / 96 (HRNet branch widths) without padding
+//   2: 1 x 4 waves, v_mfma_f32_16x16x4_f32, block tile (48 MI) x (64 NI): the same for the M side (backward-weight, M = Cout)
+// The LDS images and the staging code are identical in all three (64 MI rows of A, 64 NI rows / columns of B per K-step);
+// the narrow forms simply do not touch the last quarter of the narrow operand.
+constexpr int igemm_min_waves(int MI, int NI, int NARROW) {
+  return NARROW ? ((NARROW == 1 ? MI * 3 * NI : 3 * MI * NI) <= 12 ? 4 : 2) : ((MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4 : 1));
+}
+
+template <int LAYOUT, int MI, int NI, bool FAST, int NARROW>
+__global__ __launch_bounds__(256, igemm_min_waves(MI, NI, NARROW)) void igemm_f32_kernel(const IgemmArgs p) {
+  constexpr int BM = 64 * MI, BN = 64 * NI;                    // rows of A / B staged in LDS per K-step
+  constexpr int TILE_M = NARROW == 2 ? 48 * MI : BM;           // extent of the output tile
+  constexpr int TILE_N = NARROW == 1 ? 48 * NI : BN;
+  constexpr int TM16 = NARROW == 1 ? MI : 3 * MI;              // 16 x 16 accumulator tiles per wave (narrow forms)
+  constexpr int TN16 = NARROW == 1 ? 3 * NI : NI;
   constexpr bool A_KC = (LAYOUT != L_TN);
   constexpr bool B_KC = (LAYOUT == L_NT);
   // K sub-steps (of 16) per barrier interval.  Measured: > 1 on the small tiles costs more in occupancy
@@ -153,7 +167,7 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
   const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int tile_m = swz / p.tilesN, tile_n = swz - tile_m * p.tilesN;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * TILE_M, n0 = tile_n * TILE_N;
 
   int zb = blockIdx.z, split = 0;
   if (LAYOUT == L_TN) {
@@ -164,13 +178,27 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
   const float* obase = p.other + zb * p.o_bs;
   float* cbase = p.C + zb * p.c_bs;
 
-  f32x16 acc[MI][NI];
+  f32x16 acc[NARROW ? 1 : MI][NARROW ? 1 : NI];
+  f32x4 acc16[NARROW ? TM16 : 1][NARROW ? TN16 : 1];
+  if (NARROW == 0) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[NARROW ? 0 : i][NARROW ? 0 : j][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM16; ++i)
+#pragma unroll
+      for (int j = 0; j < TN16; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc16[NARROW ? i : 0][NARROW ? j : 0][r] = 0.f;
+  }
+  // narrow forms: lane = (i16, g): row / column i16 of a 16 x 16 tile, k-group g; wave origin inside the block tile
+  const int i16 = lane & 15, g16 = lane >> 4;
+  const int wrow16 = NARROW == 1 ? wave * 16 * MI : 0;
+  const int wcol16 = NARROW == 2 ? wave * 16 * NI : 0;
 
   // ---- per-thread staging state --------------------------------------------------------
   // K-contiguous tiles: thread handles chunk position (tid & 3) of row j*64 + (tid >> 2).
@@ -352,6 +380,44 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
   auto compute = [&](const int buf, const int sub, const bool more) {
     const float* sA = smem + (buf * KSUB + sub) * SLAB;
     const float* sB = sA + BM * 16;
+    if constexpr (NARROW != 0) {
+      // one read round per K-step: lane (i16, g) fetches k = 4g .. 4g+3 of its row / column; MFMA e consumes k = 4g + e
+      float a[TM16][4], b[TN16][4];
+#pragma unroll
+      for (int t = 0; t < TM16; ++t) {
+        const int row = wrow16 + t * 16 + i16;
+        if (A_KC) {
+          const int pos = g16 ^ ((row >> 2) & 3);
+          const f32x4 v = *(const f32x4*)(sA + row * 16 + pos * 4);
+          a[t][0] = v[0]; a[t][1] = v[1]; a[t][2] = v[2]; a[t][3] = v[3];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[t][e] = sA[(4 * g16 + e) * BM + row];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TN16; ++u) {
+        const int col = wcol16 + u * 16 + i16;
+        if (B_KC) {
+          const int pos = g16 ^ ((col >> 2) & 3);
+          const f32x4 v = *(const f32x4*)(sB + col * 16 + pos * 4);
+          b[u][0] = v[0]; b[u][1] = v[1]; b[u][2] = v[2]; b[u][3] = v[3];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[u][e] = sB[(4 * g16 + e) * BN + col];
+        }
+      }
+      if (FAST || more) prep(sub);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < TM16; ++t)
+#pragma unroll
+          for (int u = 0; u < TN16; ++u)
+            acc16[NARROW ? t : 0][NARROW ? u : 0] =
+                __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][e], b[u][e], acc16[NARROW ? t : 0][NARROW ? u : 0], 0, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       float a[MI][4], b[NI][4];
@@ -386,7 +452,8 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][ii], b[ni][ii], acc[mi][ni], 0, 0, 0);
+            acc[NARROW ? 0 : mi][NARROW ? 0 : ni] =
+                __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][ii], b[ni][ii], acc[NARROW ? 0 : mi][NARROW ? 0 : ni], 0, 0, 0);
     }
   };
 
@@ -440,35 +507,49 @@ __global__ __launch_bounds__(256, (MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4
   // ---- epilogue -------------------------------------------------------------------------
   float* cout = cbase;
   if (LAYOUT == L_TN) cout += split * p.c_split_stride + (long long)blockIdx.y * p.c_tap_stride;
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int col = n0 + wn * 32 * NI + ni * 32 + l31;
-      const float bv = (p.bias != nullptr && col < p.N) ? p.bias[zb * p.bias_bs + col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < p.M) {
-          long long orow = row;
-          if (LAYOUT != L_TN && p.remap) {
-            int b, a, c;
-            decode_row(p.g, row, b, a, c);
-            orow = ((long long)b * p.out_H + a * p.out_s + p.out_py) * p.out_W + c * p.out_s + p.out_px;
-          }
-          float* dst = cout + orow * p.ldc + col;
-          if (col < p.N) {
-            float v = acc[mi][ni][r] + bv;
-            if (p.accumulate) v += *dst;
-            if (LAYOUT == L_NT) {
-              if (p.residual) v += p.residual[orow * p.ldr + col];
-              if (p.relu) v = fmaxf(v, 0.f);
-            }
-            *dst = v;
-          } else if (col < p.zero_to) {
-            *dst = 0.f;
-          }
+  auto store = [&](const int row, const int col, const float av, const float bv) {
+    if (row < p.M) {
+      long long orow = row;
+      if (LAYOUT != L_TN && p.remap) {
+        int b, a, c;
+        decode_row(p.g, row, b, a, c);
+        orow = ((long long)b * p.out_H + a * p.out_s + p.out_py) * p.out_W + c * p.out_s + p.out_px;
+      }
+      float* dst = cout + orow * p.ldc + col;
+      if (col < p.N) {
+        float v = av + bv;
+        if (p.accumulate) v += *dst;
+        if (LAYOUT == L_NT) {
+          if (p.residual) v += p.residual[orow * p.ldr + col];
+          if (p.relu) v = fmaxf(v, 0.f);
         }
+        *dst = v;
+      } else if (col < p.zero_to) {
+        *dst = 0.f;
+      }
+    }
+  };
+  if constexpr (NARROW != 0) {
+#pragma unroll
+    for (int t = 0; t < TM16; ++t) {
+#pragma unroll
+      for (int u = 0; u < TN16; ++u) {
+        const int col = n0 + wcol16 + u * 16 + i16;
+        const float bv = (p.bias != nullptr && col < p.N) ? p.bias[zb * p.bias_bs + col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) store(m0 + wrow16 + t * 16 + 4 * g16 + r, col, acc16[NARROW ? t : 0][NARROW ? u : 0][r], bv);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int col = n0 + wn * 32 * NI + ni * 32 + l31;
+        const float bv = (p.bias != nullptr && col < p.N) ? p.bias[zb * p.bias_bs + col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          store(m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, col, acc[NARROW ? 0 : mi][NARROW ? 0 : ni][r], bv);
       }
     }
   }
@@ -507,7 +588,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, 
   out[c] = s;
 }
 
-int g_force_mi = 0, g_force_ni = 0, g_force_splits = 0;  // tuning hooks (catseg_debug_set_tile / _splits)
+int g_force_mi = 0, g_force_ni = 0, g_force_narrow = 0, g_force_splits = 0;  // tuning hooks (catseg_debug_set_tile / _splits)
 
 const float* zero_page_ptr() {
   static const float* z = nullptr;
@@ -518,12 +599,13 @@ const float* zero_page_ptr() {
   return z;
 }
 
-template <int LAYOUT, int MI, int NI>
+template <int LAYOUT, int MI, int NI, int NARROW = 0>
 void launch_one(const IgemmArgs& a0, int ncols, int nbatch, int grid_y, hipStream_t st) {
   IgemmArgs a = a0;
   a.zero = zero_page_ptr();
-  a.tilesM = (a.M + 64 * MI - 1) / (64 * MI);
-  a.tilesN = (ncols + 64 * NI - 1) / (64 * NI);
+  constexpr int TILE_M = NARROW == 2 ? 48 * MI : 64 * MI, TILE_N = NARROW == 1 ? 48 * NI : 64 * NI;
+  a.tilesM = (a.M + TILE_M - 1) / TILE_M;
+  a.tilesN = (ncols + TILE_N - 1) / TILE_N;
   dim3 grid(a.tilesM * a.tilesN, grid_y, nbatch * (LAYOUT == L_TN ? a.splits : 1));
   // 16 rows = step_b images + step_qy image rows + step_rx pixels (step_qy < Ho, step_rx < Wo: one carry each per step)
   const int img = a.g.Ho * a.g.Wo > 0 ? a.g.Ho * a.g.Wo : 1, wo = a.g.Wo > 0 ? a.g.Wo : 1;
@@ -532,20 +614,27 @@ void launch_one(const IgemmArgs& a0, int ncols, int nbatch, int grid_y, hipStrea
   a.step_rx = (16 % img) % wo;
   // TN fast path: every forward-conv gather (mode 1); rows are advanced incrementally in the K loop
   const bool fast = LAYOUT == L_TN ? (a.g.mode == 1) : (a.taps <= 32 && a.row_s > 0);
-  if (fast) hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, MI, NI, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, MI, NI, false>), grid, dim3(256), 0, st, a);
+  if (fast) hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, MI, NI, true, NARROW>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((igemm_f32_kernel<LAYOUT, MI, NI, false, NARROW>), grid, dim3(256), 0, st, a);
 }
+
+// measured (tools/bench_narrow.py): narrow-N forms 94-104 TFLOP/s on N = 48 / 96 (+27-36 % over the padded 64-wide tiles);
+// narrow-M backward-weight forms within +-10 % of the 64-row tiles: kept for tuning runs, not chosen by the planner (eff 0)
+constexpr float kEffN2 = 0.0f;
 
 // Tile / split planner: minimise a time model
 //   t = padded FLOPs / (R x tile efficiency x CU-level quantisation) [+ slab reduction for split backward-weight].
 // Quantisation is counted in tiles per CU, not per resident-block slot: blocks that share a CU share its MFMA pipes, so
 // a grid that gives every CU the same number of tiles is "full" whatever the residency (measured, tools/bench_tiles_small.py:
 // the machine rate of a tile is within 10 % for 1 ... 6 resident blocks per CU).
-struct TilePlan { int mi, ni, splits, rps; };
-struct TileInfo { int mi, ni, occ; float eff; };
+struct TilePlan { int mi, ni, splits, rps, narrow; };
+struct TileInfo { int mi, ni, occ; float eff; int narrow; };
 // eff: measured relative MFMA efficiency of each tile (tools/bench_tiles*.py); 256x64 / 64x256 tiles exist in the
 // dispatcher but never won a measurement and are not candidates.
-const TileInfo kTiles[] = {{1, 1, 8, 0.80f}, {2, 1, 6, 0.90f}, {1, 2, 6, 0.88f}, {2, 2, 4, 1.00f}, {4, 2, 2, 0.98f}, {2, 4, 2, 0.96f}};
+const TileInfo kTiles[] = {{1, 1, 8, 0.80f, 0}, {2, 1, 6, 0.90f, 0}, {1, 2, 6, 0.88f, 0}, {2, 2, 4, 1.00f, 0}, {4, 2, 2, 0.98f, 0}, {2, 4, 2, 0.96f, 0},
+                           // 16x16x4 forms: (64 mi) x (48 ni) for forward / backward-data, (48 mi) x (64 ni) for backward-weight
+                           {2, 1, 6, 0.85f, 1}, {4, 1, 4, 0.84f, 1}, {2, 2, 4, 0.90f, 1}, {4, 2, 2, 0.80f, 1},
+                           {1, 2, 6, kEffN2, 2}, {1, 4, 4, kEffN2, 2}, {2, 2, 4, kEffN2, 2}, {2, 4, 2, kEffN2, 2}};
 
 inline double cu_quant(double tiles) {
   const double c = tiles / 256.0;
@@ -553,19 +642,23 @@ inline double cu_quant(double tiles) {
   return c / (double)(long long)(c + 0.999999);
 }
 
-TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, long long red_rows) {
+TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, long long red_rows, bool allow_narrow = true) {
   TilePlan best = {2, 2, 1, 0};
   double best_t = 1e300;
   const double R = 115e12;
   for (const TileInfo& t : kTiles) {
-    if (g_force_mi > 0 && (t.mi != g_force_mi || t.ni != g_force_ni)) continue;
-    const long long tm = (M + 64 * t.mi - 1) / (64 * t.mi), tn = (ncols + 64 * t.ni - 1) / (64 * t.ni);
-    const double padded = 2.0 * (double)(tm * 64 * t.mi) * (double)(tn * 64 * t.ni) * (double)extra * (double)red_rows;
+    if (g_force_mi > 0 && (t.mi != g_force_mi || t.ni != g_force_ni || t.narrow != g_force_narrow)) continue;
+    if (g_force_mi == 0 && t.eff <= 0.f) continue;
+    if (t.narrow && !allow_narrow) continue;
+    if ((t.narrow == 1 && layout == L_TN) || (t.narrow == 2 && layout != L_TN)) continue;
+    const long long tile_m = t.narrow == 2 ? 48 * t.mi : 64 * t.mi, tile_n = t.narrow == 1 ? 48 * t.ni : 64 * t.ni;
+    const long long tm = (M + tile_m - 1) / tile_m, tn = (ncols + tile_n - 1) / tile_n;
+    const double padded = 2.0 * (double)(tm * tile_m) * (double)(tn * tile_n) * (double)extra * (double)red_rows;
     if (layout != L_TN) {
-      const double tt = padded / (R * t.eff * cu_quant((double)(tm * tn * extra)));
+      const double tt = padded / (R * (t.eff > 0.f ? t.eff : 1.f) * cu_quant((double)(tm * tn * extra)));
       if (tt < best_t) {
         best_t = tt;
-        best = {t.mi, t.ni, 1, 0};
+        best = {t.mi, t.ni, 1, 0, t.narrow};
       }
       continue;
     }
@@ -575,18 +668,18 @@ TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, l
     if (maxs > 96) maxs = 96;
     if (maxs < 1) maxs = 1;
     const double slots = 256.0 * t.occ;
-    const double eff = t.mi == 4 ? 1.03 : t.eff;  // prefers the 256x128 tile: measured 118 vs 113 TFLOP/s
+    const double eff = t.eff <= 0.f ? 1.0 : ((t.mi == 4 && t.narrow == 0) ? 1.03 : t.eff);  // 256x128: measured 118 vs 113 TFLOP/s
     for (long long sp = 1; sp <= maxs; ++sp) {
       const double rounds = (double)(tm * tn * extra * sp) / slots;
       const double q = rounds / (double)(long long)(rounds + 0.999999);
       const double tt = padded / (R * eff * q * (1.0 - 0.002 * (double)(sp - 1)));
       if (tt < best_t) {
         best_t = tt;
-        best = {t.mi, t.ni, (int)sp, 0};
+        best = {t.mi, t.ni, (int)sp, 0, t.narrow};
       }
     }
   }
-  if (g_force_mi > 0 && best_t >= 1e300) best = {g_force_mi, g_force_ni, 1, 0};
+  if (g_force_mi > 0 && best_t >= 1e300) best = {g_force_mi, g_force_ni, 1, 0, g_force_narrow};
   if (g_force_splits > 0 && layout == L_TN) best.splits = g_force_splits;
   if (layout == L_TN) {
     best.rps = (int)(((red_rows + best.splits - 1) / best.splits + 15) / 16 * 16);
@@ -600,13 +693,23 @@ int launch_igemm(const IgemmArgs& a, int nbatch, int grid_y, hipStream_t st, con
   const int ncols = a.zero_to > a.N ? a.zero_to : a.N;  // pad columns to be zero-filled are visited too
   const TilePlan pl = given ? *given : plan_tiles(LAYOUT, a.M, ncols, (long long)grid_y * nbatch, a.g.rows);
   const int mi = pl.mi, ni = pl.ni;
-#define CS_TILE(M_, N_) if (mi == M_ && ni == N_) launch_one<LAYOUT, M_, N_>(a, ncols, nbatch, grid_y, st); else
+#define CS_TILE(M_, N_) if (pl.narrow == 0 && mi == M_ && ni == N_) launch_one<LAYOUT, M_, N_>(a, ncols, nbatch, grid_y, st); else
+#define CS_NARROW(F_, M_, N_) if (pl.narrow == F_ && mi == M_ && ni == N_) launch_one<LAYOUT, M_, N_, F_>(a, ncols, nbatch, grid_y, st); else
   // (256x64, 64x256, 64x448, 128x448 and 256x256 tiles were measured and never won: not instantiated)
-  CS_TILE(1, 1) CS_TILE(1, 2) CS_TILE(2, 1) CS_TILE(2, 2) CS_TILE(4, 2) CS_TILE(2, 4) {
-    catseg_set_error("igemm: unsupported tile %dx%d", mi, ni);
-    return CATSEG_EINVAL;
+  CS_TILE(1, 1) CS_TILE(1, 2) CS_TILE(2, 1) CS_TILE(2, 2) CS_TILE(4, 2) CS_TILE(2, 4)
+  if constexpr (LAYOUT != L_TN) {
+    CS_NARROW(1, 2, 1) CS_NARROW(1, 4, 1) CS_NARROW(1, 2, 2) CS_NARROW(1, 4, 2) {
+      catseg_set_error("igemm: unsupported tile %dx%d (form %d)", mi, ni, pl.narrow);
+      return CATSEG_EINVAL;
+    }
+  } else {
+    CS_NARROW(2, 1, 2) CS_NARROW(2, 1, 4) CS_NARROW(2, 2, 2) CS_NARROW(2, 2, 4) {
+      catseg_set_error("igemm: unsupported tile %dx%d (form %d)", mi, ni, pl.narrow);
+      return CATSEG_EINVAL;
+    }
   }
 #undef CS_TILE
+#undef CS_NARROW
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
@@ -651,6 +754,8 @@ Geo fwd_geo(const catseg_conv_desc* d, const float* x) {
 }  // namespace
 
 extern "C" int catseg_debug_set_tile(int mi, int ni) {
+  g_force_narrow = mi >> 4;  // mi + 16 * form: 1 = 16x16x4 tiles narrow in N, 2 = narrow in M
+  mi &= 15;
   g_force_mi = mi;
   g_force_ni = ni;
   return CATSEG_OK;
@@ -859,7 +964,7 @@ extern "C" int catseg_gemm_batched(int layout, int batch, int M, int N, int K, c
     a.other = A; a.ldo = lda; a.o_bs = strideA;
     a.splits = 1; a.rows_per_split = (K + 15) / 16 * 16; a.c_split_stride = 0; a.c_tap_stride = 0;
     a.tap_cin = (N + 3) & ~3;
-    TilePlan pl = plan_tiles(L_NT, M, zero_to > N ? zero_to : N, batch, K);  // no split-K for the batched form
+    TilePlan pl = plan_tiles(L_NT, M, zero_to > N ? zero_to : N, batch, K, false);  // no split-K for the batched form
     pl.splits = 1;
     return launch_igemm<L_TN>(a, batch, 1, st, &pl);
   }
