@@ -567,6 +567,38 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
   }
 }
 
+// the same for MANY slabs of a small tensor (direct backward-weight: up to 512 slabs of 83-330 KB): a block owns 64
+// float4 columns, its 16 waves each add a contiguous range of slabs (8 independent loads in flight), the 16 partials
+// are combined through LDS in wave order -> fixed summation order, deterministic
+__global__ __launch_bounds__(1024) void reduce_slabs_wide_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n4,
+                                                                 int splits, long long stride4) {
+  const f32x4* s = (const f32x4*)slabs;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + lane;
+  const int per = (splits + 15) / 16;
+  const int k0 = wave * per, k1 = min(k0 + per, splits);
+  f32x4 a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (i < n4) {
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += s[i + (long long)(k + j) * stride4];
+    }
+    for (; k < k1; ++k) a[0] += s[i + (long long)k * stride4];
+  }
+  __shared__ f32x4 part[16][64];
+  part[wave][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (wave == 0 && i < n4) {
+    f32x4 t = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) t += part[w][lane];
+    ((f32x4*)out)[i] = t;
+  }
+}
+
 // dbias[o] = sum_p dy[p, o]: block = 64 channels x 4 row lanes, rows strided over gridDim.y
 __global__ void colsum_partial_kernel(const float* __restrict__ dy, int ld, long long rows, int C,
                                       float* __restrict__ part) {
@@ -588,7 +620,14 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, 
   out[c] = s;
 }
 
-int g_force_mi = 0, g_force_ni = 0, g_force_narrow = 0, g_force_splits = 0;  // tuning hooks (catseg_debug_set_tile / _splits)
+int g_force_mi = 0, g_force_ni = 0, g_force_narrow = 0, g_force_splits = 0;
+
+}  // namespace
+// wgrad_direct.hip
+size_t wgrad_direct_workspace(const catseg_conv_desc* d);
+int wgrad_direct_launch(const catseg_conv_desc* d, const float* x, const float* dy, void* workspace, hipStream_t st);
+namespace {
+  // tuning hooks (catseg_debug_set_tile / _splits)
 
 const float* zero_page_ptr() {
   static const float* z = nullptr;
@@ -882,6 +921,8 @@ extern "C" size_t catseg_conv2d_bwd_weight_workspace(const catseg_conv_desc* d) 
   const int splits = wgrad_plan(d).splits;
   const size_t wel = (size_t)d->Cout * (d->stem4 ? d->kh * 32 : d->kh * d->kw * d->Cin);
   size_t bytes = splits > 1 ? (size_t)splits * wel * 4 : 0;
+  const size_t direct = wgrad_direct_workspace(d);  // small-channel 3x3 layers take the direct kernel (wgrad_direct.hip)
+  if (direct > bytes) bytes = direct;
   bytes += (size_t)256 * d->Cout * 4;  // bias-gradient partials
   return cs_align_up(bytes, 256);
 }
@@ -899,10 +940,16 @@ extern "C" int catseg_conv2d_bwd_weight(const catseg_conv_desc* d, const float* 
   }
   hipStream_t st = (hipStream_t)stream;
   const TilePlan pl = wgrad_plan(d);
-  const int splits = pl.splits, rps = pl.rps;
+  int splits = pl.splits;
+  const int rps = pl.rps;
   const int taps = d->stem4 ? d->kh : d->kh * d->kw;
   const int ncol = d->stem4 ? 32 : d->Cin;
   const size_t wel = (size_t)d->Cout * taps * ncol;
+  const int direct_slabs = wgrad_direct_launch(d, x, dy, workspace, st);
+  if (direct_slabs > 0) {
+    splits = direct_slabs;  // the slabs are reduced (and dbias computed) below exactly as for the split GEMM
+    CS_LAUNCH_CHECK();
+  }
   IgemmArgs a = {};
   a.g = fwd_geo(d, x);
   a.other = dy; a.ldo = d->ldy;
@@ -913,11 +960,15 @@ extern "C" int catseg_conv2d_bwd_weight(const catseg_conv_desc* d, const float* 
   const int grid_y = d->stem4 ? taps : 1;
   if (d->stem4) { a.N = ncol; a.c_tap_stride = ncol; a.tap_cin = 0; }
   else { a.N = taps * ncol; a.c_tap_stride = 0; a.tap_cin = ncol; }   // all taps side by side in the N dimension
-  if (int e = launch_igemm<L_TN>(a, 1, grid_y, st, &pl)) return e;
+  if (direct_slabs == 0)
+    if (int e = launch_igemm<L_TN>(a, 1, grid_y, st, &pl)) return e;
   if (splits > 1) {
     const long long n4 = (long long)(wel / 4);
     const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n4, splits, n4);
+    if (splits >= 64 && n4 <= 64 * 1024)  // many slabs of a small tensor: more parallelism across the slabs
+      hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(1024), 0, st, (const float*)workspace, dw, n4, splits, n4);
+    else
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n4, splits, n4);
     CS_LAUNCH_CHECK();
   }
   if (dbias) {

@@ -58,6 +58,11 @@ CONV_CASES = [
     (5, 2, 3, 16, 16, 3, 1, 1, 1),
     (1, 2, 40, 8, 8, 3, 1, 1, 1),
     (3, 6, 6, 16, 12, 3, 2, 1, 1),
+    # HRNet branch widths: 48 / 96-wide 16x16x4 tiles (fwd / dgrad) and the direct backward-weight kernel
+    # (>= 1024 strips of 16 pixels; W not a multiple of 16 -> partial strips, halo at every border)
+    (4, 64, 70, 48, 48, 3, 1, 1, 1),
+    (2, 70, 120, 96, 96, 3, 1, 1, 1),
+    (1, 33, 40, 48, 96, 3, 1, 1, 1),
 ]
 
 
