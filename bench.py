@@ -220,8 +220,11 @@ def main():
         traffic = None   # HBM bytes per launch from committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.model)
         if os.path.exists(tpath) and (B, H, W) == (8, 544, 960):
-            traffic = json.load(open(tpath))["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
-        roof = {"bound": "mfma", "kernel": "igemm_f32_kernel<%s>" % dom, "achieved": fl / sec / 1e12, "peak": peak,
+            per_step = json.load(open(tpath))["kernels"].get(dom, {}).get("hbm_bytes_per_step")
+            traffic = per_step / (n // 2) if per_step else None          # per C-ABI call, like `achieved`
+        label = {"fwd": "igemm_f32_kernel<NT> (conv2d forward)", "dgrad": "igemm_f32_kernel<NN> (conv2d backward-data)",
+                 "wgrad": "igemm_f32_kernel<TN> + wgrad_direct_kernel (conv2d backward-weight, incl. slab reduction)"}.get(dom, dom)
+        roof = {"bound": "mfma", "kernel": label, "achieved": fl / sec / 1e12, "peak": peak,
                 "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak, "traffic": traffic, "launches_per_step": n // 2,
                 "avg_launch_ms": sec / n * 1e3, "algorithmic_gflop_per_launch": fl / n / 1e9,
                 "all_igemm": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / 2 * 1e3, "launches_per_step": v[2] // 2}

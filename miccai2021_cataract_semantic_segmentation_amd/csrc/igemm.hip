@@ -445,6 +445,7 @@ __global__ __launch_bounds__(256, igemm_min_waves(MI, NI, NARROW)) void igemm_f3
           for (int ii = 0; ii < 4; ++ii) b[ni][ii] = sB[(8 * jj + 4 * h + ii) * BN + row];
         }
       }
+      __builtin_amdgcn_iglp_opt(0);  // scheduler hint: interleave the LDS reads with the MFMA chain (+1 % measured)
       if (jj == 0 && (FAST || more)) prep(sub);  // address math for the interval after next rides under the MFMAs
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii)
@@ -692,6 +693,7 @@ TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, l
     if ((t.narrow == 1 && layout == L_TN) || (t.narrow == 2 && layout != L_TN)) continue;
     const long long tile_m = t.narrow == 2 ? 48 * t.mi : 64 * t.mi, tile_n = t.narrow == 1 ? 48 * t.ni : 64 * t.ni;
     const long long tm = (M + tile_m - 1) / tile_m, tn = (ncols + tile_n - 1) / tile_n;
+    if (t.narrow == 1 && tn > 1 && g_force_mi == 0) continue;  // in-network the 48/96-wide forms only win when one tile spans N
     const double padded = 2.0 * (double)(tm * tile_m) * (double)(tn * tile_n) * (double)extra * (double)red_rows;
     if (layout != L_TN) {
       const double tt = padded / (R * (t.eff > 0.f ? t.eff : 1.f) * cu_quant((double)(tm * tn * extra)));

@@ -1,28 +1,43 @@
-"""Turn two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, collected separately as
-MI355X_MICROARCH.md prescribes) of `bench.py --steps 1 --warmup 1` into HBM bytes per launch of the
-igemm kernels.  gfx950 correction: FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) streams ->
-doubled; WRITE_SIZE is exact (checked on a conv whose output size is known: 130560 KB reported = written).
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, collected separately as MI355X_MICROARCH.md prescribes) of
+`bench.py --steps 1 --warmup 1 --no-roofline --no-cpu-baseline` (= 2 training steps) into HBM bytes per step of the three
+convolution operations.  A group = every kernel the C-ABI call launches: the implicit GEMM of that layout, and for
+backward-weight also the direct small-channel kernel, the slab reductions and the bias column sums.
+gfx950 correction: FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) streams -> doubled; WRITE_SIZE is exact
+(checked on a conv whose output size is known: 130560 KB reported = written).  bench.py divides by its own count of calls.
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <model> > profiles/r01_pmc_traffic_<model>.json
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <model> [steps=2] > profiles/r01_pmc_traffic_<model>.json
 """
 import collections, csv, glob, json, re, sys
 
 fetch_dir, write_dir, model = sys.argv[1:4]
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 LAY = {"0": "fwd", "1": "dgrad", "2": "wgrad"}
-out = {"model": model, "unit": "bytes per launch (HBM/fabric side, FETCH_SIZE x2 + WRITE_SIZE)", "kernels": {}}
-acc = collections.defaultdict(lambda: {"launches": 0, "fetch_kb": 0.0, "write_kb": 0.0})
+
+
+def group(name):
+    m = re.search(r"igemm_f32_kernel<(\d)", name)
+    if m:
+        return LAY[m.group(1)]
+    if "wgrad_direct_kernel" in name or "reduce_slabs" in name or "colsum_" in name:
+        return "wgrad"
+    return None
+
+
+out = {"model": model, "steps_profiled": steps,
+       "unit": "bytes per training step per operation group (HBM/fabric side, FETCH_SIZE x2 + WRITE_SIZE)", "kernels": {}}
+acc = collections.defaultdict(lambda: {"kernel_launches": 0, "fetch_kb": 0.0, "write_kb": 0.0})
 for name, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
     f = glob.glob(d + "/*/*counter_collection.csv")[0]
     n = collections.Counter()
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == name and "igemm" in r["Kernel_Name"]:
-            k = LAY[re.search(r"igemm_f32_kernel<(\d)", r["Kernel_Name"]).group(1)]
+        k = group(r["Kernel_Name"])
+        if r["Counter_Name"] == name and k:
             acc[k]["fetch_kb" if name == "FETCH_SIZE" else "write_kb"] += float(r["Counter_Value"])
             n[k] += 1
     for k, v in n.items():
-        acc[k]["launches"] = v
+        acc[k]["kernel_launches"] = v
 for k, v in acc.items():
-    out["kernels"][k] = {"launches": v["launches"], "fetch_size_kb_raw_per_launch": v["fetch_kb"] / v["launches"],
-                         "write_size_kb_per_launch": v["write_kb"] / v["launches"],
-                         "hbm_bytes_per_launch": (2 * v["fetch_kb"] + v["write_kb"]) * 1024 / v["launches"]}
+    out["kernels"][k] = {"kernel_launches_per_step": v["kernel_launches"] / steps,
+                         "fetch_size_kb_raw_per_step": v["fetch_kb"] / steps, "write_size_kb_per_step": v["write_kb"] / steps,
+                         "hbm_bytes_per_step": (2 * v["fetch_kb"] + v["write_kb"]) * 1024 / steps}
 print(json.dumps(out, indent=1))
