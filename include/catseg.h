@@ -114,9 +114,11 @@ int catseg_bn_apply(const float* y, int ldy, const float* mean, const float* sca
                     catseg_stream_t stream);
 /* backward of the fused op.  g = dz * (z > 0 if relu).  Produces dgamma, dbeta, dy and, when
  * dres != NULL, the residual-branch gradient (dres (+)= g if dres_accumulate).
+ * z may be NULL when the forward had no residual branch: the ReLU mask is then recomputed from y, gamma, beta and
+ * the saved statistics with the forward's exact expression (one tensor read less in both passes).
  * workspace >= catseg_bn_workspace(rows, C). */
 int catseg_bn_backward(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
-                       const float* stats, const float* gamma, long long rows, int C, int relu,
+                       const float* stats, const float* gamma, const float* beta, long long rows, int C, int relu,
                        float* dy, int lddy, float* dgamma, float* dbeta, float* dres, int lddres,
                        int dres_accumulate, void* workspace, size_t workspace_bytes,
                        catseg_stream_t stream);

@@ -45,7 +45,7 @@ _SIGS = {
     "catseg_bn_train_stats": (I, [P, L, I, I, P, F, F, P, P, P, P, P, SZ, P]),
     "catseg_bn_eval_scale": (I, [I, P, P, F, P, P]),
     "catseg_bn_apply": (I, [P, I, P, P, P, P, I, P, I, L, I, I, P]),
-    "catseg_bn_backward": (I, [P, I, P, I, P, I, P, P, L, I, I, P, I, P, P, P, I, I, P, SZ, P]),
+    "catseg_bn_backward": (I, [P, I, P, I, P, I, P, P, P, L, I, I, P, I, P, P, P, I, I, P, SZ, P]),
     "catseg_nchw3_to_nhwc4": (I, [P, P, I, I, I, P]),
     "catseg_stem_pack_weight": (I, [P, P, I, P]),
     "catseg_stem_unpack_grad": (I, [P, P, I, P]),

@@ -143,6 +143,15 @@ __global__ void bn_eval_kernel(int C, const float* gamma, const float* rv, float
   if (c < C) scale[c] = gamma[c] / sqrtf(rv[c] + eps);
 }
 
+// v = fma(y - mean, scale, beta), spelled out so that forward and backward evaluate the identical expression: the backward
+// recomputes the ReLU mask from y instead of reading z when there is no residual branch (one tensor read less)
+__device__ __forceinline__ f32x4 bn_affine(f32x4 y, f32x4 mean, f32x4 scale, f32x4 beta) {
+  f32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(y[i] - mean[i], scale[i], beta[i]);
+  return v;
+}
+
 // z = act((y - mean) * scale + beta (+ res))
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ mean,
                                                        const float* __restrict__ scale, const float* __restrict__ beta,
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / cpt;
     const int c = (int)(i - r * cpt) * 4;
-    f32x4 v = (ld4(y + r * ldy + c) - ld4(mean + c)) * ld4(scale + c) + ld4(beta + c);
+    f32x4 v = bn_affine(ld4(y + r * ldy + c), ld4(mean + c), ld4(scale + c), ld4(beta + c));
     if (res) v += ld4(res + r * ldr + c);
     if (relu) {
       v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
@@ -165,7 +174,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // backward partials: sg = sum g, sgx = sum g * xhat
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z,
                                                              int ldz, const float* __restrict__ y, int ldy,
-                                                             const float* __restrict__ stats, long long rows, int C, int relu,
+                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, long long rows, int C, int relu,
                                                              RowSplit s, float* __restrict__ part) {
   const int t = threadIdx.x;
   const int cg = blockIdx.y * s.tpr + t % s.tpr;
@@ -177,14 +187,17 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   f32x4 sg = {0, 0, 0, 0}, sgx = {0, 0, 0, 0};
   if (act) {
     const f32x4 mean = ld4(stats + c), inv = ld4(stats + C + c);
+    f32x4 sc = {0, 0, 0, 0}, be = {0, 0, 0, 0};
+    if (relu && !z) { sc = ld4(gamma + c) * inv; be = ld4(beta + c); }   // scale exactly as bn_finalize stored it
     for (long long r = r0 + rl; r < r1; r += s.rpp) {
       f32x4 g = ld4(dz + r * lddz + c);
+      const f32x4 yy = ld4(y + r * ldy + c);
       if (relu) {
-        const f32x4 zz = ld4(z + r * ldz + c);
+        const f32x4 zz = z ? ld4(z + r * ldz + c) : bn_affine(yy, mean, sc, be);
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[i] = zz[i] > 0.f ? g[i] : 0.f;
       }
-      const f32x4 xh = (ld4(y + r * ldy + c) - mean) * inv;
+      const f32x4 xh = (yy - mean) * inv;
       sg += g;
       sgx += g * xh;
     }
@@ -230,8 +243,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z,
                                                            int ldz, const float* __restrict__ y, int ldy,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                           const float* __restrict__ coef, long long rows, int C, int relu,
-                                                           float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres,
+                                                           const float* __restrict__ beta, const float* __restrict__ coef, long long rows, int C,
+                                                           int relu, float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres,
                                                            int dres_acc) {
   const int cpt = C >> 2;
   const long long total = rows * cpt;
@@ -239,13 +252,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const long long r = i / cpt;
     const int c = (int)(i - r * cpt) * 4;
     f32x4 g = ld4(dz + r * lddz + c);
+    const f32x4 inv = ld4(stats + C + c), mean = ld4(stats + c);
+    const f32x4 yy = ld4(y + r * ldy + c);
     if (relu) {
-      const f32x4 zz = ld4(z + r * ldz + c);
+      const f32x4 zz = z ? ld4(z + r * ldz + c) : bn_affine(yy, mean, ld4(gamma + c) * inv, ld4(beta + c));
 #pragma unroll
       for (int k = 0; k < 4; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
     }
-    const f32x4 inv = ld4(stats + C + c);
-    const f32x4 xh = (ld4(y + r * ldy + c) - ld4(stats + c)) * inv;
+    const f32x4 xh = (yy - mean) * inv;
     const f32x4 o = ld4(gamma + c) * inv * (g - ld4(coef + c) - xh * ld4(coef + C + c));
     *(f32x4*)(dy + r * lddy + c) = o;
     if (dres) {
@@ -331,12 +345,13 @@ extern "C" int catseg_bn_apply(const float* y, int ldy, const float* mean, const
 }
 
 extern "C" int catseg_bn_backward(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
-                                  const float* stats, const float* gamma, long long rows, int C, int relu,
+                                  const float* stats, const float* gamma, const float* beta, long long rows, int C, int relu,
                                   float* dy, int lddy, float* dgamma, float* dbeta, float* dres, int lddres,
                                   int dres_accumulate, void* workspace, size_t workspace_bytes,
                                   catseg_stream_t stream) {
   CS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0, "bn bwd: C and ld must be multiples of 4");
-  CS_REQUIRE(!relu || (z != nullptr && ldz % 4 == 0), "bn bwd: relu needs z");
+  CS_REQUIRE(!relu || (z != nullptr && ldz % 4 == 0) || (z == nullptr && beta != nullptr && dres == nullptr),
+             "bn bwd: relu needs z, or (no residual branch) beta to recompute the mask from y");
   CS_REQUIRE(cs_aligned16(dz) && cs_aligned16(y) && cs_aligned16(dy) && cs_aligned16(stats) && cs_aligned16(gamma) &&
                  cs_aligned16(z) && cs_aligned16(dres), "bn bwd: alignment");
   if (workspace_bytes < catseg_bn_workspace(rows, C) || !workspace) {
@@ -347,10 +362,10 @@ extern "C" int catseg_bn_backward(const float* dz, int lddz, const float* z, int
   const RowSplit s = plan_rows(rows, C);
   float* part = (float*)workspace;
   float* coef = part + (size_t)kMaxRowBlocks * 3 * ((C + 3) & ~3);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, rows, C, relu, s, part);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma, beta, rows, C, relu, s, part);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma,
-                     (const float*)coef, rows, C, relu, dy, lddy, dres, lddres, dres_accumulate);
+                     beta, (const float*)coef, rows, C, relu, dy, lddy, dres, lddres, dres_accumulate);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

@@ -218,7 +218,10 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
             dres, acc = (None, False)
             if residual is not None:
                 dres, acc = cx.dest(residual)
-            dy = ops.bn_backward(dz, z, y, stats, bn.weight.data, relu, cx.pgrad(bn.weight), cx.pgrad(bn.bias), dres, acc)
+            # without a residual branch the ReLU mask is recomputed from y (z is not read: 1 of 3 tensor reads saved)
+            z_mask = z if (residual is not None or not relu) else None
+            dy = ops.bn_backward(dz, z_mask, y, stats, bn.weight.data, relu, cx.pgrad(bn.weight), cx.pgrad(bn.bias), dres, acc,
+                                 beta=bn.bias.data)
             del dz
             dbias = cx.pgrad(conv.bias) if conv.bias is not None else None
             if conv.stem:

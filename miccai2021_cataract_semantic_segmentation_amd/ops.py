@@ -155,14 +155,15 @@ def bn_apply(y, mean, scale, beta, residual, relu, out=None):
     return out
 
 
-def bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres=None, dres_accumulate=False, dy_out=None):
+def bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres=None, dres_accumulate=False, dy_out=None, beta=None):
+    """z=None (only without a residual branch): the ReLU mask is recomputed from y and beta instead of being read"""
     C = y.shape[-1]
     rows = rows_of(y)
     if dy_out is None:
         dy_out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
     ws = workspace(lib.catseg_bn_workspace(rows, C), y.device)
     check(lib.catseg_bn_backward(ptr(dz), ld_of(dz), ptr(z), ld_of(z) if z is not None else 0, ptr(y), ld_of(y), ptr(stats),
-                                 ptr(gamma), rows, C, 1 if relu else 0, ptr(dy_out), ld_of(dy_out), ptr(dgamma), ptr(dbeta),
+                                 ptr(gamma), ptr(beta), rows, C, 1 if relu else 0, ptr(dy_out), ld_of(dy_out), ptr(dgamma), ptr(dbeta),
                                  ptr(dres), ld_of(dres) if dres is not None else 0, 1 if dres_accumulate else 0, ptr(ws),
                                  ws.numel(), stream()))
     return dy_out
