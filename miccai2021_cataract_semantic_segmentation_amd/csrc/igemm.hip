@@ -131,19 +131,22 @@ __device__ __forceinline__ const float* sel_ptr(bool ok, const float* base, int 
 //   0: 2 x 2 waves, v_mfma_f32_32x32x2_f32, block tile (64 MI) x (64 NI)
 //   1: 4 x 1 waves, v_mfma_f32_16x16x4_f32, block tile (64 MI) x (48 NI): N = 48 / 96 (HRNet branch widths) without padding
 //   2: 1 x 4 waves, v_mfma_f32_16x16x4_f32, block tile (48 MI) x (64 NI): the same for the M side (backward-weight, M = Cout)
+//   3 / 4: as 1 with a 16 / 32 wide tile (NI = 1): per-group GEMMs of grouped convolutions (ResNeXt: 8 ... 32 channels per group)
+//          and the K-class logit layers
 // The LDS images and the staging code are identical in all three (64 MI rows of A, 64 NI rows / columns of B per K-step);
 // the narrow forms simply do not touch the last quarter of the narrow operand.
 constexpr int igemm_min_waves(int MI, int NI, int NARROW) {
-  return NARROW ? ((NARROW == 1 ? MI * 3 * NI : 3 * MI * NI) <= 12 ? 4 : 2) : ((MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4 : 1));
+  return NARROW ? ((NARROW == 1 ? MI * 3 * NI : (NARROW == 2 ? 3 * MI * NI : MI * (NARROW - 2))) <= 12 ? 4 : 2)
+                : ((MI * NI == 8) ? 2 : ((MI == 2 && NI == 2) ? 4 : 1));
 }
 
 template <int LAYOUT, int MI, int NI, bool FAST, int NARROW>
 __global__ __launch_bounds__(256, igemm_min_waves(MI, NI, NARROW)) void igemm_f32_kernel(const IgemmArgs p) {
   constexpr int BM = 64 * MI, BN = 64 * NI;                    // rows of A / B staged in LDS per K-step
   constexpr int TILE_M = NARROW == 2 ? 48 * MI : BM;           // extent of the output tile
-  constexpr int TILE_N = NARROW == 1 ? 48 * NI : BN;
-  constexpr int TM16 = NARROW == 1 ? MI : 3 * MI;              // 16 x 16 accumulator tiles per wave (narrow forms)
-  constexpr int TN16 = NARROW == 1 ? 3 * NI : NI;
+  constexpr int TILE_N = NARROW == 1 ? 48 * NI : (NARROW == 3 ? 16 : (NARROW == 4 ? 32 : BN));
+  constexpr int TM16 = NARROW == 2 ? 3 * MI : MI;              // 16 x 16 accumulator tiles per wave (narrow forms)
+  constexpr int TN16 = NARROW == 2 ? NI : TILE_N / 16;
   constexpr bool A_KC = (LAYOUT != L_TN);
   constexpr bool B_KC = (LAYOUT == L_NT);
   // K sub-steps (of 16) per barrier interval.  Measured: > 1 on the small tiles costs more in occupancy
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256, igemm_min_waves(MI, NI, NARROW)) void igemm_f3
   }
   // narrow forms: lane = (i16, g): row / column i16 of a 16 x 16 tile, k-group g; wave origin inside the block tile
   const int i16 = lane & 15, g16 = lane >> 4;
-  const int wrow16 = NARROW == 1 ? wave * 16 * MI : 0;
+  const int wrow16 = NARROW != 2 ? wave * 16 * MI : 0;
   const int wcol16 = NARROW == 2 ? wave * 16 * NI : 0;
 
   // ---- per-thread staging state --------------------------------------------------------
@@ -643,7 +646,8 @@ template <int LAYOUT, int MI, int NI, int NARROW = 0>
 void launch_one(const IgemmArgs& a0, int ncols, int nbatch, int grid_y, hipStream_t st) {
   IgemmArgs a = a0;
   a.zero = zero_page_ptr();
-  constexpr int TILE_M = NARROW == 2 ? 48 * MI : 64 * MI, TILE_N = NARROW == 1 ? 48 * NI : 64 * NI;
+  constexpr int TILE_M = NARROW == 2 ? 48 * MI : 64 * MI;
+  constexpr int TILE_N = NARROW == 1 ? 48 * NI : (NARROW == 3 ? 16 : (NARROW == 4 ? 32 : 64 * NI));
   a.tilesM = (a.M + TILE_M - 1) / TILE_M;
   a.tilesN = (ncols + TILE_N - 1) / TILE_N;
   dim3 grid(a.tilesM * a.tilesN, grid_y, nbatch * (LAYOUT == L_TN ? a.splits : 1));
@@ -674,6 +678,7 @@ struct TileInfo { int mi, ni, occ; float eff; int narrow; };
 const TileInfo kTiles[] = {{1, 1, 8, 0.80f, 0}, {2, 1, 6, 0.90f, 0}, {1, 2, 6, 0.88f, 0}, {2, 2, 4, 1.00f, 0}, {4, 2, 2, 0.98f, 0}, {2, 4, 2, 0.96f, 0},
                            // 16x16x4 forms: (64 mi) x (48 ni) for forward / backward-data, (48 mi) x (64 ni) for backward-weight
                            {2, 1, 6, 0.85f, 1}, {4, 1, 4, 0.84f, 1}, {2, 2, 4, 0.90f, 1}, {4, 2, 2, 0.80f, 1},
+                           {2, 1, 6, 0.60f, 3}, {4, 1, 6, 0.62f, 3}, {2, 1, 6, 0.70f, 4}, {4, 1, 6, 0.72f, 4},
                            {1, 2, 6, kEffN2, 2}, {1, 4, 4, kEffN2, 2}, {2, 2, 4, kEffN2, 2}, {2, 4, 2, kEffN2, 2}};
 
 inline double cu_quant(double tiles) {
@@ -690,10 +695,12 @@ TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, l
     if (g_force_mi > 0 && (t.mi != g_force_mi || t.ni != g_force_ni || t.narrow != g_force_narrow)) continue;
     if (g_force_mi == 0 && t.eff <= 0.f) continue;
     if (t.narrow && !allow_narrow) continue;
-    if ((t.narrow == 1 && layout == L_TN) || (t.narrow == 2 && layout != L_TN)) continue;
-    const long long tile_m = t.narrow == 2 ? 48 * t.mi : 64 * t.mi, tile_n = t.narrow == 1 ? 48 * t.ni : 64 * t.ni;
+    if ((t.narrow != 2 && t.narrow != 0 && layout == L_TN) || (t.narrow == 2 && layout != L_TN)) continue;
+    if (t.narrow >= 3 && layout != L_NT) continue;   // 16 / 32 wide tiles: forward only (grouped conv, class logits)
+    const long long tile_m = t.narrow == 2 ? 48 * t.mi : 64 * t.mi;
+    const long long tile_n = t.narrow == 1 ? 48 * t.ni : (t.narrow == 3 ? 16 : (t.narrow == 4 ? 32 : 64 * t.ni));
     const long long tm = (M + tile_m - 1) / tile_m, tn = (ncols + tile_n - 1) / tile_n;
-    if (t.narrow == 1 && tn > 1 && g_force_mi == 0) continue;  // in-network the 48/96-wide forms only win when one tile spans N
+    if ((t.narrow == 1 || t.narrow >= 3) && tn > 1 && g_force_mi == 0) continue;  // in-network the 48/96-wide forms only win when one tile spans N
     const double padded = 2.0 * (double)(tm * tile_m) * (double)(tn * tile_n) * (double)extra * (double)red_rows;
     if (layout != L_TN) {
       const double tt = padded / (R * (t.eff > 0.f ? t.eff : 1.f) * cu_quant((double)(tm * tn * extra)));
@@ -734,23 +741,27 @@ int launch_igemm(const IgemmArgs& a, int nbatch, int grid_y, hipStream_t st, con
   const int ncols = a.zero_to > a.N ? a.zero_to : a.N;  // pad columns to be zero-filled are visited too
   const TilePlan pl = given ? *given : plan_tiles(LAYOUT, a.M, ncols, (long long)grid_y * nbatch, a.g.rows);
   const int mi = pl.mi, ni = pl.ni;
-#define CS_TILE(M_, N_) if (pl.narrow == 0 && mi == M_ && ni == N_) launch_one<LAYOUT, M_, N_>(a, ncols, nbatch, grid_y, st); else
-#define CS_NARROW(F_, M_, N_) if (pl.narrow == F_ && mi == M_ && ni == N_) launch_one<LAYOUT, M_, N_, F_>(a, ncols, nbatch, grid_y, st); else
-  // (256x64, 64x256, 64x448, 128x448 and 256x256 tiles were measured and never won: not instantiated)
-  CS_TILE(1, 1) CS_TILE(1, 2) CS_TILE(2, 1) CS_TILE(2, 2) CS_TILE(4, 2) CS_TILE(2, 4)
-  if constexpr (LAYOUT != L_TN) {
-    CS_NARROW(1, 2, 1) CS_NARROW(1, 4, 1) CS_NARROW(1, 2, 2) CS_NARROW(1, 4, 2) {
-      catseg_set_error("igemm: unsupported tile %dx%d (form %d)", mi, ni, pl.narrow);
-      return CATSEG_EINVAL;
-    }
-  } else {
-    CS_NARROW(2, 1, 2) CS_NARROW(2, 1, 4) CS_NARROW(2, 2, 2) CS_NARROW(2, 2, 4) {
-      catseg_set_error("igemm: unsupported tile %dx%d (form %d)", mi, ni, pl.narrow);
-      return CATSEG_EINVAL;
-    }
+  bool ok = false;
+#define CS_FORM(F_, M_, N_)                                                          \
+  if (!ok && pl.narrow == F_ && mi == M_ && ni == N_) {                              \
+    launch_one<LAYOUT, M_, N_, F_>(a, ncols, nbatch, grid_y, st);                    \
+    ok = true;                                                                       \
   }
-#undef CS_TILE
-#undef CS_NARROW
+  // (256x64, 64x256, 64x448, 128x448 and 256x256 tiles were measured and never won: not instantiated)
+  CS_FORM(0, 1, 1) CS_FORM(0, 1, 2) CS_FORM(0, 2, 1) CS_FORM(0, 2, 2) CS_FORM(0, 4, 2) CS_FORM(0, 2, 4)
+  if constexpr (LAYOUT != L_TN) {
+    CS_FORM(1, 2, 1) CS_FORM(1, 4, 1) CS_FORM(1, 2, 2) CS_FORM(1, 4, 2)
+  } else {
+    CS_FORM(2, 1, 2) CS_FORM(2, 1, 4) CS_FORM(2, 2, 2) CS_FORM(2, 2, 4)
+  }
+  if constexpr (LAYOUT == L_NT) {
+    CS_FORM(3, 2, 1) CS_FORM(3, 4, 1) CS_FORM(4, 2, 1) CS_FORM(4, 4, 1)
+  }
+#undef CS_FORM
+  if (!ok) {
+    catseg_set_error("igemm: unsupported tile %dx%d (form %d)", mi, ni, pl.narrow);
+    return CATSEG_EINVAL;
+  }
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
