@@ -141,6 +141,9 @@ def main():
                     help="BASELINE config 5 instead: EncDec(ResNeXt101_32x8d + UPerNet) inference at 3x1080x1920, 4 frames per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--with-h2d", action="store_true",
+                    help="side measurement (never the reported `value` of the contract): every step also copies its batch from "
+                         "pinned host memory, float32 image + int64 labels as the reference's loader hands them over")
     args = ap.parse_args()
 
     if args.infer:
@@ -170,7 +173,12 @@ def main():
     opt = FusedAdam(model, lr=1e-4, grad_scale=gscale)
     img, lbl = synth_batch(B, H, W, K, 1000 + rank, dev)
 
+    host = (img.cpu().pin_memory(), lbl.cpu().pin_memory()) if args.with_h2d else None
+
     def step():
+        if host is not None:
+            img.copy_(host[0], non_blocking=True)
+            lbl.copy_(host[1], non_blocking=True)
         opt.zero_grad()
         interm, final = model(img)
         loss = crit(interm, final, lbl)
@@ -244,7 +252,8 @@ def main():
             "config": {"workload": "%s, 25-class (task 3), bs=%d/GPU @3x%dx%d, TwoScale Lovasz-Softmax (0.4 interm + 1.0 final), "
                                    "Adam lr 1e-4, loss/optimiser of reference configs/OCRNet_rf_lvsz.json" % (MODELS[args.model][1], B, H, W),
                        "model": args.model,
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": final_loss},
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": final_loss,
+                       "inputs": "host (pinned) -> device copy inside every step" if args.with_h2d else "resident in HBM"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
