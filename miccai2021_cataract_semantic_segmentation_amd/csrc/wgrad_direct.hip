@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(const float* __res
 }
 
 int g_wgrad_direct = 1;
+int g_direct_blocks = 512;
 
 struct DirectPlan { int kind, splits, strips_per_block; };  // kind 0 = not applicable
 
@@ -178,7 +179,7 @@ DirectPlan direct_plan(const catseg_conv_desc* d) {
   const long long S = (long long)d->B * d->H * ((d->W + 15) / 16);
   if (S < 1024) { p.kind = 0; return p; }  // tiny maps: the GEMM path with its finer split is as good
   const int ky_blocks = p.kind == 1 ? 1 : 3;
-  long long splits = 512 / ky_blocks;      // ~2 resident blocks per CU
+  long long splits = g_direct_blocks / ky_blocks;   // default 512 blocks: ~2 resident blocks per CU
   if (splits > S / 8) splits = S / 8;
   p.strips_per_block = (int)((S + splits - 1) / splits);
   p.splits = (int)((S + p.strips_per_block - 1) / p.strips_per_block);
@@ -188,6 +189,7 @@ DirectPlan direct_plan(const catseg_conv_desc* d) {
 }  // namespace
 
 extern "C" int catseg_debug_set_wgrad_direct(int on) {
+  if (on > 1) g_direct_blocks = on;   // tuning: values > 1 set the target number of blocks per launch
   g_wgrad_direct = on ? 1 : 0;
   return CATSEG_OK;
 }
