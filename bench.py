@@ -38,14 +38,17 @@ def synth_batch(B, H, W, K, seed, device):
 MODELS = {
     "ocrnet_hrnet48": ({"backbone": "hrnet48", "pretrained": False}, "OCRNet-HRNetV2-W48 (stride-4 720-ch concat + OCR heads)"),
     "ocrnet_r50": ({"backbone": "resnet50", "out_stride": 8, "pretrained": False}, "OCRNet-ResNet50-OS8"),
+    # BASELINE config 2: DeepLabv3+ ResNet50, 17-class (task 2), cross entropy with the ignore label
+    "deeplabv3plus_r50": ({"backbone": "resnet50", "out_stride": 8, "pretrained": False}, "DeepLabv3+-ResNet50-OS8"),
 }
+IS_DEEPLAB = lambda name: name.startswith("deeplab")   # noqa: E731
 
 
 def cpu_baseline(H, W, K, model_name):
     """the CPU oracle (port of the reference path) on this box's host cores: 1 train step, batch 1"""
     from oracle import nets as ON, losses as OL
     from oracle.state import fill_state, spec_of
-    from miccai2021_cataract_semantic_segmentation_amd.models import OCRNet
+    from miccai2021_cataract_semantic_segmentation_amd.models import DeepLabv3Plus, OCRNet
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -53,26 +56,32 @@ def cpu_baseline(H, W, K, model_name):
     cores = max(1, min(avail, 32))   # beyond ~32 threads the sort / BN phases of this step stop scaling
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    spec = spec_of(OCRNet(dict(MODELS[model_name][0]), 3).state_dict())
-    fwd = ON.ocrnet_hrnet_forward if "hrnet" in model_name else ON.ocrnet_forward
+    deeplab = IS_DEEPLAB(model_name)
+    net = DeepLabv3Plus(dict(MODELS[model_name][0]), 2) if deeplab else OCRNet(dict(MODELS[model_name][0]), 3)
+    spec = spec_of(net.state_dict())
+    fwd = ON.deeplabv3plus_forward if deeplab else (ON.ocrnet_hrnet_forward if "hrnet" in model_name else ON.ocrnet_forward)
     S = fill_state(spec, 0)
     params = [k for k, v in S.items() if v.dtype.is_floating_point and "running" not in k]
     for k in params:
         S[k].requires_grad_()
-    img, lbl = synth_batch(1, H, W, K, 0, "cpu")
+    nb = 2 if deeplab else 1   # ASPP's image-pooling BatchNorm needs > 1 value per channel in train mode
+    img, lbl = synth_batch(nb, H, W, K, 0, "cpu")
     m = {k: torch.zeros_like(S[k]) for k in params}
     v = {k: torch.zeros_like(S[k]) for k in params}
     t0 = time.perf_counter()
-    oi, of = fwd(S, img, train=True)
-    loss = OL.two_scale_lovasz(oi, of, lbl)
+    if deeplab:
+        loss = OL.cross_entropy(fwd(S, img, train=True), lbl, 2)
+    else:
+        oi, of = fwd(S, img, train=True)
+        loss = OL.two_scale_lovasz(oi, of, lbl)
     loss.backward()
     with torch.no_grad():
         for k in params:
             OL.adam_step(S[k], S[k].grad, m[k], v[k], 1, 1e-4)
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 train step (fwd + TwoScale-Lovasz + bwd + Adam) of the CPU oracle, batch 1, 3x%dx%d, K=%d, fp32, "
-                      "%.1f s wall" % (H, W, K, dt)}
+    return {"value": nb / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 train step (fwd + %s + bwd + Adam) of the CPU oracle, batch %d, 3x%dx%d, K=%d, fp32, "
+                      "%.1f s wall" % ("cross entropy" if deeplab else "TwoScale-Lovasz", nb, H, W, K, dt)}
 
 
 def infer_bench(args):
@@ -157,15 +166,21 @@ def main():
     torch.cuda.set_device(dev)
 
     from miccai2021_cataract_semantic_segmentation_amd import ops
-    from miccai2021_cataract_semantic_segmentation_amd.models import OCRNet
-    from miccai2021_cataract_semantic_segmentation_amd.losses import TwoScaleLoss
+    from miccai2021_cataract_semantic_segmentation_amd.models import DeepLabv3Plus, OCRNet
+    from miccai2021_cataract_semantic_segmentation_amd.losses import CrossEntropyLoss, TwoScaleLoss
     from miccai2021_cataract_semantic_segmentation_amd.optim import FusedAdam
 
-    K, B, H, W = 25, args.batch, args.height, args.width
+    deeplab = IS_DEEPLAB(args.model)
+    K, B, H, W = (17 if deeplab else 25), args.batch, args.height, args.width
     torch.manual_seed(0)
-    model = OCRNet(dict(MODELS[args.model][0]), 3).to(dev).train()
-    crit = TwoScaleLoss({"experiment": 3, "interm": {"name": "LovaszSoftmax", "args": [], "weight": 0.4},
-                         "final": {"name": "LovaszSoftmax", "args": [], "weight": 1.0}})
+    if deeplab:
+        model = DeepLabv3Plus(dict(MODELS[args.model][0]), 2).to(dev).train()
+        ce = CrossEntropyLoss(ignore_index=17)
+        crit = lambda interm, final, lbl: ce(final, lbl)   # noqa: E731
+    else:
+        model = OCRNet(dict(MODELS[args.model][0]), 3).to(dev).train()
+        crit = TwoScaleLoss({"experiment": 3, "interm": {"name": "LovaszSoftmax", "args": [], "weight": 0.4},
+                             "final": {"name": "LovaszSoftmax", "args": [], "weight": 1.0}})
     gscale = 1.0
     if world > 1:
         D.broadcast_parameters(model)
@@ -180,7 +195,8 @@ def main():
             img.copy_(host[0], non_blocking=True)
             lbl.copy_(host[1], non_blocking=True)
         opt.zero_grad()
-        interm, final = model(img)
+        out = model(img)
+        interm, final = (None, out) if deeplab else out
         loss = crit(interm, final, lbl)
         loss.backward()
         opt.step()
@@ -245,12 +261,15 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "train frames/sec @540x960 %s" % ("OCRNet-HRNetw48" if args.model == "ocrnet_hrnet48" else "OCRNet-ResNet50"),
+            "metric": "train frames/sec @540x960 %s" % {"ocrnet_hrnet48": "OCRNet-HRNetw48", "ocrnet_r50": "OCRNet-ResNet50",
+                                                       "deeplabv3plus_r50": "DeepLabv3+-ResNet50"}[args.model],
             "value": world * B * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, 25-class (task 3), bs=%d/GPU @3x%dx%d, TwoScale Lovasz-Softmax (0.4 interm + 1.0 final), "
-                                   "Adam lr 1e-4, loss/optimiser of reference configs/OCRNet_rf_lvsz.json" % (MODELS[args.model][1], B, H, W),
+            "config": {"workload": ("%s, 17-class (task 2), bs=%d/GPU @3x%dx%d, cross entropy (ignore 17), Adam lr 1e-4 (BASELINE config 2)"
+                                    if deeplab else
+                                    "%s, 25-class (task 3), bs=%d/GPU @3x%dx%d, TwoScale Lovasz-Softmax (0.4 interm + 1.0 final), "
+                                    "Adam lr 1e-4, loss/optimiser of reference configs/OCRNet_rf_lvsz.json") % (MODELS[args.model][1], B, H, W),
                        "model": args.model,
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": final_loss,
                        "inputs": "host (pinned) -> device copy inside every step" if args.with_h2d else "resident in HBM"},

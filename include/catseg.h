@@ -93,7 +93,8 @@ int catseg_debug_set_splits(int splits);
 /* measurement hook: 0 = sort every pixel of every present class in catseg_lovasz_softmax (the data-independent worst case);
  * 1 (default) = sort only the elements that can precede the last foreground pixel (bit-identical result) */
 int catseg_debug_set_lovasz_prune(int on);
-/* measurement hook: 0 = 3x3 48->48 / 96->96 backward-weight through the implicit GEMM instead of the direct kernel */
+/* measurement hook: 0 = 3x3 48->48 / 96->96 backward-weight through the implicit GEMM instead of the direct kernel,
+ * 1 = direct kernel (default); a value > 1 additionally sets the direct kernel's target block count (default 512) */
 int catseg_debug_set_wgrad_direct(int on);
 
 /* ---- BatchNorm (+ReLU, +residual) — nn.BatchNorm2d/ReLU at e.g. models/OCR.py:74-75,
