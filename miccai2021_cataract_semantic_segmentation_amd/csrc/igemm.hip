@@ -23,6 +23,9 @@
 
 // LDS ring depth of the 128x128 and larger tiles.  A/B on one MI355X (tools/bench_conv.py, same process order):
 // 3 slots / one barrier per K-step = 124 TFLOP/s forward, 2 slots / two barriers but 4 blocks per CU = 128.
+#ifndef CATSEG_NBUF_NARROW
+#define CATSEG_NBUF_NARROW 2
+#endif
 #ifndef CATSEG_NBUF_BIG
 #define CATSEG_NBUF_BIG 2
 #endif
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, igemm_min_waves(MI, NI, NARROW)) void igemm_f3
   constexpr int KSUB = 1;
   // LDS ring: 3 slots = ONE barrier per K-step (the slot refilled after the barrier of step k was last read in
   // step k-1, which every wave has left); 2 slots = two barriers.  Small tiles keep 2 (occupancy).
-  constexpr int NBUF = CATSEG_NBUF_BIG > 2 && (MI * NI >= 4) ? 3 : 2;
+  constexpr int NBUF = (CATSEG_NBUF_BIG > 2 && (MI * NI >= 4)) || (CATSEG_NBUF_NARROW > 2 && NARROW != 0 && NARROW != 2) ? 3 : 2;
   constexpr int SLAB = (BM + BN) * 16;  // floats of one (A, B) sub-step image
   __shared__ __attribute__((aligned(16))) float smem[NBUF * KSUB * SLAB];
 
