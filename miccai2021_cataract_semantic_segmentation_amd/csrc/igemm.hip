@@ -203,6 +203,12 @@ __global__ __launch_bounds__(256, igemm_min_waves(MI, NI, NARROW)) void igemm_f3
   }
   // narrow forms: lane = (i16, g): row / column i16 of a 16 x 16 tile, k-group g; wave origin inside the block tile
   const int i16 = lane & 15, g16 = lane >> 4;
+  // k-chunk read by lane group g: {0, 3, 1, 2}.  ds_read_b128 is banked over four NON-contiguous 16-lane groups
+  // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...): with the identity assignment the rows 0-3 / 4-7 (and 8-11 / 12-15) of a group
+  // land on the same 16-byte slot of the (row>>2)&3-swizzled image (2-way conflict, SQ_LDS_BANK_CONFLICT = 50 % of the LDS
+  // cycles); this permutation gives every group four distinct slots.  A and B use the same k assignment, so the MFMA still
+  // contracts matching k.
+  const int kq16 = (0x9C >> (2 * g16)) & 3;
   const int wrow16 = NARROW != 2 ? wave * 16 * MI : 0;
   const int wcol16 = NARROW == 2 ? wave * 16 * NI : 0;
 
@@ -393,24 +399,24 @@ __global__ __launch_bounds__(256, igemm_min_waves(MI, NI, NARROW)) void igemm_f3
       for (int t = 0; t < TM16; ++t) {
         const int row = wrow16 + t * 16 + i16;
         if (A_KC) {
-          const int pos = g16 ^ ((row >> 2) & 3);
+          const int pos = kq16 ^ ((row >> 2) & 3);
           const f32x4 v = *(const f32x4*)(sA + row * 16 + pos * 4);
           a[t][0] = v[0]; a[t][1] = v[1]; a[t][2] = v[2]; a[t][3] = v[3];
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a[t][e] = sA[(4 * g16 + e) * BM + row];
+          for (int e = 0; e < 4; ++e) a[t][e] = sA[(4 * kq16 + e) * BM + row];
         }
       }
 #pragma unroll
       for (int u = 0; u < TN16; ++u) {
         const int col = wcol16 + u * 16 + i16;
         if (B_KC) {
-          const int pos = g16 ^ ((col >> 2) & 3);
+          const int pos = kq16 ^ ((col >> 2) & 3);
           const f32x4 v = *(const f32x4*)(sB + col * 16 + pos * 4);
           b[u][0] = v[0]; b[u][1] = v[1]; b[u][2] = v[2]; b[u][3] = v[3];
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) b[u][e] = sB[(4 * g16 + e) * BN + col];
+          for (int e = 0; e < 4; ++e) b[u][e] = sB[(4 * kq16 + e) * BN + col];
         }
       }
       if (FAST || more) prep(sub);
