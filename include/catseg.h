@@ -86,16 +86,7 @@ int catseg_gemm_batched(int layout, int batch, int M, int N, int K, const float*
                         int ldc, long long strideC, int zero_to, int accumulate,
                         catseg_stream_t stream);
 
-/* tuning hook: force the igemm block tile to (64*mi) x (64*ni); mi = 0 restores the heuristic */
-int catseg_debug_set_tile(int mi, int ni);
-/* tuning hook: force the backward-weight split count (0 restores the planner) */
-int catseg_debug_set_splits(int splits);
-/* measurement hook: 0 = sort every pixel of every present class in catseg_lovasz_softmax (the data-independent worst case);
- * 1 (default) = sort only the elements that can precede the last foreground pixel (bit-identical result) */
-int catseg_debug_set_lovasz_prune(int on);
-/* measurement hook: 0 = 3x3 48->48 / 96->96 backward-weight through the implicit GEMM instead of the direct kernel,
- * 1 = direct kernel (default); a value > 1 additionally sets the direct kernel's target block count (default 512) */
-int catseg_debug_set_wgrad_direct(int on);
+/* (tuning / measurement hooks live in catseg_debug.h: they are process-global and not part of the product surface) */
 
 /* ---- BatchNorm (+ReLU, +residual) — nn.BatchNorm2d/ReLU at e.g. models/OCR.py:74-75,
  * torchvision Bottleneck, models/DeepLabv3Plus.py:98-104.  rows = B*H*W pixels. */

@@ -1,0 +1,38 @@
+/*
+ * catseg_debug.h — tuning / measurement hooks of libcatseg_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/catseg.h): these knobs are process-global, not
+ * thread-safe, and exist for tools/ (tile sweeps), bench.py (worst-case Lovasz timing) and the
+ * tests that pin the planner's bench-size tile choices on small inputs.  Nothing in the package's
+ * model / loss / manager code calls them.
+ */
+#ifndef CATSEG_DEBUG_H
+#define CATSEG_DEBUG_H
+
+#include "catseg.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* tuning hook: force the igemm block tile to (64*mi) x (64*ni); mi = 0 restores the heuristic */
+int catseg_debug_set_tile(int mi, int ni);
+/* tuning hook: force the backward-weight split count (0 restores the planner) */
+int catseg_debug_set_splits(int splits);
+/* measurement hook: 0 = sort every pixel of every present class in catseg_lovasz_softmax (the data-independent worst case);
+ * 1 (default) = sort only the elements that can precede the last foreground pixel (bit-identical result) */
+int catseg_debug_set_lovasz_prune(int on);
+/* measurement hook: 0 = 3x3 48->48 / 96->96 backward-weight through the implicit GEMM instead of the direct kernel,
+ * 1 = direct kernel (default); a value > 1 additionally sets the direct kernel's target block count (default 512) */
+int catseg_debug_set_wgrad_direct(int on);
+
+/* planner query: which tile / split count would the library pick for this convolution?
+ * op: 0 = forward, 1 = backward-data (for stride > 1: the launch of input-pixel parity class (0, 0)),
+ *     2 = backward-weight.  out[0..4] = mi, ni, form (0 = 32x32x2 tiles (64 mi) x (64 ni); 1 / 2 = 16x16x4 tiles narrow
+ *     in N / M; 3 / 4 = 16 / 32 wide), splits, direct (1 = the direct backward-weight kernel handles it). */
+int catseg_debug_plan_conv(const catseg_conv_desc* d, int op, int* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CATSEG_DEBUG_H */

@@ -41,6 +41,7 @@ _SIGS = {
     "catseg_debug_set_splits": (I, [I]),
     "catseg_debug_set_lovasz_prune": (I, [I]),
     "catseg_debug_set_wgrad_direct": (I, [I]),
+    "catseg_debug_plan_conv": (I, [P, I, P]),
     "catseg_bn_workspace": (SZ, [L, I]),
     "catseg_bn_train_stats": (I, [P, L, I, I, P, F, F, P, P, P, P, P, SZ, P]),
     "catseg_bn_eval_scale": (I, [I, P, P, F, P, P]),

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "catseg.h"
+#include "catseg_debug.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

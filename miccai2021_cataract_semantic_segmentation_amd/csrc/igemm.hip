@@ -642,13 +642,16 @@ int wgrad_direct_launch(const catseg_conv_desc* d, const float* x, const float* 
 namespace {
   // tuning hooks (catseg_debug_set_tile / _splits)
 
+// address of the zero page in the CURRENT device's copy of the code object (a __device__ symbol has one instance per device)
 const float* zero_page_ptr() {
-  static const float* z = nullptr;
-  if (!z) {
+  static const float* z[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!z[dev]) {
     void* q = nullptr;
-    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_page)) == hipSuccess) z = (const float*)q;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_page)) == hipSuccess) z[dev] = (const float*)q;
   }
-  return z;
+  return z[dev];
 }
 
 template <int LAYOUT, int MI, int NI, int NARROW = 0>
@@ -826,6 +829,8 @@ extern "C" int catseg_debug_set_splits(int splits) {
   return CATSEG_OK;
 }
 
+extern "C" int catseg_debug_plan_conv(const catseg_conv_desc* d, int op, int* out);
+
 extern "C" int catseg_conv2d_fwd(const catseg_conv_desc* d, const float* x, const float* w, const float* bias,
                                  float* y, int zero_to, catseg_stream_t stream) {
   if (int e = check_desc(d)) return e;
@@ -937,6 +942,26 @@ TilePlan wgrad_plan(const catseg_conv_desc* d) {
   return plan_tiles(L_TN, d->Cout, (long long)d->kh * d->kw * d->Cin, 1, rows);
 }
 }  // namespace
+
+extern "C" int catseg_debug_plan_conv(const catseg_conv_desc* d, int op, int* out) {
+  if (int e = check_desc(d)) return e;
+  CS_REQUIRE(out != nullptr && op >= 0 && op <= 2, "plan_conv: bad arguments");
+  TilePlan pl;
+  int direct = 0;
+  if (op == 0) {
+    const int g = d->groups > 1 ? d->groups : 1;
+    pl = plan_tiles(L_NT, (long long)d->B * d->Ho * d->Wo, d->Cout / g, g, (long long)d->B * d->Ho * d->Wo);
+  } else if (op == 1) {
+    const int s = d->stride;
+    const long long rows = (long long)d->B * ((d->H + s - 1) / s) * ((d->W + s - 1) / s);
+    pl = plan_tiles(L_NN, rows, d->Cin, 1, rows);
+  } else {
+    pl = wgrad_plan(d);
+    direct = wgrad_direct_workspace(d) > 0;
+  }
+  out[0] = pl.mi; out[1] = pl.ni; out[2] = pl.narrow; out[3] = pl.splits; out[4] = direct;
+  return CATSEG_OK;
+}
 
 extern "C" size_t catseg_conv2d_bwd_weight_workspace(const catseg_conv_desc* d) {
   if (check_desc(d)) return 0;

@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _header_symbols():
-    hdr = open(os.path.join(ROOT, "include", "catseg.h")).read()
+    inc = os.path.join(ROOT, "include")
+    hdr = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     return sorted(set(re.findall(r"\b(catseg_[a-z0-9_]+)\s*\(", hdr)))
 
 

@@ -1,0 +1,117 @@
+"""DeepLabv3 (reference models/DeepLabv3.py, shipped config configs/DeepLabv3_rf_lvsz.json) on the GPU against the fixture
+generated from the REAL reference at 2x3x304x320 (ASPP dilations 12 / 24 / 36 with in-image taps), and the three dilated
+2048->256 ASPP convolutions of BASELINE config 2 at their real 68x120 map against F.conv2d (forward, backward-data,
+backward-weight: the K = 18 432 path)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def test_deeplabv3_matches_reference_fixture(golden):
+    _need_gpu()
+    from make_golden_deeplabv3 import make_inputs, summarise
+    from oracle.state import fill_state
+    from miccai2021_cataract_semantic_segmentation_amd import engine
+    from miccai2021_cataract_semantic_segmentation_amd.models import DeepLabv3
+    from miccai2021_cataract_semantic_segmentation_amd.losses import LovaszSoftmax
+    from miccai2021_cataract_semantic_segmentation_amd.optim import FusedAdam
+    g = golden("deeplabv3_r50_e2_d36")
+    spec = json.loads(str(g["spec"]))
+    model = DeepLabv3({"backbone": "resnet50", "aspp": {"channels": 256}, "out_stride": 8, "pretrained": False}, 2)
+    assert [k for k, _ in spec] == list(model.state_dict().keys())
+    model.load_state_dict(fill_state(spec, int(g["seed"])))
+    model.cuda().eval()
+    x, lbl = make_inputs()
+    xd, ld = x.cuda(), lbl.cuda()
+    scale = float(g["eval_scale"])
+    ref_arg = torch.from_numpy(g["eval_argmax"].astype(np.int64))
+    margin = torch.from_numpy(g["eval_margin"].astype(np.float32))
+    for fused in (False, True):       # conv -> BN -> ReLU as separate kernels (reference order), then the folded fast path
+        engine.FUSE_EVAL_BN = fused
+        try:
+            with torch.no_grad():
+                e = model(xd)
+        finally:
+            engine.FUSE_EVAL_BN = True
+        s = summarise(e.cpu())
+        tol = (3e-3 if fused else 1e-3) * scale
+        err = max(np.abs(s["sub"] - g["eval_sub"]).max(), np.abs(s["rows"] - g["eval_rows"]).max())
+        assert err <= tol, (fused, err, scale)
+        # label maps: identical wherever the reference's own top-2 margin exceeds twice the logit error actually made
+        # (fp16-stored margin: + 1e-3 relative); the remaining near-ties must be a tiny fraction
+        decided = margin > (2.2 * err + 1e-3 * margin.abs())
+        arg = e.argmax(1).cpu()
+        assert torch.equal(arg[decided], ref_arg[decided])
+        assert float(decided.float().mean()) > 0.995, float(decided.float().mean())
+        print("deeplabv3 eval (fused=%s): max logit err %.3g of scale %.1f; %d / %d pixels inside the tie band, %d of them differ"
+              % (fused, err, scale, int((~decided).sum()), decided.numel(), int((arg != ref_arg).sum())))
+    model.train()
+    crit = LovaszSoftmax({"experiment": 2})
+    opt = FusedAdam(model, lr=1e-4)
+    losses = []
+    for step in range(2):
+        opt.zero_grad()
+        y = model(xd)
+        loss = crit(y, ld)
+        loss.backward()
+        if step == 0:
+            s = summarise(y.cpu())
+            assert np.abs(s["sub"] - g["train_sub"]).max() <= 1e-3 * np.abs(g["train_sub"]).max()
+            assert np.abs(s["rows"] - g["train_rows"]).max() <= 1e-3 * np.abs(g["train_rows"]).max()
+            names = json.loads(str(g["grad_names"]))
+            P = dict(model.named_parameters())
+            norms = np.array([float(P[k].grad.double().norm()) for k in names])
+            np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-2, atol=1e-7)
+            for i in (2, 3, 4):   # dilated branches: filter gradients tap by tap (d = 12, 24, 36)
+                ref = g["g:aspp.aspp%d.weight[0:2]" % i]
+                got = P["aspp.aspp%d.weight" % i].grad[0:2].cpu().numpy()
+                assert np.abs(got - ref).max() <= 2e-2 * np.abs(ref).max(), (i, np.abs(got - ref).max(), np.abs(ref).max())
+            sd = model.state_dict()
+            for k in g.files:
+                if k.startswith("rs:"):
+                    np.testing.assert_allclose(sd[k[3:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-5)
+        opt.step()
+        losses.append(float(loss))
+    assert abs(losses[0] - float(g["losses"][0])) < 1e-4
+    assert abs(losses[1] - float(g["losses"][1])) < 5e-3 * float(g["losses"][1])
+
+
+@pytest.mark.parametrize("dil", [12, 24, 36])
+def test_aspp_dilated_conv_at_config_size(dil):
+    """3x3 2048->256, dilation 12 / 24 / 36 on the 68x120 map of DeepLabv3(+)-R50-OS8 @544x960 (B = 1): K = 18 432"""
+    _need_gpu()
+    from miccai2021_cataract_semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(dil)
+    x = torch.randn(1, 2048, 68, 120, generator=g, requires_grad=True)
+    w = (torch.randn(256, 2048, 3, 3, generator=g) * (2.0 / 18432) ** 0.5).requires_grad_()
+    y = F.conv2d(x, w, None, 1, dil, dil)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    wd = w.detach().cuda().contiguous(memory_format=torch.channels_last)
+    gyd = gy.permute(0, 2, 3, 1).contiguous().cuda()
+
+    def close(a, b, tol):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        err = float((a - b).abs().max())
+        assert err <= tol * float(b.abs().max()), (err, float(b.abs().max()))
+    close(ops.conv_fwd(xd, wd, None, 256, 3, 3, 1, dil, dil).permute(0, 3, 1, 2), y, 3e-5)
+    close(ops.conv_bwd_data(gyd, wd, tuple(xd.shape), 3, 3, 1, dil, dil).permute(0, 3, 1, 2), x.grad, 3e-5)
+    dw = torch.empty_like(wd)
+    ops.conv_bwd_weight(xd, gyd, dw, None, 3, 3, 1, dil, dil)
+    close(dw, w.grad, 1e-4)
+    # every tap of the dilated filter carries signal at this size (nothing degenerates to the centre tap)
+    assert float(w.grad[:, :, 0, 0].abs().max()) > 0 and float(w.grad[:, :, 2, 2].abs().max()) > 0
