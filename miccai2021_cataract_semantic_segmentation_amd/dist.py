@@ -12,6 +12,7 @@ import os
 
 import torch
 import torch.distributed as dist
+import torch.utils.data
 
 
 def init_from_env(backend=None):
@@ -126,3 +127,56 @@ def shard_indices(indices, rank, world, drop_last=True):
     """rank-strided shard of a (shared-seed) epoch index list, equal length on every rank"""
     n = len(indices) // world * world if drop_last else len(indices)
     return list(indices[rank:n:world])
+
+
+class ShardedSampler(torch.utils.data.Sampler):
+    """Rank shard of an epoch's index stream.  ``source`` is either a dataset length (a fresh shared-seed permutation is
+    drawn every epoch: ``seed + epoch``) or another sampler whose stream is identical on every rank (the repeat-factor
+    sampler draws from a private ``Generator(seed=1)``, utils/repeat_factor_sampling.py:74-77 of the reference).  Every rank
+    takes ``indices[rank::world]`` of the stream truncated to a multiple of ``world * batch``: disjoint frames, equal step
+    counts on every rank (a rank that ran one step more would dead-lock the gradient all-reduce)."""
+
+    def __init__(self, source, rank, world, batch_size=1, seed=0):
+        self.source, self.rank, self.world, self.batch, self.seed = source, rank, world, max(int(batch_size), 1), seed
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def _stream(self):
+        if isinstance(self.source, int):
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            return torch.randperm(self.source, generator=g).tolist()
+        return list(iter(self.source))
+
+    def __iter__(self):
+        idx = self._stream()
+        n = len(idx) // (self.world * self.batch) * (self.world * self.batch)
+        self.epoch += 1                      # a loader that never calls set_epoch still reshuffles every epoch
+        return iter(idx[self.rank:n:self.world])
+
+    def __len__(self):
+        total = self.source if isinstance(self.source, int) else len(self.source)
+        return total // (self.world * self.batch) * self.batch
+
+
+def sync_bn_stats(model, how="mean"):
+    """BatchNorm running statistics drift apart across ranks (each rank normalises with its LOCAL batch statistics; the
+    reference has no SyncBN).  Before validation / checkpointing every rank takes the mean over ranks
+    (``how='mean'``) or rank 0's values (``how='rank0'``), so that the sharded validation pass scores exactly the weights
+    that rank 0 saves.  One all-reduce of a flat buffer of all running means / variances."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    bufs = [b for n, b in model.named_buffers() if b.dtype.is_floating_point]
+    if not bufs:
+        return
+    flat = torch.cat([b.reshape(-1) for b in bufs])
+    if how == "rank0":
+        dist.broadcast(flat, 0)
+    else:
+        dist.all_reduce(flat)
+        flat /= dist.get_world_size()
+    o = 0
+    for b in bufs:
+        b.copy_(flat[o:o + b.numel()].view_as(b))
+        o += b.numel()

@@ -100,6 +100,21 @@ class Ctx:
         self.grads = {}
         self.shared = set()
         self.on_param_grad = on_param_grad
+        self.claimed = set()
+
+    def claim(self, *params):
+        """every parameter may feed exactly one recorded layer: the backward tape WRITES (does not accumulate) parameter
+        gradients and the data-parallel reducer launches a bucket after one 'ready' signal per parameter, so a module
+        applied twice in one forward would silently lose a gradient term"""
+        if not self.record:
+            return
+        for p in params:
+            if p is None:
+                continue
+            if id(p) in self.claimed:
+                raise NotImplementedError("a parameterised layer is applied twice in one forward pass (shared module): "
+                                          "not supported by the HIP engine's backward tape")
+            self.claimed.add(id(p))
 
     def push(self, fn):
         if self.record:
@@ -191,6 +206,7 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
     bias = conv.bias.data if conv.bias is not None else None
     if conv.groups > 1 and cx.record:
         raise NotImplementedError("grouped convolution (ResNeXt) is inference-only on the HIP path")
+    cx.claim(w, conv.bias, bn.weight, bn.bias)
     if not cx.train and not cx.record and FUSE_EVAL_BN:
         # inference fast path: eval-mode BatchNorm folded into the weights, bias + residual + ReLU applied in
         # the convolution epilogue — one kernel per layer, no separate normalisation pass over HBM
@@ -252,6 +268,7 @@ def conv_bias(cx, x, conv, pad_to=32):
     ld = max(pad_to, (Cout + 3) // 4 * 4)
     bias = conv.bias.data if conv.bias is not None else None
     y = ops.conv_fwd(x, w.data, bias, Cout, kh, kw, s, p, d, zero_to=ld)
+    cx.claim(w, conv.bias)
     if cx.record:
         def bwd():
             dy = cx.take(y)
@@ -454,6 +471,7 @@ class EngineNet(nn.Module):
         super().__init__()
         self._flatp = None
         self._grad_sync = None  # optional data-parallel gradient reducer
+        self._grads_pending = False
 
     def flat(self):
         if self._flatp is None:
@@ -469,7 +487,18 @@ class EngineNet(nn.Module):
         outs = self._body(cx, x)
         return cx, outs
 
+    def zero_grad(self, set_to_none=True):
+        """clears the flat gradient buffer (one memset; the .grad views stay bound to it)"""
+        fp = self.flat()
+        if fp.grad is not None:
+            fp.grad.zero_()
+        self._grads_pending = False
+
     def _begin_backward(self, cx):
+        if self._grads_pending:
+            raise RuntimeError("second backward() before zero_grad(): the HIP engine's tape overwrites parameter gradients "
+                               "(no accumulation over several backward passes); call optimiser.zero_grad() / model.zero_grad() "
+                               "between backward passes")
         fp = self.flat()
         fp.bind_grads()
         if self._grad_sync is not None:
@@ -477,6 +506,7 @@ class EngineNet(nn.Module):
             self._grad_sync.begin(fp)
 
     def _end_backward(self, cx):
+        self._grads_pending = True
         if self._grad_sync is not None:
             self._grad_sync.finish()
 

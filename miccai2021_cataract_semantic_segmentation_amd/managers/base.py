@@ -103,8 +103,18 @@ class BaseManager:
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimiser, lr_lambda=LRFcts(tc, list(tc["lr_restarts"]), tc["epochs"]))
 
     def loaders(self):
+        """train loader (batch bs, drop_last) + validation loader (batch 1, BaseManager.py:305).  With WORLD_SIZE > 1 the
+        training frames are SHARDED by rank: one shared-seed index stream per epoch (a permutation, or the given sampler's
+        stream -- the repeat-factor sampler draws from a private Generator(seed=1) and is identical on every rank), each
+        rank taking every world-th index: global batch = world * bs, disjoint frames, equal step counts."""
         bs = self.config["data"]["batch_size"]
-        if self.train_sampler is not None:
+        self.shard_sampler = None
+        if self.world > 1:
+            src = self.train_sampler if self.train_sampler is not None else len(self.train_set)
+            self.shard_sampler = D.ShardedSampler(src, self.rank, self.world, bs, seed=self.config["seed"])
+            tl = DataLoader(self.train_set, batch_size=bs, sampler=self.shard_sampler, drop_last=True,
+                            num_workers=0 if self.train_sampler is not None else self.config["data"]["num_workers"])
+        elif self.train_sampler is not None:
             tl = DataLoader(self.train_set, batch_size=bs, sampler=self.train_sampler, drop_last=True, num_workers=0)
         else:
             tl = DataLoader(self.train_set, batch_size=bs, shuffle=True, drop_last=True,
@@ -136,6 +146,8 @@ class BaseManager:
         running_cm = torch.zeros((K, K), dtype=torch.int32, device=self.device)
         loss_sum = torch.zeros((), device=self.device)
         n = 0
+        if getattr(self, "shard_sampler", None) is not None:
+            self.shard_sampler.set_epoch(self.epoch + self.start_epoch)
         for img, lbl, _ in self.train_loader:
             img, lbl = img.to(self.device, non_blocking=True), lbl.to(self.device, non_blocking=True)
             self.optimiser.zero_grad()
@@ -148,6 +160,15 @@ class BaseManager:
             self.global_step += 1
         if self.scheduler is not None:
             self.scheduler.step()
+        if self.world > 1:                       # logged training metrics are GLOBAL: one exchange per epoch
+            import torch.distributed as dist
+            cm64 = running_cm.to(torch.int64)
+            dist.all_reduce(cm64)
+            running_cm = cm64.to(torch.int32)
+            cnt = torch.tensor([float(n)], device=self.device)
+            dist.all_reduce(cnt)
+            dist.all_reduce(loss_sum)
+            n = int(cnt)
         pa, pac = t_get_pixel_accuracy(running_cm)
         miou = t_get_mean_iou(running_cm, self.experiment)
         rec = {"epoch": self.epoch + self.start_epoch, "train_loss": float(loss_sum / max(n, 1)), "train_miou": float(miou),
@@ -186,6 +207,7 @@ class BaseManager:
 
     def validate(self):
         self.model.eval()
+        D.sync_bn_stats(self.model)      # every rank scores (and rank 0 saves) the same running statistics
         cm, valid_loss = self._eval_pass(self.valid_loader, with_loss=True)
         pa, pac = t_get_pixel_accuracy(cm)
         m_iou, m_ins, m_anat, m_rare = t_get_mean_iou(cm, self.experiment, True, rare=True)
@@ -232,6 +254,8 @@ class BaseManager:
 
     # ------------------------------------------------------------------ checkpoints (BaseManager.py:471-529)
     def save_checkpoint(self, is_best):
+        """BaseManager.py:471-495.  Called by every rank (validate() synchronised the BatchNorm running statistics just
+        before); only rank 0 writes."""
         if self.rank != 0:
             return
         base = self.log_dir / "chkpts"

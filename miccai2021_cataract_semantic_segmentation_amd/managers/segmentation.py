@@ -30,8 +30,40 @@ class DeepLabv3PlusManager(BaseManager):
         return self.loss(out, lbl.long()), out
 
 
+class DeepLabv3Manager(DeepLabv3PlusManager):
+    """managers/DeepLabv3_Manager.py: a twin of the DeepLabv3Plus manager bar the class name (configs/DeepLabv3_rf_lvsz.json)."""
+
+
 class HRNetv2Manager(DeepLabv3PlusManager):
-    pass
+    """(build-side name: the reference has no HRNetv2 manager; its HRNetv2 is a single-output net like DeepLabv3+)"""
+
+
+class EncDecManager(BaseManager):
+    """managers/EncDec_Manager.py:14-274: the model is built from the TOP-LEVEL 'encoder' / 'decoder' config entries
+    (:16-21, configs/UPN_rf_lvsz.json has no 'graph'), the loss is always a LossWrapper (:23-29), and the step is
+    ``deep_features, prediction = model(img); loss = LossWrapper(deep_features, prediction, lbl, epoch=epoch)`` (:158-185)."""
+
+    def load_model(self):
+        from .. import dist as D
+        from ..models import EncDec
+        self.model = EncDec(self.config, self.experiment).to(self.device)
+        if self.world > 1:
+            D.broadcast_parameters(self.model)
+            self.grad_scale = D.attach(self.model)
+        else:
+            self.grad_scale = 1.0
+
+    def load_loss(self):
+        self.config["loss"]["experiment"] = self.experiment
+        self.config["loss"]["device"] = str(self.device)
+        self.loss = LossWrapper(self.config["loss"])
+
+    def forward_loss(self, img, lbl):
+        deep_features, prediction = self.model(img.float())
+        return self.loss(deep_features, prediction, lbl.long(), epoch=self.epoch), prediction
+
+    def final_output(self, out):
+        return out[1] if isinstance(out, tuple) else out      # (get_features = False at inference: prediction only)
 
 
 class SyntheticCataractDataset(Dataset):

@@ -5,7 +5,7 @@ from torch import nn
 
 from ..engine import (BatchNorm2d, Conv2d, EngineNet, bilinear, image_hw, concat_views, conv_bias, conv_bn_act, global_avgpool)
 from ..utils import num_classes
-from .backbone import ResNetBackbone
+from .backbone import ResNetBackbone, load_pretrained_trunk
 
 
 def _bn(c):
@@ -83,6 +83,8 @@ class DeepLabv3Plus(EngineNet):
         self.num_classes = num_classes(experiment)
         self.backbone_cutoff = {"layer1": "low", "layer4": "high"}
         self.backbone = ResNetBackbone(self.backbone_name, striding, self.backbone_cutoff)
+        if config.get("pretrained", True):          # models/DeepLabv3Plus.py:33 (default True)
+            load_pretrained_trunk(self.backbone, self.backbone_name, config)
         self.high_level_channels = self.backbone.out_channels("layer4")
         self.low_level_channels = self.backbone.out_channels("layer1")
         mult = 1 if self.out_stride >= 16 else 2
@@ -117,6 +119,8 @@ class DeepLabv3(EngineNet):
         self.num_classes = num_classes(experiment)
         self.backbone_cutoff = {"layer4": "out"}
         self.backbone = ResNetBackbone(self.backbone_name, striding, self.backbone_cutoff)
+        if config.get("pretrained", True):          # models/DeepLabv3.py:34 (default True)
+            load_pretrained_trunk(self.backbone, self.backbone_name, config)
         self.backbone_out_channels = self.backbone.out_channels("layer4")
         self.aspp = ASPP(self.backbone_out_channels, self.c_aspp, 1 if self.out_stride >= 16 else 2)
         self.conv_out = Conv2d(self.c_aspp, self.num_classes, 1, 1)

@@ -8,7 +8,7 @@ from torch import nn
 from ..engine import (BatchNorm2d, Conv2d, EngineNet, adaptive_avgpool, add_n, bilinear, concat_views, conv_bias,
                       conv_bn_act, copy_into, maxpool)
 from ..utils import num_classes
-from .backbone import BasicBlock, Bottleneck, _c1
+from .backbone import BasicBlock, Bottleneck, _c1, load_pretrained_trunk
 
 
 class _GroupedBottleneck(nn.Module):
@@ -64,6 +64,8 @@ class Encoder(nn.Module):
             elif isinstance(m, nn.BatchNorm2d):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
+        if self.pretrained:                 # models/ResNet.py:32-33: torchvision's ImageNet checkpoint
+            load_pretrained_trunk(self, name, config)
 
     def _make_layer(self, block, planes, blocks, stride, groups, wpg):
         downsample = None

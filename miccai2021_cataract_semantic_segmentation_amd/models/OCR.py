@@ -8,7 +8,7 @@ from .. import ops
 from ..engine import (BatchNorm2d, Conv2d, EngineNet, bilinear, image_hw, concat_views, conv_bias, conv_bn_act,
                       object_attention_core, spatial_gather)
 from ..utils import num_classes
-from .backbone import ResNetBackbone
+from .backbone import ResNetBackbone, load_pretrained_trunk
 from .HRNetv2 import build_hrnet_trunk, concat_branches, run_hrnet_trunk
 
 
@@ -95,6 +95,8 @@ class OCRNet(EngineNet):
             self.backbone_cutoff = {"layer3": "low", "layer4": "high"}
             self.backbone = ResNetBackbone(self.backbone_name, strides, self.backbone_cutoff)
             self.high_out_channels = self.backbone.out_channels("layer4")
+            if config.get("pretrained", True):      # models/OCR.py:44 (default True)
+                load_pretrained_trunk(self.backbone, self.backbone_name, config)
             self.low_level_channels = self.backbone.out_channels("layer3")
         else:
             w = int(self.backbone_name[5:])

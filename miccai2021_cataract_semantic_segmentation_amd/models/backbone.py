@@ -133,3 +133,40 @@ class ResNetBackbone(nn.ModuleDict):
 
     def forward(self, x):  # pragma: no cover
         raise RuntimeError("ResNetBackbone is executed by the owning EngineNet")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ImageNet-pretrained trunks.  The reference calls ``torchvision.models.resnet50(pretrained=True)`` (models/OCR.py:44,59,
+# DeepLabv3Plus.py:33-40, DeepLabv3.py:34-41, ResNet.py:32-33), which downloads torchvision's checkpoint.  torchvision and
+# the network are not available to this package, so the SAME checkpoint file (torchvision state-dict format: keys
+# ``conv1.weight``, ``layer1.0.conv1.weight`` ..., ``fc.*`` ignored) is read from disk:
+#   config['pretrained_path'] (a file), or  $CATSEG_PRETRAINED_DIR/<arch>.pth  (e.g. resnet50.pth, resnext101_32x8d.pth).
+# Without a file the trunk keeps its random initialisation and a loud warning says so (training from scratch gives a far
+# lower mIoU than the reference's numbers).
+TORCHVISION_FILES = {"resnet18": "resnet18", "resnet34": "resnet34", "resnet50": "resnet50", "resnet101": "resnet101",
+                     "ResNet18": "resnet18", "ResNet34": "resnet34", "ResNet50": "resnet50", "ResNet101": "resnet101",
+                     "ResNeXt50": "resnext50_32x4d", "ResNeXt101": "resnext101_32x8d"}
+
+
+def load_pretrained_trunk(trunk, arch, config):
+    """trunk: module whose state-dict keys are torchvision's (conv1, bn1, layer1 ...).  Returns the path loaded or None."""
+    import os
+    import warnings
+    import torch
+    path = (config or {}).get("pretrained_path")
+    if not path and os.environ.get("CATSEG_PRETRAINED_DIR"):
+        path = os.path.join(os.environ["CATSEG_PRETRAINED_DIR"], TORCHVISION_FILES.get(arch, arch) + ".pth")
+    if not path or not os.path.isfile(path):
+        warnings.warn("config asks for pretrained=True (%s) but no torchvision checkpoint was supplied (config['pretrained_path'] or "
+                      "$CATSEG_PRETRAINED_DIR/%s.pth): the trunk is RANDOMLY INITIALISED -- results will not match the "
+                      "reference's ImageNet-initialised runs" % (arch, TORCHVISION_FILES.get(arch, arch)), RuntimeWarning, stacklevel=2)
+        return None
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    sd = sd.get("state_dict", sd)
+    own = trunk.state_dict()
+    take = {k: v for k, v in sd.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}
+    missing = [k for k in own if k not in take and not k.endswith("num_batches_tracked")]
+    if missing:
+        raise RuntimeError("pretrained checkpoint %s lacks %d trunk tensors (first: %s)" % (path, len(missing), missing[0]))
+    trunk.load_state_dict(take, strict=False)
+    return path

@@ -1,0 +1,60 @@
+"""Bit-exact label maps (BASELINE north star: "bit-exact for argmax label maps") against fixtures generated with the REAL
+reference networks (tests/golden/make_golden_argmax.py): eval-mode OCRNet-R50, DeepLabv3+-R50, DeepLabv3-R50, HRNetv2 on
+inputs whose reference top-2 margin is >= 8e-5 of the logit scale at EVERY pixel (fp32 rounding noise on these nets is
+~1e-5 of the scale), so torch.equal on the whole map is a fair requirement -- for the reference-order path (conv, BN, ReLU
+as separate kernels) and for the inference fast path (BN folded into the convolution)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NETS = {
+    "ocrnet_r50": ("OCRNet", {"backbone": "resnet50", "out_stride": 8, "pretrained": False}, 3),
+    "deeplabv3plus_r50": ("DeepLabv3Plus", {"backbone": "resnet50", "out_stride": 8, "pretrained": False}, 2),
+    "deeplabv3_r50": ("DeepLabv3", {"backbone": "resnet50", "out_stride": 8, "pretrained": False}, 2),
+    "hrnetv2": ("HRNetv2", {}, 3),
+}
+
+
+@pytest.mark.parametrize("name", sorted(NETS))
+def test_label_maps_bit_exact(golden, name):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle.state import fill_state
+    from miccai2021_cataract_semantic_segmentation_amd import engine, models
+    from miccai2021_cataract_semantic_segmentation_amd.utils.metrics import t_get_confusion_matrix
+    g = golden("argmax_maps")
+    cls, cfg, exp = NETS[name]
+    spec = json.loads(str(g[name + ":spec"]))
+    model = getattr(models, cls)(dict(cfg), exp)
+    assert [k for k, _ in spec] == list(model.state_dict().keys())
+    model.load_state_dict(fill_state(spec, int(g[name + ":wseed"])))
+    model.cuda().eval()
+    if hasattr(model, "get_intermediate"):
+        model.get_intermediate = False
+    x = torch.rand((2, 3, 64, 96), generator=torch.Generator().manual_seed(int(g[name + ":xseed"]))).cuda()
+    ref = torch.from_numpy(g[name + ":argmax"].astype(np.int64))
+    top2 = torch.from_numpy(g[name + ":top2"])
+    scale, min_rel = float(g[name + ":scale"]), float(g[name + ":min_margin_rel"])
+    assert min_rel >= 8e-5 and len(ref.unique()) >= 3
+    for fused in (False, True):
+        engine.FUSE_EVAL_BN = fused
+        try:
+            with torch.no_grad():
+                out = model(x)
+        finally:
+            engine.FUSE_EVAL_BN = True
+        err = float((out.cpu().gather(1, ref.unsqueeze(1)).squeeze(1) - top2[:, 0]).abs().max())
+        print("%s fused=%s: max |top-1 logit - reference| = %.3g of the scale (min reference margin %.3g)" % (name, fused, err / scale, min_rel))
+        assert torch.equal(out.argmax(1).cpu(), ref), "label map differs in %d pixels" % int((out.argmax(1).cpu() != ref).sum())
+        # and the metric built on it: identical label maps => identical confusion matrix (the on-device argmax + histogram kernel)
+        lbl = ref.clone()
+        lbl[:, ::3] = (lbl[:, ::3] + 1) % model.num_classes
+        cm = t_get_confusion_matrix(out, lbl.cuda())
+        cm_ref = torch.zeros_like(cm.cpu())
+        for p_, t_ in zip(ref.flatten().tolist(), lbl.flatten().tolist()):
+            cm_ref[p_, t_] += 1
+        assert torch.equal(cm.cpu(), cm_ref)

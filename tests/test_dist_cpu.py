@@ -51,6 +51,24 @@ def _worker(rank, world, port, out):
     torch.save({"local": local, "reduced": first, "again": fp.grad.clone()}, os.path.join(out, "r%d.pt" % rank))
     idx = list(range(23))
     assert D.shard_indices(idx, rank, world) == idx[rank:22:world]
+    # rank-sharded training sampler: shared-seed permutation per epoch, disjoint frames, equal step counts
+    sh = D.ShardedSampler(23, rank, world, batch_size=2, seed=5)
+    epochs = []
+    for ep in range(2):
+        sh.set_epoch(ep)
+        epochs.append(list(sh))
+    assert len(epochs[0]) == len(sh) == 10 and epochs[0] != epochs[1]
+    # ... and wrapping a sampler whose stream is identical on every rank (the repeat-factor sampler)
+    wrapped = D.ShardedSampler(torch.utils.data.SequentialSampler(range(9)), rank, world, batch_size=1)
+    assert list(wrapped) == list(range(9))[rank:8:world]
+    # BatchNorm running statistics: mean over ranks
+    bn = torch.nn.BatchNorm2d(4)
+    bn.running_mean.fill_(float(rank))
+    bn.running_var.fill_(1.0 + rank)
+    D.sync_bn_stats(bn)
+    assert torch.allclose(bn.running_mean, torch.full((4,), 0.5)) and torch.allclose(bn.running_var, torch.full((4,), 1.5))
+    assert int(bn.num_batches_tracked) == 0
+    torch.save({"epochs": epochs}, os.path.join(out, "s%d.pt" % rank))
     dist.destroy_process_group()
 
 
@@ -66,3 +84,6 @@ def test_gradsync_gloo_world2(tmp_path):
         assert torch.allclose(r["reduced"], want, atol=1e-6)
         assert torch.allclose(r["again"], want, atol=1e-6)
     assert torch.equal(r0["reduced"], r1["reduced"])
+    s0, s1 = torch.load(tmp_path / "s0.pt")["epochs"], torch.load(tmp_path / "s1.pt")["epochs"]
+    for e0, e1 in zip(s0, s1):
+        assert not set(e0) & set(e1) and len(e0) == len(e1) and len(set(e0) | set(e1)) == 20    # disjoint shards of one permutation

@@ -81,6 +81,14 @@ def test_encdec_resnet18_upernet_matches_reference_fixture(golden):
     P = dict(model.named_parameters())
     norms = np.array([float(P[k].grad.double().norm()) for k in names])
     np.testing.assert_allclose(norms, g["grad_norms"], rtol=5e-2, atol=1e-6)
+    # per-parameter gradients, calibrated against an fp64 evaluation of the oracle (tests/_calib.py)
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _calib import calibrated_grad_check
+    from oracle import losses as OL, upernet as OU
+    calibrated_grad_check(model, spec, int(g["seed"]), lambda S_, x_: OU.encdec_forward(S_, x_, "ResNet18", train=True)[1],
+                          lambda o, l: OL.lovasz_softmax(o, l), T(g["x"]), T(g["lbl"]), label="EncDec(ResNet18+UPerNet)")
 
 
 def _resnext_oracle(S, x, layers=(3, 4, 23, 3), groups=32, wpg=8):

@@ -73,10 +73,49 @@ def test_train_step_fullsize_is_deterministic_and_finite():
     outs = []
     for _ in range(2):
         model.load_state_dict(state)
-        model.flat().grad.zero_()
+        model.zero_grad()
         i, f = model(img)
         loss = crit(i, f, lbl)
         loss.backward()
         outs.append((loss.detach().clone(), model.flat().grad.clone()))
     assert torch.isfinite(outs[0][0]) and bool(torch.isfinite(outs[0][1]).all())
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_lovasz_at_config_size_vs_oracle():
+    """LovaszSoftmax at the configuration's own size, P = 8 x 544 x 960 = 4 177 920 pixels x K = 25 (the CPU oracle needs
+    about a minute here): loss against the float64 numpy oracle, gradient against the torch oracle (autograd through
+    torch.sort).  Ties in the sort order only permute gradient entries between elements of equal error, which moves
+    individual entries by ~1e-6 of the gradient scale, far below the tolerance."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.nn.functional as F
+    from oracle import losses as OL
+    from miccai2021_cataract_semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(77)
+    lg = F.interpolate(2.5 * torch.randn(8, 25, 68, 120, generator=g), size=(544, 960), mode="bilinear", align_corners=True)
+    lg += 0.05 * torch.randn(lg.shape, generator=g)                     # per-pixel texture: (almost) no exactly equal errors
+    lb = torch.randint(0, 26, (8, 17, 30), generator=g).repeat_interleave(32, 1).repeat_interleave(32, 2)
+    lb[lb == 7] = 2
+    lb[lb == 19] = 4
+    P, K = lb.numel(), 25
+    assert P == 4177920
+    ref64 = OL.lovasz_softmax_np(lg.numpy(), lb.numpy())
+    lgr = lg.clone().requires_grad_()
+    ref = OL.lovasz_softmax(lgr, lb)
+    ref.backward()
+    gref = lgr.grad.permute(0, 2, 3, 1).reshape(-1, K)
+    ld = lg.permute(0, 2, 3, 1).reshape(-1, K).contiguous().cuda()
+    dl = torch.empty_like(ld)
+    loss = ops.lovasz_softmax(ld, lb.reshape(-1).cuda(), 1.0, dl)
+    assert abs(float(loss) - ref64) < 5e-6, (float(loss), ref64)
+    assert abs(float(loss) - float(ref)) < 2e-5, (float(loss), float(ref))     # (the fp32 CPU oracle itself is ~1e-5 from fp64)
+    d = dl.cpu().double()
+    gd = gref.double()
+    scale = float(gd.abs().max())
+    err = (d - gd).abs()
+    rel_l2 = float((d - gd).norm() / gd.norm())
+    print("lovasz P=%d K=%d: loss %.7f (f64 oracle %.7f); grad max err %.3g of scale %.3g, relative L2 %.3g"
+          % (P, K, float(loss), ref64, float(err.max()), scale, rel_l2))
+    assert float(err.max()) <= 1e-3 * scale and rel_l2 < 1e-4
+    assert float(dl.sum(1).abs().max()) < 1e-9 + 1e-4 * float(dl.abs().max())

@@ -41,6 +41,13 @@ def test_hrnetv2_matches_reference_fixture(golden):
     P = dict(model.named_parameters())
     norms = np.array([float(P[k].grad.double().norm()) for k in names])
     np.testing.assert_allclose(norms, g["grad_norms"], rtol=5e-2, atol=1e-6)
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _calib import calibrated_grad_check
+    from oracle import hrnet as OH, losses as OL
+    calibrated_grad_check(model, spec, int(g["seed"]), lambda S_, x_: OH.hrnetv2_forward(S_, x_, train=True),
+                          lambda o, l: OL.cross_entropy(o, l, 3), T(g["x"]), T(g["lbl"]), label="HRNetv2")
     sd = model.state_dict()
     for k in g.files:
         if k.startswith("rs:"):
