@@ -42,18 +42,45 @@ MODELS = {
     "deeplabv3plus_r50": ({"backbone": "resnet50", "out_stride": 8, "pretrained": False}, "DeepLabv3+-ResNet50-OS8"),
 }
 IS_DEEPLAB = lambda name: name.startswith("deeplab")   # noqa: E731
+PROFILE_ROUND = "r02"   # profiles/<round>_pmc_traffic_<model>.json feeds roofline.traffic
 
 
-def cpu_baseline(H, W, K, model_name):
-    """the CPU oracle (port of the reference path) on this box's host cores: 1 train step, batch 1"""
-    from oracle import nets as ON, losses as OL
-    from oracle.state import fill_state, spec_of
-    from miccai2021_cataract_semantic_segmentation_amd.models import DeepLabv3Plus, OCRNet
+def host_cpu_info():
+    """(model name, physical cores, logical cpus available to this process)"""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not line.strip():
+                if core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 32))   # beyond ~32 threads the sort / BN phases of this step stop scaling
+    return model, (len(cores) or avail), avail
+
+
+def cpu_baseline(H, W, K, model_name):
+    """the CPU oracle (port of the reference path) on this box's host cores -- the identical synthetic
+    train step (zero_grad -> forward -> loss -> backward -> Adam), fp32, batch 2: 1 warm-up + 3 timed steps with anomaly
+    detection off, then 1 step with torch.autograd.set_detect_anomaly(True) as the reference's main.py:8 sets it."""
+    from oracle import nets as ON, losses as OL
+    from oracle.state import fill_state, spec_of
+    from miccai2021_cataract_semantic_segmentation_amd.models import DeepLabv3Plus, OCRNet
+    cpu_model, physical, avail = host_cpu_info()
+    cores = max(1, min(avail, physical, 32))   # beyond ~32 threads the sort / BN phases of this step stop scaling
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     deeplab = IS_DEEPLAB(model_name)
@@ -64,24 +91,40 @@ def cpu_baseline(H, W, K, model_name):
     params = [k for k, v in S.items() if v.dtype.is_floating_point and "running" not in k]
     for k in params:
         S[k].requires_grad_()
-    nb = 2 if deeplab else 1   # ASPP's image-pooling BatchNorm needs > 1 value per channel in train mode
+    nb = 2
     img, lbl = synth_batch(nb, H, W, K, 0, "cpu")
     m = {k: torch.zeros_like(S[k]) for k in params}
     v = {k: torch.zeros_like(S[k]) for k in params}
-    t0 = time.perf_counter()
-    if deeplab:
-        loss = OL.cross_entropy(fwd(S, img, train=True), lbl, 2)
-    else:
-        oi, of = fwd(S, img, train=True)
-        loss = OL.two_scale_lovasz(oi, of, lbl)
-    loss.backward()
-    with torch.no_grad():
+
+    def step(i):
         for k in params:
-            OL.adam_step(S[k], S[k].grad, m[k], v[k], 1, 1e-4)
-    dt = time.perf_counter() - t0
+            S[k].grad = None
+        if deeplab:
+            loss = OL.cross_entropy(fwd(S, img, train=True), lbl, 2)
+        else:
+            oi, of = fwd(S, img, train=True)
+            loss = OL.two_scale_lovasz(oi, of, lbl)
+        loss.backward()
+        with torch.no_grad():
+            for k in params:
+                OL.adam_step(S[k], S[k].grad, m[k], v[k], i, 1e-4)
+
+    step(1)                                     # warm-up (allocator, thread pool, oneDNN primitive caches)
+    timed = 3
+    t0 = time.perf_counter()
+    for i in range(timed):
+        step(2 + i)
+    dt = (time.perf_counter() - t0) / timed
+    with torch.autograd.set_detect_anomaly(True):
+        t0 = time.perf_counter()
+        step(5)
+        dt_anom = time.perf_counter() - t0
     return {"value": nb / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 train step (fwd + %s + bwd + Adam) of the CPU oracle, batch %d, 3x%dx%d, K=%d, fp32, "
-                      "%.1f s wall" % ("cross entropy" if deeplab else "TwoScale-Lovasz", nb, H, W, K, dt)}
+            "cpu_model": cpu_model, "physical_cores": physical, "logical_cpus_available": avail,
+            "value_anomaly_mode_on": nb / dt_anom,
+            "sample": "1 warm-up + %d timed train steps (fwd + %s + bwd + Adam) of the CPU oracle, batch %d, 3x%dx%d, K=%d, fp32, "
+                      "%.1f s per step; + 1 step with torch.autograd.set_detect_anomaly(True) (reference main.py:8): %.1f s"
+                      % (timed, "cross entropy" if deeplab else "TwoScale-Lovasz", nb, H, W, K, dt, dt_anom)}
 
 
 def infer_bench(args):
@@ -241,15 +284,17 @@ def main():
         dom = max(agg, key=lambda k: agg[k][1])
         fl, sec, n = agg[dom]
         peak = 157.3
-        traffic = None   # HBM bytes per launch from committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.model)
+        traffic = traffic_src = None   # HBM bytes per launch from committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
+        tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (PROFILE_ROUND, args.model))
         if os.path.exists(tpath) and (B, H, W) == (8, 544, 960):
+            traffic_src = "profiles/" + os.path.basename(tpath) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
             per_step = json.load(open(tpath))["kernels"].get(dom, {}).get("hbm_bytes_per_step")
             traffic = per_step / (n // 2) if per_step else None          # per C-ABI call, like `achieved`
         label = {"fwd": "igemm_f32_kernel<NT> (conv2d forward)", "dgrad": "igemm_f32_kernel<NN> (conv2d backward-data)",
                  "wgrad": "igemm_f32_kernel<TN> + wgrad_direct_kernel (conv2d backward-weight, incl. slab reduction)"}.get(dom, dom)
         roof = {"bound": "mfma", "kernel": label, "achieved": fl / sec / 1e12, "peak": peak,
-                "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak, "traffic": traffic, "launches_per_step": n // 2,
+                "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "launches_per_step": n // 2,
                 "avg_launch_ms": sec / n * 1e3, "algorithmic_gflop_per_launch": fl / n / 1e9,
                 "all_igemm": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / 2 * 1e3, "launches_per_step": v[2] // 2}
                               for k, v in agg.items()}}
@@ -270,7 +315,6 @@ def main():
                                     if deeplab else
                                     "%s, 25-class (task 3), bs=%d/GPU @3x%dx%d, TwoScale Lovasz-Softmax (0.4 interm + 1.0 final), "
                                     "Adam lr 1e-4, loss/optimiser of reference configs/OCRNet_rf_lvsz.json") % (MODELS[args.model][1], B, H, W),
-                       "model": args.model,
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": final_loss,
                        "inputs": "host (pinned) -> device copy inside every step" if args.with_h2d else "resident in HBM"},
             "roofline": roof, "cpu_baseline": cpu,

@@ -32,6 +32,25 @@ NETS = {
 }
 
 
+# OCRNet in eval mode with fill_state's arbitrary running statistics is badly conditioned (logits of scale 300-500 through two
+# peaked softmaxes: any two fp32 implementations differ by ~1e-3 of the scale there).  "Trained-like" statistics: one
+# training-mode forward with BatchNorm momentum 1 sets every running mean / variance to the batch statistics of a calibration
+# batch; those statistics are stored in the fixture.
+CALIBRATE = ("ocrnet_r50",)
+
+
+def calibrate_bn(model):
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    old = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        model(image(6999))
+    for m, o in zip(bns, old):
+        m.momentum = o
+
+
 def image(seed):
     return torch.rand(SHAPE, generator=torch.Generator().manual_seed(seed))
 
@@ -47,6 +66,8 @@ if __name__ == "__main__":
             model = getattr(R.models, cls)(dict(cfg), exp)
             spec = spec_of(model.state_dict())
             model.load_state_dict(fill_state(spec, ws))
+            if name in CALIBRATE:
+                calibrate_bn(model)
             model.eval()
             if hasattr(model, "get_intermediate"):
                 model.get_intermediate = False
@@ -58,8 +79,11 @@ if __name__ == "__main__":
                 ncls = len(o.argmax(1).unique())
                 if ncls >= 3 and (best is None or rel > best[0]):
                     best = (rel, 7000 + seed, o, ncls, ws)
+                    stats = {k: v.numpy().copy() for k, v in model.state_dict().items() if "running_" in k} if name in CALIBRATE else {}
         wseed = best[4]
         best = best[:4]
+        for k, v in stats.items():
+            out[name + ":rs:" + k] = v
         rel, seed, o, ncls = best
         print("%s: image seed %d, min top-2 margin %.3g of the logit scale %.2f, %d classes in the map" % (name, seed, rel, float(o.abs().max()), ncls))
         out[name + ":spec"] = np.array(json.dumps(spec))

@@ -31,7 +31,11 @@ def test_label_maps_bit_exact(golden, name):
     spec = json.loads(str(g[name + ":spec"]))
     model = getattr(models, cls)(dict(cfg), exp)
     assert [k for k, _ in spec] == list(model.state_dict().keys())
-    model.load_state_dict(fill_state(spec, int(g[name + ":wseed"])))
+    S = fill_state(spec, int(g[name + ":wseed"]))
+    for k in g.files:                      # "trained-like" BatchNorm statistics stored with the fixture (OCRNet)
+        if k.startswith(name + ":rs:"):
+            S[k[len(name) + 4:]] = torch.from_numpy(g[k])
+    model.load_state_dict(S)
     model.cuda().eval()
     if hasattr(model, "get_intermediate"):
         model.get_intermediate = False

@@ -84,9 +84,11 @@ def test_train_step_fullsize_is_deterministic_and_finite():
 
 def test_lovasz_at_config_size_vs_oracle():
     """LovaszSoftmax at the configuration's own size, P = 8 x 544 x 960 = 4 177 920 pixels x K = 25 (the CPU oracle needs
-    about a minute here): loss against the float64 numpy oracle, gradient against the torch oracle (autograd through
-    torch.sort).  Ties in the sort order only permute gradient entries between elements of equal error, which moves
-    individual entries by ~1e-6 of the gradient scale, far below the tolerance."""
+    1-2 minutes here).  Loss against the oracle evaluated in float64.  Gradient: at this P the reference's own fp32
+    arithmetic is noisy -- lovasz_grad differences two Jaccard values near 1 (fp32 spacing 6e-8) to get entries of size
+    ~1/P = 2e-7 (losses/LovaszSoftmax.py:83-95), and which noise sample an element receives depends on its rank among
+    near-equal errors -- so the fp32 CPU oracle's gradient is itself ~1e-3 (relative L2) away from the float64 one.  The HIP
+    gradient (same fp32 formula, exact integer counts) must be as close to the float64 gradient as the CPU fp32 path is."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import torch.nn.functional as F
@@ -100,22 +102,23 @@ def test_lovasz_at_config_size_vs_oracle():
     lb[lb == 19] = 4
     P, K = lb.numel(), 25
     assert P == 4177920
-    ref64 = OL.lovasz_softmax_np(lg.numpy(), lb.numpy())
-    lgr = lg.clone().requires_grad_()
-    ref = OL.lovasz_softmax(lgr, lb)
-    ref.backward()
-    gref = lgr.grad.permute(0, 2, 3, 1).reshape(-1, K)
+    grads, losses = {}, {}
+    for dt in (torch.float64, torch.float32):
+        lgr = lg.to(dt).requires_grad_()
+        ref = OL.lovasz_softmax(lgr, lb)
+        ref.backward()
+        grads[dt] = lgr.grad.permute(0, 2, 3, 1).reshape(-1, K).double()
+        losses[dt] = float(ref.detach())
     ld = lg.permute(0, 2, 3, 1).reshape(-1, K).contiguous().cuda()
     dl = torch.empty_like(ld)
     loss = ops.lovasz_softmax(ld, lb.reshape(-1).cuda(), 1.0, dl)
-    assert abs(float(loss) - ref64) < 5e-6, (float(loss), ref64)
-    assert abs(float(loss) - float(ref)) < 2e-5, (float(loss), float(ref))     # (the fp32 CPU oracle itself is ~1e-5 from fp64)
-    d = dl.cpu().double()
-    gd = gref.double()
-    scale = float(gd.abs().max())
-    err = (d - gd).abs()
-    rel_l2 = float((d - gd).norm() / gd.norm())
-    print("lovasz P=%d K=%d: loss %.7f (f64 oracle %.7f); grad max err %.3g of scale %.3g, relative L2 %.3g"
-          % (P, K, float(loss), ref64, float(err.max()), scale, rel_l2))
-    assert float(err.max()) <= 1e-3 * scale and rel_l2 < 1e-4
+    assert abs(float(loss) - losses[torch.float64]) < 5e-6, (float(loss), losses)
+    d, g64, g32 = dl.cpu().double(), grads[torch.float64], grads[torch.float32]
+    n64 = float(g64.norm())
+    e_hip, e_cpu = float((d - g64).norm()) / n64, float((g32 - g64).norm()) / n64
+    m_hip, m_cpu = float((d - g64).abs().max()), float((g32 - g64).abs().max())
+    print("lovasz P=%d K=%d: loss hip %.7f, f64 oracle %.7f, f32 oracle %.7f; gradient vs f64: relative L2 hip %.3g cpu32 %.3g, "
+          "max abs hip %.3g cpu32 %.3g (scale %.3g)" % (P, K, float(loss), losses[torch.float64], losses[torch.float32], e_hip, e_cpu,
+                                                        m_hip, m_cpu, float(g64.abs().max())))
+    assert e_hip <= 1.5 * e_cpu + 1e-5 and m_hip <= 2.0 * m_cpu + 1e-4 * float(g64.abs().max())
     assert float(dl.sum(1).abs().max()) < 1e-9 + 1e-4 * float(dl.abs().max())
