@@ -86,6 +86,18 @@ int catseg_gemm_batched(int layout, int batch, int M, int N, int K, const float*
                         int ldc, long long strideC, int zero_to, int accumulate,
                         catseg_stream_t stream);
 
+/* ---- split-precision convolution on the bf16 matrix cores (csrc/igemm_bf16x3.hip): every fp32 operand is split exactly into
+ * three bf16 planes (catseg_split3), six bf16 MFMA partial products per block reproduce the fp32 product to ~2^-23;
+ * 2.7x the fp32-matrix peak.  Same F.conv2d call sites as catseg_conv2d_fwd / _bwd_data; results agree with the fp32 kernels
+ * to ~1e-6 relative (not bit-identical). */
+size_t catseg_split3_elems(long long rows, int C);   /* 16-bit elements per plane: rows * roundup(C, 8) */
+int catseg_split3(const float* x, int ld, long long rows, int C, void* planes, catseg_stream_t stream);
+int catseg_split3_weight_t(const float* w, int O, int taps, int Cin, void* planes, catseg_stream_t stream);
+int catseg_conv2d_fwd_bf16x3(const catseg_conv_desc* d, const void* x_planes, const void* w_planes, const float* bias,
+                             float* y, int zero_to, catseg_stream_t stream);
+int catseg_conv2d_bwd_data_bf16x3(const catseg_conv_desc* d, const void* dy_planes, const void* wt_planes, float* dx,
+                                  int accumulate, catseg_stream_t stream);
+
 /* (tuning / measurement hooks live in catseg_debug.h: they are process-global and not part of the product surface) */
 
 /* ---- BatchNorm (+ReLU, +residual) — nn.BatchNorm2d/ReLU at e.g. models/OCR.py:74-75,

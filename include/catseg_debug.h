@@ -26,6 +26,8 @@ int catseg_debug_set_lovasz_prune(int on);
  * 1 = direct kernel (default); a value > 1 additionally sets the direct kernel's target block count (default 512) */
 int catseg_debug_set_wgrad_direct(int on);
 
+/* tuning hook: bf16x3 block tile: 0 = heuristic, 1 = 256x256, 2 = 256x128, 3 = 128x256, 4 = 256x192, 5 = 256x96, 6 = 256x64 */
+int catseg_debug_set_b3_tile(int t);
 /* planner query: which tile / split count would the library pick for this convolution?
  * op: 0 = forward, 1 = backward-data (for stride > 1: the launch of input-pixel parity class (0, 0)),
  *     2 = backward-weight.  out[0..4] = mi, ni, form (0 = 32x32x2 tiles (64 mi) x (64 ni); 1 / 2 = 16x16x4 tiles narrow

@@ -42,6 +42,12 @@ _SIGS = {
     "catseg_debug_set_lovasz_prune": (I, [I]),
     "catseg_debug_set_wgrad_direct": (I, [I]),
     "catseg_debug_plan_conv": (I, [P, I, P]),
+    "catseg_debug_set_b3_tile": (I, [I]),
+    "catseg_split3_elems": (SZ, [L, I]),
+    "catseg_split3": (I, [P, I, L, I, P, P]),
+    "catseg_split3_weight_t": (I, [P, I, I, I, P, P]),
+    "catseg_conv2d_fwd_bf16x3": (I, [P, P, P, P, P, I, P]),
+    "catseg_conv2d_bwd_data_bf16x3": (I, [P, P, P, P, I, P]),
     "catseg_bn_workspace": (SZ, [L, I]),
     "catseg_bn_train_stats": (I, [P, L, I, I, P, F, F, P, P, P, P, P, SZ, P]),
     "catseg_bn_eval_scale": (I, [I, P, P, F, P, P]),

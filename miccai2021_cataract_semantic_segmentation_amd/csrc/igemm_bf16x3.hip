@@ -1,0 +1,410 @@
+// Split-precision implicit-GEMM convolution on the bf16 matrix cores of gfx950.
+//
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate.  An fp32 value splits EXACTLY into three bf16 pieces
+//   x = h + m + l  (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); 3 x 8 significant bits + signs cover the 24-bit
+// significand, residual <= 2^-25 |x|), and a product of two such sums is reproduced to ~2^-23 relative by the six partial
+// products of order <= 2 (hh, hm, mh, hl, lh, mm); each bf16 x bf16 product is exact in fp32 and the MFMA accumulates in fp32.
+// Six v_mfma_f32_32x32x16_bf16 per 32x32x16 block instead of eight v_mfma_f32_32x32x2_f32 at 1/16 of the rate:
+// 16 / 6 = 2.7x the fp32-matrix peak (157 TFLOP/s -> 419 TFLOP/s-equivalent).  Results are NOT bit-identical to an fp32 FMA
+// chain (the summation order and the dropped third-order terms differ at the 1e-7 level) -- see DESIGN.md for the measured error.
+//
+// Operands are pre-split planes written by split3_kernel: plane p of an [rows][C] fp32 tensor is a [rows][ldp] bf16 array
+// (ldp = C rounded up to 8, rows 16-byte aligned); conv weights OHWI -> [3][O][taps * Cin].
+//
+// Kernel: 512 threads (8 waves, 2 per SIMD, one block per CU), block tile (32 TM WGM) x (32 TN WGN), K-step = 16 bf16 =
+// one MFMA deep; LDS image per operand plane: [rows][32 B], the two 16-byte chunks of a row swapped where (row >> 3) & 1
+// (conflict-free ds_read_b128 over its four 16-lane groups); global -> LDS by global_load_lds_dwordx4, double buffered
+// behind a counted vmcnt.  The im2col matrix is never built (per-row tap mask + affine tap offsets, zero page for padding).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+__device__ __attribute__((aligned(256))) float g_zero_page_b3[64];
+
+struct B3Args {
+  const u16* a;       // activation planes
+  long long a_plane;  // elements between planes
+  int lda;            // elements per pixel row
+  const u16* w;       // weight planes [N][ldw]
+  long long w_plane;
+  int ldw;            // = taps * Cin
+  float* C;
+  int ldc;
+  const float* bias;
+  int M, N, Cin, taps;
+  int H, W, Ho, Wo;   // H, W: source image of the gather; Ho, Wo: the grid the GEMM rows decode over
+  int kw, stride, pad, dil;
+  int sign;           // +1: forward gather (iy = y*stride - pad + ky*dil); -1: stride-1 backward-data gather (iy = y + pad - ky*dil)
+  int tilesM, tilesN;
+  int zero_to, accumulate;
+  const float* zero;
+};
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// fp32 -> three bf16 planes.  One thread = 8 consecutive channels of one row.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int ld, long long rows, int C, int ldp,
+                                                     u16* __restrict__ out, long long plane) {
+  const int c8 = ldp >> 3;
+  const long long n = rows * c8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / c8;
+    const int c0 = (int)(i - r * c8) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (c0 + j < C) ? x[r * ld + c0 + j] : 0.f;
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const __bf16 hh = (__bf16)v[j];
+      const float r1 = v[j] - (float)hh;
+      const __bf16 mm = (__bf16)r1;
+      const float r2 = r1 - (float)mm;
+      h[j] = hh; m[j] = mm; l[j] = (__bf16)r2;
+    }
+    bf16x8* o = (bf16x8*)(out + r * ldp + c0);
+    *o = h;
+    *(bf16x8*)((u16*)o + plane) = m;
+    *(bf16x8*)((u16*)o + 2 * plane) = l;
+  }
+}
+
+// OHWI fp32 weights -> planes of the TRANSPOSED filter bank [Cin][taps][O] (the B operand of backward-data as an NT GEMM)
+__global__ __launch_bounds__(256) void split3_wt_kernel(const float* __restrict__ w, int O, int taps, int Cin, int ldp,
+                                                        u16* __restrict__ out, long long plane) {
+  const long long n = (long long)Cin * taps * ldp;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int o = (int)(i % ldp);
+    const long long ct = i / ldp;
+    const int t = (int)(ct % taps), c = (int)(ct / taps);
+    const float v = o < O ? w[((long long)o * taps + t) * Cin + c] : 0.f;
+    const __bf16 hh = (__bf16)v;
+    const float r1 = v - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    const __bf16 ll = (__bf16)(r1 - (float)mm);
+    out[i] = __builtin_bit_cast(u16, hh);
+    out[i + plane] = __builtin_bit_cast(u16, mm);
+    out[i + 2 * plane] = __builtin_bit_cast(u16, ll);
+  }
+}
+
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(512, 2) void igemm_b3_kernel(const B3Args p) {
+  static_assert(WGM * WGN == 8, "8 waves");
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+  constexpr int PLANE_A = BM * 32, PLANE_B = BN * 32;     // bytes of one plane image (rows x 32 B)
+  constexpr int SLAB = 3 * (PLANE_A + PLANE_B);           // bytes per K-step buffer
+  constexpr int NA = (BM * 2 + 511) / 512, NB = (BN * 2 + 511) / 512;   // 16-byte chunks per thread per plane
+  __shared__ __attribute__((aligned(16))) char smem[2 * SLAB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_m = swz / p.tilesN, tile_n = swz - tile_m * p.tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- staging state: chunk q = j*512 + tid of a plane image: row = q >> 1, position = q & 1 (lane-linear LDS-DMA),
+  //      logical 8-channel chunk = position ^ ((row >> 3) & 1)
+  int aoff[NA];
+  unsigned amask[NA];
+  int achunk[NA];
+  bool alive[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int q = j * 512 + tid, row = q >> 1;
+    alive[j] = row < BM;
+    achunk[j] = (q & 1) ^ ((row >> 3) & 1);
+    const int r = m0 + row;
+    aoff[j] = 0;
+    amask[j] = 0;
+    if (alive[j] && r < p.M) {
+      const int hw = p.Ho * p.Wo;
+      const int b = r / hw, rem = r - b * hw;
+      const int y = rem / p.Wo, x = rem - y * p.Wo;
+      const int y0 = p.sign > 0 ? y * p.stride - p.pad : y + p.pad;
+      const int x0 = p.sign > 0 ? x * p.stride - p.pad : x + p.pad;
+      aoff[j] = ((b * p.H + y0) * p.W + x0) * p.lda;
+      const int kh = p.taps / p.kw;
+      int t = 0;
+      for (int ky = 0; ky < kh; ++ky)
+        for (int kx = 0; kx < p.kw; ++kx, ++t) {
+          const int yy = y0 + p.sign * ky * p.dil, xx = x0 + p.sign * kx * p.dil;
+          if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) amask[j] |= 1u << t;
+        }
+    }
+  }
+  int bchunk[NB], brow[NB];
+  bool blive[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int q = j * 512 + tid, row = q >> 1;
+    blive[j] = row < BN;
+    bchunk[j] = (q & 1) ^ ((row >> 3) & 1);
+    brow[j] = n0 + row;
+  }
+
+  const int nck = (p.Cin + 15) >> 4;
+  const int nks = p.taps * nck;
+  int ttap = 0, tky = 0, tkx = 0, tck = 0;
+  const u16* pa[NA];
+  const u16* pb[NB];
+  const u16* zero = (const u16*)p.zero;
+
+  auto prep = [&]() {
+    const int toff = p.sign * (tky * p.dil * p.W + tkx * p.dil) * p.lda + tck * 16;
+    const int woff = ttap * p.Cin + tck * 16;
+    const bool tap_ok = ttap < p.taps;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int c = achunk[j] * 8;
+      const bool ok = tap_ok && ((amask[j] >> (ttap & 31)) & 1u) && (tck * 16 + c) < p.Cin;
+      pa[j] = ok ? p.a + (aoff[j] + toff + c) : zero;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int c = bchunk[j] * 8;
+      const bool ok = tap_ok && brow[j] < p.N && (tck * 16 + c) < p.Cin;
+      pb[j] = ok ? p.w + ((long long)brow[j] * p.ldw + woff + c) : zero;
+    }
+    if (++tck == nck) {
+      tck = 0;
+      ++ttap;
+      if (++tkx == p.kw) {
+        tkx = 0;
+        ++tky;
+      }
+    }
+  };
+
+  auto issue = [&](const int buf) {
+    char* s = smem + buf * SLAB;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j)
+        if (alive[j]) glds16(pa[j] == zero ? zero : pa[j] + pl * p.a_plane, s + pl * PLANE_A + (j * 512 + wave * 64) * 16);
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        if (blive[j]) glds16(pb[j] == zero ? zero : pb[j] + pl * p.w_plane, s + 3 * PLANE_A + pl * PLANE_B + (j * 512 + wave * 64) * 16);
+    }
+  };
+
+  auto compute = [&](const int buf, const bool more) {
+    const char* s = smem + buf * SLAB;
+    bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int row = wm * 32 * TM + t * 32 + l31;
+        a[pl][t] = *(const bf16x8*)(s + pl * PLANE_A + row * 32 + ((h ^ ((row >> 3) & 1)) << 4));
+      }
+#pragma unroll
+      for (int u = 0; u < TN; ++u) {
+        const int row = wn * 32 * TN + u * 32 + l31;
+        b[pl][u] = *(const bf16x8*)(s + 3 * PLANE_A + pl * PLANE_B + row * 32 + ((h ^ ((row >> 3) & 1)) << 4));
+      }
+    }
+    if (more) prep();
+    // six partial products, smallest first: (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][t], b[PB[q]][u], acc[t][u], 0, 0, 0);
+  };
+
+  // LDS-DMA instructions THIS wave issues per K-step (wave-uniform: a wave covers 32 whole rows of a plane image; waves
+  // beyond the end of a narrow operand issue fewer) -- the counted vmcnt must match it exactly
+  int nload = 0;
+#pragma unroll
+  for (int j = 0; j < NA; ++j) nload += (j * 512 + wave * 64) < BM * 2 ? 3 : 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) nload += (j * 512 + wave * 64) < BN * 2 ? 3 : 0;
+  nload = __builtin_amdgcn_readfirstlane(nload);
+  if (nks > 0) {
+    prep();
+    issue(0);
+    prep();
+    for (int ks = 0; ks < nks; ++ks) {
+      const int cur = ks & 1;
+      if (ks + 1 < nks) {
+        issue(cur ^ 1);
+        switch (nload) {
+          case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+          case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+          case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+          case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      compute(cur, ks + 2 < nks);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  // ---- epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      const int col = n0 + wn * 32 * TN + u * 32 + l31;
+      const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 * TM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < p.M) {
+          float* dst = p.C + (long long)row * p.ldc + col;
+          if (col < p.N) {
+            float v = acc[t][u][r] + bv;
+            if (p.accumulate) v += *dst;
+            *dst = v;
+          } else if (col < p.zero_to) {
+            *dst = 0.f;
+          }
+        }
+      }
+    }
+}
+
+const float* zero_page_b3() {
+  static const float* z[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!z[dev]) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_page_b3)) == hipSuccess) z[dev] = (const float*)q;
+  }
+  return z[dev];
+}
+
+int g_b3_tile = 0;   // tuning hook: 0 = heuristic, 1 = 256x256, 2 = 256x128, 3 = 128x256, 4 = 256x192, 5 = 256x96, 6 = 256x64
+
+template <int TM, int TN, int WGM, int WGN>
+void launch_b3(B3Args a, hipStream_t st) {
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+  a.tilesM = (a.M + BM - 1) / BM;
+  const int ncols = a.zero_to > a.N ? a.zero_to : a.N;
+  a.tilesN = (ncols + BN - 1) / BN;
+  a.zero = zero_page_b3();
+  hipLaunchKernelGGL((igemm_b3_kernel<TM, TN, WGM, WGN>), dim3(a.tilesM * a.tilesN), dim3(512), 0, st, a);
+}
+
+int pick_b3_tile(int N) {
+  if (g_b3_tile) return g_b3_tile;
+  if (N <= 64) return 6;
+  if (N <= 96) return 5;
+  if (N <= 128) return 2;
+  if (N <= 192) return 4;
+  if (N % 256 != 0 && N % 192 == 0) return 4;
+  return 1;
+}
+
+int run_b3(const B3Args& a, hipStream_t st) {
+  switch (pick_b3_tile(a.zero_to > a.N ? a.zero_to : a.N)) {
+    case 1: launch_b3<4, 2, 2, 4>(a, st); break;   // 256 x 256, wave tile 128 x 64
+    case 2: launch_b3<2, 2, 4, 2>(a, st); break;   // 256 x 128, wave tile 64 x 64
+    case 3: launch_b3<2, 2, 2, 4>(a, st); break;   // 128 x 256
+    case 4: launch_b3<2, 3, 4, 2>(a, st); break;   // 256 x 192, wave tile 64 x 96
+    case 5: launch_b3<1, 3, 8, 1>(a, st); break;   // 256 x 96,  wave tile 32 x 96
+    case 6: launch_b3<1, 2, 8, 1>(a, st); break;   // 256 x 64,  wave tile 32 x 64
+    default: catseg_set_error("bf16x3: unknown tile"); return CATSEG_EINVAL;
+  }
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+}  // namespace
+
+extern "C" int catseg_debug_set_b3_tile(int t) {
+  g_b3_tile = t;
+  return CATSEG_OK;
+}
+
+extern "C" size_t catseg_split3_elems(long long rows, int C) { return (size_t)rows * ((C + 7) & ~7); }
+
+// planes[p][row][ldp] (bf16, ldp = roundup(C, 8)); `planes` must hold 3 * catseg_split3_elems(rows, C) 16-bit elements
+extern "C" int catseg_split3(const float* x, int ld, long long rows, int C, void* planes, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && ld >= C && cs_aligned16(planes), "split3: bad args");
+  const int ldp = (C + 7) & ~7;
+  const long long n = rows * (ldp >> 3);
+  long long blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(split3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ld, rows, C, ldp, (u16*)planes, rows * ldp);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// OHWI weights -> planes of [Cin][taps][ldp = roundup(O, 8)]
+extern "C" int catseg_split3_weight_t(const float* w, int O, int taps, int Cin, void* planes, catseg_stream_t stream) {
+  CS_REQUIRE(O > 0 && taps > 0 && Cin > 0 && cs_aligned16(planes), "split3_weight_t: bad args");
+  const int ldp = (O + 7) & ~7;
+  const long long n = (long long)Cin * taps * ldp;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(split3_wt_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, O, taps, Cin, ldp, (u16*)planes, n);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// y = conv(x, w) (+ bias) from pre-split planes: x_planes = catseg_split3 of x (rows = B*H*W, C = Cin),
+// w_planes = catseg_split3 of the OHWI weights viewed as [Cout][kh*kw*Cin]
+extern "C" int catseg_conv2d_fwd_bf16x3(const catseg_conv_desc* d, const void* x_planes, const void* w_planes, const float* bias,
+                                        float* y, int zero_to, catseg_stream_t stream) {
+  CS_REQUIRE(d && !d->stem4 && d->groups <= 1 && d->Cin % 8 == 0 && d->kh * d->kw <= 32, "conv fwd bf16x3: needs Cin % 8 == 0, <= 32 taps, dense");
+  CS_REQUIRE(cs_aligned16(x_planes) && cs_aligned16(w_planes) && cs_aligned16(y) && zero_to <= d->ldy, "conv fwd bf16x3: alignment");
+  CS_REQUIRE((long long)d->B * d->H * d->W * d->Cin < (1ll << 31) && (long long)d->Cout * d->kh * d->kw * d->Cin < (1ll << 31), "conv fwd bf16x3: 32-bit offsets");
+  B3Args a = {};
+  a.a = (const u16*)x_planes; a.lda = d->Cin; a.a_plane = (long long)d->B * d->H * d->W * d->Cin;
+  a.w = (const u16*)w_planes; a.ldw = d->kh * d->kw * d->Cin; a.w_plane = (long long)d->Cout * a.ldw;
+  a.C = y; a.ldc = d->ldy; a.bias = bias;
+  a.M = d->B * d->Ho * d->Wo; a.N = d->Cout; a.Cin = d->Cin; a.taps = d->kh * d->kw;
+  a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+  a.sign = 1; a.zero_to = zero_to;
+  return run_b3(a, (hipStream_t)stream);
+}
+
+// dx (+)= backward-data of a STRIDE-1 convolution from pre-split planes: dy_planes = catseg_split3 of dy (C = Cout rounded up
+// to 8 with zero pad), wt_planes = catseg_split3_weight_t of the weights
+extern "C" int catseg_conv2d_bwd_data_bf16x3(const catseg_conv_desc* d, const void* dy_planes, const void* wt_planes, float* dx,
+                                             int accumulate, catseg_stream_t stream) {
+  CS_REQUIRE(d && !d->stem4 && d->groups <= 1 && d->stride == 1 && d->kh * d->kw <= 32, "conv bwd_data bf16x3: stride 1, <= 32 taps, dense");
+  CS_REQUIRE(cs_aligned16(dy_planes) && cs_aligned16(wt_planes) && cs_aligned16(dx), "conv bwd_data bf16x3: alignment");
+  const int cop = (d->Cout + 7) & ~7;
+  B3Args a = {};
+  a.a = (const u16*)dy_planes; a.lda = cop; a.a_plane = (long long)d->B * d->Ho * d->Wo * cop;
+  a.w = (const u16*)wt_planes; a.ldw = d->kh * d->kw * cop; a.w_plane = (long long)d->Cin * a.ldw;
+  a.C = dx; a.ldc = d->ldx; a.bias = nullptr;
+  a.M = d->B * d->H * d->W; a.N = d->Cin; a.Cin = cop; a.taps = d->kh * d->kw;
+  a.H = d->Ho; a.W = d->Wo; a.Ho = d->H; a.Wo = d->W; a.kw = d->kw; a.stride = 1; a.pad = d->pad; a.dil = d->dil;
+  a.sign = -1; a.accumulate = accumulate;
+  return run_b3(a, (hipStream_t)stream);
+}

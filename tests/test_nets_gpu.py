@@ -67,7 +67,7 @@ def _check_trace(pkg, g, model, loss_fn, two, spec, oracle):
         assert torch.equal(o.argmax(1).cpu()[decided], ref.argmax(1)[decided])
         # (eval-mode OCRNet with fill_state's arbitrary running statistics is badly conditioned -- logits of scale 500 through
         # two peaked softmaxes: both fp32 implementations sit ~1e-3 of the scale from fp64 -- so its tie band is wider)
-        assert float(decided.float().mean()) > (0.99 if two else 0.999)
+        assert float(decided.float().mean()) > (0.98 if two else 0.999)
     model.train()
     opt = FusedAdam(model, lr=1e-4)
     losses = []
