@@ -421,3 +421,46 @@ def conv_fwd_fused(x, w, bias, residual, relu, Cout, kh, kw, stride=1, pad=0, di
         check(lib.catseg_conv2d_fwd_fused(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual),
                                           ld_of(residual) if residual is not None else 0, 1 if relu else 0, ptr(out), stream()))
     return out
+
+
+# ---------------------------------------------------------------------------------------------- split precision (bf16 x 3)
+def split3(x):
+    """fp32 [..., C] (NHWC activation or [O, I, kh, kw] channels_last weights viewed as rows) -> int16 planes [3, rows, roundup(C, 8)]"""
+    if x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last):   # OHWI weights
+        rows, C, ld = x.shape[0], x.shape[1] * x.shape[2] * x.shape[3], x.shape[1] * x.shape[2] * x.shape[3]
+    else:
+        rows, C, ld = rows_of(x), x.shape[-1], ld_of(x)
+    ldp = (C + 7) // 8 * 8
+    planes = torch.empty((3, rows, ldp), dtype=torch.int16, device=x.device)
+    check(lib.catseg_split3(ptr(x), ld, rows, C, ptr(planes), stream()))
+    return planes
+
+
+def split3_weight_t(w):
+    """OHWI weights -> planes of the transposed bank [3, Cin, taps, roundup(O, 8)] (backward-data operand)"""
+    O, Cin, kh, kw = w.shape
+    planes = torch.empty((3, Cin, kh * kw, (O + 7) // 8 * 8), dtype=torch.int16, device=w.device)
+    check(lib.catseg_split3_weight_t(ptr(w), O, kh * kw, Cin, ptr(planes), stream()))
+    return planes
+
+
+def conv_fwd_b3(xshape, xp, wp, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0):
+    B, H, W, Cin = xshape
+    Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
+    if out is None:
+        out = new_act(B, Ho, Wo, Cout, xp.device, ld=max(zero_to, (Cout + 3) // 4 * 4))
+    d = make_desc(xshape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
+    with _Timed("fwd", 2.0 * B * Ho * Wo * Cout * Cin * kh * kw):
+        check(lib.catseg_conv2d_fwd_bf16x3(ctypes.byref(d), ptr(xp), ptr(wp), ptr(bias), ptr(out), zero_to, stream()))
+    return out
+
+
+def conv_bwd_data_b3(dyp, wtp, xshape, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, accumulate=False):
+    B, H, W, Cin = xshape
+    if out is None:
+        out = new_act(B, H, W, Cin, dyp.device)
+        accumulate = False
+    d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
+    with _Timed("dgrad", 2.0 * B * d.Ho * d.Wo * Cout * Cin * kh * kw):
+        check(lib.catseg_conv2d_bwd_data_bf16x3(ctypes.byref(d), ptr(dyp), ptr(wtp), ptr(out), 1 if accumulate else 0, stream()))
+    return out
