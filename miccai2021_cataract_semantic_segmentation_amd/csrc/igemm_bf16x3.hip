@@ -94,14 +94,14 @@ __global__ __launch_bounds__(256) void split3_wt_kernel(const float* __restrict_
   }
 }
 
-template <int TM, int TN, int WGM, int WGN>
+template <int TM, int TN, int WGM, int WGN, int NBUF>
 __global__ __launch_bounds__(512, 2) void igemm_b3_kernel(const B3Args p) {
   static_assert(WGM * WGN == 8, "8 waves");
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   constexpr int PLANE_A = BM * 32, PLANE_B = BN * 32;     // bytes of one plane image (rows x 32 B)
   constexpr int SLAB = 3 * (PLANE_A + PLANE_B);           // bytes per K-step buffer
   constexpr int NA = (BM * 2 + 511) / 512, NB = (BN * 2 + 511) / 512;   // 16-byte chunks per thread per plane
-  __shared__ __attribute__((aligned(16))) char smem[2 * SLAB];
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * SLAB];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -226,8 +226,9 @@ __global__ __launch_bounds__(512, 2) void igemm_b3_kernel(const B3Args p) {
       }
     }
     if (more) prep();
-    // six partial products, smallest first: (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
-    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+    // six partial products in the order the planes were read (h first): the MFMAs on the h planes start while the m / l
+    // fragment reads are still in flight (counted lgkmcnt); the accumulation order is irrelevant at this precision
+    constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
 #pragma unroll
     for (int q = 0; q < 6; ++q)
 #pragma unroll
@@ -245,7 +246,16 @@ __global__ __launch_bounds__(512, 2) void igemm_b3_kernel(const B3Args p) {
 #pragma unroll
   for (int j = 0; j < NB; ++j) nload += (j * 512 + wave * 64) < BN * 2 ? 3 : 0;
   nload = __builtin_amdgcn_readfirstlane(nload);
-  if (nks > 0) {
+  auto wait_one_step = [&]() {   // all but the youngest K-step's loads of this wave have landed
+    switch (nload) {
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+  if (nks > 0 && NBUF == 2) {
     prep();
     issue(0);
     prep();
@@ -253,13 +263,7 @@ __global__ __launch_bounds__(512, 2) void igemm_b3_kernel(const B3Args p) {
       const int cur = ks & 1;
       if (ks + 1 < nks) {
         issue(cur ^ 1);
-        switch (nload) {
-          case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-          case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-          case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-          case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        }
+        wait_one_step();
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -268,6 +272,27 @@ __global__ __launch_bounds__(512, 2) void igemm_b3_kernel(const B3Args p) {
       compute(cur, ks + 2 < nks);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+    }
+  } else if (nks > 0) {
+    // three-slot ring, ONE barrier per K-step: K-steps k+1 and k+2 are in flight while k is computed.  The slot refilled after
+    // the barrier of step k was last read in step k-1, which every wave has left (its fragment reads are complete: lgkmcnt(0)
+    // before it entered the barrier).
+    prep();
+    issue(0);
+    prep();
+    if (nks > 1) issue(1);
+    prep();
+    int cur = 0, fill = 2;
+    for (int ks = 0; ks < nks; ++ks) {
+      if (ks + 1 < nks) wait_one_step();
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (ks + 2 < nks) issue(fill);
+      compute(cur, ks + 3 < nks);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      cur = cur == 2 ? 0 : cur + 1;
+      fill = fill == 2 ? 0 : fill + 1;
     }
   }
 
@@ -308,14 +333,14 @@ const float* zero_page_b3() {
 
 int g_b3_tile = 0;   // tuning hook: 0 = heuristic, 1 = 256x256, 2 = 256x128, 3 = 128x256, 4 = 256x192, 5 = 256x96, 6 = 256x64
 
-template <int TM, int TN, int WGM, int WGN>
+template <int TM, int TN, int WGM, int WGN, int NBUF = 3>
 void launch_b3(B3Args a, hipStream_t st) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   a.tilesM = (a.M + BM - 1) / BM;
   const int ncols = a.zero_to > a.N ? a.zero_to : a.N;
   a.tilesN = (ncols + BN - 1) / BN;
   a.zero = zero_page_b3();
-  hipLaunchKernelGGL((igemm_b3_kernel<TM, TN, WGM, WGN>), dim3(a.tilesM * a.tilesN), dim3(512), 0, st, a);
+  hipLaunchKernelGGL((igemm_b3_kernel<TM, TN, WGM, WGN, NBUF>), dim3(a.tilesM * a.tilesN), dim3(512), 0, st, a);
 }
 
 int pick_b3_tile(int N) {
@@ -331,11 +356,13 @@ int pick_b3_tile(int N) {
 int run_b3(const B3Args& a, hipStream_t st) {
   switch (pick_b3_tile(a.zero_to > a.N ? a.zero_to : a.N)) {
     case 1: launch_b3<4, 2, 2, 4>(a, st); break;   // 256 x 256, wave tile 128 x 64
-    case 2: launch_b3<2, 2, 4, 2>(a, st); break;   // 256 x 128, wave tile 64 x 64
+    case 2: launch_b3<2, 2, 4, 2, 2>(a, st); break;   // 256 x 128, wave tile 64 x 64 (two slots: two blocks per CU)
+    case 7: launch_b3<2, 2, 4, 2, 3>(a, st); break;   // 256 x 128, three slots
+    case 8: launch_b3<4, 2, 2, 4, 2>(a, st); break;   // 256 x 256, two slots (A/B measurement)
     case 3: launch_b3<2, 2, 2, 4>(a, st); break;   // 128 x 256
     case 4: launch_b3<2, 3, 4, 2>(a, st); break;   // 256 x 192, wave tile 64 x 96
-    case 5: launch_b3<1, 3, 8, 1>(a, st); break;   // 256 x 96,  wave tile 32 x 96
-    case 6: launch_b3<1, 2, 8, 1>(a, st); break;   // 256 x 64,  wave tile 32 x 64
+    case 5: launch_b3<1, 3, 8, 1, 2>(a, st); break;   // 256 x 96,  wave tile 32 x 96
+    case 6: launch_b3<1, 2, 8, 1, 2>(a, st); break;   // 256 x 64,  wave tile 32 x 64
     default: catseg_set_error("bf16x3: unknown tile"); return CATSEG_EINVAL;
   }
   CS_LAUNCH_CHECK();

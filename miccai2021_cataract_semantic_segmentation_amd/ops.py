@@ -425,14 +425,18 @@ def conv_fwd_fused(x, w, bias, residual, relu, Cout, kh, kw, stride=1, pad=0, di
 
 # ---------------------------------------------------------------------------------------------- split precision (bf16 x 3)
 def split3(x):
-    """fp32 [..., C] (NHWC activation or [O, I, kh, kw] channels_last weights viewed as rows) -> int16 planes [3, rows, roundup(C, 8)]"""
-    if x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last):   # OHWI weights
-        rows, C, ld = x.shape[0], x.shape[1] * x.shape[2] * x.shape[3], x.shape[1] * x.shape[2] * x.shape[3]
-    else:
-        rows, C, ld = rows_of(x), x.shape[-1], ld_of(x)
-    ldp = (C + 7) // 8 * 8
-    planes = torch.empty((3, rows, ldp), dtype=torch.int16, device=x.device)
+    """fp32 NHWC activation [..., C] (pixel stride ld) -> int16 planes [3, rows, roundup(C, 8)]"""
+    rows, C, ld = rows_of(x), x.shape[-1], ld_of(x)
+    planes = torch.empty((3, rows, (C + 7) // 8 * 8), dtype=torch.int16, device=x.device)
     check(lib.catseg_split3(ptr(x), ld, rows, C, ptr(planes), stream()))
+    return planes
+
+
+def split3_weight(w):
+    """[O, I, kh, kw] weights (physical OHWI) -> planes [3, O, kh*kw*I] (forward operand; I % 8 == 0)"""
+    O, I, kh, kw = w.shape
+    planes = torch.empty((3, O, kh * kw * I), dtype=torch.int16, device=w.device)
+    check(lib.catseg_split3(ptr(w), kh * kw * I, O, kh * kw * I, ptr(planes), stream()))
     return planes
 
 

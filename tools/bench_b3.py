@@ -21,7 +21,7 @@ def timeit(fn, n=5):
 def accuracy():
     print("== accuracy vs fp64 (CPU) ==")
     for (B, H, W, Ci, Co, k, s, p, d) in [(2, 21, 27, 64, 96, 3, 1, 1, 1), (1, 30, 34, 48, 40, 3, 1, 2, 2), (2, 19, 23, 720, 512, 3, 1, 1, 1),
-                                          (2, 24, 24, 256, 256, 1, 1, 0, 1), (2, 33, 29, 96, 192, 3, 2, 1, 1), (1, 16, 20, 24, 25, 1, 1, 0, 1)]:
+                                          (2, 24, 24, 256, 256, 1, 1, 0, 1), (2, 33, 29, 96, 192, 3, 2, 1, 1), (1, 16, 20, 24, 25, 1, 1, 0, 1), (2, 40, 44, 16, 512, 3, 1, 1, 1)]:
         g = torch.Generator().manual_seed(Ci + Co)
         x = torch.randn(B, Ci, H, W, generator=g) * torch.exp(2 * torch.randn(B, Ci, 1, 1, generator=g))   # wide dynamic range
         w = torch.randn(Co, Ci, k, k, generator=g) * (2.0 / (Ci * k * k)) ** 0.5
@@ -31,7 +31,7 @@ def accuracy():
         xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
         wd = w.to(dev).contiguous(memory_format=torch.channels_last)
         y32 = ops.conv_fwd(xd, wd, b.to(dev), Co, k, k, s, p, d)
-        yb3 = ops.conv_fwd_b3(tuple(xd.shape), ops.split3(xd), ops.split3(wd), b.to(dev), Co, k, k, s, p, d)
+        yb3 = ops.conv_fwd_b3(tuple(xd.shape), ops.split3(xd), ops.split3_weight(wd), b.to(dev), Co, k, k, s, p, d)
         ref = y64.permute(0, 2, 3, 1)
         sc = float(ref.abs().max())
         e32 = float((y32.cpu().double() - ref).abs().max()) / sc
@@ -69,10 +69,10 @@ def speed(tiles):
         fl = 2.0 * y.numel() * Ci * k * k
         t32 = timeit(lambda: ops.conv_fwd(x, w, None, Co, k, k, s, p, d, out=y))
         td32 = timeit(lambda: ops.conv_bwd_data(dy, w, tuple(x.shape), k, k, s, p, d, out=dx))
-        xp, wp = ops.split3(x), ops.split3(w)
+        xp, wp = ops.split3(x), ops.split3_weight(w)
         dyp, wtp = ops.split3(dy), ops.split3_weight_t(w)
         tsx = timeit(lambda: ops.split3(x))
-        tsw = timeit(lambda: ops.split3(w))
+        tsw = timeit(lambda: ops.split3_weight(w))
         res = []
         for t in tiles:
             _lib.lib.catseg_debug_set_b3_tile(t)

@@ -1,4 +1,4 @@
-"""Run one conv shape repeatedly (for rocprofv3 --pmc passes).  usage: bench_one.py [fwd|dgrad|wgrad] [n]"""
+"""Run one conv shape repeatedly (for rocprofv3 --pmc passes).  usage: bench_one.py [fwd|dgrad|wgrad|b3fwd|b3dgrad] [n] [B,H,W,Ci,Co,k,s,p,d] [b3 tile]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,9 +13,16 @@ x = torch.randn(B, H, W, Ci, device=dev)
 w = (torch.randn(Co, Ci, k, k, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
 y = ops.conv_fwd(x, w, None, Co, k, k, s, p, d)
 dy = torch.randn_like(y); dx = torch.empty_like(x); dw = torch.empty_like(w)
+if kind.startswith("b3"):
+    from miccai2021_cataract_semantic_segmentation_amd import _lib
+    if len(sys.argv) > 4:
+        _lib.lib.catseg_debug_set_b3_tile(int(sys.argv[4]))
+    xp, wp, dyp, wtp = ops.split3(x), ops.split3_weight(w), ops.split3(dy), ops.split3_weight_t(w)
 torch.cuda.synchronize()
 for _ in range(n):
-    if kind == "fwd": ops.conv_fwd(x, w, None, Co, k, k, s, p, d, out=y)
+    if kind == "b3fwd": ops.conv_fwd_b3(tuple(x.shape), xp, wp, None, Co, k, k, s, p, d, out=y)
+    elif kind == "b3dgrad": ops.conv_bwd_data_b3(dyp, wtp, tuple(x.shape), Co, k, k, s, p, d, out=dx)
+    elif kind == "fwd": ops.conv_fwd(x, w, None, Co, k, k, s, p, d, out=y)
     elif kind == "dgrad": ops.conv_bwd_data(dy, w, tuple(x.shape), k, k, s, p, d, out=dx)
     else: ops.conv_bwd_weight(x, dy, dw, None, k, k, s, p, d)
 torch.cuda.synchronize()
