@@ -320,6 +320,241 @@ __global__ __launch_bounds__(512, 2) void igemm_b3_kernel(const B3Args p) {
     }
 }
 
+
+// ---- the large-tile form: 4 waves (ONE per SIMD, up to 512 registers each), block tile 256 x 256, wave tile 128 x 128.
+// With one wave per SIMD nothing else can fill the matrix pipe while a wave waits, so every memory operation is software-
+// pipelined under the wave's own MFMA stream (96 MFMAs = 3072 cycles per K-step).  The six products run in the order
+//   hh | hl lh | hm mh | mm
+// and the fragments of the NEXT K-step are re-read into the same registers right after a plane's last use: l after "hl lh",
+// h after "hm mh", m after "mm"; each is needed 16 ... 64 MFMAs (512 ... 2048 cycles) later, so the matrix pipe never waits
+// for LDS and no fragment is double buffered (96 fragment registers + 256 accumulators in AGPRs).
+// LDS: three 48 KB slots.  K-step k computes from registers, reads the fragments of k+1 from slot (k+1) % 3, while the LDS-DMA
+// of k+2 (issued right after the barrier at the top of step k) fills slot (k+2) % 3, whose last reader was step k-1.
+// ONE barrier per K-step; the loads have a whole K-step of latency budget.
+
+// s_waitcnt immediate of gfx9 (vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]); issued through the builtin so that the
+// compiler's own wait-count insertion knows the counters' state (inline asm is opaque to it)
+constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
+
+__global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
+  constexpr int TM = 4, TN = 4, WGN = 2;
+  constexpr int BM = 256, BN = 256;
+  constexpr int PLANE_A = BM * 32, PLANE_B = BN * 32;
+  constexpr int SLAB = 3 * (PLANE_A + PLANE_B);
+  constexpr int NA = 2, NB = 2;   // 16-byte chunks per thread per plane
+  __shared__ __attribute__((aligned(16))) char smem[3 * SLAB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_m = swz / p.tilesN, tile_n = swz - tile_m * p.tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int aoff[NA], achunk[NA], bchunk[NB], brow[NB];
+  unsigned amask[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int q = j * 256 + tid, row = q >> 1;
+    achunk[j] = ((q & 1) ^ ((row >> 3) & 1)) * 8;
+    const int r = m0 + row;
+    aoff[j] = 0;
+    amask[j] = 0;
+    if (r < p.M) {
+      const int hw = p.Ho * p.Wo;
+      const int b = r / hw, rem = r - b * hw;
+      const int y = rem / p.Wo, x = rem - y * p.Wo;
+      const int y0 = p.sign > 0 ? y * p.stride - p.pad : y + p.pad;
+      const int x0 = p.sign > 0 ? x * p.stride - p.pad : x + p.pad;
+      aoff[j] = ((b * p.H + y0) * p.W + x0) * p.lda + achunk[j];
+      const int kh = p.taps / p.kw;
+      int t = 0;
+      for (int ky = 0; ky < kh; ++ky)
+        for (int kx = 0; kx < p.kw; ++kx, ++t) {
+          const int yy = y0 + p.sign * ky * p.dil, xx = x0 + p.sign * kx * p.dil;
+          if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) amask[j] |= 1u << t;
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int q = j * 256 + tid, row = q >> 1;
+    bchunk[j] = ((q & 1) ^ ((row >> 3) & 1)) * 8;
+    brow[j] = n0 + row;
+  }
+  int boff[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) boff[j] = brow[j] < p.N ? brow[j] * p.ldw + bchunk[j] : -1;   // (weights < 2^31 elements: checked on the host)
+
+  const int nck = (p.Cin + 15) >> 4;
+  const int nks = p.taps * nck;
+  int ttap = 0, tky = 0, tkx = 0, tck = 0;
+  const u16* pa[NA];
+  const u16* pb[NB];
+  const u16* zero = (const u16*)p.zero;
+  const long long apl = p.a_plane, wpl = p.w_plane;
+
+  auto prep = [&]() {   // branch-free: addresses of the next un-prepared K-step (plane 0), or the zero page
+    const int toff = p.sign * (tky * p.dil * p.W + tkx * p.dil) * p.lda + tck * 16;
+    const int woff = ttap * p.Cin + tck * 16;
+    const bool tap_ok = ttap < p.taps;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const bool ok = tap_ok && ((amask[j] >> (ttap & 31)) & 1u) && (tck * 16 + achunk[j]) < p.Cin;
+      const u16* q = p.a + (unsigned)(ok ? aoff[j] + toff : 0);
+      pa[j] = ok ? q : zero;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const bool ok = tap_ok && boff[j] >= 0 && (tck * 16 + bchunk[j]) < p.Cin;
+      const u16* q = p.w + (unsigned)(ok ? boff[j] + woff : 0);
+      pb[j] = ok ? q : zero;
+    }
+    const int nt = tck + 1, nx = tkx + 1;
+    const bool wrap = nt == nck, wrapx = wrap && (nx == p.kw);
+    tck = wrap ? 0 : nt;
+    ttap += wrap ? 1 : 0;
+    tkx = wrap ? (wrapx ? 0 : nx) : tkx;
+    tky += wrapx ? 1 : 0;
+  };
+
+  auto issue = [&](const int buf) {
+    char* s = smem + buf * SLAB;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const u16* q = pa[j] == zero ? zero : pa[j] + pl * apl;
+        glds16(q, s + pl * PLANE_A + (j * 256 + wave * 64) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const u16* q = pb[j] == zero ? zero : pb[j] + pl * wpl;
+        glds16(q, s + 3 * PLANE_A + pl * PLANE_B + (j * 256 + wave * 64) * 16);
+      }
+    }
+  };
+
+  bf16x8 Ah[TM], Bh[TN], Al[TM], Bl[TN], Am[TM], Bm[TN];
+  // Fragment reads and their waits are written as inline asm: the compiler's own wait-count insertion is conservative at the
+  // loop header (it emits lgkmcnt(0) in front of the first MFMA of a K-step, i.e. it waits for the reads issued just before,
+  // which are needed 48 MFMAs later).  LDS reads return in order, so counted waits are exact:
+  //   reads per K-step, in issue order:  l' (8)  h' (8)  m' (8);   "hh" needs h': lgkmcnt(8) (only m' may be pending);
+  //   "hm" needs m': by then the 8 reads of the next l' are the only younger ones: lgkmcnt(8) again.
+  // The wait statements name the fragments as in/out operands, which orders them against the reads and the MFMAs.
+  typedef __attribute__((address_space(3))) char lds_char;
+  const unsigned sbase = (unsigned)(unsigned long long)(lds_char*)smem;
+  unsigned ra0, rb0;
+  {
+    const int rowa = wm * 128 + l31, rowb = wn * 128 + l31;   // (row + 32 t keeps (row >> 3) & 1: one swizzle per lane)
+    ra0 = sbase + rowa * 32 + ((h ^ ((rowa >> 3) & 1)) << 4);
+    rb0 = sbase + 3 * PLANE_A + rowb * 32 + ((h ^ ((rowb >> 3) & 1)) << 4);
+  }
+#define B3_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define B3_READ_PLANE(slot, pl, A_, B_)                                   \
+  do {                                                                    \
+    const unsigned aa_ = ra0 + (slot) * SLAB, bb_ = rb0 + (slot) * SLAB;  \
+    B3_DS_READ(A_[0], aa_, (pl) * PLANE_A + 0 * 1024);                    \
+    B3_DS_READ(A_[1], aa_, (pl) * PLANE_A + 1 * 1024);                    \
+    B3_DS_READ(A_[2], aa_, (pl) * PLANE_A + 2 * 1024);                    \
+    B3_DS_READ(A_[3], aa_, (pl) * PLANE_A + 3 * 1024);                    \
+    B3_DS_READ(B_[0], bb_, (pl) * PLANE_B + 0 * 1024);                    \
+    B3_DS_READ(B_[1], bb_, (pl) * PLANE_B + 1 * 1024);                    \
+    B3_DS_READ(B_[2], bb_, (pl) * PLANE_B + 2 * 1024);                    \
+    B3_DS_READ(B_[3], bb_, (pl) * PLANE_B + 3 * 1024);                    \
+  } while (0)
+#define B3_WAIT8(A_, B_)                                                                                              \
+  asm volatile("s_waitcnt lgkmcnt(8)"                                                                                 \
+               : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]), "+v"(A_[3]), "+v"(B_[0]), "+v"(B_[1]), "+v"(B_[2]), "+v"(B_[3]) \
+               :: "memory")
+  auto mm = [&](const bf16x8* a, const bf16x8* b) {
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b[u], acc[t][u], 0, 0, 0);
+  };
+
+  if (nks > 0) {
+    prep();
+    issue(0);
+    prep();
+    if (nks > 1) issue(1);
+    prep();
+    if (nks > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    B3_READ_PLANE(0, 2, Al, Bl);
+    B3_READ_PLANE(0, 0, Ah, Bh);
+    B3_READ_PLANE(0, 1, Am, Bm);
+    int nxt = 1, fill = 2;          // slot of K-step k+1, slot K-step k+2 is loaded into
+    for (int k = 0; k < nks; ++k) {
+      // (everything below is unconditional so that the K-step is ONE scheduling region per fence: past the end of the
+      //  reduction prep() yields zero-page addresses, the extra LDS-DMA fills and fragment reads touch slots nobody uses)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my LDS-DMA of K-step k+1 has landed (issued a K-step ago)
+      __builtin_amdgcn_s_barrier();                      // ... everybody's; every wave has consumed the fragments of step k-1
+      asm volatile("" ::: "memory");
+      B3_WAIT8(Ah, Bh);                                  // h (and the older l) fragments of step k are in registers
+      issue(fill);                                       // K-step k+2
+      mm(Ah, Bh);                                        // h h
+      mm(Ah, Bl);                                        // h l
+      mm(Al, Bh);                                        // l h
+      __builtin_amdgcn_sched_barrier(0);
+      B3_READ_PLANE(nxt, 2, Al, Bl);
+      B3_WAIT8(Am, Bm);                                  // m fragments of step k (only the l reads just issued are younger)
+      prep();                                            // addresses of K-step k+3 ride under the MFMAs
+      mm(Ah, Bm);                                        // h m
+      mm(Am, Bh);                                        // m h
+      __builtin_amdgcn_sched_barrier(0);
+      B3_READ_PLANE(nxt, 0, Ah, Bh);
+      mm(Am, Bm);                                        // m m
+      __builtin_amdgcn_sched_barrier(0);
+      B3_READ_PLANE(nxt, 1, Am, Bm);
+      nxt = nxt == 2 ? 0 : nxt + 1;
+      fill = fill == 2 ? 0 : fill + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+#undef B3_DS_READ
+#undef B3_READ_PLANE
+#undef B3_WAIT8
+
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      const int col = n0 + wn * 128 + u * 32 + l31;
+      const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 128 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < p.M) {
+          float* dst = p.C + (long long)row * p.ldc + col;
+          if (col < p.N) {
+            float v = acc[t][u][r] + bv;
+            if (p.accumulate) v += *dst;
+            *dst = v;
+          } else if (col < p.zero_to) {
+            *dst = 0.f;
+          }
+        }
+      }
+    }
+}
+
 const float* zero_page_b3() {
   static const float* z[64] = {};
   int dev = 0;
@@ -363,6 +598,14 @@ int run_b3(const B3Args& a, hipStream_t st) {
     case 4: launch_b3<2, 3, 4, 2>(a, st); break;   // 256 x 192, wave tile 64 x 96
     case 5: launch_b3<1, 3, 8, 1, 2>(a, st); break;   // 256 x 96,  wave tile 32 x 96
     case 6: launch_b3<1, 2, 8, 1, 2>(a, st); break;   // 256 x 64,  wave tile 32 x 64
+    case 9: {                                      // 256 x 256, one wave per SIMD, register-pipelined
+      B3Args q = a;
+      q.tilesM = (q.M + 255) / 256;
+      q.tilesN = ((q.zero_to > q.N ? q.zero_to : q.N) + 255) / 256;
+      q.zero = zero_page_b3();
+      hipLaunchKernelGGL(igemm_b3w_kernel, dim3(q.tilesM * q.tilesN), dim3(256), 0, st, q);
+      break;
+    }
     default: catseg_set_error("bf16x3: unknown tile"); return CATSEG_EINVAL;
   }
   CS_LAUNCH_CHECK();
