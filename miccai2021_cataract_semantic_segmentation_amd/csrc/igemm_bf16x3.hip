@@ -407,22 +407,29 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
   const u16* zero = (const u16*)p.zero;
   const long long apl = p.a_plane, wpl = p.w_plane;
 
-  auto prep = [&]() {   // branch-free: addresses of the next un-prepared K-step (plane 0), or the zero page
+  // Addresses of one K-step's twelve LDS-DMA pieces (A rows j = 0, 1 and B rows j = 0, 1, three planes each), prepared in
+  // four pieces + a cursor advance so that the address arithmetic can be spread over several MFMA gaps
+  const u16* PA[NA][3];
+  const u16* PB[NB][3];
+  auto prepA = [&](const int j) {
     const int toff = p.sign * (tky * p.dil * p.W + tkx * p.dil) * p.lda + tck * 16;
+    const bool ok = (int)(ttap < p.taps) & (int)((amask[j] >> (ttap & 31)) & 1u) & (int)((tck * 16 + achunk[j]) < p.Cin);
+    const u16* q = p.a + (unsigned)(ok ? aoff[j] + toff : 0);
+    const long long st = ok ? apl : 0;
+    PA[j][0] = ok ? q : zero;
+    PA[j][1] = PA[j][0] + st;
+    PA[j][2] = PA[j][1] + st;
+  };
+  auto prepB = [&](const int j) {
     const int woff = ttap * p.Cin + tck * 16;
-    const bool tap_ok = ttap < p.taps;
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      const bool ok = tap_ok && ((amask[j] >> (ttap & 31)) & 1u) && (tck * 16 + achunk[j]) < p.Cin;
-      const u16* q = p.a + (unsigned)(ok ? aoff[j] + toff : 0);
-      pa[j] = ok ? q : zero;
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const bool ok = tap_ok && boff[j] >= 0 && (tck * 16 + bchunk[j]) < p.Cin;
-      const u16* q = p.w + (unsigned)(ok ? boff[j] + woff : 0);
-      pb[j] = ok ? q : zero;
-    }
+    const bool ok = (int)(ttap < p.taps) & (int)(boff[j] >= 0) & (int)((tck * 16 + bchunk[j]) < p.Cin);
+    const u16* q = p.w + (unsigned)(ok ? boff[j] + woff : 0);
+    const long long st = ok ? wpl : 0;
+    PB[j][0] = ok ? q : zero;
+    PB[j][1] = PB[j][0] + st;
+    PB[j][2] = PB[j][1] + st;
+  };
+  auto advance = [&]() {
     const int nt = tck + 1, nx = tkx + 1;
     const bool wrap = nt == nck, wrapx = wrap && (nx == p.kw);
     tck = wrap ? 0 : nt;
@@ -430,22 +437,19 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
     tkx = wrap ? (wrapx ? 0 : nx) : tkx;
     tky += wrapx ? 1 : 0;
   };
-
-  auto issue = [&](const int buf) {
+  auto prep = [&]() {
+    prepA(0); prepA(1); prepB(0); prepB(1); advance();
+  };
+  // LDS-DMA piece i of a K-step: i = 4 * plane + {A0, A1, B0, B1}
+  auto piece = [&](const int buf, const int i) {
     char* s = smem + buf * SLAB;
+    const int pl = i >> 2, w = i & 3;
+    if (w < 2) glds16(PA[w][pl], s + pl * PLANE_A + (w * 256 + wave * 64) * 16);
+    else glds16(PB[w - 2][pl], s + 3 * PLANE_A + pl * PLANE_B + ((w - 2) * 256 + wave * 64) * 16);
+  };
+  auto issue = [&](const int buf) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-      for (int j = 0; j < NA; ++j) {
-        const u16* q = pa[j] == zero ? zero : pa[j] + pl * apl;
-        glds16(q, s + pl * PLANE_A + (j * 256 + wave * 64) * 16);
-      }
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const u16* q = pb[j] == zero ? zero : pb[j] + pl * wpl;
-        glds16(q, s + 3 * PLANE_A + pl * PLANE_B + (j * 256 + wave * 64) * 16);
-      }
-    }
+    for (int i = 0; i < 12; ++i) piece(buf, i);
   };
 
   bf16x8 Ah[TM], Bh[TN], Al[TM], Bl[TN], Am[TM], Bm[TN];
@@ -480,6 +484,15 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
   asm volatile("s_waitcnt lgkmcnt(8)"                                                                                 \
                : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]), "+v"(A_[3]), "+v"(B_[0]), "+v"(B_[1]), "+v"(B_[2]), "+v"(B_[3]) \
                :: "memory")
+#define B3_WAIT0(A_, B_)                                                                                              \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
+               : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]), "+v"(A_[3]), "+v"(B_[0]), "+v"(B_[1]), "+v"(B_[2]), "+v"(B_[3]) \
+               :: "memory")
+#define B3_MFMA(A_, t_, B_, u_)                                                                                \
+  do {                                                                                                        \
+    acc[t_][u_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[t_], B_[u_], acc[t_][u_], 0, 0, 0);               \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  } while (0)
   auto mm = [&](const bf16x8* a, const bf16x8* b) {
 #pragma unroll
     for (int t = 0; t < TM; ++t)
@@ -502,27 +515,117 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
     B3_READ_PLANE(0, 1, Am, Bm);
     int nxt = 1, fill = 2;          // slot of K-step k+1, slot K-step k+2 is loaded into
     for (int k = 0; k < nks; ++k) {
-      // (everything below is unconditional so that the K-step is ONE scheduling region per fence: past the end of the
-      //  reduction prep() yields zero-page addresses, the extra LDS-DMA fills and fragment reads touch slots nobody uses)
+      // (everything below is unconditional: past the end of the reduction the prepared addresses are the zero page, the
+      //  extra LDS-DMA fills and fragment reads touch slots nobody uses)
+      // One wave per SIMD issues in order, so a cluster of non-matrix instructions longer than an MFMA's 24 free issue cycles
+      // idles the matrix pipe.  The K-step is therefore written slot by slot: every MFMA carries at most one LDS-DMA piece,
+      // one fragment read or one piece of address arithmetic, pinned by scheduling fences.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my LDS-DMA of K-step k+1 has landed (issued a K-step ago)
       __builtin_amdgcn_s_barrier();                      // ... everybody's; every wave has consumed the fragments of step k-1
       asm volatile("" ::: "memory");
       B3_WAIT8(Ah, Bh);                                  // h (and the older l) fragments of step k are in registers
-      issue(fill);                                       // K-step k+2
-      mm(Ah, Bh);                                        // h h
-      mm(Ah, Bl);                                        // h l
-      mm(Al, Bh);                                        // l h
-      __builtin_amdgcn_sched_barrier(0);
-      B3_READ_PLANE(nxt, 2, Al, Bl);
-      B3_WAIT8(Am, Bm);                                  // m fragments of step k (only the l reads just issued are younger)
-      prep();                                            // addresses of K-step k+3 ride under the MFMAs
-      mm(Ah, Bm);                                        // h m
-      mm(Am, Bh);                                        // m h
-      __builtin_amdgcn_sched_barrier(0);
-      B3_READ_PLANE(nxt, 0, Ah, Bh);
-      mm(Am, Bm);                                        // m m
-      __builtin_amdgcn_sched_barrier(0);
-      B3_READ_PLANE(nxt, 1, Am, Bm);
+      const unsigned aa_ = ra0 + nxt * SLAB, bb_ = rb0 + nxt * SLAB;
+      piece(fill, 0); B3_MFMA(Ah, 0, Bh, 0);
+       B3_MFMA(Ah, 0, Bh, 1);
+       B3_MFMA(Ah, 0, Bh, 2);
+      piece(fill, 1); B3_MFMA(Ah, 0, Bh, 3);
+       B3_MFMA(Ah, 1, Bh, 0);
+       B3_MFMA(Ah, 1, Bh, 1);
+      piece(fill, 2); B3_MFMA(Ah, 1, Bh, 2);
+       B3_MFMA(Ah, 1, Bh, 3);
+       B3_MFMA(Ah, 2, Bh, 0);
+      piece(fill, 3); B3_MFMA(Ah, 2, Bh, 1);
+       B3_MFMA(Ah, 2, Bh, 2);
+       B3_MFMA(Ah, 2, Bh, 3);
+      piece(fill, 4); B3_MFMA(Ah, 3, Bh, 0);
+       B3_MFMA(Ah, 3, Bh, 1);
+       B3_MFMA(Ah, 3, Bh, 2);
+      piece(fill, 5); B3_MFMA(Ah, 3, Bh, 3);
+       B3_MFMA(Ah, 0, Bl, 0);
+       B3_MFMA(Ah, 0, Bl, 1);
+      piece(fill, 6); B3_MFMA(Ah, 0, Bl, 2);
+       B3_MFMA(Ah, 0, Bl, 3);
+       B3_MFMA(Ah, 1, Bl, 0);
+      piece(fill, 7); B3_MFMA(Ah, 1, Bl, 1);
+       B3_MFMA(Ah, 1, Bl, 2);
+       B3_MFMA(Ah, 1, Bl, 3);
+      piece(fill, 8); B3_MFMA(Ah, 2, Bl, 0);
+       B3_MFMA(Ah, 2, Bl, 1);
+       B3_MFMA(Ah, 2, Bl, 2);
+      piece(fill, 9); B3_MFMA(Ah, 2, Bl, 3);
+       B3_MFMA(Ah, 3, Bl, 0);
+       B3_MFMA(Ah, 3, Bl, 1);
+      piece(fill, 10); B3_MFMA(Ah, 3, Bl, 2);
+       B3_MFMA(Ah, 3, Bl, 3);
+       B3_MFMA(Al, 0, Bh, 0);
+      piece(fill, 11); B3_MFMA(Al, 0, Bh, 1);
+       B3_MFMA(Al, 0, Bh, 2);
+       B3_MFMA(Al, 0, Bh, 3);
+      prepA(0); B3_MFMA(Al, 1, Bh, 0);
+       B3_MFMA(Al, 1, Bh, 1);
+      prepA(1); B3_MFMA(Al, 1, Bh, 2);
+       B3_MFMA(Al, 1, Bh, 3);
+      prepB(0); B3_MFMA(Al, 2, Bh, 0);
+       B3_MFMA(Al, 2, Bh, 1);
+      prepB(1); B3_MFMA(Al, 2, Bh, 2);
+       B3_MFMA(Al, 2, Bh, 3);
+      advance(); B3_MFMA(Al, 3, Bh, 0);
+       B3_MFMA(Al, 3, Bh, 1);
+       B3_MFMA(Al, 3, Bh, 2);
+       B3_MFMA(Al, 3, Bh, 3);
+      B3_WAIT0(Am, Bm);   // m fragments of step k (issued a K-step ago; nothing younger is pending) B3_MFMA(Ah, 0, Bm, 0);
+      B3_DS_READ(Al[0], aa_, 2 * PLANE_A + 0 * 1024); B3_MFMA(Ah, 0, Bm, 1);
+      B3_DS_READ(Al[1], aa_, 2 * PLANE_A + 1 * 1024); B3_MFMA(Ah, 0, Bm, 2);
+      B3_DS_READ(Al[2], aa_, 2 * PLANE_A + 2 * 1024); B3_MFMA(Ah, 0, Bm, 3);
+      B3_DS_READ(Al[3], aa_, 2 * PLANE_A + 3 * 1024); B3_MFMA(Ah, 1, Bm, 0);
+      B3_DS_READ(Bl[0], bb_, 2 * PLANE_B + 0 * 1024); B3_MFMA(Ah, 1, Bm, 1);
+      B3_DS_READ(Bl[1], bb_, 2 * PLANE_B + 1 * 1024); B3_MFMA(Ah, 1, Bm, 2);
+      B3_DS_READ(Bl[2], bb_, 2 * PLANE_B + 2 * 1024); B3_MFMA(Ah, 1, Bm, 3);
+      B3_DS_READ(Bl[3], bb_, 2 * PLANE_B + 3 * 1024); B3_MFMA(Ah, 2, Bm, 0);
+       B3_MFMA(Ah, 2, Bm, 1);
+       B3_MFMA(Ah, 2, Bm, 2);
+       B3_MFMA(Ah, 2, Bm, 3);
+       B3_MFMA(Ah, 3, Bm, 0);
+       B3_MFMA(Ah, 3, Bm, 1);
+       B3_MFMA(Ah, 3, Bm, 2);
+       B3_MFMA(Ah, 3, Bm, 3);
+      B3_DS_READ(Ah[0], aa_, 0 * PLANE_A + 0 * 1024); B3_MFMA(Am, 0, Bh, 0);
+      B3_DS_READ(Ah[1], aa_, 0 * PLANE_A + 1 * 1024); B3_MFMA(Am, 0, Bh, 1);
+      B3_DS_READ(Ah[2], aa_, 0 * PLANE_A + 2 * 1024); B3_MFMA(Am, 0, Bh, 2);
+      B3_DS_READ(Ah[3], aa_, 0 * PLANE_A + 3 * 1024); B3_MFMA(Am, 0, Bh, 3);
+       B3_MFMA(Am, 1, Bh, 0);
+       B3_MFMA(Am, 1, Bh, 1);
+       B3_MFMA(Am, 1, Bh, 2);
+       B3_MFMA(Am, 1, Bh, 3);
+       B3_MFMA(Am, 2, Bh, 0);
+       B3_MFMA(Am, 2, Bh, 1);
+       B3_MFMA(Am, 2, Bh, 2);
+       B3_MFMA(Am, 2, Bh, 3);
+       B3_MFMA(Am, 3, Bh, 0);
+       B3_MFMA(Am, 3, Bh, 1);
+       B3_MFMA(Am, 3, Bh, 2);
+       B3_MFMA(Am, 3, Bh, 3);
+      B3_DS_READ(Bh[0], bb_, 0 * PLANE_B + 0 * 1024); B3_MFMA(Am, 0, Bm, 0);
+      B3_DS_READ(Bh[1], bb_, 0 * PLANE_B + 1 * 1024); B3_MFMA(Am, 0, Bm, 1);
+      B3_DS_READ(Bh[2], bb_, 0 * PLANE_B + 2 * 1024); B3_MFMA(Am, 0, Bm, 2);
+      B3_DS_READ(Bh[3], bb_, 0 * PLANE_B + 3 * 1024); B3_MFMA(Am, 0, Bm, 3);
+      B3_DS_READ(Am[0], aa_, 1 * PLANE_A + 0 * 1024); B3_MFMA(Am, 1, Bm, 0);
+       B3_MFMA(Am, 1, Bm, 1);
+       B3_MFMA(Am, 1, Bm, 2);
+       B3_MFMA(Am, 1, Bm, 3);
+      B3_DS_READ(Am[1], aa_, 1 * PLANE_A + 1 * 1024); B3_MFMA(Am, 2, Bm, 0);
+       B3_MFMA(Am, 2, Bm, 1);
+       B3_MFMA(Am, 2, Bm, 2);
+       B3_MFMA(Am, 2, Bm, 3);
+      B3_DS_READ(Am[2], aa_, 1 * PLANE_A + 2 * 1024); B3_MFMA(Am, 3, Bm, 0);
+       B3_MFMA(Am, 3, Bm, 1);
+       B3_MFMA(Am, 3, Bm, 2);
+       B3_MFMA(Am, 3, Bm, 3);
+      B3_DS_READ(Am[3], aa_, 1 * PLANE_A + 3 * 1024);
+      B3_DS_READ(Bm[0], bb_, 1 * PLANE_B + 0 * 1024);
+      B3_DS_READ(Bm[1], bb_, 1 * PLANE_B + 1 * 1024);
+      B3_DS_READ(Bm[2], bb_, 1 * PLANE_B + 2 * 1024);
+      B3_DS_READ(Bm[3], bb_, 1 * PLANE_B + 3 * 1024);
       nxt = nxt == 2 ? 0 : nxt + 1;
       fill = fill == 2 ? 0 : fill + 1;
     }
@@ -531,6 +634,8 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
 #undef B3_DS_READ
 #undef B3_READ_PLANE
 #undef B3_WAIT8
+#undef B3_WAIT0
+#undef B3_MFMA
 
 #pragma unroll
   for (int t = 0; t < TM; ++t)

@@ -18,8 +18,9 @@ def timeit(fn, n=5):
     return e0.elapsed_time(e1) / n
 
 
-def accuracy():
-    print("== accuracy vs fp64 (CPU) ==")
+def accuracy(tile=0):
+    _lib.lib.catseg_debug_set_b3_tile(tile)
+    print("== accuracy vs fp64 (CPU), bf16x3 tile %d ==" % tile)
     for (B, H, W, Ci, Co, k, s, p, d) in [(2, 21, 27, 64, 96, 3, 1, 1, 1), (1, 30, 34, 48, 40, 3, 1, 2, 2), (2, 19, 23, 720, 512, 3, 1, 1, 1),
                                           (2, 24, 24, 256, 256, 1, 1, 0, 1), (2, 33, 29, 96, 192, 3, 2, 1, 1), (1, 16, 20, 24, 25, 1, 1, 0, 1), (2, 40, 44, 16, 512, 3, 1, 1, 1)]:
         g = torch.Generator().manual_seed(Ci + Co)
@@ -86,4 +87,6 @@ def speed(tiles):
 
 if __name__ == "__main__":
     accuracy()
+    accuracy(9)
+    _lib.lib.catseg_debug_set_b3_tile(0)
     speed([int(t) for t in sys.argv[1:]] or [0])
