@@ -453,41 +453,29 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
   };
 
   bf16x8 Ah[TM], Bh[TN], Al[TM], Bl[TN], Am[TM], Bm[TN];
-  // Fragment reads and their waits are written as inline asm: the compiler's own wait-count insertion is conservative at the
-  // loop header (it emits lgkmcnt(0) in front of the first MFMA of a K-step, i.e. it waits for the reads issued just before,
-  // which are needed 48 MFMAs later).  LDS reads return in order, so counted waits are exact:
-  //   reads per K-step, in issue order:  l' (8)  h' (8)  m' (8);   "hh" needs h': lgkmcnt(8) (only m' may be pending);
-  //   "hm" needs m': by then the 8 reads of the next l' are the only younger ones: lgkmcnt(8) again.
-  // The wait statements name the fragments as in/out operands, which orders them against the reads and the MFMAs.
-  typedef __attribute__((address_space(3))) char lds_char;
-  const unsigned sbase = (unsigned)(unsigned long long)(lds_char*)smem;
-  unsigned ra0, rb0;
+  // Fragment reads are ordinary LDS loads (the compiler inserts the waits; at the loop header it is conservative and waits
+  // for the five trailing m' reads issued just before, which have had the barrier's time to complete).  (Inline-asm reads with
+  // hand-counted lgkmcnt waits were tried: the register allocator copies asm results before they have arrived.)
+  int ra0, rb0;
   {
     const int rowa = wm * 128 + l31, rowb = wn * 128 + l31;   // (row + 32 t keeps (row >> 3) & 1: one swizzle per lane)
-    ra0 = sbase + rowa * 32 + ((h ^ ((rowa >> 3) & 1)) << 4);
-    rb0 = sbase + 3 * PLANE_A + rowb * 32 + ((h ^ ((rowb >> 3) & 1)) << 4);
+    ra0 = rowa * 32 + ((h ^ ((rowa >> 3) & 1)) << 4);
+    rb0 = 3 * PLANE_A + rowb * 32 + ((h ^ ((rowb >> 3) & 1)) << 4);
   }
-#define B3_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define B3_READ_PLANE(slot, pl, A_, B_)                                   \
-  do {                                                                    \
-    const unsigned aa_ = ra0 + (slot) * SLAB, bb_ = rb0 + (slot) * SLAB;  \
-    B3_DS_READ(A_[0], aa_, (pl) * PLANE_A + 0 * 1024);                    \
-    B3_DS_READ(A_[1], aa_, (pl) * PLANE_A + 1 * 1024);                    \
-    B3_DS_READ(A_[2], aa_, (pl) * PLANE_A + 2 * 1024);                    \
-    B3_DS_READ(A_[3], aa_, (pl) * PLANE_A + 3 * 1024);                    \
-    B3_DS_READ(B_[0], bb_, (pl) * PLANE_B + 0 * 1024);                    \
-    B3_DS_READ(B_[1], bb_, (pl) * PLANE_B + 1 * 1024);                    \
-    B3_DS_READ(B_[2], bb_, (pl) * PLANE_B + 2 * 1024);                    \
-    B3_DS_READ(B_[3], bb_, (pl) * PLANE_B + 3 * 1024);                    \
+#define B3_DS_READ(dst, base, off) dst = *(const bf16x8*)((base) + (off))
+#define B3_READ_PLANE(slot, pl, A_, B_)                                                \
+  do {                                                                                 \
+    const char* aa_ = smem + (slot) * SLAB + ra0;                                      \
+    const char* bb_ = smem + (slot) * SLAB + rb0;                                      \
+    B3_DS_READ(A_[0], aa_, (pl) * PLANE_A + 0 * 1024);                                 \
+    B3_DS_READ(A_[1], aa_, (pl) * PLANE_A + 1 * 1024);                                 \
+    B3_DS_READ(A_[2], aa_, (pl) * PLANE_A + 2 * 1024);                                 \
+    B3_DS_READ(A_[3], aa_, (pl) * PLANE_A + 3 * 1024);                                 \
+    B3_DS_READ(B_[0], bb_, (pl) * PLANE_B + 0 * 1024);                                 \
+    B3_DS_READ(B_[1], bb_, (pl) * PLANE_B + 1 * 1024);                                 \
+    B3_DS_READ(B_[2], bb_, (pl) * PLANE_B + 2 * 1024);                                 \
+    B3_DS_READ(B_[3], bb_, (pl) * PLANE_B + 3 * 1024);                                 \
   } while (0)
-#define B3_WAIT8(A_, B_)                                                                                              \
-  asm volatile("s_waitcnt lgkmcnt(8)"                                                                                 \
-               : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]), "+v"(A_[3]), "+v"(B_[0]), "+v"(B_[1]), "+v"(B_[2]), "+v"(B_[3]) \
-               :: "memory")
-#define B3_WAIT0(A_, B_)                                                                                              \
-  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
-               : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]), "+v"(A_[3]), "+v"(B_[0]), "+v"(B_[1]), "+v"(B_[2]), "+v"(B_[3]) \
-               :: "memory")
 #define B3_MFMA(A_, t_, B_, u_)                                                                                \
   do {                                                                                                        \
     acc[t_][u_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[t_], B_[u_], acc[t_][u_], 0, 0, 0);               \
@@ -523,8 +511,8 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my LDS-DMA of K-step k+1 has landed (issued a K-step ago)
       __builtin_amdgcn_s_barrier();                      // ... everybody's; every wave has consumed the fragments of step k-1
       asm volatile("" ::: "memory");
-      B3_WAIT8(Ah, Bh);                                  // h (and the older l) fragments of step k are in registers
-      const unsigned aa_ = ra0 + nxt * SLAB, bb_ = rb0 + nxt * SLAB;
+      const char* aa_ = smem + nxt * SLAB + ra0;
+      const char* bb_ = smem + nxt * SLAB + rb0;
       piece(fill, 0); B3_MFMA(Ah, 0, Bh, 0);
        B3_MFMA(Ah, 0, Bh, 1);
        B3_MFMA(Ah, 0, Bh, 2);
@@ -573,7 +561,7 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
        B3_MFMA(Al, 3, Bh, 1);
        B3_MFMA(Al, 3, Bh, 2);
        B3_MFMA(Al, 3, Bh, 3);
-      B3_WAIT0(Am, Bm);   // m fragments of step k (issued a K-step ago; nothing younger is pending) B3_MFMA(Ah, 0, Bm, 0);
+      B3_MFMA(Ah, 0, Bm, 0);
       B3_DS_READ(Al[0], aa_, 2 * PLANE_A + 0 * 1024); B3_MFMA(Ah, 0, Bm, 1);
       B3_DS_READ(Al[1], aa_, 2 * PLANE_A + 1 * 1024); B3_MFMA(Ah, 0, Bm, 2);
       B3_DS_READ(Al[2], aa_, 2 * PLANE_A + 2 * 1024); B3_MFMA(Ah, 0, Bm, 3);
@@ -629,12 +617,9 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
       nxt = nxt == 2 ? 0 : nxt + 1;
       fill = fill == 2 ? 0 : fill + 1;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 #undef B3_DS_READ
 #undef B3_READ_PLANE
-#undef B3_WAIT8
-#undef B3_WAIT0
 #undef B3_MFMA
 
 #pragma unroll
