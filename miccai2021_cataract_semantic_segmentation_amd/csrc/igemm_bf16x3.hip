@@ -656,7 +656,7 @@ const float* zero_page_b3() {
   return z[dev];
 }
 
-int g_b3_tile = 0;   // tuning hook: 0 = heuristic, 1 = 256x256, 2 = 256x128, 3 = 128x256, 4 = 256x192, 5 = 256x96, 6 = 256x64
+int g_b3_tile = 0;   // tuning hook: 0 = heuristic, 1 = 256x256 (8 waves), 2 / 7 = 256x128, 3 = 128x256, 4 = 256x192, 5 = 256x96, 6 = 256x64, 9 = 256x256 (4 waves, register-pipelined)
 
 template <int TM, int TN, int WGM, int WGN, int NBUF = 3>
 void launch_b3(B3Args a, hipStream_t st) {
@@ -674,8 +674,8 @@ int pick_b3_tile(int N) {
   if (N <= 96) return 5;
   if (N <= 128) return 2;
   if (N <= 192) return 4;
-  if (N % 256 != 0 && N % 192 == 0) return 4;
-  return 1;
+  if (N == 192) return 4;
+  return 9;   // 256 x 256, one wave per SIMD, register-pipelined
 }
 
 int run_b3(const B3Args& a, hipStream_t st) {

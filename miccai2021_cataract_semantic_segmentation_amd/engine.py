@@ -485,6 +485,7 @@ class EngineNet(nn.Module):
     def _run(self, x, record):
         cx = Ctx(self.training, record, None)
         outs = self._body(cx, x)
+        ops.release_b3_cache()
         return cx, outs
 
     def zero_grad(self, set_to_none=True):
@@ -506,6 +507,7 @@ class EngineNet(nn.Module):
             self._grad_sync.begin(fp)
 
     def _end_backward(self, cx):
+        ops.release_b3_cache()
         self._grads_pending = True
         if self._grad_sync is not None:
             self._grad_sync.finish()

@@ -87,13 +87,53 @@ class _Timed:
             PROFILE.append((self.kind, self.flops, self.e0, self.e1))
 
 
+# Arithmetic of the large convolutions: "fp32" = v_mfma_f32_32x32x2_f32 (an exact fp32 FMA chain), "bf16x3" = every fp32
+# operand split exactly into three bf16 planes, six bf16 MFMA partial products per block, fp32 accumulate (csrc/igemm_bf16x3.hip:
+# error vs an fp64 reference equal to or below the fp32 kernel's, 1.45-1.6x its speed on the layers it takes).  Only forward /
+# backward-data of dense 3x3-class convolutions with a long reduction and >= 192 output columns qualify; everything else runs
+# the fp32 kernels.  CATSEG_PRECISION=fp32 selects the exact fp32 path everywhere.
+import os as _os
+PRECISION = _os.environ.get("CATSEG_PRECISION", "bf16x3")
+_b3_cache = {"key": None, "x": None, "planes": None}
+# thresholds of the layer selection (tests lower them to push small layers through the split-precision kernels)
+B3_MIN_TAPS, B3_MIN_K, B3_MIN_N, B3_MIN_TILES = 2, 2048, 192, 192
+
+
+def _b3_eligible(rows, ncols, taps, cred, stride_ok=True):
+    return (PRECISION == "bf16x3" and stride_ok and B3_MIN_TAPS <= taps <= 32 and cred % 8 == 0 and taps * cred >= B3_MIN_K
+            and ncols >= B3_MIN_N and ((rows + 255) // 256) * ((ncols + 255) // 256) >= B3_MIN_TILES)
+
+
+def _split3_cached(x):
+    """three-plane split of an activation; the last one is kept (the two 720-channel head convolutions of OCRNet-HRNet and the
+    ASPP branches read one tensor)"""
+    key = (x.data_ptr(), x._version, tuple(x.shape), ld_of(x))
+    if _b3_cache["key"] == key:
+        return _b3_cache["planes"]
+    planes = split3(x)
+    _b3_cache.update(key=key, x=x, planes=planes)
+    return planes
+
+
+def release_b3_cache():
+    _b3_cache.update(key=None, x=None, planes=None)
+
+
 def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False, groups=1):
     B, H, W, Cin = x.shape
     Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
     if out is None:
         out = new_act(B, Ho, Wo, Cout, x.device, ld=max(zero_to, (Cout + 3) // 4 * 4))
+    flops = 2.0 * B * Ho * Wo * Cout * (3 if stem4 else Cin // groups) * kh * kw
+    if not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(B * Ho * Wo, Cout, kh * kw, Cin):
+        d = make_desc(x.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
+        with _Timed("fwd", flops):
+            xp = _split3_cached(x)
+            wp = split3_weight(w_ptr_tensor)
+            check(lib.catseg_conv2d_fwd_bf16x3(ctypes.byref(d), ptr(xp), ptr(wp), ptr(bias), ptr(out), zero_to, stream()))
+        return out
     d = make_desc(x.shape, ld_of(x), Cout, ld_of(out), kh, kw, stride, pad, dil, stem4, groups)
-    with _Timed("fwd", 2.0 * B * Ho * Wo * Cout * (3 if stem4 else Cin // groups) * kh * kw):
+    with _Timed("fwd", flops):
         check(lib.catseg_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_ptr_tensor), ptr(bias), ptr(out), zero_to, stream()))
     return out
 
@@ -104,8 +144,16 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
     if out is None:
         out = new_act(B, H, W, Cin, dy.device)
         accumulate = False
+    flops = 2.0 * rows_of(dy) * Cout * Cin * kh * kw
+    if _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1):
+        d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
+        with _Timed("dgrad", flops):
+            dyp = split3(dy)
+            wtp = split3_weight_t(w)
+            check(lib.catseg_conv2d_bwd_data_bf16x3(ctypes.byref(d), ptr(dyp), ptr(wtp), ptr(out), 1 if accumulate else 0, stream()))
+        return out
     d = make_desc(xshape, ld_of(out), Cout, ld_of(dy), kh, kw, stride, pad, dil)
-    with _Timed("dgrad", 2.0 * rows_of(dy) * Cout * Cin * kh * kw):
+    with _Timed("dgrad", flops):
         check(lib.catseg_conv2d_bwd_data(ctypes.byref(d), ptr(dy), ptr(w), ptr(out), 1 if accumulate else 0, stream()))
     return out
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("precision")]
 
 NETS = {
     "ocrnet_r50": ("OCRNet", {"backbone": "resnet50", "out_stride": 8, "pretrained": False}, 3),

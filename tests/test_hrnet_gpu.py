@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("precision")]
 T = torch.from_numpy
 
 

@@ -419,3 +419,60 @@ def test_adam(ops):
         ops.adam_step(pd, gr.cuda(), md, vd, 1e-3, step)
     close(pd, p, atol=1e-6)
     close(vd, v, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------- split precision (bf16 x 3)
+B3_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 21, 27, 64, 96, 3, 1, 1, 1), (1, 30, 34, 48, 40, 3, 1, 2, 2), (2, 19, 23, 720, 512, 3, 1, 1, 1), (2, 24, 24, 256, 256, 1, 1, 0, 1),
+    (2, 33, 29, 96, 192, 3, 2, 1, 1), (1, 16, 20, 24, 25, 1, 1, 0, 1), (2, 40, 44, 16, 512, 3, 1, 1, 1), (1, 68, 120, 256, 256, 3, 1, 12, 12),
+    (3, 9, 7, 8, 8, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("case", B3_CASES)
+def test_conv_bf16x3_split_precision(ops, case, tile):
+    """catseg_split3 + catseg_conv2d_fwd_bf16x3 / _bwd_data_bf16x3 (six bf16 MFMA partial products per block) against an fp64
+    F.conv2d: the error must be of fp32 size (2e-5 of the output scale; measured 2e-7 ... 3e-6), for every block-tile form,
+    on inputs with a wide dynamic range (per-channel scales e^(2 N(0,1)))"""
+    from miccai2021_cataract_semantic_segmentation_amd import _lib
+    B, H, W, Cin, Cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(2 * torch.randn(1, Cin, 1, 1, generator=g))
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xr = x.double().requires_grad_()
+    y64 = F.conv2d(xr, w.double(), b.double(), s, p, d)
+    gy = torch.randn(y64.shape, generator=g)
+    y64.backward(gy.double())
+    xd, wd = nhwc(x), ohwi(w)
+    try:
+        _lib.lib.catseg_debug_set_b3_tile(tile)
+        ld = (Cout + 3) // 4 * 4 + 4
+        y = ops.conv_fwd_b3(tuple(xd.shape), ops.split3(xd), ops.split3_weight(wd), b.cuda(), Cout, k, k, s, p, d, zero_to=ld)
+        close(nchw(y), y64.detach(), atol=0, rtol=2e-5)
+        full = torch.as_strided(y, y.shape[:3] + (ld,), y.stride())
+        assert float(full[..., Cout:].abs().max()) == 0.0
+        if s == 1:
+            gyd = ops.new_act(B, y64.shape[2], y64.shape[3], Cout, xd.device, zero=True)
+            gyd.copy_(nhwc(gy))
+            dx = ops.conv_bwd_data_b3(ops.split3(gyd), ops.split3_weight_t(wd), tuple(xd.shape), Cout, k, k, s, p, d)
+            close(nchw(dx), xr.grad, atol=0, rtol=2e-5)
+            dx2 = ops.conv_bwd_data_b3(ops.split3(gyd), ops.split3_weight_t(wd), tuple(xd.shape), Cout, k, k, s, p, d, out=dx.clone(), accumulate=True)
+            close(nchw(dx2), 2 * xr.grad, atol=0, rtol=2e-5)
+    finally:
+        _lib.lib.catseg_debug_set_b3_tile(0)
+
+
+def test_split3_is_exact(ops):
+    """x == h + m + l exactly (to the last bit) for every finite fp32 value in a wide range, pad columns are zero"""
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(1000, 20, generator=g) * torch.exp(8 * torch.randn(1000, 1, generator=g))).cuda()
+    x[0, :4] = torch.tensor([0.0, -0.0, 1.0, 3.0e-39])          # zeros and a subnormal
+    pl = ops.split3(x.view(1, 1000, 1, 20))
+    assert pl.shape == (3, 1000, 24)
+    parts = pl.view(torch.bfloat16).float()
+    assert float(parts[:, :, 20:].abs().max()) == 0.0
+    s = (parts[0, :, :20].double() + parts[1, :, :20].double() + parts[2, :, :20].double()).float()
+    assert torch.equal(s, x)

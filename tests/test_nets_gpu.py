@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("precision")]
 T = torch.from_numpy
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
