@@ -97,6 +97,7 @@ PRECISION = _os.environ.get("CATSEG_PRECISION", "bf16x3")
 _b3_cache = {"key": None, "x": None, "planes": None}
 # thresholds of the layer selection (tests lower them to push small layers through the split-precision kernels)
 B3_MIN_TAPS, B3_MIN_K, B3_MIN_N, B3_MIN_TILES = 2, 2048, 192, 192
+B3_OPS = ("fwd", "dgrad")
 
 
 def _b3_eligible(rows, ncols, taps, cred, stride_ok=True):
@@ -125,7 +126,7 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
     if out is None:
         out = new_act(B, Ho, Wo, Cout, x.device, ld=max(zero_to, (Cout + 3) // 4 * 4))
     flops = 2.0 * B * Ho * Wo * Cout * (3 if stem4 else Cin // groups) * kh * kw
-    if not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(B * Ho * Wo, Cout, kh * kw, Cin):
+    if "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(B * Ho * Wo, Cout, kh * kw, Cin):
         d = make_desc(x.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
         with _Timed("fwd", flops):
             xp = _split3_cached(x)
@@ -145,7 +146,7 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
         out = new_act(B, H, W, Cin, dy.device)
         accumulate = False
     flops = 2.0 * rows_of(dy) * Cout * Cin * kh * kw
-    if _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1):
+    if "dgrad" in B3_OPS and _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1):
         d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         with _Timed("dgrad", flops):
             dyp = split3(dy)
