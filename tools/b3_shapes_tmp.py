@@ -1,37 +1,46 @@
 import sys, os, json
 sys.path.insert(0, "/root/repo")
-import numpy as np, torch, torch.nn.functional as F
-from miccai2021_cataract_semantic_segmentation_amd import ops, engine
+import numpy as np, torch
+from miccai2021_cataract_semantic_segmentation_amd import ops, _lib
 from miccai2021_cataract_semantic_segmentation_amd.models import HRNetv2
+from miccai2021_cataract_semantic_segmentation_amd.losses import CrossEntropyLoss
 from oracle.state import fill_state
+from oracle import hrnet as OH, losses as OL
 g = np.load("/root/repo/tests/golden/hrnetv2_e3_tiny.npz")
 spec = json.loads(str(g["spec"])); seed = int(g["seed"])
-x = torch.from_numpy(g["x"])
-ops.PRECISION = "fp32"
-m = HRNetv2({}, 3); m.load_state_dict(fill_state(spec, seed)); m.cuda().train()
-orig = ops.conv_fwd
-rows = []
-def hook(x, w, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False, groups=1):
-    y = orig(x, w, bias, Cout, kh, kw, stride, pad, dil, out=out, zero_to=zero_to, stem4=stem4, groups=groups)
-    if not stem4 and x.shape[-1] % 8 == 0 and w.dim() == 4:
-        xc = x.contiguous()
-        y64 = F.conv2d(xc.permute(0, 3, 1, 2).double(), w.double(), bias.double() if bias is not None else None, stride, pad, dil).permute(0, 2, 3, 1)
-        yb = ops.conv_fwd_b3(tuple(x.shape), ops.split3(x), ops.split3_weight(w), bias, Cout, kh, kw, stride, pad, dil)
-        sc = float(y64.abs().max())
-        # error after removing the per-channel mean over positions (what BatchNorm sees), relative to the per-channel std
-        def bn_err(t):
-            d = (t.double() - y64).reshape(-1, Cout)
-            std = y64.reshape(-1, Cout).std(0, unbiased=False) + 1e-30
-            return float(((d - d.mean(0)) / std).abs().max()), float((d.mean(0) / std).abs().max())
-        e32, eb = bn_err(y[..., :Cout]), bn_err(yb[..., :Cout])
-        rows.append((tuple(x.shape), Cout, kh, stride, float((y[..., :Cout].double() - y64).abs().max()) / sc, float((yb[..., :Cout].double() - y64).abs().max()) / sc, e32, eb))
-    return y
-engine.ops.conv_fwd = hook
-with torch.no_grad():
-    m(x.cuda())
-engine.ops.conv_fwd = orig
-rows.sort(key=lambda r: -r[7][0] / (r[6][0] + 1e-12))
-print("x shape, Cout, k, s | max err/scale fp32, b3 | BN-relative err (centred, mean-shift) fp32 | b3")
-for r in rows[:25]:
-    print(r[0], r[1], r[2], r[3], "| %.2e %.2e | %.2e %.2e | %.2e %.2e" % (r[4], r[5], r[6][0], r[6][1], r[7][0], r[7][1]))
-print("layers:", len(rows), "median ratio centred", np.median([r[7][0] / (r[6][0] + 1e-12) for r in rows]))
+x, lbl = torch.from_numpy(g["x"]), torch.from_numpy(g["lbl"])
+grads = {}
+for dt in (torch.float32, torch.float64):
+    S = {k: (v.to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in fill_state(spec, seed).items()}
+    params = [k for k, v in S.items() if v.dtype.is_floating_point and "running" not in k]
+    for k in params: S[k].requires_grad_()
+    OL.cross_entropy(OH.hrnetv2_forward(S, x.to(dt), train=True), lbl, 3).backward()
+    grads[dt] = {k: S[k].grad.double() for k in params}
+calls = {"fwd": 0, "dgrad": 0}
+of, od = _lib.lib.catseg_conv2d_fwd_bf16x3, _lib.lib.catseg_conv2d_bwd_data_bf16x3
+def run(prec, opsel, nocache=False, tile=0):
+    ops.PRECISION = prec; ops.B3_OPS = opsel
+    ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES = (1, 64, 32, 1)
+    _lib.lib.catseg_debug_set_b3_tile(tile)
+    saved = ops._split3_cached
+    if nocache: ops._split3_cached = ops.split3
+    m = HRNetv2({}, 3); m.load_state_dict(fill_state(spec, seed)); m.cuda().train()
+    ops.PROFILE = []
+    y = m(x.cuda()); loss = CrossEntropyLoss(ignore_index=25)(y, lbl.cuda()); loss.backward()
+    torch.cuda.synchronize()
+    n_f = sum(1 for p in ops.PROFILE if p[0] == "fwd"); n_d = sum(1 for p in ops.PROFILE if p[0] == "dgrad"); ops.PROFILE = None
+    ops._split3_cached = saved
+    P = dict(m.named_parameters()); r = []
+    for k, g64 in grads[torch.float64].items():
+        n = float(g64.norm())
+        if n < 1e-7: continue
+        e32 = float((grads[torch.float32][k] - g64).norm()); eh = float((P[k].grad.cpu().double() - g64).norm())
+        r.append(eh / (e32 + 1e-4 * n))
+    r = np.array(r)
+    print(prec, opsel, "nocache" if nocache else "", "tile", tile, "median %.2f p95 %.2f max %.2f loss %.7f" % (np.median(r), np.percentile(r, 95), r.max(), float(loss)), flush=True)
+run("fp32", ("fwd", "dgrad"))
+run("bf16x3", ("fwd",))
+run("bf16x3", ("fwd",), nocache=True)
+run("bf16x3", ("dgrad",))
+for t in (1, 2, 6, 9):
+    run("bf16x3", ("fwd",), tile=t)
