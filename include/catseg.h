@@ -97,6 +97,13 @@ int catseg_conv2d_fwd_bf16x3(const catseg_conv_desc* d, const void* x_planes, co
                              float* y, int zero_to, catseg_stream_t stream);
 int catseg_conv2d_bwd_data_bf16x3(const catseg_conv_desc* d, const void* dy_planes, const void* wt_planes, float* dx,
                                   int accumulate, catseg_stream_t stream);
+/* dw = backward-weight from pre-split planes (x: C = Cin, dy: C = Cout); workspace = split-reduction slabs */
+size_t catseg_conv2d_bwd_weight_bf16x3_workspace(const catseg_conv_desc* d);
+int catseg_conv2d_bwd_weight_bf16x3(const catseg_conv_desc* d, const void* x_planes, const void* dy_planes, float* dw,
+                                    void* workspace, size_t workspace_bytes, catseg_stream_t stream);
+/* dbias[o] = sum_p dy[p, o] (the bias-gradient part of catseg_conv2d_bwd_weight on its own); workspace >= 256 * C floats */
+int catseg_bias_grad(const float* dy, int ld, long long rows, int C, float* dbias, void* workspace, size_t workspace_bytes,
+                     catseg_stream_t stream);
 
 /* (tuning / measurement hooks live in catseg_debug.h: they are process-global and not part of the product surface) */
 

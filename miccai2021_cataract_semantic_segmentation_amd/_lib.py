@@ -48,6 +48,9 @@ _SIGS = {
     "catseg_split3_weight_t": (I, [P, I, I, I, P, P]),
     "catseg_conv2d_fwd_bf16x3": (I, [P, P, P, P, P, I, P]),
     "catseg_conv2d_bwd_data_bf16x3": (I, [P, P, P, P, I, P]),
+    "catseg_conv2d_bwd_weight_bf16x3_workspace": (SZ, [P]),
+    "catseg_conv2d_bwd_weight_bf16x3": (I, [P, P, P, P, P, SZ, P]),
+    "catseg_bias_grad": (I, [P, I, L, I, P, P, SZ, P]),
     "catseg_bn_workspace": (SZ, [L, I]),
     "catseg_bn_train_stats": (I, [P, L, I, I, P, F, F, P, P, P, P, P, SZ, P]),
     "catseg_bn_eval_scale": (I, [I, P, P, F, P, P]),

@@ -1029,6 +1029,19 @@ extern "C" int catseg_conv2d_bwd_weight(const catseg_conv_desc* d, const float* 
   return CATSEG_OK;
 }
 
+// dbias[o] = sum_p dy[p][o] on its own (the split-precision backward-weight path computes only dW); workspace >= 256 * C floats
+extern "C" int catseg_bias_grad(const float* dy, int ld, long long rows, int C, float* dbias, void* workspace, size_t workspace_bytes,
+                                catseg_stream_t stream) {
+  CS_REQUIRE(dy && dbias && rows > 0 && C > 0 && ld >= C, "bias_grad: bad args");
+  CS_REQUIRE(workspace && workspace_bytes >= (size_t)256 * C * 4, "bias_grad: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int gy = (int)((rows + 1023) / 1024 < 256 ? (rows + 1023) / 1024 : 256);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, gy), dim3(256), 0, st, dy, ld, rows, C, (float*)workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace, gy, C, dbias);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
 extern "C" int catseg_gemm_batched(int layout, int batch, int M, int N, int K, const float* A, int lda,
                                    long long strideA, const float* Bm, int ldb, long long strideB, float* C,
                                    int ldc, long long strideC, int zero_to, int accumulate,

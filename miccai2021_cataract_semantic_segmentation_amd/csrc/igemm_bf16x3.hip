@@ -645,6 +645,319 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
     }
 }
 
+
+// ---- backward-weight: dW[o][tap][c] = sum_p dy[p][o] * x[pix(p, tap)][c] as a "TN" GEMM, M = Cout, N = taps * Cin (all filter
+// taps side by side), reduction over the output pixels p (split over blockIdx.z, partial slabs reduced afterwards).
+// Both operands are pixel-major in memory (the reduction index is the slow one), so the LDS images are [16 pixels][256 columns]
+// per plane and the MFMA fragments (8 consecutive k for one column) are read with the hardware transpose ds_read_b64_tr_b16:
+// per 16-lane group a block of 4 pixels x 16 columns, lane 4q + p supplying the address of pixel-row q, columns 4p .. 4p+3.
+// The 16-byte chunks of a pixel row are stored at chunk ^ ((pixel & 3) << 2): the four pixel rows of a block then hit four
+// different 64-byte bank groups (conflict-free; the swizzle is applied to the LDS-DMA SOURCE chunk, the destination is lane-linear).
+// Structure otherwise as igemm_b3w_kernel: 4 waves, one per SIMD, 256 x 256 tile, register-pipelined, pinned slot schedule.
+struct B3TArgs {
+  const u16* dy;  long long dy_plane; int ldo;     // [P][ldo] planes, ldo = roundup(Cout, 8)
+  const u16* x;   long long x_plane;  int ldx;     // [B*H*W][ldx] planes
+  float* C;       int ldc; long long c_split_stride;
+  int M, N, Cin, taps;                             // M = Cout, N = taps * Cin
+  int P, rows_per_split;                           // output pixels; multiple of 16 per split
+  int H, W, Ho, Wo, kw, stride, pad, dil;
+  int step_b, step_qy, step_rx;                    // 16 pixels = step_b images + step_qy rows + step_rx pixels
+  int tilesM, tilesN;
+  const float* zero;
+};
+
+__global__ __launch_bounds__(256, 1) void igemm_b3t_kernel(const B3TArgs p) {
+  constexpr int TM = 4, TN = 4;
+  constexpr int PLANE = 16 * 256 * 2;             // bytes of one operand plane image: 16 pixel rows x 256 columns of bf16
+  constexpr int SLAB = 6 * PLANE;                 // A planes 0..2, then B planes 0..2
+  __shared__ __attribute__((aligned(16))) char smem[3 * SLAB];
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_m = swz / p.tilesN, tile_n = swz - tile_m * p.tilesN;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const int split = blockIdx.z;
+  const int r_begin = split * p.rows_per_split;
+  const int r_end = min(r_begin + p.rows_per_split, p.P);
+  const int nks = (max(r_end - r_begin, 0) + 15) >> 4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- staging: chunk q = j * 256 + tid of a plane image: pixel row krow = q >> 5, position q & 31 (lane-linear LDS-DMA),
+  //      logical 8-column chunk = position ^ ((krow & 3) << 2)
+  const u16* zero = (const u16*)p.zero;
+  int arow[2];            // pixel row of the NEXT un-prepared K-step
+  int acol[2];            // column offset into the dy row, or -1 if outside [0, ldo)
+  int brow[2], tb[2], ty[2], tx[2], bky[2], bkx[2], bch[2];
+  bool bcv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = j * 256 + tid, krow = q >> 5, cl = (q & 31) ^ ((krow & 3) << 2);
+    arow[j] = r_begin + krow;
+    acol[j] = (m0 + cl * 8) < p.ldo ? m0 + cl * 8 : -1;
+    brow[j] = r_begin + krow;
+    const int n = n0 + cl * 8;
+    bcv[j] = n < p.N;
+    const int tap = bcv[j] ? n / p.Cin : 0;
+    bch[j] = n - tap * p.Cin;
+    bky[j] = tap / p.kw;
+    bkx[j] = tap - bky[j] * p.kw;
+    const int r = brow[j] < p.P ? brow[j] : 0;
+    const int hw = p.Ho * p.Wo;
+    tb[j] = r / hw;
+    const int rem = r - tb[j] * hw;
+    ty[j] = rem / p.Wo;
+    tx[j] = rem - ty[j] * p.Wo;
+  }
+  const u16* PA[2][3];
+  const u16* PB[2][3];
+  const long long apl = p.dy_plane, xpl = p.x_plane;
+  auto prepA = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = (int)(arow[j] < r_end) & (int)(acol[j] >= 0);
+      const u16* q = p.dy + ((long long)(ok ? arow[j] : 0) * p.ldo + (ok ? acol[j] : 0));
+      const long long st = ok ? apl : 0;
+      PA[j][0] = ok ? q : zero;
+      PA[j][1] = PA[j][0] + st;
+      PA[j][2] = PA[j][1] + st;
+      arow[j] += 16;
+    }
+  };
+  auto prepB = [&](const int j) {
+    const int iy = ty[j] * p.stride - p.pad + bky[j] * p.dil;
+    const int ix = tx[j] * p.stride - p.pad + bkx[j] * p.dil;
+    const bool ok = (int)(brow[j] < r_end) & (int)bcv[j] & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W);
+    const u16* q = p.x + (unsigned)(ok ? ((tb[j] * p.H + iy) * p.W + ix) * p.ldx + bch[j] : 0);
+    const long long st = ok ? xpl : 0;
+    PB[j][0] = ok ? q : zero;
+    PB[j][1] = PB[j][0] + st;
+    PB[j][2] = PB[j][1] + st;
+    // advance this row by 16 pixels
+    brow[j] += 16;
+    tx[j] += p.step_rx;
+    ty[j] += p.step_qy;
+    const bool cx = tx[j] >= p.Wo;
+    tx[j] -= cx ? p.Wo : 0;
+    ty[j] += cx ? 1 : 0;
+    const bool cy = ty[j] >= p.Ho;
+    ty[j] -= cy ? p.Ho : 0;
+    tb[j] += p.step_b + (cy ? 1 : 0);
+  };
+  auto prep = [&]() { prepA(); prepB(0); prepB(1); };
+  auto piece = [&](const int buf, const int i) {     // i = 4 * plane + {A0, A1, B0, B1}
+    char* s = smem + buf * SLAB;
+    const int pl = i >> 2, w = i & 3;
+    if (w < 2) glds16(PA[w][pl], s + pl * PLANE + (w * 256 + wave * 64) * 16);
+    else glds16(PB[w - 2][pl], s + (3 + pl) * PLANE + ((w - 2) * 256 + wave * 64) * 16);
+  };
+  auto issue = [&](const int buf) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) piece(buf, i);
+  };
+
+  // ---- fragment addresses (transposed reads): lane = 16 g + 4 q + pp inside its 32-lane half
+  int ra[TM], rb[TN];
+  {
+    const int g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+    const int rowb = (8 * h + q) * 512;               // pixel row 8h + q (+ 4 for the second read: + 2048 bytes)
+#pragma unroll
+    for (int t = 0; t < TM; ++t) ra[t] = rowb + ((wm * 16 + ((t ^ q) << 2) + 2 * g1 + (pp >> 1)) << 4) + ((pp & 1) << 3);
+#pragma unroll
+    for (int u = 0; u < TN; ++u) rb[u] = 3 * PLANE + rowb + ((wn * 16 + ((u ^ q) << 2) + 2 * g1 + (pp >> 1)) << 4) + ((pp & 1) << 3);
+  }
+  bf16x8 Ah[TM], Bh[TN], Al[TM], Bl[TN], Am[TM], Bm[TN];
+#define T_READ(dst, base, off)                                                                              \
+  do {                                                                                                      \
+    const s16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)((base) + (off)));                \
+    const s16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)((base) + (off) + 2048));         \
+    typedef short s16x8_ __attribute__((ext_vector_type(8)));                                               \
+    const s16x8_ v_ = {lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};                       \
+    dst = __builtin_bit_cast(bf16x8, v_);                                                                   \
+  } while (0)
+#define B3_MFMA(A_, t_, B_, u_)                                                                                \
+  do {                                                                                                        \
+    acc[t_][u_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[t_], B_[u_], acc[t_][u_], 0, 0, 0);               \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  } while (0)
+
+  if (nks > 0) {
+    prep();
+    issue(0);
+    prep();
+    if (nks > 1) issue(1);
+    prep();
+    if (nks > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      const char* aa_[TM]; const char* bb_[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) { aa_[t] = smem + ra[t]; bb_[t] = smem + rb[t]; }
+#pragma unroll
+      for (int t = 0; t < TM; ++t) { T_READ(Al[t], aa_[t], 2 * PLANE); T_READ(Bl[t], bb_[t], 2 * PLANE); }
+#pragma unroll
+      for (int t = 0; t < TM; ++t) { T_READ(Ah[t], aa_[t], 0 * PLANE); T_READ(Bh[t], bb_[t], 0 * PLANE); }
+#pragma unroll
+      for (int t = 0; t < TM; ++t) { T_READ(Am[t], aa_[t], 1 * PLANE); T_READ(Bm[t], bb_[t], 1 * PLANE); }
+    }
+    int nxt = 1, fill = 2;
+    for (int k = 0; k < nks; ++k) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my LDS-DMA of K-step k+1 has landed (issued a K-step ago)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* aa_[TM]; const char* bb_[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) { aa_[t] = smem + nxt * SLAB + ra[t]; bb_[t] = smem + nxt * SLAB + rb[t]; }
+      piece(fill, 0); B3_MFMA(Ah, 0, Bh, 0);
+       B3_MFMA(Ah, 0, Bh, 1);
+       B3_MFMA(Ah, 0, Bh, 2);
+      piece(fill, 1); B3_MFMA(Ah, 0, Bh, 3);
+       B3_MFMA(Ah, 1, Bh, 0);
+       B3_MFMA(Ah, 1, Bh, 1);
+      piece(fill, 2); B3_MFMA(Ah, 1, Bh, 2);
+       B3_MFMA(Ah, 1, Bh, 3);
+       B3_MFMA(Ah, 2, Bh, 0);
+      piece(fill, 3); B3_MFMA(Ah, 2, Bh, 1);
+       B3_MFMA(Ah, 2, Bh, 2);
+       B3_MFMA(Ah, 2, Bh, 3);
+      piece(fill, 4); B3_MFMA(Ah, 3, Bh, 0);
+       B3_MFMA(Ah, 3, Bh, 1);
+       B3_MFMA(Ah, 3, Bh, 2);
+      piece(fill, 5); B3_MFMA(Ah, 3, Bh, 3);
+       B3_MFMA(Ah, 0, Bl, 0);
+       B3_MFMA(Ah, 0, Bl, 1);
+      piece(fill, 6); B3_MFMA(Ah, 0, Bl, 2);
+       B3_MFMA(Ah, 0, Bl, 3);
+       B3_MFMA(Ah, 1, Bl, 0);
+      piece(fill, 7); B3_MFMA(Ah, 1, Bl, 1);
+       B3_MFMA(Ah, 1, Bl, 2);
+       B3_MFMA(Ah, 1, Bl, 3);
+      piece(fill, 8); B3_MFMA(Ah, 2, Bl, 0);
+       B3_MFMA(Ah, 2, Bl, 1);
+       B3_MFMA(Ah, 2, Bl, 2);
+      piece(fill, 9); B3_MFMA(Ah, 2, Bl, 3);
+       B3_MFMA(Ah, 3, Bl, 0);
+       B3_MFMA(Ah, 3, Bl, 1);
+      piece(fill, 10); B3_MFMA(Ah, 3, Bl, 2);
+       B3_MFMA(Ah, 3, Bl, 3);
+       B3_MFMA(Al, 0, Bh, 0);
+      piece(fill, 11); B3_MFMA(Al, 0, Bh, 1);
+       B3_MFMA(Al, 0, Bh, 2);
+       B3_MFMA(Al, 0, Bh, 3);
+      prepA(); B3_MFMA(Al, 1, Bh, 0);
+       B3_MFMA(Al, 1, Bh, 1);
+      prepB(0); B3_MFMA(Al, 1, Bh, 2);
+       B3_MFMA(Al, 1, Bh, 3);
+      prepB(1); B3_MFMA(Al, 2, Bh, 0);
+       B3_MFMA(Al, 2, Bh, 1);
+       B3_MFMA(Al, 2, Bh, 2);
+       B3_MFMA(Al, 2, Bh, 3);
+       B3_MFMA(Al, 3, Bh, 0);
+       B3_MFMA(Al, 3, Bh, 1);
+       B3_MFMA(Al, 3, Bh, 2);
+       B3_MFMA(Al, 3, Bh, 3);
+      T_READ(Al[0], aa_[0], 2 * PLANE); B3_MFMA(Ah, 0, Bm, 0);
+      T_READ(Al[1], aa_[1], 2 * PLANE); B3_MFMA(Ah, 0, Bm, 1);
+      T_READ(Al[2], aa_[2], 2 * PLANE); B3_MFMA(Ah, 0, Bm, 2);
+      T_READ(Al[3], aa_[3], 2 * PLANE); B3_MFMA(Ah, 0, Bm, 3);
+      T_READ(Bl[0], bb_[0], 2 * PLANE); B3_MFMA(Ah, 1, Bm, 0);
+      T_READ(Bl[1], bb_[1], 2 * PLANE); B3_MFMA(Ah, 1, Bm, 1);
+      T_READ(Bl[2], bb_[2], 2 * PLANE); B3_MFMA(Ah, 1, Bm, 2);
+      T_READ(Bl[3], bb_[3], 2 * PLANE); B3_MFMA(Ah, 1, Bm, 3);
+       B3_MFMA(Ah, 2, Bm, 0);
+       B3_MFMA(Ah, 2, Bm, 1);
+       B3_MFMA(Ah, 2, Bm, 2);
+       B3_MFMA(Ah, 2, Bm, 3);
+       B3_MFMA(Ah, 3, Bm, 0);
+       B3_MFMA(Ah, 3, Bm, 1);
+       B3_MFMA(Ah, 3, Bm, 2);
+       B3_MFMA(Ah, 3, Bm, 3);
+      T_READ(Ah[0], aa_[0], 0 * PLANE); B3_MFMA(Am, 0, Bh, 0);
+      T_READ(Ah[1], aa_[1], 0 * PLANE); B3_MFMA(Am, 0, Bh, 1);
+      T_READ(Ah[2], aa_[2], 0 * PLANE); B3_MFMA(Am, 0, Bh, 2);
+      T_READ(Ah[3], aa_[3], 0 * PLANE); B3_MFMA(Am, 0, Bh, 3);
+       B3_MFMA(Am, 1, Bh, 0);
+       B3_MFMA(Am, 1, Bh, 1);
+       B3_MFMA(Am, 1, Bh, 2);
+       B3_MFMA(Am, 1, Bh, 3);
+       B3_MFMA(Am, 2, Bh, 0);
+       B3_MFMA(Am, 2, Bh, 1);
+       B3_MFMA(Am, 2, Bh, 2);
+       B3_MFMA(Am, 2, Bh, 3);
+       B3_MFMA(Am, 3, Bh, 0);
+       B3_MFMA(Am, 3, Bh, 1);
+       B3_MFMA(Am, 3, Bh, 2);
+       B3_MFMA(Am, 3, Bh, 3);
+      T_READ(Bh[0], bb_[0], 0 * PLANE); B3_MFMA(Am, 0, Bm, 0);
+      T_READ(Bh[1], bb_[1], 0 * PLANE); B3_MFMA(Am, 0, Bm, 1);
+      T_READ(Bh[2], bb_[2], 0 * PLANE); B3_MFMA(Am, 0, Bm, 2);
+      T_READ(Bh[3], bb_[3], 0 * PLANE); B3_MFMA(Am, 0, Bm, 3);
+      T_READ(Am[0], aa_[0], 1 * PLANE); B3_MFMA(Am, 1, Bm, 0);
+       B3_MFMA(Am, 1, Bm, 1);
+       B3_MFMA(Am, 1, Bm, 2);
+       B3_MFMA(Am, 1, Bm, 3);
+      T_READ(Am[1], aa_[1], 1 * PLANE); B3_MFMA(Am, 2, Bm, 0);
+       B3_MFMA(Am, 2, Bm, 1);
+       B3_MFMA(Am, 2, Bm, 2);
+       B3_MFMA(Am, 2, Bm, 3);
+      T_READ(Am[2], aa_[2], 1 * PLANE); B3_MFMA(Am, 3, Bm, 0);
+       B3_MFMA(Am, 3, Bm, 1);
+       B3_MFMA(Am, 3, Bm, 2);
+       B3_MFMA(Am, 3, Bm, 3);
+      T_READ(Am[3], aa_[3], 1 * PLANE);
+      T_READ(Bm[0], bb_[0], 1 * PLANE);
+      T_READ(Bm[1], bb_[1], 1 * PLANE);
+      T_READ(Bm[2], bb_[2], 1 * PLANE);
+      T_READ(Bm[3], bb_[3], 1 * PLANE);
+      nxt = nxt == 2 ? 0 : nxt + 1;
+      fill = fill == 2 ? 0 : fill + 1;
+    }
+  }
+#undef T_READ
+#undef B3_MFMA
+
+  float* cout = p.C + (long long)split * p.c_split_stride;
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      const int col = n0 + wn * 128 + u * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 128 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < p.M && col < p.N) cout[(long long)row * p.ldc + col] = acc[t][u][r];
+      }
+    }
+}
+
+// out[i] = sum_s slab[s][i]  (fixed order: deterministic)
+__global__ void b3_reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n4, int splits, long long stride4) {
+  const f32x4* s = (const f32x4*)slabs;
+  f32x4* o = (f32x4*)out;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 a = s[i];
+    for (int k = 1; k < splits; ++k) a += s[i + k * stride4];
+    o[i] = a;
+  }
+}
+
 const float* zero_page_b3() {
   static const float* z[64] = {};
   int dev = 0;
@@ -767,4 +1080,67 @@ extern "C" int catseg_conv2d_bwd_data_bf16x3(const catseg_conv_desc* d, const vo
   a.H = d->Ho; a.W = d->Wo; a.Ho = d->H; a.Wo = d->W; a.kw = d->kw; a.stride = 1; a.pad = d->pad; a.dil = d->dil;
   a.sign = -1; a.accumulate = accumulate;
   return run_b3(a, (hipStream_t)stream);
+}
+
+namespace {
+int b3t_splits(int tiles, long long P) {
+  int best = 1;
+  double best_fill = 0.0;
+  for (int sp = 1; sp <= 64; ++sp) {
+    if (P / sp < 2048 && sp > 1) break;                 // at least 128 K-steps per block
+    const double rounds = (double)tiles * sp / 256.0;
+    const double fill = rounds / (double)(long long)(rounds + 0.999999);
+    if (fill > best_fill + 0.01) { best_fill = fill; best = sp; }
+  }
+  return best;
+}
+}  // namespace
+
+// workspace: split-reduction slabs (only when more than one split is planned)
+extern "C" size_t catseg_conv2d_bwd_weight_bf16x3_workspace(const catseg_conv_desc* d) {
+  if (!d) return 0;
+  const long long P = (long long)d->B * d->Ho * d->Wo;
+  const int N = d->kh * d->kw * d->Cin;
+  const int tiles = ((d->Cout + 255) / 256) * ((N + 255) / 256);
+  const int sp = b3t_splits(tiles, P);
+  return sp > 1 ? cs_align_up((size_t)sp * d->Cout * N * 4, 256) : 0;
+}
+
+// dw[o][ky][kx][c] = sum_p dy[p][o] x[pix(p,ky,kx)][c] from pre-split planes: dy_planes = catseg_split3 of dy (C = Cout),
+// x_planes = catseg_split3 of x (C = Cin, Cin % 8 == 0)
+extern "C" int catseg_conv2d_bwd_weight_bf16x3(const catseg_conv_desc* d, const void* x_planes, const void* dy_planes, float* dw,
+                                               void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(d && !d->stem4 && d->groups <= 1 && d->Cin % 8 == 0, "conv bwd_weight bf16x3: dense, Cin % 8 == 0");
+  CS_REQUIRE(cs_aligned16(x_planes) && cs_aligned16(dy_planes) && cs_aligned16(dw), "conv bwd_weight bf16x3: alignment");
+  CS_REQUIRE((long long)d->B * d->H * d->W * d->Cin < (1ll << 31), "conv bwd_weight bf16x3: 32-bit offsets");
+  const size_t need = catseg_conv2d_bwd_weight_bf16x3_workspace(d);
+  if (workspace_bytes < need || (need && !workspace)) {
+    catseg_set_error("conv bwd_weight bf16x3: workspace %zu < %zu", workspace_bytes, need);
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  B3TArgs a = {};
+  a.P = d->B * d->Ho * d->Wo;
+  a.M = d->Cout; a.Cin = d->Cin; a.taps = d->kh * d->kw; a.N = a.taps * d->Cin;
+  a.ldo = (d->Cout + 7) & ~7; a.dy = (const u16*)dy_planes; a.dy_plane = (long long)a.P * a.ldo;
+  a.ldx = d->Cin; a.x = (const u16*)x_planes; a.x_plane = (long long)d->B * d->H * d->W * d->Cin;
+  a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+  const int img = d->Ho * d->Wo;
+  a.step_b = 16 / img; a.step_qy = (16 % img) / d->Wo; a.step_rx = (16 % img) % d->Wo;
+  a.tilesM = (a.M + 255) / 256; a.tilesN = (a.N + 255) / 256;
+  const int sp0 = b3t_splits(a.tilesM * a.tilesN, a.P);
+  a.rows_per_split = (int)((((long long)a.P + sp0 - 1) / sp0 + 15) / 16 * 16);
+  const int sp = (a.P + a.rows_per_split - 1) / a.rows_per_split;
+  a.ldc = a.N; a.c_split_stride = (long long)a.M * a.N;
+  a.C = sp > 1 ? (float*)workspace : dw;
+  a.zero = zero_page_b3();
+  hipLaunchKernelGGL(igemm_b3t_kernel, dim3(a.tilesM * a.tilesN, 1, sp), dim3(256), 0, st, a);
+  CS_LAUNCH_CHECK();
+  if (sp > 1) {
+    const long long n4 = (long long)a.M * a.N / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(b3_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n4, sp, n4);
+    CS_LAUNCH_CHECK();
+  }
+  return CATSEG_OK;
 }

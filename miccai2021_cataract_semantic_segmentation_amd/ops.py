@@ -97,7 +97,9 @@ PRECISION = _os.environ.get("CATSEG_PRECISION", "bf16x3")
 _b3_cache = {"key": None, "x": None, "planes": None}
 # thresholds of the layer selection (tests lower them to push small layers through the split-precision kernels)
 B3_MIN_TAPS, B3_MIN_K, B3_MIN_N, B3_MIN_TILES = 2, 2048, 192, 192
-B3_OPS = ("fwd", "dgrad")
+B3_OPS = ("fwd", "dgrad", "wgrad")
+B3_MIN_WGRAD_ROWS = 32768
+_b3_cache_dy = {"key": None, "x": None, "planes": None}
 
 
 def _b3_eligible(rows, ncols, taps, cred, stride_ok=True):
@@ -116,8 +118,19 @@ def _split3_cached(x):
     return planes
 
 
+def _split3_cached_dy(dy):
+    """the dy planes of a layer are used twice in its backward (backward-weight, then backward-data)"""
+    key = (dy.data_ptr(), tuple(dy.shape), ld_of(dy))
+    if _b3_cache_dy["key"] == key and _b3_cache_dy["x"] is dy:
+        return _b3_cache_dy["planes"]
+    planes = split3(dy)
+    _b3_cache_dy.update(key=key, x=dy, planes=planes)
+    return planes
+
+
 def release_b3_cache():
     _b3_cache.update(key=None, x=None, planes=None)
+    _b3_cache_dy.update(key=None, x=None, planes=None)
 
 
 def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False, groups=1):
@@ -149,7 +162,7 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
     if "dgrad" in B3_OPS and _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1):
         d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         with _Timed("dgrad", flops):
-            dyp = split3(dy)
+            dyp = _split3_cached_dy(dy)
             wtp = split3_weight_t(w)
             check(lib.catseg_conv2d_bwd_data_bf16x3(ctypes.byref(d), ptr(dyp), ptr(wtp), ptr(out), 1 if accumulate else 0, stream()))
         return out
@@ -161,10 +174,23 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
 
 def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=False):
     """dw: destination tensor (physical OHWI, or packed [O][7][8][4] for the stem)."""
-    d = make_desc(x.shape, ld_of(x), dy.shape[-1], ld_of(dy), kh, kw, stride, pad, dil, stem4)
+    Cout, Cin = dy.shape[-1], x.shape[-1]
+    flops = 2.0 * rows_of(dy) * Cout * (3 if stem4 else Cin) * kh * kw
+    if ("wgrad" in B3_OPS and not stem4 and PRECISION == "bf16x3" and Cin % 8 == 0 and B3_MIN_TAPS <= kh * kw and kh * kw * Cin >= B3_MIN_K
+            and Cout >= B3_MIN_N and rows_of(dy) >= B3_MIN_WGRAD_ROWS):
+        d = make_desc(x.shape, Cin, Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
+        ws = workspace(lib.catseg_conv2d_bwd_weight_bf16x3_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
+        with _Timed("wgrad", flops):
+            xp = _split3_cached(x)
+            dyp = _split3_cached_dy(dy)
+            check(lib.catseg_conv2d_bwd_weight_bf16x3(ctypes.byref(d), ptr(xp), ptr(dyp), ptr(dw), ptr(ws), ws.numel(), stream()))
+            if dbias is not None:
+                check(lib.catseg_bias_grad(ptr(dy), ld_of(dy), rows_of(dy), Cout, ptr(dbias), ptr(ws), ws.numel(), stream()))
+        return dw
+    d = make_desc(x.shape, ld_of(x), Cout, ld_of(dy), kh, kw, stride, pad, dil, stem4)
     need = lib.catseg_conv2d_bwd_weight_workspace(ctypes.byref(d))
     ws = workspace(need, x.device)
-    with _Timed("wgrad", 2.0 * rows_of(dy) * dy.shape[-1] * (3 if stem4 else x.shape[-1]) * kh * kw):
+    with _Timed("wgrad", flops):
         check(lib.catseg_conv2d_bwd_weight(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), stream()))
     return dw
 

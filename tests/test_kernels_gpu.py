@@ -465,6 +465,39 @@ def test_conv_bf16x3_split_precision(ops, case, tile):
         _lib.lib.catseg_debug_set_b3_tile(0)
 
 
+B3_WGRAD_CASES = B3_CASES + [(2, 70, 90, 64, 64, 3, 1, 1, 1), (1, 68, 120, 720, 512, 3, 1, 1, 1), (3, 40, 40, 128, 300, 3, 2, 1, 1)]
+
+
+@pytest.mark.parametrize("case", B3_WGRAD_CASES)
+def test_conv_bwd_weight_bf16x3(ops, case):
+    """catseg_conv2d_bwd_weight_bf16x3 (pixel-major operands, ds_read_b64_tr_b16 transposed fragments, split reduction) and
+    catseg_bias_grad against an fp64 F.conv2d weight gradient"""
+    import ctypes
+    from miccai2021_cataract_semantic_segmentation_amd import _lib
+    B, H, W, Cin, Cout, k, s, p, d = case
+    if Cin % 8:
+        pytest.skip("Cin % 8 != 0 stays on the fp32 kernel")
+    g = torch.Generator().manual_seed(sum(case) + 2)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(1, Cin, 1, 1, generator=g))
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.1).double().requires_grad_()
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double(), w, b, s, p, d)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.double())
+    xd = nhwc(x)
+    gyd = ops.new_act(B, y.shape[2], y.shape[3], Cout, xd.device, zero=True)
+    gyd.copy_(nhwc(gy))
+    dw = torch.empty((Cout, Cin, k, k), device="cuda").contiguous(memory_format=torch.channels_last)
+    db = torch.empty(Cout, device="cuda")
+    desc = ops.make_desc(xd.shape, Cin, Cout, (Cout + 7) // 8 * 8, k, k, s, p, d)
+    ws = ops.workspace(_lib.lib.catseg_conv2d_bwd_weight_bf16x3_workspace(ctypes.byref(desc)) + 256 * Cout * 4, xd.device)
+    _lib.check(_lib.lib.catseg_conv2d_bwd_weight_bf16x3(ctypes.byref(desc), ops.ptr(ops.split3(xd)), ops.ptr(ops.split3(gyd)), ops.ptr(dw),
+                                                        ops.ptr(ws), ws.numel(), ops.stream()))
+    _lib.check(_lib.lib.catseg_bias_grad(ops.ptr(gyd), ops.ld_of(gyd), ops.rows_of(gyd), Cout, ops.ptr(db), ops.ptr(ws), ws.numel(), ops.stream()))
+    close(dw.cpu(), w.grad, atol=0, rtol=3e-5)
+    close(db, b.grad, atol=0, rtol=3e-5)
+
+
 def test_split3_is_exact(ops):
     """x == h + m + l exactly (to the last bit) over 30 orders of magnitude (values below ~1e-33, whose third piece would be a
     bf16 subnormal, are split with an absolute error < 1e-38: irrelevant), pad columns are zero"""

@@ -59,6 +59,20 @@ SHAPES = [("head 3x3 720>512 @136x240", 8, 136, 240, 720, 512, 3, 1, 1, 1), ("oc
           ("r50 l3 1x1 256>1024", 8, 68, 120, 256, 1024, 1, 1, 0, 1)]
 
 
+def _wgrad32(x, dy, dw, k, s, p, d):
+    import ctypes
+    desc = ops.make_desc(x.shape, ops.ld_of(x), dy.shape[-1], ops.ld_of(dy), k, k, s, p, d)
+    ws = ops.workspace(_lib.lib.catseg_conv2d_bwd_weight_workspace(ctypes.byref(desc)), x.device)
+    _lib.check(_lib.lib.catseg_conv2d_bwd_weight(ctypes.byref(desc), ops.ptr(x), ops.ptr(dy), ops.ptr(dw), 0, ops.ptr(ws), ws.numel(), ops.stream()))
+
+
+def _wgradb3(x, dy, dw, xp, dyp, Co, Ci, k, s, p, d):
+    import ctypes
+    desc = ops.make_desc(x.shape, Ci, Co, (Co + 7) // 8 * 8, k, k, s, p, d)
+    ws = ops.workspace(_lib.lib.catseg_conv2d_bwd_weight_bf16x3_workspace(ctypes.byref(desc)) + 1024, x.device)
+    _lib.check(_lib.lib.catseg_conv2d_bwd_weight_bf16x3(ctypes.byref(desc), ops.ptr(xp), ops.ptr(dyp), ops.ptr(dw), ops.ptr(ws), ws.numel(), ops.stream()))
+
+
 def speed(tiles):
     print("== speed (TFLOP/s-equivalent = 2MNK / time) ==")
     for name, B, H, W, Ci, Co, k, s, p, d in SHAPES:
@@ -72,6 +86,9 @@ def speed(tiles):
         td32 = timeit(lambda: ops.conv_bwd_data(dy, w, tuple(x.shape), k, k, s, p, d, out=dx))
         xp, wp = ops.split3(x), ops.split3_weight(w)
         dyp, wtp = ops.split3(dy), ops.split3_weight_t(w)
+        dw = torch.empty_like(w)
+        tw32 = timeit(lambda: ops.conv_bwd_weight.__wrapped__(x, dy, dw, None, k, k, s, p, d) if hasattr(ops.conv_bwd_weight, "__wrapped__") else _wgrad32(x, dy, dw, k, s, p, d))
+        twb = timeit(lambda: _wgradb3(x, dy, dw, xp, dyp, Co, Ci, k, s, p, d))
         tsx = timeit(lambda: ops.split3(x))
         tsw = timeit(lambda: ops.split3_weight(w))
         res = []
@@ -81,8 +98,8 @@ def speed(tiles):
             tdb = timeit(lambda: ops.conv_bwd_data_b3(dyp, wtp, tuple(x.shape), Co, k, k, s, p, d, out=dx))
             res.append("t%d: fwd %.3f ms %.0f TF, dgrad %.3f ms %.0f TF" % (t, tb, fl / tb / 1e9, tdb, fl / tdb / 1e9))
         _lib.lib.catseg_debug_set_b3_tile(0)
-        print("%-28s %6.1f GF | fp32 fwd %.3f ms %.0f TF dgrad %.3f ms %.0f TF | split x %.3f w %.3f ms | %s"
-              % (name, fl / 1e9, t32, fl / t32 / 1e9, td32, fl / td32 / 1e9, tsx, tsw, " ; ".join(res)), flush=True)
+        print("%-28s %6.1f GF | fp32 fwd %.3f ms %.0f TF dgrad %.3f ms %.0f TF wgrad %.3f ms %.0f TF | b3 wgrad %.3f ms %.0f TF | split x %.3f w %.3f ms | %s"
+              % (name, fl / 1e9, t32, fl / t32 / 1e9, td32, fl / td32 / 1e9, tw32, fl / tw32 / 1e9, twb, fl / twb / 1e9, tsx, tsw, " ; ".join(res)), flush=True)
 
 
 if __name__ == "__main__":
