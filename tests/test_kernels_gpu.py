@@ -491,7 +491,8 @@ def test_conv_bwd_weight_bf16x3(ops, case):
     db = torch.empty(Cout, device="cuda")
     desc = ops.make_desc(xd.shape, Cin, Cout, (Cout + 7) // 8 * 8, k, k, s, p, d)
     ws = ops.workspace(_lib.lib.catseg_conv2d_bwd_weight_bf16x3_workspace(ctypes.byref(desc)) + 256 * Cout * 4, xd.device)
-    _lib.check(_lib.lib.catseg_conv2d_bwd_weight_bf16x3(ctypes.byref(desc), ops.ptr(ops.split3(xd)), ops.ptr(ops.split3(gyd)), ops.ptr(dw),
+    xp, dyp = ops.split3(xd), ops.split3(gyd)      # (keep both alive: the planes are only referenced by raw pointers)
+    _lib.check(_lib.lib.catseg_conv2d_bwd_weight_bf16x3(ctypes.byref(desc), ops.ptr(xp), ops.ptr(dyp), ops.ptr(dw),
                                                         ops.ptr(ws), ws.numel(), ops.stream()))
     _lib.check(_lib.lib.catseg_bias_grad(ops.ptr(gyd), ops.ld_of(gyd), ops.rows_of(gyd), Cout, ops.ptr(db), ops.ptr(ws), ws.numel(), ops.stream()))
     close(dw.cpu(), w.grad, atol=0, rtol=3e-5)
