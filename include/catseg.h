@@ -54,6 +54,12 @@ typedef struct {
  * [Cout, zero_to) of y are written as zeros (zero_to <= ldy, 0 = none). */
 int catseg_conv2d_fwd(const catseg_conv_desc* d, const float* x, const float* w, const float* bias,
                       float* y, int zero_to, catseg_stream_t stream);
+/* training forward of conv -> BatchNorm (models/OCR.py:72-76 etc.): catseg_conv2d_fwd whose epilogue also writes per-(M-tile,
+ * channel) BatchNorm partials [n_tiles][3][Cout] (K, s1, s2) for catseg_bn_finalize -- no separate statistics pass over y.
+ * *tile_rows == 0 on return: this layer's tile form has no fused statistics; use catseg_bn_train_stats. */
+int catseg_conv2d_fwd_bnstats(const catseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                              int zero_to, float* bn_part, size_t bn_part_floats, int* tile_rows, int* n_tiles,
+                              catseg_stream_t stream);
 /* inference: y = act(conv(x, w) + bias (+ residual)), act = relu if relu != 0, in one kernel.  With
  * catseg_fold_bn this is Conv2d + eval-mode BatchNorm2d + residual add + ReLU of a ResNet / UPerNet block. */
 int catseg_conv2d_fwd_fused(const catseg_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -95,6 +101,9 @@ int catseg_split3(const float* x, int ld, long long rows, int C, void* planes, c
 int catseg_split3_weight_t(const float* w, int O, int taps, int Cin, void* planes, catseg_stream_t stream);
 int catseg_conv2d_fwd_bf16x3(const catseg_conv_desc* d, const void* x_planes, const void* w_planes, const float* bias,
                              float* y, int zero_to, catseg_stream_t stream);
+int catseg_conv2d_fwd_bf16x3_bnstats(const catseg_conv_desc* d, const void* x_planes, const void* w_planes, const float* bias,
+                                     float* y, int zero_to, float* bn_part, size_t bn_part_floats, int* tile_rows, int* n_tiles,
+                                     catseg_stream_t stream);
 int catseg_conv2d_bwd_data_bf16x3(const catseg_conv_desc* d, const void* dy_planes, const void* wt_planes, float* dx,
                                   int accumulate, catseg_stream_t stream);
 /* dw = backward-weight from pre-split planes (x: C = Cin, dy: C = Cout); workspace = split-reduction slabs */
@@ -116,6 +125,11 @@ size_t catseg_bn_workspace(long long rows, int C);
 int catseg_bn_train_stats(const float* y, long long rows, int C, int ldy, const float* gamma, float eps,
                           float momentum, float* running_mean, float* running_var, float* stats_out,
                           float* scale, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
+/* merge of [n_blocks][3][C] partials (per row block: K, sum(y - K), sum((y - K)^2)) into the batch statistics: the second half
+ * of catseg_bn_train_stats, fed by the convolution epilogues above */
+int catseg_bn_finalize(const float* partials, int n_blocks, long long rows_per_block, long long rows, int C, const float* gamma,
+                       float eps, float momentum, float* running_mean, float* running_var, float* stats_out, float* scale,
+                       catseg_stream_t stream);
 /* eval mode: scale = gamma / sqrt(running_var + eps) (use with mean = running_mean) */
 int catseg_bn_eval_scale(int C, const float* gamma, const float* running_var, float eps, float* scale,
                          catseg_stream_t stream);

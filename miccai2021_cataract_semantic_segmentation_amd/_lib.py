@@ -31,6 +31,9 @@ _SIGS = {
     "catseg_last_error": (C.c_char_p, []),
     "catseg_version": (I, []),
     "catseg_conv2d_fwd": (I, [P, P, P, P, P, I, P]),
+    "catseg_conv2d_fwd_bnstats": (I, [P, P, P, P, P, I, P, SZ, P, P, P]),
+    "catseg_conv2d_fwd_bf16x3_bnstats": (I, [P, P, P, P, P, I, P, SZ, P, P, P]),
+    "catseg_bn_finalize": (I, [P, I, L, L, I, P, F, F, P, P, P, P, P]),
     "catseg_conv2d_fwd_fused": (I, [P, P, P, P, P, I, I, P, P]),
     "catseg_fold_bn": (I, [P, P, P, P, P, P, F, I, I, P, P, P]),
     "catseg_conv2d_bwd_data": (I, [P, P, P, P, I, P]),

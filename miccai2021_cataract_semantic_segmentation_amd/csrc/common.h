@@ -43,3 +43,87 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+
+// ---- BatchNorm batch statistics in the convolution epilogue --------------------------------------------------------------
+// Per (M-tile, channel) partials (K = tile mean, s1 = sum(v - K), s2 = sum((v - K)^2)) computed from the accumulator tile
+// while it is still in registers: the separate statistics pass over the convolution output (one full HBM read of y)
+// disappears; bn_finalize merges the tiles' partials exactly as it merges the row-block partials of bn_partial_kernel
+// (fp64 Chan merge, fixed order: deterministic).
+// A lane owns NS column slots (tile-local column col[s]) with R values each; lanes l ^ 32 (and l ^ 16 for the 16x16 MFMA map)
+// hold other rows of the same columns, as do the WM waves stacked along M.  Must be called by every thread of the block.
+//   lds: >= 2 * WM * tile_cols floats (the K-loop's buffers; the caller has synchronised the block after its last LDS read)
+//   part: this tile's 3 x C partial rows (K, s1, s2), indexed by global column gcol0 + col
+template <int NS, int R, int WM, bool X16, class Val, class Valid>
+__device__ __forceinline__ void cs_tile_bn_partials(float* lds, int tile_cols, const int (&col)[NS], bool writer_lane, int wave_m, int nvalid,
+                                                    Val val, Valid valid, float* part, int C, int gcol0) {
+  float s[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) a += valid(i) ? val(j, i) : 0.f;
+    a += __shfl_xor(a, 32, 64);
+    if (X16) a += __shfl_xor(a, 16, 64);
+    s[j] = a;
+  }
+  if (writer_lane) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) lds[wave_m * tile_cols + col[j]] = s[j];
+  }
+  __syncthreads();
+  float mean[NS];
+  const float inv = 1.f / (float)nvalid;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) t += lds[w * tile_cols + col[j]];
+    mean[j] = t * inv;
+  }
+  __syncthreads();
+  float d1[NS], d2[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const float d = valid(i) ? val(j, i) - mean[j] : 0.f;
+      a += d;
+      b += d * d;
+    }
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 32, 64);
+    if (X16) {
+      a += __shfl_xor(a, 16, 64);
+      b += __shfl_xor(b, 16, 64);
+    }
+    d1[j] = a;
+    d2[j] = b;
+  }
+  if (writer_lane) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      lds[wave_m * tile_cols + col[j]] = d1[j];
+      lds[(WM + wave_m) * tile_cols + col[j]] = d2[j];
+    }
+  }
+  __syncthreads();
+  if (writer_lane && wave_m == 0) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int gc = gcol0 + col[j];
+      if (gc < C) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          a += lds[w * tile_cols + col[j]];
+          b += lds[(WM + w) * tile_cols + col[j]];
+        }
+        part[gc] = mean[j];
+        part[C + gc] = a;
+        part[2 * C + gc] = b;
+      }
+    }
+  }
+}

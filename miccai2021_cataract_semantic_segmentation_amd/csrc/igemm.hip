@@ -76,6 +76,7 @@ struct IgemmArgs {
   const float* residual;
   int ldr, relu;
   const float* zero;  // 256-byte zero page (kernel argument: no GOT load / lgkmcnt wait inside the K loop)
+  float* bn_part;     // L_NT: per (M-tile, channel) BatchNorm partials [tilesM][3][N] (K, s1, s2), or nullptr
 };
 
 __device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
@@ -542,6 +543,39 @@ __global__ __launch_bounds__(256, igemm_min_waves(MI, NI, NARROW)) void igemm_f3
       }
     }
   };
+  // BatchNorm batch statistics of this tile (training forward): see cs_tile_bn_partials in common.h
+  if (LAYOUT == L_NT && (NARROW == 0 || NARROW == 1) && p.bn_part != nullptr) {
+    __syncthreads();   // every wave has left the K loop: its LDS buffers are free
+    const int nvalid = min(TILE_M, p.M - m0);
+    float* part = p.bn_part + (long long)tile_m * 3 * p.N;
+    if constexpr (NARROW == 0) {
+      int colv[NI];
+      float bv[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        colv[ni] = wn * 32 * NI + ni * 32 + l31;
+        bv[ni] = (p.bias != nullptr && n0 + colv[ni] < p.N) ? p.bias[n0 + colv[ni]] : 0.f;
+      }
+      const int rbase = m0 + wm * 32 * MI + 4 * h;
+      cs_tile_bn_partials<NI, MI * 16, 2, false>(
+          smem, TILE_N, colv, h == 0, wm, nvalid,
+          [&](int j, int i) { return acc[NARROW ? 0 : (i >> 4)][NARROW ? 0 : j][i & 15] + bv[j]; },
+          [&](int i) { return rbase + (i >> 4) * 32 + (i & 3) + 8 * ((i & 15) >> 2) < p.M; }, part, p.N, n0);
+    } else {
+      int colv[TN16];
+      float bv[TN16];
+#pragma unroll
+      for (int u = 0; u < TN16; ++u) {
+        colv[u] = u * 16 + i16;
+        bv[u] = (p.bias != nullptr && n0 + colv[u] < p.N) ? p.bias[n0 + colv[u]] : 0.f;
+      }
+      const int rbase = m0 + wrow16 + 4 * g16;
+      cs_tile_bn_partials<TN16, TM16 * 4, 4, true>(
+          smem, TILE_N, colv, g16 == 0, wave, nvalid,
+          [&](int j, int i) { return acc16[NARROW ? (i >> 2) : 0][NARROW ? j : 0][i & 3] + bv[j]; },
+          [&](int i) { return rbase + (i >> 2) * 16 + (i & 3) < p.M; }, part, p.N, n0);
+    }
+  }
   if constexpr (NARROW != 0) {
 #pragma unroll
     for (int t = 0; t < TM16; ++t) {
@@ -853,6 +887,38 @@ extern "C" int catseg_conv2d_fwd(const catseg_conv_desc* d, const float* x, cons
     return launch_igemm<L_NT>(a, d->groups, 1, (hipStream_t)stream);
   }
   return launch_igemm<L_NT>(a, 1, 1, (hipStream_t)stream);
+}
+
+// Training forward of conv -> BatchNorm: as catseg_conv2d_fwd, and the kernel's epilogue also writes the per-(M-tile, channel)
+// BatchNorm partials for catseg_bn_finalize (no separate statistics pass over y).  *tile_rows / *n_tiles describe the
+// partials ([n_tiles][3][Cout] floats in bn_part); *tile_rows == 0 means this layer's tile form has no fused statistics
+// (grouped / 16-32 wide forms): the convolution has run, the caller uses catseg_bn_train_stats instead.
+extern "C" int catseg_conv2d_fwd_bnstats(const catseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                                         int zero_to, float* bn_part, size_t bn_part_floats, int* tile_rows, int* n_tiles,
+                                         catseg_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  CS_REQUIRE(cs_aligned16(x) && cs_aligned16(w) && cs_aligned16(y), "conv fwd: pointers must be 16-byte aligned");
+  CS_REQUIRE(zero_to <= d->ldy && tile_rows && n_tiles, "conv fwd bnstats: bad args");
+  *tile_rows = 0; *n_tiles = 0;
+  if (d->groups > 1) return catseg_conv2d_fwd(d, x, w, bias, y, zero_to, stream);
+  IgemmArgs a = {};
+  a.g = fwd_geo(d, x);
+  a.other = w; a.C = y; a.bias = bias;
+  a.M = a.g.rows; a.N = d->Cout; a.ldc = d->ldy;
+  if (d->stem4) { a.taps = d->kh; a.Cred = 32; a.ldo = d->kh * 32; a.tap_stride = 32; }
+  else { a.taps = d->kh * d->kw; a.Cred = d->Cin; a.ldo = a.taps * d->Cin; a.tap_stride = d->Cin; }
+  a.Cred_b = a.Cred; a.zero_to = zero_to; a.accumulate = 0;
+  if (!d->stem4) fill_taps(a, d->kh, d->kw, d->dil, +1, d->stride, -d->pad);
+  const int ncols = zero_to > a.N ? zero_to : a.N;
+  const TilePlan pl = plan_tiles(L_NT, a.M, ncols, 1, a.g.rows);
+  if (pl.narrow == 0 || pl.narrow == 1) {
+    const int tm = 64 * pl.mi, nt = (a.M + tm - 1) / tm;
+    if (bn_part != nullptr && (size_t)nt * 3 * d->Cout <= bn_part_floats) {
+      a.bn_part = bn_part;
+      *tile_rows = tm; *n_tiles = nt;
+    }
+  }
+  return launch_igemm<L_NT>(a, 1, 1, (hipStream_t)stream, &pl);
 }
 
 // Inference: y = act(conv(x, w) + bias (+ residual)) in ONE kernel — Conv2d + eval-mode BatchNorm2d (folded into

@@ -41,6 +41,7 @@ struct B3Args {
   int tilesM, tilesN;
   int zero_to, accumulate;
   const float* zero;
+  float* bn_part;     // per (M-tile, channel) BatchNorm partials [tilesM][3][N], or nullptr
 };
 
 __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
@@ -296,6 +297,21 @@ __global__ __launch_bounds__(512, 2) void igemm_b3_kernel(const B3Args p) {
     }
   }
 
+  if (p.bn_part != nullptr) {   // BatchNorm batch statistics of this tile (common.h: cs_tile_bn_partials)
+    __syncthreads();
+    int colv[TN];
+    float bv[TN];
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      colv[u] = wn * 32 * TN + u * 32 + l31;
+      bv[u] = (p.bias != nullptr && n0 + colv[u] < p.N) ? p.bias[n0 + colv[u]] : 0.f;
+    }
+    const int rbase = m0 + wm * 32 * TM + 4 * h;
+    cs_tile_bn_partials<TN, TM * 16, WGM, false>(
+        (float*)smem, BN, colv, h == 0, wm, min(BM, p.M - m0),
+        [&](int j, int i) { return acc[i >> 4][j][i & 15] + bv[j]; },
+        [&](int i) { return rbase + (i >> 4) * 32 + (i & 3) + 8 * ((i & 15) >> 2) < p.M; }, p.bn_part + (long long)tile_m * 3 * p.N, p.N, n0);
+  }
   // ---- epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
 #pragma unroll
   for (int t = 0; t < TM; ++t)
@@ -622,6 +638,21 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
 #undef B3_READ_PLANE
 #undef B3_MFMA
 
+  if (p.bn_part != nullptr) {   // BatchNorm batch statistics of this tile (common.h: cs_tile_bn_partials)
+    __syncthreads();
+    int colv[TN];
+    float bvv[TN];
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      colv[u] = wn * 128 + u * 32 + l31;
+      bvv[u] = (p.bias != nullptr && n0 + colv[u] < p.N) ? p.bias[n0 + colv[u]] : 0.f;
+    }
+    const int rbase = m0 + wm * 128 + 4 * h;
+    cs_tile_bn_partials<TN, TM * 16, 2, false>(
+        (float*)smem, BN, colv, h == 0, wm, min(BM, p.M - m0),
+        [&](int j, int i) { return acc[i >> 4][j][i & 15] + bvv[j]; },
+        [&](int i) { return rbase + (i >> 4) * 32 + (i & 3) + 8 * ((i & 15) >> 2) < p.M; }, p.bn_part + (long long)tile_m * 3 * p.N, p.N, n0);
+  }
 #pragma unroll
   for (int t = 0; t < TM; ++t)
 #pragma unroll
@@ -1062,6 +1093,29 @@ extern "C" int catseg_conv2d_fwd_bf16x3(const catseg_conv_desc* d, const void* x
   a.M = d->B * d->Ho * d->Wo; a.N = d->Cout; a.Cin = d->Cin; a.taps = d->kh * d->kw;
   a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
   a.sign = 1; a.zero_to = zero_to;
+  return run_b3(a, (hipStream_t)stream);
+}
+
+// as catseg_conv2d_fwd_bf16x3, plus per-(M-tile, channel) BatchNorm partials from the epilogue (see catseg_conv2d_fwd_bnstats)
+extern "C" int catseg_conv2d_fwd_bf16x3_bnstats(const catseg_conv_desc* d, const void* x_planes, const void* w_planes, const float* bias,
+                                                float* y, int zero_to, float* bn_part, size_t bn_part_floats, int* tile_rows, int* n_tiles,
+                                                catseg_stream_t stream) {
+  CS_REQUIRE(d && !d->stem4 && d->groups <= 1 && d->Cin % 8 == 0 && d->kh * d->kw <= 32, "conv fwd bf16x3: needs Cin % 8 == 0, <= 32 taps, dense");
+  CS_REQUIRE(cs_aligned16(x_planes) && cs_aligned16(w_planes) && cs_aligned16(y) && zero_to <= d->ldy && tile_rows && n_tiles, "conv fwd bf16x3: bad args");
+  CS_REQUIRE((long long)d->B * d->H * d->W * d->Cin < (1ll << 31) && (long long)d->Cout * d->kh * d->kw * d->Cin < (1ll << 31), "conv fwd bf16x3: 32-bit offsets");
+  B3Args a = {};
+  a.a = (const u16*)x_planes; a.lda = d->Cin; a.a_plane = (long long)d->B * d->H * d->W * d->Cin;
+  a.w = (const u16*)w_planes; a.ldw = d->kh * d->kw * d->Cin; a.w_plane = (long long)d->Cout * a.ldw;
+  a.C = y; a.ldc = d->ldy; a.bias = bias;
+  a.M = d->B * d->Ho * d->Wo; a.N = d->Cout; a.Cin = d->Cin; a.taps = d->kh * d->kw;
+  a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+  a.sign = 1; a.zero_to = zero_to;
+  const int nt = (a.M + 255) / 256;     // every bf16x3 tile form is 256 rows tall (128 x 256 excepted: never picked by the heuristic)
+  *tile_rows = 0; *n_tiles = 0;
+  if (bn_part != nullptr && (size_t)nt * 3 * d->Cout <= bn_part_floats && pick_b3_tile(zero_to > a.N ? zero_to : a.N) != 3) {
+    a.bn_part = bn_part;
+    *tile_rows = 256; *n_tiles = nt;
+  }
   return run_b3(a, (hipStream_t)stream);
 }
 

@@ -323,6 +323,19 @@ extern "C" int catseg_bn_train_stats(const float* y, long long rows, int C, int 
   return CATSEG_OK;
 }
 
+// the second half of catseg_bn_train_stats on its own: merges [n_blocks][3][C] partials (K, s1, s2) over row blocks of
+// rows_per_block rows (the last one shorter) -- written by catseg_conv2d_fwd_bnstats / _bf16x3_bnstats
+extern "C" int catseg_bn_finalize(const float* partials, int n_blocks, long long rows_per_block, long long rows, int C, const float* gamma,
+                                  float eps, float momentum, float* running_mean, float* running_var, float* stats_out, float* scale,
+                                  catseg_stream_t stream) {
+  CS_REQUIRE(partials && n_blocks > 0 && rows > 0 && C > 0 && (long long)(n_blocks - 1) * rows_per_block < rows &&
+                 (long long)n_blocks * rows_per_block >= rows, "bn finalize: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partials, n_blocks, rows_per_block, rows, C,
+                     gamma, eps, momentum, running_mean, running_var, stats_out, scale);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
 extern "C" int catseg_bn_eval_scale(int C, const float* gamma, const float* running_var, float eps, float* scale,
                                     catseg_stream_t stream) {
   CS_REQUIRE(C > 0, "bn eval: C");

@@ -184,6 +184,7 @@ def image_hw(x):
     return tuple(x.shape[1:3]) if is_nhwc4(x) else tuple(x.shape[-2:])
 
 
+FUSE_BN_STATS = True  # training forward: BatchNorm batch statistics from the convolution epilogue (False: separate statistics pass)
 FUSE_EVAL_BN = True   # eval-mode forward: fold BatchNorm into the conv and fuse bias/residual/ReLU into its epilogue
 
 
@@ -213,12 +214,18 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
         per_out = wk.numel() // Cout
         wf, bf = ops.fold_bn(wk, bias, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps, Cout, per_out)
         return ops.conv_fwd_fused(x_in, wf, bf, residual, relu, Cout, kh, kw, s, p, d, out=out, stem4=conv.stem, groups=conv.groups)
-    y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups)
     if cx.train:
-        stats, scale = ops.bn_train_stats(y, bn.weight.data, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        # batch statistics: per-tile partial sums come out of the convolution's epilogue (no separate pass over y)
+        y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups, bn_stats=FUSE_BN_STATS)
+        y, partials = y if FUSE_BN_STATS else (y, None)
+        if partials is not None:
+            stats, scale = ops.bn_finalize(partials, ops.rows_of(y), Cout, bn.weight.data, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        else:
+            stats, scale = ops.bn_train_stats(y, bn.weight.data, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
         bn._pending_batches += 1
         mean = stats[:Cout]
     else:
+        y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups)
         stats = None
         mean = bn.running_mean
         scale = ops.bn_eval_scale(bn.weight.data, bn.running_var, bn.eps)

@@ -133,23 +133,63 @@ def release_b3_cache():
     _b3_cache_dy.update(key=None, x=None, planes=None)
 
 
-def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False, groups=1):
+_bn_part = {}
+
+
+def _bn_part_buffer(nfloats, device):
+    """grow-only buffer for the per-tile BatchNorm partials a convolution epilogue writes (consumed by the next launch)"""
+    key = (device.type, device.index)
+    buf = _bn_part.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1 << 18), dtype=torch.float32, device=device)
+        _bn_part[key] = buf
+    return buf
+
+
+def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False, groups=1, bn_stats=False):
+    """bn_stats=True: returns (out, partials) where partials = (buffer, n_tiles, tile_rows) are the per-(M-tile, channel)
+    BatchNorm partial sums written by the convolution's epilogue (for bn_finalize), or None if this layer's kernel has none"""
     B, H, W, Cin = x.shape
     Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
     if out is None:
         out = new_act(B, Ho, Wo, Cout, x.device, ld=max(zero_to, (Cout + 3) // 4 * 4))
     flops = 2.0 * B * Ho * Wo * Cout * (3 if stem4 else Cin // groups) * kh * kw
-    if "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(B * Ho * Wo, Cout, kh * kw, Cin):
+    rows = B * Ho * Wo
+    part = tr = nt = None
+    if bn_stats:
+        part = _bn_part_buffer(3 * ((rows + 63) // 64) * Cout, x.device)
+        tr, nt = ctypes.c_int(0), ctypes.c_int(0)
+    if "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(rows, Cout, kh * kw, Cin):
         d = make_desc(x.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
         with _Timed("fwd", flops):
             xp = _split3_cached(x)
             wp = split3_weight(w_ptr_tensor)
-            check(lib.catseg_conv2d_fwd_bf16x3(ctypes.byref(d), ptr(xp), ptr(wp), ptr(bias), ptr(out), zero_to, stream()))
-        return out
-    d = make_desc(x.shape, ld_of(x), Cout, ld_of(out), kh, kw, stride, pad, dil, stem4, groups)
-    with _Timed("fwd", flops):
-        check(lib.catseg_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_ptr_tensor), ptr(bias), ptr(out), zero_to, stream()))
+            if bn_stats:
+                check(lib.catseg_conv2d_fwd_bf16x3_bnstats(ctypes.byref(d), ptr(xp), ptr(wp), ptr(bias), ptr(out), zero_to, ptr(part),
+                                                           part.numel(), ctypes.byref(tr), ctypes.byref(nt), stream()))
+            else:
+                check(lib.catseg_conv2d_fwd_bf16x3(ctypes.byref(d), ptr(xp), ptr(wp), ptr(bias), ptr(out), zero_to, stream()))
+    else:
+        d = make_desc(x.shape, ld_of(x), Cout, ld_of(out), kh, kw, stride, pad, dil, stem4, groups)
+        with _Timed("fwd", flops):
+            if bn_stats:
+                check(lib.catseg_conv2d_fwd_bnstats(ctypes.byref(d), ptr(x), ptr(w_ptr_tensor), ptr(bias), ptr(out), zero_to, ptr(part),
+                                                    part.numel(), ctypes.byref(tr), ctypes.byref(nt), stream()))
+            else:
+                check(lib.catseg_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_ptr_tensor), ptr(bias), ptr(out), zero_to, stream()))
+    if bn_stats:
+        return out, ((part, nt.value, tr.value) if tr.value > 0 else None)
     return out
+
+
+def bn_finalize(partials, rows, C, gamma, eps, momentum, running_mean, running_var):
+    """batch statistics from the convolution epilogue's per-tile partials: (stats [mean(C), invstd(C)], scale)"""
+    part, n_tiles, tile_rows = partials
+    stats = torch.empty(2 * C, dtype=torch.float32, device=part.device)
+    scale = torch.empty(C, dtype=torch.float32, device=part.device)
+    check(lib.catseg_bn_finalize(ptr(part), n_tiles, tile_rows, rows, C, ptr(gamma), eps, momentum, ptr(running_mean), ptr(running_var),
+                                 ptr(stats), ptr(scale), stream()))
+    return stats, scale
 
 
 def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accumulate=False):

@@ -511,3 +511,48 @@ def test_split3_is_exact(ops):
     assert float(parts[:, :, 20:].abs().max()) == 0.0
     s = (parts[0, :, :20].double() + parts[1, :, :20].double() + parts[2, :, :20].double()).float()
     assert torch.equal(s, x)
+
+
+BNSTAT_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad  (fp32 tile forms: 64x64 ... 256x128 and the 48 / 96-wide 16x16x4 forms; bias on)
+    (2, 21, 27, 64, 64, 3, 1, 1), (2, 33, 41, 64, 256, 1, 1, 0), (1, 70, 90, 256, 512, 3, 1, 1), (4, 64, 70, 48, 48, 3, 1, 1),
+    (2, 70, 120, 96, 96, 3, 1, 1), (2, 9, 7, 32, 40, 3, 2, 1), (1, 5, 3, 16, 16, 1, 1, 0), (2, 40, 44, 128, 192, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("case", BNSTAT_CASES)
+def test_conv_epilogue_bn_statistics(ops, case, mode):
+    """BatchNorm batch statistics from the convolution epilogue (catseg_conv2d_fwd_bnstats / _bf16x3_bnstats + catseg_bn_finalize)
+    against torch's float64 statistics of the convolution output, and against the separate statistics pass (catseg_bn_train_stats)"""
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g) + 0.5
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 3          # a large bias: the shifted sums must cope with mean >> std
+    y64 = F.conv2d(x.double(), w.double(), b.double(), s, p).permute(0, 2, 3, 1).reshape(-1, Cout)
+    xd, wd = nhwc(x), ohwi(w)
+    saved = (ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES)
+    ops.PRECISION = mode
+    if mode == "bf16x3":
+        ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES = 1, 16, 16, 1
+    try:
+        y, partials = ops.conv_fwd(xd, wd, b.cuda(), Cout, k, k, s, p, 1, bn_stats=True)
+    finally:
+        ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES = saved
+        ops.release_b3_cache()
+    assert partials is not None
+    gamma = (1 + 0.1 * torch.randn(Cout, generator=g)).cuda()
+    rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    stats, scale = ops.bn_finalize(partials, y64.shape[0], Cout, gamma, 1e-5, 0.1, rm, rv)
+    mean64, var64 = y64.mean(0), y64.var(0, unbiased=False)
+    close(stats[:Cout], mean64, atol=1e-6, rtol=2e-6)
+    close(stats[Cout:], 1.0 / torch.sqrt(var64 + 1e-5), atol=0, rtol=2e-5)
+    close(scale, gamma.cpu().double() / torch.sqrt(var64 + 1e-5), atol=0, rtol=2e-5)
+    n = y64.shape[0]
+    close(rm, 0.1 * mean64, atol=1e-6, rtol=1e-5)
+    close(rv, 0.9 + 0.1 * var64 * n / max(n - 1, 1), atol=0, rtol=2e-5)
+    # the two-kernel path gives the same statistics to fp32 rounding
+    rm2, rv2 = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    stats2, _ = ops.bn_train_stats(y, gamma, 1e-5, 0.1, rm2, rv2)
+    close(stats, stats2.cpu(), atol=1e-6, rtol=1e-5)
