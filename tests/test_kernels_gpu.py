@@ -541,7 +541,9 @@ def test_conv_epilogue_bn_statistics(ops, case, mode):
     finally:
         ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES = saved
         ops.release_b3_cache()
-    assert partials is not None
+    if partials is None:        # 16 / 32-wide tile forms (class logits, grouped convolutions) have no fused statistics
+        assert mode == "fp32" and Cout <= 32
+        return
     gamma = (1 + 0.1 * torch.randn(Cout, generator=g)).cuda()
     rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
     stats, scale = ops.bn_finalize(partials, y64.shape[0], Cout, gamma, 1e-5, 0.1, rm, rv)
