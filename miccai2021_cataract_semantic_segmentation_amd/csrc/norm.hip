@@ -74,9 +74,12 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-// merge of the per-row-block partials: block = 16 channels x 64 row-block lanes (short dependent-load chains:
-// <= 8 partials per thread), two passes over the L2-resident partials, no division inside the loops:
-//   mean = sum_b n_b * mean_b / n ;  M2 = sum_b [ M2_b + n_b * (mean_b - mean)^2 ]     (fp64)
+// merge of the per-row-block partials (K, s1, s2): block = 16 channels x 64 row-block lanes, ONE pass over the L2-resident
+// partials with 4 independent load chains per thread (the convolution epilogues produce up to M / 64 = 4080 of them per layer:
+// the two-pass form of round 1 spent 19 us per launch on dependent loads), fp64 throughout:
+//   mean_b = K_b + s1_b / n_b,   M2_b = s2_b - s1_b^2 / n_b
+//   mean = sum_b n_b mean_b / n,   M2 = sum_b (M2_b + n_b mean_b^2) - n mean^2
+// (the last subtraction cancels at most mean^2 / var digits of the 16 fp64 carries: exact to fp32 for |mean| / std < 1e4)
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nrb, long long rpb, long long rows, int C,
                                                            const float* __restrict__ gamma, float eps, float momentum, float* running_mean,
                                                            float* running_var, float* __restrict__ stats, float* __restrict__ scale) {
@@ -85,46 +88,40 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   const bool live = c < C;
   const double n_full = (double)rpb, inv_full = 1.0 / n_full;
   const double n_last = (double)(rows - (long long)(nrb - 1) * rpb), inv_last = 1.0 / n_last;
-  __shared__ double sh[64][17];
-  __shared__ double smean[16];
-  double acc = 0;
+  __shared__ double sh0[64][17], sh1[64][17];
+  double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
   if (live) {
-#pragma unroll 4
-    for (int b = rl; b < nrb; b += 64) {
-      const float* o = part + ((long long)b * 3) * C;
-      const double nb = b == nrb - 1 ? n_last : n_full;
-      acc += nb * (double)o[c] + (double)o[C + c];   // n_b * mean_b = n_b * K + s1
-    }
-  }
-  sh[rl][cl] = acc;
-  __syncthreads();
-  if (rl == 0) {
-    double t = 0;
-#pragma unroll 8
-    for (int k = 0; k < 64; ++k) t += sh[k][cl];
-    smean[cl] = t / (double)rows;
-  }
-  __syncthreads();
-  const double mean = smean[cl];
-  acc = 0;
-  if (live) {
-#pragma unroll 4
-    for (int b = rl; b < nrb; b += 64) {
+    auto one = [&](int b, double& s0, double& s1) {
       const float* o = part + ((long long)b * 3) * C;
       const bool last = b == nrb - 1;
       const double nb = last ? n_last : n_full, inv = last ? inv_last : inv_full;
-      const double K = o[c], s1 = o[C + c], s2 = o[2 * C + c];
-      const double d = K + s1 * inv - mean;
-      acc += (s2 - s1 * s1 * inv) + nb * d * d;
+      const double K = o[c], t1 = o[C + c], t2 = o[2 * C + c];
+      const double mb = K + t1 * inv;
+      s0 += nb * mb;
+      s1 += (t2 - t1 * t1 * inv) + nb * mb * mb;
+    };
+    int b = rl;
+    for (; b + 192 < nrb; b += 256) {
+      one(b, a0[0], a1[0]);
+      one(b + 64, a0[1], a1[1]);
+      one(b + 128, a0[2], a1[2]);
+      one(b + 192, a0[3], a1[3]);
     }
+    for (; b < nrb; b += 64) one(b, a0[0], a1[0]);
   }
-  __syncthreads();
-  sh[rl][cl] = acc;
+  sh0[rl][cl] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+  sh1[rl][cl] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
   __syncthreads();
   if (rl != 0 || !live) return;
-  double m2 = 0;
+  double t0 = 0, t1 = 0;
 #pragma unroll 8
-  for (int k = 0; k < 64; ++k) m2 += sh[k][cl];
+  for (int k = 0; k < 64; ++k) {
+    t0 += sh0[k][cl];
+    t1 += sh1[k][cl];
+  }
+  const double mean = t0 / (double)rows;
+  double m2 = t1 - (double)rows * mean * mean;
+  if (m2 < 0) m2 = 0;
   const double n = (double)rows;
   const float var = (float)(m2 / n);
   const float invstd = 1.0f / sqrtf(var + eps);
