@@ -77,18 +77,19 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 // merge of the per-row-block partials (K, s1, s2): block = 16 channels x 64 row-block lanes, ONE pass over the L2-resident
 // partials with 4 independent load chains per thread (the convolution epilogues produce up to M / 64 = 4080 of them per layer:
 // the two-pass form of round 1 spent 19 us per launch on dependent loads), fp64 throughout:
+// Block = 4 channels x 256 row-block lanes (<= 16 partials per thread in 4 independent chains: ~4 L2 round trips).
 //   mean_b = K_b + s1_b / n_b,   M2_b = s2_b - s1_b^2 / n_b
 //   mean = sum_b n_b mean_b / n,   M2 = sum_b (M2_b + n_b mean_b^2) - n mean^2
 // (the last subtraction cancels at most mean^2 / var digits of the 16 fp64 carries: exact to fp32 for |mean| / std < 1e4)
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nrb, long long rpb, long long rows, int C,
                                                            const float* __restrict__ gamma, float eps, float momentum, float* running_mean,
                                                            float* running_var, float* __restrict__ stats, float* __restrict__ scale) {
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   const bool live = c < C;
   const double n_full = (double)rpb, inv_full = 1.0 / n_full;
   const double n_last = (double)(rows - (long long)(nrb - 1) * rpb), inv_last = 1.0 / n_last;
-  __shared__ double sh0[64][17], sh1[64][17];
+  __shared__ double sh0[256][5], sh1[256][5];
   double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
   if (live) {
     auto one = [&](int b, double& s0, double& s1) {
@@ -101,24 +102,27 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
       s1 += (t2 - t1 * t1 * inv) + nb * mb * mb;
     };
     int b = rl;
-    for (; b + 192 < nrb; b += 256) {
+    for (; b + 768 < nrb; b += 1024) {
       one(b, a0[0], a1[0]);
-      one(b + 64, a0[1], a1[1]);
-      one(b + 128, a0[2], a1[2]);
-      one(b + 192, a0[3], a1[3]);
+      one(b + 256, a0[1], a1[1]);
+      one(b + 512, a0[2], a1[2]);
+      one(b + 768, a0[3], a1[3]);
     }
-    for (; b < nrb; b += 64) one(b, a0[0], a1[0]);
+    for (; b < nrb; b += 256) one(b, a0[0], a1[0]);
   }
   sh0[rl][cl] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
   sh1[rl][cl] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
   __syncthreads();
-  if (rl != 0 || !live) return;
-  double t0 = 0, t1 = 0;
-#pragma unroll 8
-  for (int k = 0; k < 64; ++k) {
-    t0 += sh0[k][cl];
-    t1 += sh1[k][cl];
+  // tree over the 256 row lanes (fixed order: deterministic)
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (rl < st) {
+      sh0[rl][cl] += sh0[rl + st][cl];
+      sh1[rl][cl] += sh1[rl + st][cl];
+    }
+    __syncthreads();
   }
+  if (rl != 0 || !live) return;
+  const double t0 = sh0[0][cl], t1 = sh1[0][cl];
   const double mean = t0 / (double)rows;
   double m2 = t1 - (double)rows * mean * mean;
   if (m2 < 0) m2 = 0;
@@ -314,7 +318,7 @@ extern "C" int catseg_bn_train_stats(const float* y, long long rows, int C, int 
   const RowSplit s = plan_rows(rows, C);
   float* part = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, y, ldy, rows, C, s, part);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, (const float*)part, s.nrb, s.rpb, rows, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, st, (const float*)part, s.nrb, s.rpb, rows, C,
                      gamma, eps, momentum, running_mean, running_var, stats_out, scale);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
@@ -327,7 +331,7 @@ extern "C" int catseg_bn_finalize(const float* partials, int n_blocks, long long
                                   catseg_stream_t stream) {
   CS_REQUIRE(partials && n_blocks > 0 && rows > 0 && C > 0 && (long long)(n_blocks - 1) * rows_per_block < rows &&
                  (long long)n_blocks * rows_per_block >= rows, "bn finalize: bad args");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partials, n_blocks, rows_per_block, rows, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, (hipStream_t)stream, partials, n_blocks, rows_per_block, rows, C,
                      gamma, eps, momentum, running_mean, running_var, stats_out, scale);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
