@@ -276,28 +276,49 @@ def main():
     if not args.no_roofline and rank == 0:
         prof, ops.PROFILE = ops.PROFILE, None
         agg = {}
-        for kind, flops, e0, e1 in prof:
+        for kind, work, e0, e1 in prof:
             a = agg.setdefault(kind, [0.0, 0.0, 0])
-            a[0] += flops
+            a[0] += work
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
-        dom = max(agg, key=lambda k: agg[k][1])
-        fl, sec, n = agg[dom]
-        peak = 157.3
+        # matrix-core operations: three ops x two arithmetics.  "*_b3" = the bf16x3 split-precision kernels (six bf16 MFMA
+        # products per fp32-equivalent product: their peak is the dense bf16 peak / 6); the rest = exact fp32 MFMA.
+        PEAK_F32, PEAK_B3 = 157.3, 2500.0 / 6.0
+        mm = {k: v for k, v in agg.items() if not k.startswith("hbm:") and k != "split3" and v[1] > 0}
+        dom = max(mm, key=lambda k: mm[k][1])
+        fl, sec, n = mm[dom]
+        peak = PEAK_B3 if dom.endswith("_b3") else PEAK_F32
         traffic = traffic_src = None   # HBM bytes per launch from committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
         tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (PROFILE_ROUND, args.model))
         if os.path.exists(tpath) and (B, H, W) == (8, 544, 960):
-            traffic_src = "profiles/" + os.path.basename(tpath) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
-            per_step = json.load(open(tpath))["kernels"].get(dom, {}).get("hbm_bytes_per_step")
-            traffic = per_step / (n // 2) if per_step else None          # per C-ABI call, like `achieved`
-        label = {"fwd": "igemm_f32_kernel<NT> (conv2d forward)", "dgrad": "igemm_f32_kernel<NN> (conv2d backward-data)",
-                 "wgrad": "igemm_f32_kernel<TN> + wgrad_direct_kernel (conv2d backward-weight, incl. slab reduction)"}.get(dom, dom)
+            tkey = "b3w" if dom in ("fwd_b3", "dgrad_b3") else dom      # one bf16x3 kernel serves forward and backward-data
+            ncalls = (mm.get("fwd_b3", [0, 0, 0])[2] + mm.get("dgrad_b3", [0, 0, 0])[2]) if tkey == "b3w" else n
+            per_step = json.load(open(tpath))["kernels"].get(tkey, {}).get("hbm_bytes_per_step")
+            if per_step:
+                traffic = per_step / (ncalls // 2)          # per C-ABI call, like `achieved`
+                traffic_src = "profiles/" + os.path.basename(tpath) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
+        label = {"fwd": "igemm_f32_kernel<NT> (conv2d forward, fp32 MFMA)", "dgrad": "igemm_f32_kernel<NN> (conv2d backward-data, fp32 MFMA)",
+                 "wgrad": "igemm_f32_kernel<TN> + wgrad_direct_kernel (conv2d backward-weight, fp32 MFMA, incl. slab reduction)",
+                 "fwd_b3": "igemm_b3w_kernel (conv2d forward, bf16x3 split precision)",
+                 "dgrad_b3": "igemm_b3w_kernel (conv2d backward-data, bf16x3 split precision)",
+                 "wgrad_b3": "igemm_b3t_kernel (conv2d backward-weight, bf16x3 split precision, incl. slab reduction)"}.get(dom, dom)
+        tot_fl = sum(v[0] for v in mm.values())
+        tot_s = sum(v[1] for v in mm.values()) + agg.get("split3", [0, 0, 0])[1]
+        hbm = {k[4:]: {"achieved_GBps": v[0] / v[1] / 1e9, "frac_of_8TBps": v[0] / v[1] / 8e12, "ms_per_step": v[1] / 2 * 1e3,
+                       "calls_per_step": v[2] // 2, "algorithmic_GB_per_step": v[0] / 2 / 1e9}
+               for k, v in agg.items() if k.startswith("hbm:") and v[1] > 0}
         roof = {"bound": "mfma", "kernel": label, "achieved": fl / sec / 1e12, "peak": peak,
                 "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": n // 2,
                 "avg_launch_ms": sec / n * 1e3, "algorithmic_gflop_per_launch": fl / n / 1e9,
-                "all_igemm": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / 2 * 1e3, "launches_per_step": v[2] // 2}
-                              for k, v in agg.items()}}
+                "peak_note": "fp32 MFMA 157.3 TFLOP/s; bf16x3 kernels: dense bf16 MFMA 2500 TFLOP/s / 6 products = 416.7 TFLOP/s-equivalent",
+                "all_igemm": {k: {"tflops": v[0] / v[1] / 1e12, "frac": v[0] / v[1] / 1e12 / (PEAK_B3 if k.endswith("_b3") else PEAK_F32),
+                                  "ms_per_step": v[1] / 2 * 1e3, "launches_per_step": v[2] // 2}
+                              for k, v in mm.items()},
+                "all_matrix_ops": {"algorithmic_tflop_per_step": tot_fl / 2 / 1e12, "ms_per_step": tot_s / 2 * 1e3,
+                                   "tflops_equivalent": tot_fl / tot_s / 1e12, "frac_of_fp32_matrix_peak": tot_fl / tot_s / 1e12 / PEAK_F32,
+                                   "split3_ms_per_step": agg.get("split3", [0, 0, 0])[1] / 2 * 1e3},
+                "hbm_kernels": hbm}
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(H, W, K, args.model)
@@ -310,7 +331,10 @@ def main():
                                                        "deeplabv3plus_r50": "DeepLabv3+-ResNet50"}[args.model],
             "value": world * B * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if ops.PRECISION == "fp32" else "f32 (convolutions with K >= 2048 and >= 192 output columns: fp32 operands split "
+                                                            "exactly into 3 bf16 planes, 6 bf16 MFMA products, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": ("%s, 17-class (task 2), bs=%d/GPU @3x%dx%d, cross entropy (ignore 17), Adam lr 1e-4 (BASELINE config 2)"
                                     if deeplab else
                                     "%s, 25-class (task 3), bs=%d/GPU @3x%dx%d, TwoScale Lovasz-Softmax (0.4 interm + 1.0 final), "

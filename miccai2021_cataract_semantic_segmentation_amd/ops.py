@@ -161,9 +161,10 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
         tr, nt = ctypes.c_int(0), ctypes.c_int(0)
     if "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(rows, Cout, kh * kw, Cin):
         d = make_desc(x.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
-        with _Timed("fwd", flops):
+        with _Timed("split3", 0.0):
             xp = _split3_cached(x)
             wp = split3_weight(w_ptr_tensor)
+        with _Timed("fwd_b3", flops):
             if bn_stats:
                 check(lib.catseg_conv2d_fwd_bf16x3_bnstats(ctypes.byref(d), ptr(xp), ptr(wp), ptr(bias), ptr(out), zero_to, ptr(part),
                                                            part.numel(), ctypes.byref(tr), ctypes.byref(nt), stream()))
@@ -201,9 +202,10 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
     flops = 2.0 * rows_of(dy) * Cout * Cin * kh * kw
     if "dgrad" in B3_OPS and _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1):
         d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
-        with _Timed("dgrad", flops):
+        with _Timed("split3", 0.0):
             dyp = _split3_cached_dy(dy)
             wtp = split3_weight_t(w)
+        with _Timed("dgrad_b3", flops):
             check(lib.catseg_conv2d_bwd_data_bf16x3(ctypes.byref(d), ptr(dyp), ptr(wtp), ptr(out), 1 if accumulate else 0, stream()))
         return out
     d = make_desc(xshape, ld_of(out), Cout, ld_of(dy), kh, kw, stride, pad, dil)
@@ -220,12 +222,13 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
             and Cout >= B3_MIN_N and rows_of(dy) >= B3_MIN_WGRAD_ROWS):
         d = make_desc(x.shape, Cin, Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         ws = workspace(lib.catseg_conv2d_bwd_weight_bf16x3_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
-        with _Timed("wgrad", flops):
+        with _Timed("split3", 0.0):
             xp = _split3_cached(x)
             dyp = _split3_cached_dy(dy)
+        with _Timed("wgrad_b3", flops):
             check(lib.catseg_conv2d_bwd_weight_bf16x3(ctypes.byref(d), ptr(xp), ptr(dyp), ptr(dw), ptr(ws), ws.numel(), stream()))
-            if dbias is not None:
-                check(lib.catseg_bias_grad(ptr(dy), ld_of(dy), rows_of(dy), Cout, ptr(dbias), ptr(ws), ws.numel(), stream()))
+        if dbias is not None:
+            check(lib.catseg_bias_grad(ptr(dy), ld_of(dy), rows_of(dy), Cout, ptr(dbias), ptr(ws), ws.numel(), stream()))
         return dw
     d = make_desc(x.shape, ld_of(x), Cout, ld_of(dy), kh, kw, stride, pad, dil, stem4)
     need = lib.catseg_conv2d_bwd_weight_workspace(ctypes.byref(d))
@@ -264,6 +267,12 @@ def bn_eval_scale(gamma, running_var, eps):
 def bn_apply(y, mean, scale, beta, residual, relu, out=None):
     if out is None:
         out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    with _Timed("hbm:bn_apply", 4.0 * y.numel() * (3 if residual is not None else 2)):
+        _bn_apply(y, mean, scale, beta, residual, relu, out)
+    return out
+
+
+def _bn_apply(y, mean, scale, beta, residual, relu, out):
     check(lib.catseg_bn_apply(ptr(y), ld_of(y), ptr(mean), ptr(scale), ptr(beta), ptr(residual),
                               ld_of(residual) if residual is not None else 0, ptr(out), ld_of(out), rows_of(y),
                               y.shape[-1], 1 if relu else 0, stream()))
@@ -277,6 +286,13 @@ def bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres=None, dres_acc
     if dy_out is None:
         dy_out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
     ws = workspace(lib.catseg_bn_workspace(rows, C), y.device)
+    # algorithmic bytes: two passes over (dz, y [or z]) + dy written (+ the residual gradient)
+    with _Timed("hbm:bn_backward", 4.0 * y.numel() * (5 + (1 if dres is not None else 0))):
+        _bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres, dres_accumulate, dy_out, beta, rows, C, ws)
+    return dy_out
+
+
+def _bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres, dres_accumulate, dy_out, beta, rows, C, ws):
     check(lib.catseg_bn_backward(ptr(dz), ld_of(dz), ptr(z), ld_of(z) if z is not None else 0, ptr(y), ld_of(y), ptr(stats),
                                  ptr(gamma), ptr(beta), rows, C, 1 if relu else 0, ptr(dy_out), ld_of(dy_out), ptr(dgamma), ptr(dbeta),
                                  ptr(dres), ld_of(dres) if dres is not None else 0, 1 if dres_accumulate else 0, ptr(ws),
@@ -336,8 +352,9 @@ def bilinear_fwd(x, Ho, Wo, align_corners, out=None, accumulate=False):
     B, H, W, C = x.shape
     if out is None:
         out = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
-    check(lib.catseg_bilinear_fwd(ptr(x), ld_of(x), ptr(out), ld_of(out), B, H, W, C, Ho, Wo, 1 if align_corners else 0,
-                                  1 if accumulate else 0, stream()))
+    with _Timed("hbm:bilinear_fwd", 4.0 * (x.numel() + out.numel() * (2 if accumulate else 1))):
+        check(lib.catseg_bilinear_fwd(ptr(x), ld_of(x), ptr(out), ld_of(out), B, H, W, C, Ho, Wo, 1 if align_corners else 0,
+                                      1 if accumulate else 0, stream()))
     return out
 
 
@@ -348,6 +365,12 @@ def bilinear_bwd(dy, xshape, align_corners, out=None, zero_to=0, accumulate=Fals
         out = new_act(B, H, W, C, dy.device, ld=max(zero_to, (C + 3) // 4 * 4))
         accumulate = False
     ws = workspace(B * H * Wo * C * 4, dy.device)
+    with _Timed("hbm:bilinear_bwd", 4.0 * (dy.numel() + B * H * W * C * (2 if accumulate else 1))):
+        _bilinear_bwd(dy, out, B, H, W, C, Ho, Wo, align_corners, zero_to, accumulate, ws)
+    return out
+
+
+def _bilinear_bwd(dy, out, B, H, W, C, Ho, Wo, align_corners, zero_to, accumulate, ws):
     check(lib.catseg_bilinear_bwd(ptr(dy), ld_of(dy), ptr(out), ld_of(out), B, H, W, C, Ho, Wo, 1 if align_corners else 0,
                                   zero_to, 1 if accumulate else 0, ptr(ws), ws.numel(), stream()))
     return out
@@ -403,6 +426,13 @@ def lovasz_softmax(logits, labels, weight=1.0, dlogits=None, accumulate=False, l
     if loss_out is None:
         loss_out = torch.empty(1, dtype=torch.float32, device=logits.device)
     ws = workspace(lib.catseg_lovasz_workspace(Pn, K), logits.device)
+    # algorithmic minimum: logits read + gradient written (the sort passes on top are data dependent: active-set pruning)
+    with _Timed("hbm:lovasz", 4.0 * Pn * K * (2 if dlogits is not None else 1) + 8.0 * Pn):
+        _lovasz(logits, labels, Pn, K, weight, loss_out, dlogits, accumulate, ws)
+    return loss_out
+
+
+def _lovasz(logits, labels, Pn, K, weight, loss_out, dlogits, accumulate, ws):
     check(lib.catseg_lovasz_softmax(ptr(logits), ptr(labels), Pn, K, weight, ptr(loss_out), ptr(dlogits),
                                     1 if accumulate else 0, ptr(ws), ws.numel(), stream()))
     return loss_out
@@ -473,6 +503,11 @@ def confusion_matrix(logits, labels, cm=None):
 
 
 def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    with _Timed("hbm:adam", 28.0 * p.numel()):          # 16 B read + 12 B written per parameter
+        _adam_step(p, g, m, v, lr, step, beta1, beta2, eps, grad_scale)
+
+
+def _adam_step(p, g, m, v, lr, step, beta1, beta2, eps, grad_scale):
     check(lib.catseg_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, stream()))
 
 

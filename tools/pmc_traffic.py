@@ -18,6 +18,12 @@ def group(name):
     m = re.search(r"igemm_f32_kernel<(\d)", name)
     if m:
         return LAY[m.group(1)]
+    if "igemm_b3w_kernel" in name or "igemm_b3_kernel" in name:
+        return "b3w"            # bf16x3 forward AND backward-data (one kernel serves both)
+    if "igemm_b3t_kernel" in name or "b3_reduce_slabs" in name:
+        return "wgrad_b3"
+    if "split3" in name:
+        return "split3"
     if "wgrad_direct_kernel" in name or "reduce_slabs" in name or "colsum_" in name:
         return "wgrad"
     return None
