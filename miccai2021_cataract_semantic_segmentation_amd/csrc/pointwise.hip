@@ -182,6 +182,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, int lddy, const
 }
 
 // ------------------------------------------------------------------ bilinear
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
 // ATen's area_pixel_compute_source_index in fp32
 __device__ __forceinline__ float src_index(float scale, int dst, bool align) {
   if (align) return scale * dst;
@@ -201,9 +202,14 @@ __host__ __device__ inline float resize_scale(int in, int out, bool align) {
   return (float)in / (float)out;
 }
 
+// MODE 0: scalar (any C / ld); MODE 1: contiguous output rows (ldy == C), 4 consecutive floats of the flat (ox, c) index per
+// thread, 16-byte stores (the K-class logits at full resolution: C = 25); MODE 2: C % 4 == 0, 4 channels of one pixel per thread,
+// 16-byte loads and stores (HRNet / ASPP / decoder feature maps, also into channel slices of a concat buffer).
+// The per-element arithmetic is the same expression in all modes (bit-identical results).
+template <int MODE>
 __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int B, int H, int W, int C,
                                     int Ho, int Wo, int align, float sh, float sw, int acc) {
-  // one block per output row (b, oy); threads sweep (ox, c), which is contiguous when ldy == C
+  // one block per output row (b, oy)
   const int b = blockIdx.x / Ho, oy = blockIdx.x - b * Ho;
   int y0, y1;
   float ly0, ly1;
@@ -211,19 +217,57 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ldx, float*
   const float* r0 = x + ((long long)b * H + y0) * W * ldx;
   const float* r1 = x + ((long long)b * H + y1) * W * ldx;
   float* o = y + ((long long)b * Ho + oy) * Wo * ldy;
-  const int n = Wo * C;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int ox = i / C, c = i - ox * C;
-    int x0, x1;
-    float lx0, lx1;
-    lerp_setup(sw, ox, align, W, x0, x1, lx0, lx1);
-    const float v = ly0 * (lx0 * r0[x0 * ldx + c] + lx1 * r0[x1 * ldx + c]) + ly1 * (lx0 * r1[x0 * ldx + c] + lx1 * r1[x1 * ldx + c]);
-    float* d = o + (long long)ox * ldy + c;
-    *d = acc ? (*d + v) : v;
+  if (MODE == 0) {
+    const int n = Wo * C;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const int ox = i / C, c = i - ox * C;
+      int x0, x1;
+      float lx0, lx1;
+      lerp_setup(sw, ox, align, W, x0, x1, lx0, lx1);
+      const float v = ly0 * (lx0 * r0[x0 * ldx + c] + lx1 * r0[x1 * ldx + c]) + ly1 * (lx0 * r1[x0 * ldx + c] + lx1 * r1[x1 * ldx + c]);
+      float* d = o + (long long)ox * ldy + c;
+      *d = acc ? (*d + v) : v;
+    }
+  } else if (MODE == 1) {
+    const int n4 = (Wo * C) >> 2;
+    for (int u = threadIdx.x; u < n4; u += blockDim.x) {
+      int ox = (u * 4) / C, c = u * 4 - ox * C;
+      int x0, x1;
+      float lx0, lx1;
+      lerp_setup(sw, ox, align, W, x0, x1, lx0, lx1);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = ly0 * (lx0 * r0[x0 * ldx + c] + lx1 * r0[x1 * ldx + c]) + ly1 * (lx0 * r1[x0 * ldx + c] + lx1 * r1[x1 * ldx + c]);
+        if (++c == C) {
+          c = 0;
+          ++ox;
+          if (e < 3) lerp_setup(sw, ox < Wo ? ox : Wo - 1, align, W, x0, x1, lx0, lx1);
+        }
+      }
+      f32x4* d = (f32x4*)(o + u * 4);
+      *d = acc ? (*d + v) : v;
+    }
+  } else {
+    const int c4n = C >> 2, n = Wo * c4n;
+    for (int u = threadIdx.x; u < n; u += blockDim.x) {
+      const int ox = u / c4n, c = (u - ox * c4n) * 4;
+      int x0, x1;
+      float lx0, lx1;
+      lerp_setup(sw, ox, align, W, x0, x1, lx0, lx1);
+      const f32x4 a0 = ld4(r0 + x0 * ldx + c), a1 = ld4(r0 + x1 * ldx + c), b0 = ld4(r1 + x0 * ldx + c), b1 = ld4(r1 + x1 * ldx + c);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ly0 * (lx0 * a0[e] + lx1 * a1[e]) + ly1 * (lx0 * b0[e] + lx1 * b1[e]);
+      f32x4* d = (f32x4*)(o + (long long)ox * ldy + c);
+      *d = acc ? (*d + v) : v;
+    }
   }
 }
 
 // backward pass 1: tmp[b, iy, ox, c] = sum_{oy} wy(oy -> iy) * dy[b, oy, ox, c]
+// The weights of the candidate output rows depend only on (iy, oy): computed once per block.  MODE as above (1: lddy == C).
+template <int MODE>
 __global__ void bilinear_bwd_rows_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ tmp, int B, int H, int C, int Ho,
                                          int Wo, int align, float sh) {
   const int b = blockIdx.x / H, iy = blockIdx.x - b * H;
@@ -237,20 +281,50 @@ __global__ void bilinear_bwd_rows_kernel(const float* __restrict__ dy, int lddy,
   }
   if (lo < 0) lo = 0;
   if (hi > Ho - 1) hi = Ho - 1;
+  auto weight = [&](int oy) {
+    int y0, y1;
+    float l0, l1;
+    lerp_setup(sh, oy, align, H, y0, y1, l0, l1);
+    float w = 0.f;
+    if (y0 == iy) w += l0;
+    if (y1 == iy) w += l1;
+    return w;
+  };
   const int n = Wo * C;
-  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
-    const int ox = i / C, c = i - ox * C;
-    float s = 0.f;
-    for (int oy = lo; oy <= hi; ++oy) {
-      int y0, y1;
-      float l0, l1;
-      lerp_setup(sh, oy, align, H, y0, y1, l0, l1);
-      float w = 0.f;
-      if (y0 == iy) w += l0;
-      if (y1 == iy) w += l1;
-      if (w != 0.f) s += w * dy[(((long long)b * Ho + oy) * Wo + ox) * lddy + c];
+  float* trow = tmp + ((long long)blockIdx.x * Wo) * C;
+  if (MODE == 0) {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
+      const int ox = i / C, c = i - ox * C;
+      float s = 0.f;
+      for (int oy = lo; oy <= hi; ++oy) {
+        const float w = weight(oy);
+        if (w != 0.f) s += w * dy[(((long long)b * Ho + oy) * Wo + ox) * lddy + c];
+      }
+      trow[i] = s;
     }
-    tmp[((long long)blockIdx.x * Wo) * C + i] = s;
+  } else {
+    // (the weights are wave-uniform: the branch on w != 0 is not divergent)
+    const int c4n = C >> 2;
+    const int n4 = MODE == 1 ? n >> 2 : Wo * c4n;
+    for (int u = blockIdx.y * blockDim.x + threadIdx.x; u < n4; u += gridDim.y * blockDim.x) {
+      long long off;
+      if (MODE == 1) {
+        off = (long long)u * 4;
+      } else {
+        const int ox = u / c4n;
+        off = (long long)ox * lddy + (u - ox * c4n) * 4;
+      }
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int oy = lo; oy <= hi; ++oy) {
+        const float w = weight(oy);
+        if (w != 0.f) {
+          const f32x4 v = ld4(dy + ((long long)b * Ho + oy) * Wo * lddy + off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[e] += w * v[e];
+        }
+      }
+      *(f32x4*)(trow + (long long)u * 4) = s;
+    }
   }
 }
 // backward pass 2: dx[b, iy, ix, c] = sum_{ox} wx(ox -> ix) * tmp[b, iy, ox, c]
@@ -525,8 +599,14 @@ extern "C" int catseg_maxpool3x3s2_bwd(const float* dy, int lddy, const uint8_t*
 extern "C" int catseg_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C, int Ho,
                                    int Wo, int align_corners, int accumulate, catseg_stream_t stream) {
   CS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && ldx >= C && ldy >= C, "bilinear fwd: bad args");
-  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(B * Ho), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, H, W, C, Ho, Wo, align_corners,
-                     resize_scale(H, Ho, align_corners), resize_scale(W, Wo, align_corners), accumulate);
+  const float sh = resize_scale(H, Ho, align_corners), sw = resize_scale(W, Wo, align_corners);
+  hipStream_t st = (hipStream_t)stream;
+  if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && cs_aligned16(x) && cs_aligned16(y))
+    hipLaunchKernelGGL(bilinear_fwd_kernel<2>, dim3(B * Ho), dim3(256), 0, st, x, ldx, y, ldy, B, H, W, C, Ho, Wo, align_corners, sh, sw, accumulate);
+  else if (ldy == C && (Wo * C) % 4 == 0 && cs_aligned16(y))
+    hipLaunchKernelGGL(bilinear_fwd_kernel<1>, dim3(B * Ho), dim3(256), 0, st, x, ldx, y, ldy, B, H, W, C, Ho, Wo, align_corners, sh, sw, accumulate);
+  else
+    hipLaunchKernelGGL(bilinear_fwd_kernel<0>, dim3(B * Ho), dim3(256), 0, st, x, ldx, y, ldy, B, H, W, C, Ho, Wo, align_corners, sh, sw, accumulate);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
@@ -545,8 +625,14 @@ extern "C" int catseg_bilinear_bwd(const float* dy, int lddy, float* dx, int ldd
                            ? (int)((2048 + (long long)B * H - 1) / ((long long)B * H)) : (Wo * C + 255) / 256;
   const int ysplit_c = (int)((2048 + (long long)B * H - 1) / ((long long)B * H)) < (W * C + 255) / 256
                            ? (int)((2048 + (long long)B * H - 1) / ((long long)B * H)) : (W * C + 255) / 256;
-  hipLaunchKernelGGL(bilinear_bwd_rows_kernel, dim3(B * H, ysplit_r < 1 ? 1 : ysplit_r), dim3(256), 0, st, dy, lddy, (float*)workspace, B, H, C, Ho, Wo, align_corners,
-                     resize_scale(H, Ho, align_corners));
+  const dim3 grid_r(B * H, ysplit_r < 1 ? 1 : ysplit_r);
+  const float shr = resize_scale(H, Ho, align_corners);
+  if (lddy == C && (Wo * C) % 4 == 0 && cs_aligned16(dy) && cs_aligned16(workspace))
+    hipLaunchKernelGGL(bilinear_bwd_rows_kernel<1>, grid_r, dim3(256), 0, st, dy, lddy, (float*)workspace, B, H, C, Ho, Wo, align_corners, shr);
+  else if (C % 4 == 0 && lddy % 4 == 0 && cs_aligned16(dy) && cs_aligned16(workspace))
+    hipLaunchKernelGGL(bilinear_bwd_rows_kernel<2>, grid_r, dim3(256), 0, st, dy, lddy, (float*)workspace, B, H, C, Ho, Wo, align_corners, shr);
+  else
+    hipLaunchKernelGGL(bilinear_bwd_rows_kernel<0>, grid_r, dim3(256), 0, st, dy, lddy, (float*)workspace, B, H, C, Ho, Wo, align_corners, shr);
   hipLaunchKernelGGL(bilinear_bwd_cols_kernel, dim3(B * H, ysplit_c < 1 ? 1 : ysplit_c), dim3(256), 0, st, (const float*)workspace, dx, lddx, W, C, Wo, align_corners,
                      resize_scale(W, Wo, align_corners), zero_to, accumulate);
   CS_LAUNCH_CHECK();
