@@ -37,6 +37,15 @@ def lovasz_softmax(pred, target, weight=1.0):
 
 
 class LovaszSoftmax(nn.Module):
+    """losses/LovaszSoftmax.py:8-80.  The configuration every shipped config uses (per_image=False, classes_to_ignore=None,
+    classes_to_consider='present') is ONE fused kernel sequence.  The other options are built on the same kernel:
+      * per_image: one kernel call per image (slices of the NHWC logits), mean over images (:27-29);
+      * classes_to_ignore = v: pixels labelled v are removed before the sort (:72-80) -- a torch gather of the remaining rows;
+      * classes_to_consider = 'all' or a list S (:44-55): labels outside S are remapped to the no-class label, so the kernel
+        sums exactly the PRESENT classes of S; a class of S without a foreground pixel contributes max_p prob_c (what
+        dot(sort(errors), lovasz_grad(zeros)) evaluates to), added with torch ops; the mean runs over all of S.
+    (these option paths use a few torch pointwise / reduction kernels; the default path does not)"""
+
     def __init__(self, config):
         super().__init__()
         self.experiment = config["experiment"]
@@ -44,9 +53,36 @@ class LovaszSoftmax(nn.Module):
         self.per_image = config.get("per_image", False)
         self.classes_to_ignore = config.get("classes_to_ignore", None)
         self.classes_to_consider = config.get("classes_to_consider", "present")
-        if self.per_image or self.classes_to_ignore is not None or self.classes_to_consider != "present":
-            raise NotImplementedError("only the configuration the shipped configs use is accelerated "
-                                      "(per_image=False, classes_to_ignore=None, classes_to_consider='present')")
 
     def forward(self, prediction, target):
-        return lovasz_softmax(prediction, target, 1.0)
+        if not self.per_image:
+            return self._flat(prediction, target)
+        losses = [self._flat(prediction[b:b + 1], target[b:b + 1]) for b in range(prediction.shape[0])]
+        return sum(losses) / len(losses)
+
+    def _flat(self, prediction, target):
+        K = prediction.shape[1]
+        if self.classes_to_ignore is not None:
+            if not prediction.is_cuda:
+                raise RuntimeError("HIP losses need device tensors (no CPU fallback)")
+            valid = target.reshape(-1) != self.classes_to_ignore
+            rows = prediction.permute(0, 2, 3, 1).reshape(-1, K)[valid]
+            target = target.reshape(-1)[valid].reshape(1, -1, 1)
+            if rows.shape[0] == 0:
+                return prediction.sum() * 0.0
+            prediction = rows.t().reshape(1, K, -1, 1)           # NCHW view of the kept pixel rows (no copy)
+        if isinstance(self.classes_to_consider, str) and self.classes_to_consider == "present":
+            return lovasz_softmax(prediction, target, 1.0)
+        S = list(range(K)) if isinstance(self.classes_to_consider, str) else [int(c) for c in self.classes_to_consider]
+        if self.experiment in (2, 3) and K in S:                # the 'ignore' class is never summed (:48-49)
+            S.remove(K)
+        sel = torch.zeros(K + 1, dtype=torch.bool, device=prediction.device)
+        sel[S] = True
+        lbl = target.reshape(-1).long().clamp(0, K)
+        remapped = torch.where(sel[lbl], lbl, torch.full_like(lbl, K)).reshape(target.shape)
+        present = torch.bincount(lbl, minlength=K + 1)[S] > 0
+        n_present = present.sum().to(torch.float32)
+        loss_present = lovasz_softmax(prediction, remapped, 1.0)                       # mean over the present classes of S
+        probs = torch.softmax(prediction.permute(0, 2, 3, 1).reshape(-1, K), dim=1)[:, S]
+        absent = (probs.max(dim=0).values * (~present)).sum()
+        return (loss_present * n_present + absent) / float(len(S))
