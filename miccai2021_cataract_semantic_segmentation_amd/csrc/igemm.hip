@@ -951,8 +951,21 @@ extern "C" int catseg_conv2d_bwd_data(const catseg_conv_desc* d, const float* dy
                                       int accumulate, catseg_stream_t stream) {
   if (int e = check_desc(d)) return e;
   CS_REQUIRE(!d->stem4, "conv bwd_data: not defined for the stem (the image needs no gradient)");
-  CS_REQUIRE(d->groups <= 1, "conv bwd_data: grouped convolution is forward-only");
   CS_REQUIRE(cs_aligned16(dy) && cs_aligned16(w) && cs_aligned16(dx), "conv bwd_data: pointers must be 16-byte aligned");
+  if (d->groups > 1) {
+    // grouped (ResNeXt, models/ResNeXt.py:29-60 as a TRAINING encoder): one dense backward-data GEMM per group through the
+    // batch strides -- group g reads dy channels [g cog, (g+1) cog), its filter bank, and writes dx channels [g cig, (g+1) cig)
+    const int cig = d->Cin / d->groups, cog = d->Cout / d->groups;
+    CS_REQUIRE(d->stride == 1 || d->kh * d->kw <= 32, "conv bwd_data: grouped strided convolution needs <= 32 taps");
+    CS_REQUIRE(cog % 4 == 0, "conv bwd_data: Cout/groups must be a multiple of 4");
+    catseg_conv_desc g1 = *d;
+    g1.groups = 1; g1.Cin = cig; g1.Cout = cog;          // per-group geometry; ldx / ldy stay the full pixel strides
+    // run the dense path once per group with shifted base pointers (stride > 1 launches several kernels per call)
+    for (int g = 0; g < d->groups; ++g)
+      if (int e = catseg_conv2d_bwd_data(&g1, dy + (size_t)g * cog, w + (size_t)g * cog * d->kh * d->kw * cig, dx + (size_t)g * cig, accumulate, stream))
+        return e;
+    return CATSEG_OK;
+  }
   IgemmArgs a = {};
   Geo& g = a.g;
   g.base = dy; g.mode = 2; g.rows = d->B * d->H * d->W; g.ld = d->ldy;
@@ -1031,6 +1044,11 @@ extern "C" int catseg_debug_plan_conv(const catseg_conv_desc* d, int op, int* ou
 
 extern "C" size_t catseg_conv2d_bwd_weight_workspace(const catseg_conv_desc* d) {
   if (check_desc(d)) return 0;
+  if (d->groups > 1) {
+    catseg_conv_desc g1 = *d;
+    g1.groups = 1; g1.Cin = d->Cin / d->groups; g1.Cout = d->Cout / d->groups;
+    return catseg_conv2d_bwd_weight_workspace(&g1);
+  }
   const int splits = wgrad_plan(d).splits;
   const size_t wel = (size_t)d->Cout * (d->stem4 ? d->kh * 32 : d->kh * d->kw * d->Cin);
   size_t bytes = splits > 1 ? (size_t)splits * wel * 4 : 0;
@@ -1045,7 +1063,17 @@ extern "C" int catseg_conv2d_bwd_weight(const catseg_conv_desc* d, const float* 
                                         catseg_stream_t stream) {
   if (int e = check_desc(d)) return e;
   CS_REQUIRE(cs_aligned16(dy) && cs_aligned16(x) && cs_aligned16(dw), "conv bwd_weight: pointers must be 16-byte aligned");
-  CS_REQUIRE(d->groups <= 1, "conv bwd_weight: grouped convolution is forward-only");
+  if (d->groups > 1) {   // grouped: one dense backward-weight per group (shifted bases; the per-group filter banks are contiguous in dw)
+    const int cig = d->Cin / d->groups, cog = d->Cout / d->groups;
+    CS_REQUIRE(cog % 4 == 0 && cig % 4 == 0, "conv bwd_weight: channels per group must be multiples of 4");
+    catseg_conv_desc g1 = *d;
+    g1.groups = 1; g1.Cin = cig; g1.Cout = cog;
+    for (int g = 0; g < d->groups; ++g)
+      if (int e = catseg_conv2d_bwd_weight(&g1, x + (size_t)g * cig, dy + (size_t)g * cog, dw + (size_t)g * cog * d->kh * d->kw * cig,
+                                           dbias ? dbias + (size_t)g * cog : nullptr, workspace, workspace_bytes, stream))
+        return e;
+    return CATSEG_OK;
+  }
   const size_t need = catseg_conv2d_bwd_weight_workspace(d);
   if (workspace_bytes < need || (need && !workspace)) {
     catseg_set_error("conv bwd_weight: workspace %zu < %zu", workspace_bytes, need);

@@ -205,8 +205,6 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
     else:
         x_in, wk = x, w.data
     bias = conv.bias.data if conv.bias is not None else None
-    if conv.groups > 1 and cx.record:
-        raise NotImplementedError("grouped convolution (ResNeXt) is inference-only on the HIP path")
     cx.claim(w, conv.bias, bn.weight, bn.bias)
     if not cx.train and not cx.record and FUSE_EVAL_BN:
         # inference fast path: eval-mode BatchNorm folded into the weights, bias + residual + ReLU applied in
@@ -256,10 +254,10 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
                 ops.conv_bwd_weight(x_in, dy, dpk, dbias, kh, kw, s, p, d)
                 ops.weight_unpad_cin(dpk, cx.pgrad(w), Cout, kh * kw, 3, 4)
             else:
-                ops.conv_bwd_weight(x_in, dy, cx.pgrad(w), dbias, kh, kw, s, p, d)
+                ops.conv_bwd_weight(x_in, dy, cx.pgrad(w), dbias, kh, kw, s, p, d, groups=conv.groups)
                 if need_dx:
                     dx, accx = cx.dest(x)
-                    ops.conv_bwd_data(dy, w.data, tuple(x.shape), kh, kw, s, p, d, out=dx, accumulate=accx)
+                    ops.conv_bwd_data(dy, w.data, tuple(x.shape), kh, kw, s, p, d, out=dx, accumulate=accx, groups=conv.groups)
             cx.done(bn.weight, bn.bias, w, conv.bias)
         cx.push(bwd)
     return z

@@ -193,14 +193,14 @@ def bn_finalize(partials, rows, C, gamma, eps, momentum, running_mean, running_v
     return stats, scale
 
 
-def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accumulate=False):
+def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accumulate=False, groups=1):
     B, H, W, Cin = xshape
     Cout = dy.shape[-1]
     if out is None:
         out = new_act(B, H, W, Cin, dy.device)
         accumulate = False
-    flops = 2.0 * rows_of(dy) * Cout * Cin * kh * kw
-    if "dgrad" in B3_OPS and _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1):
+    flops = 2.0 * rows_of(dy) * Cout * (Cin // groups) * kh * kw
+    if groups == 1 and "dgrad" in B3_OPS and _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1):
         d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         with _Timed("split3", 0.0):
             dyp = _split3_cached_dy(dy)
@@ -208,17 +208,17 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
         with _Timed("dgrad_b3", flops):
             check(lib.catseg_conv2d_bwd_data_bf16x3(ctypes.byref(d), ptr(dyp), ptr(wtp), ptr(out), 1 if accumulate else 0, stream()))
         return out
-    d = make_desc(xshape, ld_of(out), Cout, ld_of(dy), kh, kw, stride, pad, dil)
+    d = make_desc(xshape, ld_of(out), Cout, ld_of(dy), kh, kw, stride, pad, dil, False, groups)
     with _Timed("dgrad", flops):
         check(lib.catseg_conv2d_bwd_data(ctypes.byref(d), ptr(dy), ptr(w), ptr(out), 1 if accumulate else 0, stream()))
     return out
 
 
-def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=False):
+def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=False, groups=1):
     """dw: destination tensor (physical OHWI, or packed [O][7][8][4] for the stem)."""
     Cout, Cin = dy.shape[-1], x.shape[-1]
-    flops = 2.0 * rows_of(dy) * Cout * (3 if stem4 else Cin) * kh * kw
-    if ("wgrad" in B3_OPS and not stem4 and PRECISION == "bf16x3" and Cin % 8 == 0 and B3_MIN_TAPS <= kh * kw and kh * kw * Cin >= B3_MIN_K
+    flops = 2.0 * rows_of(dy) * Cout * (3 if stem4 else Cin // groups) * kh * kw
+    if (groups == 1 and "wgrad" in B3_OPS and not stem4 and PRECISION == "bf16x3" and Cin % 8 == 0 and B3_MIN_TAPS <= kh * kw and kh * kw * Cin >= B3_MIN_K
             and Cout >= B3_MIN_N and rows_of(dy) >= B3_MIN_WGRAD_ROWS):
         d = make_desc(x.shape, Cin, Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         ws = workspace(lib.catseg_conv2d_bwd_weight_bf16x3_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
@@ -230,7 +230,7 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
         if dbias is not None:
             check(lib.catseg_bias_grad(ptr(dy), ld_of(dy), rows_of(dy), Cout, ptr(dbias), ptr(ws), ws.numel(), stream()))
         return dw
-    d = make_desc(x.shape, ld_of(x), Cout, ld_of(dy), kh, kw, stride, pad, dil, stem4)
+    d = make_desc(x.shape, ld_of(x), Cout, ld_of(dy), kh, kw, stride, pad, dil, stem4, groups)
     need = lib.catseg_conv2d_bwd_weight_workspace(ctypes.byref(d))
     ws = workspace(need, x.device)
     with _Timed("wgrad", flops):

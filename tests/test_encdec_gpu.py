@@ -150,3 +150,34 @@ def test_eval_fused_conv_bn_matches_unfused():
         engine.FUSE_EVAL_BN = True
         b = model(x)[1]
     _close(b, a.cpu().numpy(), 0, 1e-3)   # folding the BN scale into w changes the rounding order, ~2e-4 through 53 layers
+
+
+def test_resnext50_upernet_trains():
+    """EncDec(ResNeXt50_32x4d + UPerNet) as a TRAINING network (grouped-convolution backward): a few Adam steps reduce the loss
+    and every parameter receives a finite gradient"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from miccai2021_cataract_semantic_segmentation_amd.models import EncDec
+    from miccai2021_cataract_semantic_segmentation_amd.losses import LossWrapper
+    from miccai2021_cataract_semantic_segmentation_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    model = EncDec({"encoder": {"model": "ResNeXt50", "pretrained": False}, "decoder": {"model": "UPerNet"}}, 1).cuda().train()
+    crit = LossWrapper({"losses": {"LovaszSoftmax": 1}, "experiment": 1, "device": "cuda"})
+    opt = FusedAdam(model, lr=1e-3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 3, 64, 96, generator=g).cuda()
+    lbl = torch.randint(0, 8, (2, 8, 12), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2).cuda()
+    losses = []
+    for step in range(6):
+        opt.zero_grad()
+        feat, y = model(x)
+        loss = crit(feat, y, lbl)
+        loss.backward()
+        if step == 0:
+            grads = model.flat().grad
+            assert bool(torch.isfinite(grads).all())
+            w = model.enc_model.layer2[0].conv2.weight
+            assert w.shape[1] * 32 == w.shape[0] and float(w.grad.abs().max()) > 0        # grouped 3x3: [O, I/32, 3, 3]
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0], losses

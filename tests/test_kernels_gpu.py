@@ -576,3 +576,21 @@ def test_lovasz_options_match_reference(golden, name):
     loss.backward()
     assert abs(float(loss) - float(g[name + ":loss"])) < 2e-6, (float(loss), float(g[name + ":loss"]))
     close(lg.grad, torch.from_numpy(g[name + ":grad"]), atol=1e-7, rtol=1e-3)
+
+
+@pytest.mark.parametrize("case", [(2, 12, 14, 64, 64, 3, 1, 1, 1, 8), (1, 17, 19, 128, 256, 3, 2, 1, 1, 32), (2, 9, 9, 32, 32, 3, 1, 2, 2, 4)])
+def test_grouped_conv_fwd_bwd(ops, case):
+    """grouped convolution (torchvision ResNeXt, models/ResNeXt.py:29-60): forward, backward-data and backward-weight vs F.conv2d(groups)"""
+    B, H, W, Cin, Cout, k, s, p, d, G = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin // G, k, k, generator=g) * 0.1).requires_grad_()
+    y = F.conv2d(x, w, None, s, p, d, G)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd, wd, gyd = nhwc(x.detach()), ohwi(w.detach()), nhwc(gy)
+    close(nchw(ops.conv_fwd(xd, wd, None, Cout, k, k, s, p, d, groups=G)), y)
+    close(nchw(ops.conv_bwd_data(gyd, wd, tuple(xd.shape), k, k, s, p, d, groups=G)), x.grad)
+    dw = torch.empty_like(wd)
+    ops.conv_bwd_weight(xd, gyd, dw, None, k, k, s, p, d, groups=G)
+    close(dw.cpu(), w.grad, atol=5e-4, rtol=5e-4)
