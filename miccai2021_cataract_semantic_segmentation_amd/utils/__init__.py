@@ -8,4 +8,7 @@ def __getattr__(name):  # metrics need the HIP library: import lazily so CPU-onl
     if name in ("t_get_confusion_matrix", "t_get_pixel_accuracy", "t_get_miou", "t_get_mean_iou"):
         from . import metrics
         return getattr(metrics, name)
+    if name == "PinnedFrameLoader":
+        from .loader import PinnedFrameLoader
+        return PinnedFrameLoader
     raise AttributeError(name)

@@ -1,0 +1,126 @@
+"""Rank-sharded, pinned-memory uint8 frame loader feeding ``GpuIngest``.
+
+The reference's loaders (managers/BaseManager.py:286-405) decode and augment on the main thread (the repeat-factor loader is
+hard-wired to ``num_workers=0``, :391) and hand float32 tensors to ``img.to(device)`` from pageable memory (OCRNet_Manager.py:75):
+62.5 MB of float32 + int64 per 8-frame batch.  Here the host side only stacks RAW uint8 frames (12.4 + 4.1 MB per batch) into
+pinned staging buffers on background threads; the copy to the device runs on a side HIP stream while the previous step
+computes, and remap / flip / reflect-pad / ToTensor / Normalize happen in one kernel on the device (``GpuIngest``).
+
+    loader = PinnedFrameLoader(dataset, batch_size=8, experiment=3, sampler=RepeatFactorSampler(...))   # or indices / None
+    for x, labels in loader:        # x float32 [B,3,H+4,W] (or NHWC-4), labels int64 [B,H+4,W], both on the device
+
+``dataset[i]`` returns ``(img uint8 [H,W,3] RGB, lbl uint8 [H,W] raw CaDIS ids)`` (numpy arrays or tensors; anything after the
+second element is ignored) -- e.g. ``cv2.imread`` + BGR->RGB as datasets/Dataset_from_df.py:36-44 does.  With WORLD_SIZE > 1
+the index stream is sharded by rank (dist.ShardedSampler).  Colour jitter / blur (PIL) are not applied (out of scope).
+"""
+import queue
+import threading
+
+import numpy as np
+import torch
+
+from .ingest import GpuIngest, sample_flips
+
+
+class PinnedFrameLoader:
+    def __init__(self, dataset, batch_size, experiment, sampler=None, shuffle=True, drop_last=True, flip_probability=(0.0, 0.5),
+                 pad=(2, 2), normalise=False, nhwc4=False, device="cuda", prefetch=3, workers=4, seed=0, rank=0, world=1):
+        self.dataset, self.batch, self.drop_last = dataset, int(batch_size), drop_last
+        self.device = torch.device(device)
+        self.ingest = GpuIngest(experiment, pad=pad, normalise=normalise, device=device)
+        self.flip_p, self.nhwc4 = flip_probability, nhwc4
+        self.prefetch, self.workers = max(int(prefetch), 1), max(int(workers), 1)
+        self.seed, self.epoch, self.rank, self.world = seed, 0, rank, world
+        self.sampler, self.shuffle = sampler, shuffle
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._slots = None
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def _indices(self):
+        if self.sampler is not None:
+            idx = list(iter(self.sampler))
+        else:
+            n = len(self.dataset)
+            idx = torch.randperm(n, generator=torch.Generator().manual_seed(self.seed + self.epoch)).tolist() if self.shuffle else list(range(n))
+        if self.world > 1:
+            n = len(idx) // (self.world * self.batch) * (self.world * self.batch)
+            idx = idx[self.rank:n:self.world]
+        return idx
+
+    def __len__(self):
+        n = len(self._indices()) if self.sampler is None else len(self.sampler) // max(self.world, 1)
+        return n // self.batch if self.drop_last else (n + self.batch - 1) // self.batch
+
+    def _alloc(self, h, w):
+        self._slots = [(torch.empty((self.batch, h, w, 3), dtype=torch.uint8).pin_memory(),
+                        torch.empty((self.batch, h, w), dtype=torch.uint8).pin_memory()) for _ in range(self.prefetch + 1)]
+
+    def __iter__(self):
+        idx = self._indices()
+        self.epoch += 1
+        batches = [idx[i:i + self.batch] for i in range(0, len(idx), self.batch)]
+        if self.drop_last and batches and len(batches[-1]) < self.batch:
+            batches.pop()
+        rng = np.random.RandomState(self.seed * 1000003 + self.epoch)
+        flips = [sample_flips(len(b), self.flip_p, rng) for b in batches]
+        ready = queue.Queue(maxsize=self.prefetch)
+        free = queue.Queue()
+        first = self.dataset[batches[0][0]] if batches else None
+        if first is not None and (self._slots is None or tuple(self._slots[0][0].shape[1:3]) != tuple(np.asarray(first[0]).shape[:2])):
+            self._alloc(*np.asarray(first[0]).shape[:2])
+        for s in range(len(self._slots or [])):
+            free.put(s)
+        stop = threading.Event()
+
+        def fill(slot, ids):
+            img_buf, lbl_buf = self._slots[slot]
+            def one(j):
+                item = self.dataset[ids[j]]
+                img_buf[j].copy_(torch.as_tensor(np.ascontiguousarray(item[0])))
+                lbl_buf[j].copy_(torch.as_tensor(np.ascontiguousarray(item[1])))
+            if self.workers > 1 and len(ids) > 1:
+                ts = [threading.Thread(target=lambda a=a: [one(j) for j in range(a, len(ids), self.workers)]) for a in range(min(self.workers, len(ids)))]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join()
+            else:
+                for j in range(len(ids)):
+                    one(j)
+
+        def producer():
+            try:
+                for bi, ids in enumerate(batches):
+                    if stop.is_set():
+                        return
+                    slot = free.get()
+                    fill(slot, ids)
+                    ready.put((slot, len(ids), flips[bi]))
+            finally:
+                ready.put(None)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    break
+                slot, n, fl = item
+                img_buf, lbl_buf = self._slots[slot]
+                with torch.cuda.stream(self.copy_stream):          # host -> device on the side stream (pinned: truly asynchronous)
+                    img_d = img_buf[:n].to(self.device, non_blocking=True)
+                    lbl_d = lbl_buf[:n].to(self.device, non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(self.copy_stream)
+                torch.cuda.current_stream(self.device).wait_event(done)   # the ingest kernel waits for the copy, the host does not
+                img_d.record_stream(torch.cuda.current_stream(self.device))
+                lbl_d.record_stream(torch.cuda.current_stream(self.device))
+                x, labels = self.ingest(img_d, lbl_d, fl, nhwc4=self.nhwc4)
+                done.synchronize()                                         # the staging slot may be refilled once the copy has left it
+                free.put(slot)
+                yield x, labels
+        finally:
+            stop.set()

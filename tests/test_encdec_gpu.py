@@ -181,3 +181,40 @@ def test_resnext50_upernet_trains():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.usefixtures("precision")
+def test_config1_plumbing_shape_vs_oracle():
+    """BASELINE config 1 ("FCN-ResNet18, 8-class (task 1), 2x3x256x256"): no such network exists in the reference (SURVEY F8);
+    the mapping used here is its ResNet18 part, EncDec(ResNet18 + UPerNet), task 1 (K = 8), at exactly 2 x 3 x 256 x 256 with the
+    LossWrapper / LovaszSoftmax loss of configs/UPN_rf_lvsz.json: logits, loss and calibrated gradients against the CPU oracle"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _calib import calibrated_grad_check
+    from oracle import losses as OL, upernet as OU
+    from oracle.state import fill_state, spec_of
+    from miccai2021_cataract_semantic_segmentation_amd.models import EncDec
+    from miccai2021_cataract_semantic_segmentation_amd.losses import LossWrapper
+    model = EncDec({"encoder": {"model": "ResNet18", "pretrained": False}, "decoder": {"model": "UPerNet"}}, 1)
+    spec = spec_of(model.state_dict())
+    S = fill_state(spec, 41)
+    model.load_state_dict(S)
+    model.cuda().train()
+    g = torch.Generator().manual_seed(42)
+    x = torch.rand(2, 3, 256, 256, generator=g)
+    lbl = torch.randint(0, 8, (2, 16, 16), generator=g).repeat_interleave(16, 1).repeat_interleave(16, 2)
+    crit = LossWrapper({"losses": {"LovaszSoftmax": 1}, "experiment": 1, "device": "cuda"})
+    feat, y = model(x.cuda())
+    assert y.shape == (2, 8, 256, 256)
+    loss = crit(feat, y, lbl.cuda())
+    loss.backward()
+    with torch.no_grad():
+        of, oy = OU.encdec_forward({k: v.clone() for k, v in S.items()}, x, "ResNet18", train=True)
+    _close(y, oy.numpy(), 0, 1e-3)
+    _close(feat, of.numpy(), 1e-4, 1e-3)
+    assert abs(float(loss) - float(OL.lovasz_softmax(oy, lbl))) < 1e-4
+    calibrated_grad_check(model, spec, 41, lambda S_, x_: OU.encdec_forward(S_, x_, "ResNet18", train=True)[1],
+                          lambda o, l: OL.lovasz_softmax(o, l), x, lbl, label="config 1: EncDec(ResNet18+UPerNet) 2x3x256x256")

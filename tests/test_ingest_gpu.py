@@ -61,3 +61,40 @@ def test_ingest_feeds_the_network():
     with torch.no_grad():
         a = model(x)[1]
     assert a.shape == (2, 25, 64, 96) and labels.shape == (2, 64, 96)
+
+
+def test_pinned_frame_loader_matches_direct_ingest():
+    """rank-sharded pinned-memory uint8 loader (utils/loader.py): batches equal the direct GpuIngest of the same frames / flips,
+    every frame of the shard is visited once per epoch, two ranks see disjoint frames"""
+    _need_gpu()
+    from miccai2021_cataract_semantic_segmentation_amd.utils import GpuIngest, PinnedFrameLoader
+    from miccai2021_cataract_semantic_segmentation_amd.utils.ingest import sample_flips
+
+    class Frames:
+        def __len__(self):
+            return 23
+
+        def __getitem__(self, i):
+            rng = np.random.RandomState(i)
+            return rng.randint(0, 256, (60, 96, 3)).astype(np.uint8), rng.randint(0, 36, (60, 96)).astype(np.uint8), {"index": i}
+
+    ds = Frames()
+    seen = {}
+    for rank in range(2):
+        loader = PinnedFrameLoader(ds, batch_size=4, experiment=3, seed=7, rank=rank, world=2, workers=3)
+        idx = loader._indices()
+        assert len(idx) == 8 and len(loader) == 2
+        seen[rank] = idx
+        out = list(loader)
+        assert len(out) == 2
+        rng = np.random.RandomState(7 * 1000003 + 1)
+        for bi, (x, labels) in enumerate(out):
+            ids = idx[bi * 4:(bi + 1) * 4]
+            flips = sample_flips(4, (0.0, 0.5), rng)
+            img = torch.from_numpy(np.stack([ds[i][0] for i in ids]))
+            lbl = torch.from_numpy(np.stack([ds[i][1] for i in ids]))
+            xr, lr = GpuIngest(3)(img, lbl, flips)
+            assert torch.equal(x, xr) and torch.equal(labels, lr) and x.shape == (4, 3, 64, 96)
+        # a second epoch reshuffles
+        assert loader._indices() != idx
+    assert not set(seen[0]) & set(seen[1])
