@@ -92,6 +92,27 @@ class FlatParams:
 
 
 # --------------------------------------------------------------------------- tape
+_side_streams = {}
+
+
+def side_streams(device, n):
+    """a small pool of HIP streams per device for the parallel-branch regions (HRNet's branches are independent)"""
+    key = (device.type, device.index)
+    pool = _side_streams.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+PARALLEL_BRANCHES = True   # run independent branches (HRNet stages) on separate HIP streams, forward and backward
+
+
+class _Region:
+    """tape marker of a parallel region: the streams its branches ran on"""
+    def __init__(self, streams):
+        self.streams = streams
+
+
 class Ctx:
     def __init__(self, train, record, on_param_grad=None):
         self.train = train
@@ -101,6 +122,8 @@ class Ctx:
         self.shared = set()
         self.on_param_grad = on_param_grad
         self.claimed = set()
+        self.branch_stream = None      # stream of the branch being recorded (None: the main stream)
+        self.region = None
 
     def claim(self, *params):
         """every parameter may feed exactly one recorded layer: the backward tape WRITES (does not accumulate) parameter
@@ -118,7 +141,66 @@ class Ctx:
 
     def push(self, fn):
         if self.record:
-            self.tape.append(fn)
+            self.tape.append((fn, self.branch_stream))
+
+    # ---- parallel regions: independent branches on separate HIP streams --------------------------------------------------
+    # The kernels of a 192- or 384-channel HRNet branch fill a fraction of the 256 CUs; its three sibling branches are
+    # independent until the fuse layer.  Forward: every branch runs on its own side stream (all of them wait for the main
+    # stream at the region's start, the main stream waits for all of them at its end and launches nothing in between, so that
+    # the caching allocator never hands a block that a side stream still reads to main-stream work).  The tape remembers each
+    # closure's stream and the region's boundaries; the backward replay mirrors the same fork / join.
+    def parallel(self, device, n):
+        cx = self
+
+        class _Par:
+            def __enter__(self_):
+                self_.on = PARALLEL_BRANCHES and n > 1 and device.type == "cuda"
+                if not self_.on:
+                    return self_
+                self_.main = torch.cuda.current_stream(device)
+                self_.streams = side_streams(device, n)
+                ev = torch.cuda.Event()
+                ev.record(self_.main)
+                for st in self_.streams:
+                    st.wait_event(ev)
+                cx.region = _Region(self_.streams)
+                if cx.record:
+                    cx.tape.append(("region_begin", cx.region))
+                return self_
+
+            def branch(self_, i):
+                return _Branch(self_, i)
+
+            def __exit__(self_, *exc):
+                if not self_.on:
+                    return False
+                for st in self_.streams:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    self_.main.wait_event(ev)
+                if cx.record:
+                    cx.tape.append(("region_end", cx.region))
+                cx.region = None
+                return False
+
+        class _Branch:
+            def __init__(self_, par, i):
+                self_.par, self_.i = par, i
+
+            def __enter__(self_):
+                if self_.par.on:
+                    self_.ctxm = torch.cuda.stream(self_.par.streams[self_.i])
+                    self_.ctxm.__enter__()
+                    cx.branch_stream = self_.par.streams[self_.i]
+                return self_
+
+            def __exit__(self_, *exc):
+                if self_.par.on:
+                    cx.branch_stream = None
+                    self_.ctxm.__exit__(*exc)
+                return False
+
+        return _Par()
 
     def take(self, t):
         self.shared.discard(id(t))
@@ -168,8 +250,29 @@ class Ctx:
 
     def backward(self):
         tape = self.tape
+        main = None
         while tape:
-            tape.pop()()
+            fn, tag = tape.pop()
+            if isinstance(fn, str):
+                region = tag
+                if main is None:
+                    main = torch.cuda.current_stream(region.streams[0].device)
+                if fn == "region_end":          # (reverse order) entering the region: the side streams wait for the main stream
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    for st in region.streams:
+                        st.wait_event(ev)
+                else:                           # leaving it: the main stream waits for every branch
+                    for st in region.streams:
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        main.wait_event(ev)
+                continue
+            if tag is None:
+                fn()
+            else:
+                with torch.cuda.stream(tag):
+                    fn()
         self.grads.clear()
         self.shared.clear()
 

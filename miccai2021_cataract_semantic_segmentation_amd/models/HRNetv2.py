@@ -144,7 +144,12 @@ class HighResolutionModule(nn.Module):
     def run(self, cx, xs):
         if self.num_branches == 1:
             return [_run_seq(cx, self.branches[0], xs[0])]
-        xs = [_run_seq(cx, self.branches[i], xs[i]) for i in range(self.num_branches)]
+        # the branches are independent until the fuse layers: one HIP stream each (engine.Ctx.parallel)
+        xs = list(xs)
+        with cx.parallel(xs[0].device, self.num_branches) as par:
+            for i in range(self.num_branches):
+                with par.branch(i):
+                    xs[i] = _run_seq(cx, self.branches[i], xs[i])
         outs = []
         for i in range(len(self.fuse_layers)):
             H, W = xs[i].shape[1:3]

@@ -16,8 +16,9 @@ _ws = {}
 
 
 def workspace(nbytes, device):
-    """Grow-only scratch buffer per device (all launches are ordered on one stream)."""
-    key = (device.type, device.index)
+    """Grow-only scratch buffer per (device, stream): launches on one stream are ordered; parallel-branch regions
+    (engine.Ctx.parallel) run on side streams, each with its own scratch"""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -137,8 +138,9 @@ _bn_part = {}
 
 
 def _bn_part_buffer(nfloats, device):
-    """grow-only buffer for the per-tile BatchNorm partials a convolution epilogue writes (consumed by the next launch)"""
-    key = (device.type, device.index)
+    """grow-only buffer (per device and stream) for the per-tile BatchNorm partials a convolution epilogue writes (consumed by
+    the next launch on the same stream)"""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _bn_part.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(int(nfloats), 1 << 18), dtype=torch.float32, device=device)
