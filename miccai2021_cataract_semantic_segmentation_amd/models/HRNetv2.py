@@ -150,19 +150,23 @@ class HighResolutionModule(nn.Module):
             for i in range(self.num_branches):
                 with par.branch(i):
                     xs[i] = _run_seq(cx, self.branches[i], xs[i])
-        outs = []
-        for i in range(len(self.fuse_layers)):
-            H, W = xs[i].shape[1:3]
-            terms = []
+        # fuse (models/HRNetv2.py:237-261): out_i = relu(sum_j f_ij(x_j)).  The 12 chains f_ij are independent; they run grouped by
+        # their SOURCE branch j, one stream per j (the gradient of x_j is then accumulated by one stream, in a fixed order);
+        # the sums follow on the main stream
+        n_out = len(self.fuse_layers)
+        terms = [[None] * self.num_branches for _ in range(n_out)]
+        with cx.parallel(xs[0].device, self.num_branches) as par:
             for j in range(self.num_branches):
-                if j == i:
-                    terms.append(xs[j])
-                elif j > i:
-                    t = _run_seq(cx, self.fuse_layers[i][j], xs[j])
-                    terms.append(bilinear(cx, t, H, W, False))
-                else:
-                    terms.append(_run_seq(cx, self.fuse_layers[i][j], xs[j]))
-            outs.append(add_n(cx, terms, relu=True))
+                with par.branch(j):
+                    for i in range(n_out):
+                        if j == i:
+                            continue
+                        t = _run_seq(cx, self.fuse_layers[i][j], xs[j])
+                        terms[i][j] = bilinear(cx, t, xs[i].shape[1], xs[i].shape[2], False) if j > i else t
+        outs = []
+        for i in range(n_out):
+            terms[i][i] = xs[i]
+            outs.append(add_n(cx, terms[i], relu=True))
         return outs
 
 
