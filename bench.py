@@ -269,10 +269,17 @@ def main():
     if not args.no_roofline:
         # per-launch HIP-event timing of the implicit-GEMM kernels on the launch stream (2 extra steps, run by
         # EVERY rank because a step contains the gradient all-reduce; only rank 0 records)
+        # (the instrumented steps run the HRNet branches one after the other: with the branches overlapped on side streams, as
+        #  in the timed region, the HIP events around one launch would also time its concurrent siblings)
+        from miccai2021_cataract_semantic_segmentation_amd import engine
+        par, engine.PARALLEL_BRANCHES = engine.PARALLEL_BRANCHES, False
+        step()
+        torch.cuda.synchronize()
         ops.PROFILE = [] if rank == 0 else None
         for _ in range(2):
             step()
         torch.cuda.synchronize()
+        engine.PARALLEL_BRANCHES = par
     if not args.no_roofline and rank == 0:
         prof, ops.PROFILE = ops.PROFILE, None
         agg = {}
