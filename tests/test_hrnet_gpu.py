@@ -87,3 +87,40 @@ def test_ocrnet_hrnet_assembly_vs_oracle():
                     if float(S[k].grad.norm()) > 1e-6])
     print("median / max relative grad error vs cpu fp32 oracle: %.3g / %.3g" % (np.median(rel), rel.max()))
     assert np.median(rel) < 5e-2
+
+
+def test_parallel_regions_bit_identical():
+    """HRNet branches / fuse chains on concurrent streams (engine.Ctx.parallel) launch the same kernels in the same per-tensor
+    order as the sequential schedule: logits, BN running statistics and every gradient must be bit-identical."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle.state import fill_state, spec_of
+    from miccai2021_cataract_semantic_segmentation_amd import engine
+    from miccai2021_cataract_semantic_segmentation_amd.models import OCRNet
+    from miccai2021_cataract_semantic_segmentation_amd.losses import TwoScaleLoss
+    cfg = {"backbone": "hrnet18", "pretrained": False, "hrnet": {"width": 16, "stage1_width": 32, "modules": (1, 2, 2)}}
+    gen = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 3, 96, 160, generator=gen).cuda()
+    lbl = torch.randint(0, 26, (2, 12, 20), generator=gen).repeat_interleave(8, 1).repeat_interleave(8, 2).cuda()
+    crit = TwoScaleLoss({"experiment": 3, "interm": {"name": "LovaszSoftmax", "args": []}, "final": {"name": "LovaszSoftmax", "args": []}})
+    res = []
+    old = engine.PARALLEL_BRANCHES
+    try:
+        for par in (True, False, True):
+            engine.PARALLEL_BRANCHES = par
+            model = OCRNet(dict(cfg), 3)
+            model.load_state_dict(fill_state(spec_of(model.state_dict()), 3))
+            model.cuda().train()
+            interm, final = model(x)
+            crit(interm, final, lbl).backward()
+            torch.cuda.synchronize()
+            res.append((final.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()},
+                        {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
+    finally:
+        engine.PARALLEL_BRANCHES = old
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0])
+        for k in res[0][1]:
+            assert torch.equal(res[0][1][k], other[1][k]), k
+        for k in res[0][2]:
+            assert torch.equal(res[0][2][k], other[2][k]), k

@@ -29,16 +29,18 @@ def step():
     opt.zero_grad(); i, f = model(img); l = crit(i, f, lbl); l.backward(); opt.step()
 for _ in range(2): step()
 E.ops.conv_fwd, E.ops.conv_bwd_data, E.ops.conv_bwd_weight = cf, cd, cw
+E.PARALLEL_BRANCHES = False   # sequential branches: the events around one launch then time that launch only
+step(); torch.cuda.synchronize()
 ops.PROFILE = []
 step(); torch.cuda.synchronize()
-prof = ops.PROFILE; ops.PROFILE = None
+prof = [q for q in ops.PROFILE if q[0].split('_')[0] in ('fwd', 'dgrad', 'wgrad')]; ops.PROFILE = None
 agg = collections.OrderedDict()
 for (kind, fl, e0, e1), sh in zip(prof, shapes):
-    assert kind == sh[0]
-    k = sh
+    assert kind.split('_')[0] == sh[0], (kind, sh)
+    k = (kind,) + sh[1:]
     a = agg.setdefault(k, [0, 0.0, 0.0]); a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1)
 rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
 tot = sum(v[2] for v in agg.values())
 print("total igemm ms %.1f" % tot)
-for k, (n, fl, ms) in rows[:45]:
-    print("%-6s x%-3d in%-22s Cout %-5d k%d %-10s %8.2f ms %6.1f TF %5.1f%%" % (k[0], n, k[1], k[2], k[3], k[4], ms, fl / ms / 1e9, 100 * ms / tot))
+for k, (n, fl, ms) in rows[:70]:
+    print("%-8s x%-3d in%-22s Cout %-5d k%d %-10s %8.2f ms %6.1f TF %5.1f%%" % (k[0], n, k[1], k[2], k[3], k[4], ms, fl / ms / 1e9, 100 * ms / tot))
