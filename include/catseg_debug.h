@@ -19,6 +19,9 @@ extern "C" {
 int catseg_debug_set_tile(int mi, int ni);
 /* tuning hook: force the backward-weight split count (0 restores the planner) */
 int catseg_debug_set_splits(int splits);
+/* measurement hook: 0 = stride-2 backward-data as one launch per input-pixel parity class (round 1), 1 (default) = all classes in
+ * one launch (igemm_f32_multi_kernel) */
+int catseg_debug_set_strided_multi(int on);
 /* measurement hook: 0 = sort every pixel of every present class in catseg_lovasz_softmax (the data-independent worst case);
  * 1 (default) = sort only the elements that can precede the last foreground pixel (bit-identical result) */
 int catseg_debug_set_lovasz_prune(int on);

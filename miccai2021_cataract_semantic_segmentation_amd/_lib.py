@@ -42,6 +42,7 @@ _SIGS = {
     "catseg_gemm_batched": (I, [I, I, I, I, I, P, I, L, P, I, L, P, I, L, I, I, P]),
     "catseg_debug_set_tile": (I, [I, I]),
     "catseg_debug_set_splits": (I, [I]),
+    "catseg_debug_set_strided_multi": (I, [I]),
     "catseg_debug_set_lovasz_prune": (I, [I]),
     "catseg_debug_set_wgrad_direct": (I, [I]),
     "catseg_debug_plan_conv": (I, [P, I, P]),

@@ -145,7 +145,7 @@ constexpr int igemm_min_waves(int MI, int NI, int NARROW) {
 }
 
 template <int LAYOUT, int MI, int NI, bool FAST, int NARROW>
-__global__ __launch_bounds__(256, igemm_min_waves(MI, NI, NARROW)) void igemm_f32_kernel(const IgemmArgs p) {
+__device__ __forceinline__ void igemm_f32_body(const IgemmArgs& p) {
   constexpr int BM = 64 * MI, BN = 64 * NI;                    // rows of A / B staged in LDS per K-step
   constexpr int TILE_M = NARROW == 2 ? 48 * MI : BM;           // extent of the output tile
   constexpr int TILE_N = NARROW == 1 ? 48 * NI : (NARROW == 3 ? 16 : (NARROW == 4 ? 32 : BN));
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, igemm_min_waves(MI, NI, NARROW)) void igemm_f3
 
   // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
   // contiguous run of tiles (bijective for any grid size).
-  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int nblk = p.tilesM * p.tilesN, bid = blockIdx.x;   // (= gridDim.x, except in the multi-problem launch)
   const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int tile_m = swz / p.tilesN, tile_n = swz - tile_m * p.tilesN;
@@ -602,6 +602,22 @@ __global__ __launch_bounds__(256, igemm_min_waves(MI, NI, NARROW)) void igemm_f3
   }
 }
 
+template <int LAYOUT, int MI, int NI, bool FAST, int NARROW>
+__global__ __launch_bounds__(256, igemm_min_waves(MI, NI, NARROW)) void igemm_f32_kernel(const IgemmArgs p) {
+  igemm_f32_body<LAYOUT, MI, NI, FAST, NARROW>(p);
+}
+
+// Strided backward-data: the (up to four) input-pixel parity classes of one convolution as ONE launch, blockIdx.y = class.  The
+// classes are independent dense problems with their own tap sets (1 / 2 / 2 / 4 taps of a 3x3 stride-2 filter) and row counts;
+// launched one after the other (round 1) each of them filled a fraction of the chip and paid its own launch.
+struct IgemmMulti { IgemmArgs a[4]; };
+template <int MI, int NI, int NARROW>
+__global__ __launch_bounds__(256, igemm_min_waves(MI, NI, NARROW)) void igemm_f32_multi_kernel(const IgemmMulti q) {
+  const IgemmArgs& p = q.a[blockIdx.y];
+  if ((int)blockIdx.x >= p.tilesM * p.tilesN) return;
+  igemm_f32_body<L_NN, MI, NI, true, NARROW>(p);
+}
+
 // out[i] = sum_s slab[s][i]  (deterministic split reduction of backward-weight partials)
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n4,
                                     int splits, long long stride4) {
@@ -667,7 +683,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, 
   out[c] = s;
 }
 
-int g_force_mi = 0, g_force_ni = 0, g_force_narrow = 0, g_force_splits = 0;
+int g_force_mi = 0, g_force_ni = 0, g_force_narrow = 0, g_force_splits = 0, g_strided_multi = 1;
 
 }  // namespace
 // wgrad_direct.hip
@@ -812,6 +828,40 @@ int launch_igemm(const IgemmArgs& a, int nbatch, int grid_y, hipStream_t st, con
   return CATSEG_OK;
 }
 
+// the parity classes of a strided backward-data as one launch (classes sorted by work, heaviest first)
+int launch_multi_nn(IgemmArgs* cls, int ncls, hipStream_t st) {
+  long long maxM = 0;
+  for (int i = 0; i < ncls; ++i) maxM = cls[i].M > maxM ? cls[i].M : maxM;
+  const TilePlan pl = plan_tiles(L_NN, maxM, cls[0].N, ncls, maxM);
+  IgemmMulti q = {};
+  const float* zero = zero_page_ptr();
+  bool ok = false;
+#define CS_FORM(F_, M_, N_)                                                                                   \
+  if (!ok && pl.narrow == F_ && pl.mi == M_ && pl.ni == N_) {                                                 \
+    constexpr int TILE_M = 64 * M_, TILE_N = F_ == 1 ? 48 * N_ : 64 * N_;                                     \
+    int maxt = 0;                                                                                             \
+    for (int i = 0; i < ncls; ++i) {                                                                          \
+      q.a[i] = cls[i];                                                                                        \
+      q.a[i].zero = zero;                                                                                     \
+      q.a[i].tilesM = (cls[i].M + TILE_M - 1) / TILE_M;                                                       \
+      q.a[i].tilesN = (cls[i].N + TILE_N - 1) / TILE_N;                                                       \
+      const int t = q.a[i].tilesM * q.a[i].tilesN;                                                            \
+      maxt = t > maxt ? t : maxt;                                                                             \
+    }                                                                                                         \
+    hipLaunchKernelGGL((igemm_f32_multi_kernel<M_, N_, F_>), dim3(maxt, ncls, 1), dim3(256), 0, st, q);       \
+    ok = true;                                                                                                \
+  }
+  CS_FORM(0, 1, 1) CS_FORM(0, 1, 2) CS_FORM(0, 2, 1) CS_FORM(0, 2, 2) CS_FORM(0, 4, 2) CS_FORM(0, 2, 4)
+  CS_FORM(1, 2, 1) CS_FORM(1, 4, 1) CS_FORM(1, 2, 2) CS_FORM(1, 4, 2)
+#undef CS_FORM
+  if (!ok) {
+    catseg_set_error("igemm: unsupported tile %dx%d (form %d)", pl.mi, pl.ni, pl.narrow);
+    return CATSEG_EINVAL;
+  }
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
 int check_desc(const catseg_conv_desc* d) {
   CS_REQUIRE(d != nullptr, "conv: null descriptor");
   CS_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0, "conv: bad dims");
@@ -856,6 +906,10 @@ extern "C" int catseg_debug_set_tile(int mi, int ni) {
   mi &= 15;
   g_force_mi = mi;
   g_force_ni = ni;
+  return CATSEG_OK;
+}
+extern "C" int catseg_debug_set_strided_multi(int on) {
+  g_strided_multi = on;
   return CATSEG_OK;
 }
 extern "C" int catseg_debug_set_splits(int splits) {
@@ -985,6 +1039,9 @@ extern "C" int catseg_conv2d_bwd_data(const catseg_conv_desc* d, const float* dy
   // receives taps ky with (py + pad - ky*dil) % s == 0, from output row a + (py + pad - ky*dil) / s: no wasted MACs.
   const int sdv = d->stride;
   if (d->kh * d->kw > 32) return launch_igemm<L_NN>(a, 1, 1, (hipStream_t)stream);   // generic (slow) path
+  IgemmArgs cls[4];
+  int ncls = 0;
+  const bool multi = sdv == 2 && g_strided_multi;
   for (int py = 0; py < sdv; ++py)
     for (int px = 0; px < sdv; ++px) {
       const int Hs = (d->H - py + sdv - 1) / sdv, Ws = (d->W - px + sdv - 1) / sdv;
@@ -1009,8 +1066,15 @@ extern "C" int catseg_conv2d_bwd_data(const catseg_conv_desc* d, const float* dy
       }
       q.taps = q.nky * q.nkx;
       q.remap = 1; q.out_s = sdv; q.out_py = py; q.out_px = px; q.out_H = d->H; q.out_W = d->W;
-      if (int e = launch_igemm<L_NN>(q, 1, 1, (hipStream_t)stream)) return e;
+      if (multi) {
+        int at = ncls++;
+        while (at > 0 && cls[at - 1].taps < q.taps) { cls[at] = cls[at - 1]; --at; }   // heaviest class first
+        cls[at] = q;
+      } else if (int e = launch_igemm<L_NN>(q, 1, 1, (hipStream_t)stream)) {
+        return e;
+      }
     }
+  if (multi && ncls > 0) return launch_multi_nn(cls, ncls, (hipStream_t)stream);
   return CATSEG_OK;
 }
 
@@ -1033,7 +1097,7 @@ extern "C" int catseg_debug_plan_conv(const catseg_conv_desc* d, int op, int* ou
   } else if (op == 1) {
     const int s = d->stride;
     const long long rows = (long long)d->B * ((d->H + s - 1) / s) * ((d->W + s - 1) / s);
-    pl = plan_tiles(L_NN, rows, d->Cin, 1, rows);
+    pl = plan_tiles(L_NN, rows, d->Cin, (s == 2 && g_strided_multi) ? 4 : 1, rows);
   } else {
     pl = wgrad_plan(d);
     direct = wgrad_direct_workspace(d) > 0;

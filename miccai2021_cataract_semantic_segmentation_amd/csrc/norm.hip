@@ -22,8 +22,8 @@ RowSplit plan_rows(long long rows, int C) {
   s.tpr = cpt < 64 ? cpt : 64;
   s.rpp = 256 / s.tpr;
   s.gy = (cpt + s.tpr - 1) / s.tpr;
-  int want = 1024 / s.gy;  // ~1024 blocks in total fill the chip; fewer partials = cheaper merge
-  if (want > 512) want = 512;
+  int want = 2048 / s.gy;  // ~2048 blocks in total (8 per CU, 4 independent row loads per thread in flight: the reductions are
+  if (want > 1024) want = 1024;   // latency-bound below that); fewer partials = cheaper merge
   if (want < 64) want = 64;
   long long rpb = (rows + want - 1) / want;
   if (rpb < 4 * s.rpp) rpb = 4 * s.rpp;
@@ -48,7 +48,15 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   f32x4 K = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
   if (act) {
     K = ld4(y + r0 * ld + c);
-    for (long long r = r0 + rl; r < r1; r += s.rpp) {
+    const long long st = s.rpp;
+    long long r = r0 + rl;
+    for (; r + 3 * st < r1; r += 4 * st) {   // four independent loads in flight
+      const f32x4 d0 = ld4(y + r * ld + c) - K, d1 = ld4(y + (r + st) * ld + c) - K;
+      const f32x4 d2 = ld4(y + (r + 2 * st) * ld + c) - K, d3 = ld4(y + (r + 3 * st) * ld + c) - K;
+      s1 += (d0 + d1) + (d2 + d3);
+      s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    for (; r < r1; r += st) {
       const f32x4 d = ld4(y + r * ld + c) - K;
       s1 += d;
       s2 += d * d;
@@ -190,7 +198,31 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     const f32x4 mean = ld4(stats + c), inv = ld4(stats + C + c);
     f32x4 sc = {0, 0, 0, 0}, be = {0, 0, 0, 0};
     if (relu && !z) { sc = ld4(gamma + c) * inv; be = ld4(beta + c); }   // scale exactly as bn_finalize stored it
-    for (long long r = r0 + rl; r < r1; r += s.rpp) {
+    const long long st = s.rpp;
+    long long r = r0 + rl;
+    for (; r + 3 * st < r1; r += 4 * st) {   // four independent rows in flight (8 - 12 loads)
+      f32x4 g[4], yy[4], zz[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        g[u] = ld4(dz + (r + u * st) * lddz + c);
+        yy[u] = ld4(y + (r + u * st) * ldy + c);
+      }
+      if (relu) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) zz[u] = z ? ld4(z + (r + u * st) * ldz + c) : bn_affine(yy[u], mean, sc, be);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) g[u][i] = zz[u][i] > 0.f ? g[u][i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f32x4 xh = (yy[u] - mean) * inv;
+        sg += g[u];
+        sgx += g[u] * xh;
+      }
+    }
+    for (; r < r1; r += st) {
       f32x4 g = ld4(dz + r * lddz + c);
       const f32x4 yy = ld4(y + r * ldy + c);
       if (relu) {

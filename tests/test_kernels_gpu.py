@@ -594,3 +594,33 @@ def test_grouped_conv_fwd_bwd(ops, case):
     dw = torch.empty_like(wd)
     ops.conv_bwd_weight(xd, gyd, dw, None, k, k, s, p, d, groups=G)
     close(dw.cpu(), w.grad, atol=5e-4, rtol=5e-4)
+
+
+@pytest.mark.parametrize("case", [(2, 43, 55, 48, 96, 3, 2, 1, 1), (1, 40, 64, 96, 192, 3, 2, 1, 1), (2, 21, 20, 64, 40, 3, 2, 1, 1),
+                                  (1, 33, 31, 32, 48, 1, 2, 0, 1), (1, 37, 41, 24, 64, 3, 2, 2, 2), (3, 5, 7, 256, 64, 3, 2, 1, 1)])
+@pytest.mark.parametrize("multi", [1, 0])
+def test_strided_backward_data_parity_classes(ops, case, multi):
+    """stride-2 backward-data: the four input-pixel parity classes in ONE launch (igemm_f32_multi_kernel; odd extents give the
+    classes different row counts, 1x1 / dilated filters leave classes without a tap) and as four launches, vs torch"""
+    from miccai2021_cataract_semantic_segmentation_amd import _lib
+    B, H, W, Ci, Co, k, s, p, d = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Ci, H, W, generator=g, requires_grad=True)
+    w = torch.randn(Co, Ci, k, k, generator=g) * (2.0 / (Ci * k * k)) ** 0.5
+    y = F.conv2d(x, w, None, s, p, d)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    gyd = ops.new_act(B, y.shape[2], y.shape[3], Co, torch.device("cuda"), zero=True)
+    gyd.copy_(gy.permute(0, 2, 3, 1))
+    try:
+        _lib.check(_lib.lib.catseg_debug_set_strided_multi(multi))
+        dx = ops.conv_bwd_data(gyd, wd, (B, H, W, Ci), k, k, s, p, d)
+        base = torch.full((B, H, W, Ci), 0.5, device="cuda")
+        acc = ops.conv_bwd_data(gyd, wd, (B, H, W, Ci), k, k, s, p, d, out=base.clone(), accumulate=True)
+    finally:
+        _lib.lib.catseg_debug_set_strided_multi(1)
+    ref = x.grad.permute(0, 2, 3, 1)
+    sc = float(ref.abs().max())
+    assert float((dx.cpu() - ref).abs().max()) <= 2e-5 * sc + 2e-6
+    assert float((acc.cpu() - ref - 0.5).abs().max()) <= 2e-5 * sc + 2e-6
