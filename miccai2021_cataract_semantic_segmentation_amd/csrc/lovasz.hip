@@ -576,12 +576,24 @@ __global__ __launch_bounds__(PIX) void lv_backward_kernel(const float* __restric
     const long long p = p0 + t;
     float* grow = sh + PIX * KS + t * KS;  // second LDS image: d loss / d prob of this pixel
     float dot = 0.f;
-    for (int c = 0; c < K; ++c) {
-      const float pr = row[c] / s;
-      const float g = counts[c] ? dprob[(long long)c * P + p] * w : 0.f;
-      row[c] = pr;
-      grow[c] = g;
-      dot += g * pr;
+    for (int c0 = 0; c0 < K; c0 += 8) {   // eight independent class-plane loads in flight (absent classes: dprob is not written, g = 0)
+      float gv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + u;
+        gv[u] = (c < K && counts[c]) ? dprob[(long long)c * P + p] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + u;
+        if (c < K) {
+          const float pr = row[c] / s;
+          const float g = gv[u] * w;
+          row[c] = pr;
+          grow[c] = g;
+          dot += g * pr;
+        }
+      }
     }
     for (int c = 0; c < K; ++c) row[c] = row[c] * (grow[c] - dot);
   }

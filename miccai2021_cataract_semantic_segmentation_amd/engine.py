@@ -124,6 +124,8 @@ class Ctx:
         self.claimed = set()
         self.branch_stream = None      # stream of the branch being recorded (None: the main stream)
         self.region = None
+        self._region_depth = 0         # backward: parallel regions entered and not yet joined
+        self._deferred = []            # backward: parameters whose 'gradient ready' signal waits for the join
 
     def claim(self, *params):
         """every parameter may feed exactly one recorded layer: the backward tape WRITES (does not accumulate) parameter
@@ -243,10 +245,16 @@ class Ctx:
         return p.grad
 
     def done(self, *params):
+        """gradient of these parameters has been enqueued.  Inside a parallel region the signal is held back until the region
+        has joined: the data-parallel reducer launches a bucket's all-reduce behind the CURRENT stream only, and the other
+        members of the bucket may have been written on sibling streams."""
         if self.on_param_grad is not None:
             for p in params:
                 if p is not None:
-                    self.on_param_grad(p)
+                    if self._region_depth > 0:
+                        self._deferred.append(p)
+                    else:
+                        self.on_param_grad(p)
 
     def backward(self):
         tape = self.tape
@@ -262,11 +270,17 @@ class Ctx:
                     ev.record(main)
                     for st in region.streams:
                         st.wait_event(ev)
+                    self._region_depth += 1
                 else:                           # leaving it: the main stream waits for every branch
                     for st in region.streams:
                         ev = torch.cuda.Event()
                         ev.record(st)
                         main.wait_event(ev)
+                    self._region_depth -= 1
+                    if self._region_depth == 0 and self._deferred:
+                        ready, self._deferred = self._deferred, []
+                        for p in ready:         # (on the main stream, which now follows every branch of the region)
+                            self.on_param_grad(p)
                 continue
             if tag is None:
                 fn()

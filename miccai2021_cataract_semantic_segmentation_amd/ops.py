@@ -103,9 +103,23 @@ B3_MIN_WGRAD_ROWS = 32768
 _b3_cache_dy = {"key": None, "x": None, "planes": None}
 
 
+# wide 1x1 layers (the 1024 -> 512 bottleneck of the OCR head at stride 4): both GEMM extents >= 512, their product >= 512 * 1024,
+# >= 131072 pixels -- there the split pass (one read + 1.5 writes of the activation) is paid back (tools/bench_b3.py: forward
+# 2.38 -> 1.54 + 0.57 ms, backward-data 2.42 -> 1.80 + 0.30 ms at 8 x 136 x 240); smaller 1x1 layers stay on the fp32 kernels
+B3_1X1_MIN_DIM, B3_1X1_MIN_PROD, B3_1X1_MIN_ROWS = 512, 512 * 1024, 131072
+
+
+def _b3_wide_1x1(rows, ncols, taps, cred):
+    return taps == 1 and min(cred, ncols) >= B3_1X1_MIN_DIM and cred * ncols >= B3_1X1_MIN_PROD and rows >= B3_1X1_MIN_ROWS
+
+
 def _b3_eligible(rows, ncols, taps, cred, stride_ok=True):
-    return (PRECISION == "bf16x3" and stride_ok and B3_MIN_TAPS <= taps <= 32 and cred % 8 == 0 and taps * cred >= B3_MIN_K
-            and ncols >= B3_MIN_N and ((rows + 255) // 256) * ((ncols + 255) // 256) >= B3_MIN_TILES)
+    if not (PRECISION == "bf16x3" and stride_ok and taps <= 32 and cred % 8 == 0):
+        return False
+    if (B3_MIN_TAPS <= taps and taps * cred >= B3_MIN_K and ncols >= B3_MIN_N
+            and ((rows + 255) // 256) * ((ncols + 255) // 256) >= B3_MIN_TILES):
+        return True
+    return _b3_wide_1x1(rows, ncols, taps, cred)
 
 
 def _split3_cached(x):
@@ -220,8 +234,9 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
     """dw: destination tensor (physical OHWI, or packed [O][7][8][4] for the stem)."""
     Cout, Cin = dy.shape[-1], x.shape[-1]
     flops = 2.0 * rows_of(dy) * Cout * (3 if stem4 else Cin // groups) * kh * kw
-    if (groups == 1 and "wgrad" in B3_OPS and not stem4 and PRECISION == "bf16x3" and Cin % 8 == 0 and B3_MIN_TAPS <= kh * kw and kh * kw * Cin >= B3_MIN_K
-            and Cout >= B3_MIN_N and rows_of(dy) >= B3_MIN_WGRAD_ROWS):
+    if (groups == 1 and "wgrad" in B3_OPS and not stem4 and PRECISION == "bf16x3" and Cin % 8 == 0 and
+            ((B3_MIN_TAPS <= kh * kw and kh * kw * Cin >= B3_MIN_K and Cout >= B3_MIN_N and rows_of(dy) >= B3_MIN_WGRAD_ROWS)
+             or (stride == 1 and _b3_wide_1x1(rows_of(dy), Cout, kh * kw, Cin)))):
         d = make_desc(x.shape, Cin, Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         ws = workspace(lib.catseg_conv2d_bwd_weight_bf16x3_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
         with _Timed("split3", 0.0):
