@@ -110,6 +110,22 @@ int catseg_conv2d_bwd_data_bf16x3(const catseg_conv_desc* d, const void* dy_plan
 size_t catseg_conv2d_bwd_weight_bf16x3_workspace(const catseg_conv_desc* d);
 int catseg_conv2d_bwd_weight_bf16x3(const catseg_conv_desc* d, const void* x_planes, const void* dy_planes, float* dw,
                                     void* workspace, size_t workspace_bytes, catseg_stream_t stream);
+/* BLOCKED operand planes for the large layers (>= 193 output columns): activations [3][ceil(C/16)][rows][16], weights
+ * [3][K/16][N][16] -- the 256 rows of one K-step form one contiguous run, so that every LDS-DMA instruction of the 256 x 256
+ * kernel reads whole cache lines (the [rows][C] planes above gave each lane pair its own line and bounded that kernel by the
+ * vector L1's line rate).  catseg_split3_blocked writes, from ONE pass over x, the blocked planes and -- if planar_planes is not
+ * null -- the catseg_split3 layout as well (the backward-weight kernel keeps reading that one). */
+size_t catseg_split3_blocked_elems(long long rows, int C);   /* 16-bit elements of ALL three planes: 3 * roundup(C, 16) * rows */
+int catseg_split3_blocked(const float* x, long long rows, int C, int ld, void* blocked_planes, void* planar_planes,
+                          catseg_stream_t stream);
+int catseg_split3_weight_blocked(const float* w, int O, int taps, int Cin, void* planes, catseg_stream_t stream);    /* Cin % 16 == 0 */
+int catseg_split3_weight_t_blocked(const float* w, int O, int taps, int Cin, void* planes, catseg_stream_t stream);  /* [taps*roundup(O,16)/16][Cin][16] */
+/* forward (Cin % 16 == 0; bn_part may be NULL: no BatchNorm partials) and stride-1 backward-data from blocked planes */
+int catseg_conv2d_fwd_bf16x3_blocked(const catseg_conv_desc* d, const void* x_planes, const void* w_planes, const float* bias,
+                                     float* y, int zero_to, float* bn_part, size_t bn_part_floats, int* tile_rows, int* n_tiles,
+                                     catseg_stream_t stream);
+int catseg_conv2d_bwd_data_bf16x3_blocked(const catseg_conv_desc* d, const void* dy_planes, const void* wt_planes, float* dx,
+                                          int accumulate, catseg_stream_t stream);
 /* dbias[o] = sum_p dy[p, o] (the bias-gradient part of catseg_conv2d_bwd_weight on its own); workspace >= 256 * C floats */
 int catseg_bias_grad(const float* dy, int ld, long long rows, int C, float* dbias, void* workspace, size_t workspace_bytes,
                      catseg_stream_t stream);

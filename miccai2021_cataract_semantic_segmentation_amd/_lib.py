@@ -50,6 +50,12 @@ _SIGS = {
     "catseg_split3_elems": (SZ, [L, I]),
     "catseg_split3": (I, [P, I, L, I, P, P]),
     "catseg_split3_weight_t": (I, [P, I, I, I, P, P]),
+    "catseg_split3_blocked_elems": (SZ, [L, I]),
+    "catseg_split3_blocked": (I, [P, L, I, I, P, P, P]),
+    "catseg_split3_weight_blocked": (I, [P, I, I, I, P, P]),
+    "catseg_split3_weight_t_blocked": (I, [P, I, I, I, P, P]),
+    "catseg_conv2d_fwd_bf16x3_blocked": (I, [P, P, P, P, P, I, P, SZ, P, P, P]),
+    "catseg_conv2d_bwd_data_bf16x3_blocked": (I, [P, P, P, P, I, P]),
     "catseg_conv2d_fwd_bf16x3": (I, [P, P, P, P, P, I, P]),
     "catseg_conv2d_bwd_data_bf16x3": (I, [P, P, P, P, I, P]),
     "catseg_conv2d_bwd_weight_bf16x3_workspace": (SZ, [P]),

@@ -42,6 +42,8 @@ struct B3Args {
   int zero_to, accumulate;
   const float* zero;
   float* bn_part;     // per (M-tile, channel) BatchNorm partials [tilesM][3][N], or nullptr
+  // blocked operand planes (igemm_b3w_kernel<true> only): activations [Cin/16][a_rows][16], weights [taps*Cin/16][w_rows][16]
+  int blocked, a_rows, w_rows;
 };
 
 __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
@@ -92,6 +94,101 @@ __global__ __launch_bounds__(256) void split3_wt_kernel(const float* __restrict_
     out[i] = __builtin_bit_cast(u16, hh);
     out[i + plane] = __builtin_bit_cast(u16, mm);
     out[i + 2 * plane] = __builtin_bit_cast(u16, ll);
+  }
+}
+
+__device__ __forceinline__ void split3_one(float v, u16& h, u16& m, u16& l) {
+  const __bf16 hh = (__bf16)v;
+  const float r1 = v - (float)hh;
+  const __bf16 mm = (__bf16)r1;
+  h = __builtin_bit_cast(u16, hh);
+  m = __builtin_bit_cast(u16, mm);
+  l = __builtin_bit_cast(u16, (__bf16)(r1 - (float)mm));
+}
+
+// fp32 [rows][ld] -> three bf16 planes in the BLOCKED layout [C16][rows][16] (C16 = ceil(C / 16), channel tail zero) and, in the
+// same pass, optionally the planar layout [rows][ldp] of split3_kernel.  Block = 64 rows x 128 channels through LDS: the source
+// is read with 512-byte row segments, the blocked planes are written as 2 KB runs (64 rows x 32 B of one chunk), the planar planes
+// as 256-byte row segments.
+__global__ __launch_bounds__(256) void split3_blocked_kernel(const float* __restrict__ x, int ld, long long rows, int C, int ldp,
+                                                             u16* __restrict__ blk, long long blk_plane, u16* __restrict__ planar,
+                                                             long long planar_plane) {
+  constexpr int RS = 128 + 8;                      // LDS row stride in bf16 elements (16-byte aligned, skewed)
+  __shared__ __attribute__((aligned(16))) u16 sh[3][64 * RS];
+  const long long r0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 128;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = i * 256 + t, row = q >> 5, c4 = (q & 31) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r0 + row < rows) {
+      const float* src = x + (r0 + row) * ld + c0 + c4;
+      if (c0 + c4 + 3 < C) {
+        const f32x4 f = *(const f32x4*)src;
+        v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (c0 + c4 + j < C) ? src[j] : 0.f;
+      }
+    }
+    u16 h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split3_one(v[j], h[j], m[j], l[j]);
+    u16* d = &sh[0][row * RS + c4];
+    *(unsigned long long*)d = (unsigned long long)h[0] | ((unsigned long long)h[1] << 16) | ((unsigned long long)h[2] << 32) | ((unsigned long long)h[3] << 48);
+    *(unsigned long long*)(d + 64 * RS) = (unsigned long long)m[0] | ((unsigned long long)m[1] << 16) | ((unsigned long long)m[2] << 32) | ((unsigned long long)m[3] << 48);
+    *(unsigned long long*)(d + 2 * 64 * RS) = (unsigned long long)l[0] | ((unsigned long long)l[1] << 16) | ((unsigned long long)l[2] << 32) | ((unsigned long long)l[3] << 48);
+  }
+  __syncthreads();
+  if (planar != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = i * 256 + t, row = q >> 4, c8 = (q & 15) * 8;
+      if (r0 + row < rows && c0 + c8 < ldp) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          *(bf16x8*)(planar + pl * planar_plane + (r0 + row) * ldp + c0 + c8) = *(const bf16x8*)&sh[pl][row * RS + c8];
+      }
+    }
+  }
+  const int c16 = (C + 15) >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 256 + t, cc = q >> 7, row = (q & 127) >> 1, half = (q & 1) * 8;
+    const int chunk = (c0 >> 4) + cc;
+    if (r0 + row < rows && chunk < c16) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        *(bf16x8*)(blk + pl * blk_plane + ((long long)chunk * rows + r0 + row) * 16 + half) = *(const bf16x8*)&sh[pl][row * RS + cc * 16 + half];
+    }
+  }
+}
+
+// fp32 weights viewed as [N][K] (row n, reduction index k; source element = w[n * sn + k * sk]) -> blocked planes [K/16][N][16]
+// (K a multiple of 16): one K-step's 256 tile rows are one contiguous run.  T = the transposed filter bank of backward-data:
+// row n = input channel c, k = tap * Opad + o, source w[(o * taps + tap) * Cin + c], zero for o >= O.
+template <bool T>
+__global__ __launch_bounds__(256) void split3_weight_blocked_kernel(const float* __restrict__ w, int N, int K, int O, int Opad, int taps, int Cin,
+                                                                    u16* __restrict__ out, long long plane) {
+  const long long n_el = (long long)N * K;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_el; i += (long long)gridDim.x * blockDim.x) {
+    const int kk = (int)(i & 15);
+    const long long rest = i >> 4;
+    const int n = (int)(rest % N), k16 = (int)(rest / N);
+    const int k = k16 * 16 + kk;
+    float v;
+    if (T) {
+      const int tap = k / Opad, o = k - tap * Opad;
+      v = o < O ? w[((long long)o * taps + tap) * Cin + n] : 0.f;
+    } else {
+      v = w[(long long)n * K + k];
+    }
+    u16 h, m, l;
+    split3_one(v, h, m, l);
+    out[i] = h;
+    out[i + plane] = m;
+    out[i + 2 * plane] = l;
   }
 }
 
@@ -352,6 +449,7 @@ __global__ __launch_bounds__(512, 2) void igemm_b3_kernel(const B3Args p) {
 // compiler's own wait-count insertion knows the counters' state (inline asm is opaque to it)
 constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
 
+template <bool BLK>
 __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
   constexpr int TM = 4, TN = 4, WGN = 2;
   constexpr int BM = 256, BN = 256;
@@ -395,7 +493,7 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
       const int y = rem / p.Wo, x = rem - y * p.Wo;
       const int y0 = p.sign > 0 ? y * p.stride - p.pad : y + p.pad;
       const int x0 = p.sign > 0 ? x * p.stride - p.pad : x + p.pad;
-      aoff[j] = ((b * p.H + y0) * p.W + x0) * p.lda + achunk[j];
+      aoff[j] = BLK ? (b * p.H + y0) * p.W + x0 : ((b * p.H + y0) * p.W + x0) * p.lda + achunk[j];   // BLK: pixel index of tap (0, 0)
       const int kh = p.taps / p.kw;
       int t = 0;
       for (int ky = 0; ky < kh; ++ky)
@@ -418,32 +516,31 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
   const int nck = (p.Cin + 15) >> 4;
   const int nks = p.taps * nck;
   int ttap = 0, tky = 0, tkx = 0, tck = 0;
-  const u16* pa[NA];
-  const u16* pb[NB];
-  const u16* zero = (const u16*)p.zero;
-  const long long apl = p.a_plane, wpl = p.w_plane;
-
-  // Addresses of one K-step's twelve LDS-DMA pieces (A rows j = 0, 1 and B rows j = 0, 1, three planes each), prepared in
-  // four pieces + a cursor advance so that the address arithmetic can be spread over several MFMA gaps
-  const u16* PA[NA][3];
-  const u16* PB[NB][3];
+  // LDS-DMA source addressing through two raw buffer resources (one per operand, all three planes inside; the host takes this
+  // kernel only when 3 planes < 4 GB): a lane's source = 32-bit BYTE offset; padding taps, channel tails and rows past M / N get an
+  // out-of-range offset, for which the hardware writes zeros into LDS (tools/probe/buffer_lds_probe.hip) -- no zero page, no
+  // 64-bit pointer arithmetic: per K-step 4 offsets instead of 12 pointers.
+  const unsigned apl_b = (unsigned)(p.a_plane * 2), wpl_b = (unsigned)(p.w_plane * 2);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, (short)0, (int)(3u * apl_b), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)(3u * wpl_b), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  unsigned VA[NA], VB[NB];   // byte offsets of one K-step's pieces inside plane 0 (the plane offset rides in the instruction's soffset)
   auto prepA = [&](const int j) {
     const int toff = p.sign * (tky * p.dil * p.W + tkx * p.dil) * p.lda + tck * 16;
     const bool ok = (int)(ttap < p.taps) & (int)((amask[j] >> (ttap & 31)) & 1u) & (int)((tck * 16 + achunk[j]) < p.Cin);
-    const u16* q = p.a + (unsigned)(ok ? aoff[j] + toff : 0);
-    const long long st = ok ? apl : 0;
-    PA[j][0] = ok ? q : zero;
-    PA[j][1] = PA[j][0] + st;
-    PA[j][2] = PA[j][1] + st;
+    // BLK: planes laid out [Cin/16][pixel][16]: the 256 rows of a K-step are one contiguous run of 32-byte pieces (whole
+    // cache lines per LDS-DMA instruction; with [pixel][Cin] planes every lane pair touched its own line: the vector L1's line
+    // rate, not HBM or L2, bounded the kernel at 190 TFLOP/s-equivalent -- 248 with both operands blocked)
+    const unsigned v = BLK ? (unsigned)((tck * p.a_rows + aoff[j] + p.sign * (tky * p.dil * p.W + tkx * p.dil)) * 16 + achunk[j]) * 2u
+                           : (unsigned)(aoff[j] + toff) * 2u;
+    VA[j] = ok ? v : OOB;
   };
   auto prepB = [&](const int j) {
     const int woff = ttap * p.Cin + tck * 16;
     const bool ok = (int)(ttap < p.taps) & (int)(boff[j] >= 0) & (int)((tck * 16 + bchunk[j]) < p.Cin);
-    const u16* q = p.w + (unsigned)(ok ? boff[j] + woff : 0);
-    const long long st = ok ? wpl : 0;
-    PB[j][0] = ok ? q : zero;
-    PB[j][1] = PB[j][0] + st;
-    PB[j][2] = PB[j][1] + st;
+    const unsigned v = BLK ? (unsigned)(((ttap * nck + tck) * p.w_rows + brow[j]) * 16 + bchunk[j]) * 2u   // [K/16][N][16]
+                           : (unsigned)(boff[j] + woff) * 2u;
+    VB[j] = ok ? v : OOB;
   };
   auto advance = [&]() {
     const int nt = tck + 1, nx = tkx + 1;
@@ -460,8 +557,12 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
   auto piece = [&](const int buf, const int i) {
     char* s = smem + buf * SLAB;
     const int pl = i >> 2, w = i & 3;
-    if (w < 2) glds16(PA[w][pl], s + pl * PLANE_A + (w * 256 + wave * 64) * 16);
-    else glds16(PB[w - 2][pl], s + 3 * PLANE_A + pl * PLANE_B + ((w - 2) * 256 + wave * 64) * 16);
+    if (w < 2)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(s + pl * PLANE_A + (w * 256 + wave * 64) * 16), 16,
+                                               VA[w], pl * apl_b, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(s + 3 * PLANE_A + pl * PLANE_B + ((w - 2) * 256 + wave * 64) * 16),
+                                               16, VB[w - 2], pl * wpl_b, 0, 0);
   };
   auto issue = [&](const int buf) {
 #pragma unroll
@@ -478,6 +579,36 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
     ra0 = rowa * 32 + ((h ^ ((rowa >> 3) & 1)) << 4);
     rb0 = 3 * PLANE_A + rowb * 32 + ((h ^ ((rowb >> 3) & 1)) << 4);
   }
+// (differential timing builds, tools/ab_b3w.sh: -DB3X_NO_PREP / _NO_DMA / _NO_READS / _NO_SYNC drop one ingredient of the K loop -- wrong
+//  results, the time difference is that ingredient's cost)
+#ifdef B3X_NO_DMA
+#define B3X_PIECE(f, i) do {} while (0)
+#else
+#define B3X_PIECE(f, i) piece(f, i)
+#endif
+#ifdef B3X_NO_PREP
+#define B3X_PREPA(j) do {} while (0)
+#define B3X_PREPB(j) do {} while (0)
+#define B3X_ADVANCE() do {} while (0)
+#else
+#define B3X_PREPA(j) prepA(j)
+#define B3X_PREPB(j) prepB(j)
+#define B3X_ADVANCE() advance()
+#endif
+#ifdef B3X_NO_READS
+#define B3X_READ(dst, base, off) do {} while (0)
+#else
+#define B3X_READ(dst, base, off) B3_DS_READ(dst, base, off)
+#endif
+#ifdef B3X_NO_SYNC
+#define B3X_SYNC() do {} while (0)
+#else
+#define B3X_SYNC()                                        \
+  do {                                                    \
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(12, 0));       \
+    __builtin_amdgcn_s_barrier();                         \
+  } while (0)
+#endif
 #define B3_DS_READ(dst, base, off) dst = *(const bf16x8*)((base) + (off))
 #define B3_READ_PLANE(slot, pl, A_, B_)                                                \
   do {                                                                                 \
@@ -508,99 +639,106 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
     prep();
     issue(0);
     prep();
-    if (nks > 1) issue(1);
+    issue(1);                       // (unconditional: past the end of the reduction every offset is out of range = zeros)
     prep();
-    if (nks > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue(2);
+    prep();
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     B3_READ_PLANE(0, 2, Al, Bl);
     B3_READ_PLANE(0, 0, Ah, Bh);
     B3_READ_PLANE(0, 1, Am, Bm);
-    int nxt = 1, fill = 2;          // slot of K-step k+1, slot K-step k+2 is loaded into
+    // The K loop is rotated: an iteration = the second half of K-step k (products hm, mh, mm: they retire every fragment set, so
+    // the h / l fragment reads of step k+1 and the 12 LDS-DMA pieces of step k+2 ride there) followed by the first half of step
+    // k+1 (hh, hl, lh + the address arithmetic of step k+3; the m-plane fragments, retired by mm, are read here: nothing in this half
+    // waits for them).  The loop header -- where the compiler waits for ALL outstanding LDS reads -- and the barrier then sit
+    // behind ~40 MFMAs without a new read.  One wave per SIMD issues in order, so every MFMA carries at most one other
+    // operation, pinned by scheduling fences.  Step nks is all zeros: its first half adds zeros.
+     B3_MFMA(Ah, 0, Bh, 0);
+     B3_MFMA(Ah, 0, Bh, 1);
+     B3_MFMA(Ah, 0, Bh, 2);
+     B3_MFMA(Ah, 0, Bh, 3);
+     B3_MFMA(Ah, 1, Bh, 0);
+     B3_MFMA(Ah, 1, Bh, 1);
+     B3_MFMA(Ah, 1, Bh, 2);
+     B3_MFMA(Ah, 1, Bh, 3);
+     B3_MFMA(Ah, 2, Bh, 0);
+     B3_MFMA(Ah, 2, Bh, 1);
+     B3_MFMA(Ah, 2, Bh, 2);
+     B3_MFMA(Ah, 2, Bh, 3);
+     B3_MFMA(Ah, 3, Bh, 0);
+     B3_MFMA(Ah, 3, Bh, 1);
+     B3_MFMA(Ah, 3, Bh, 2);
+     B3_MFMA(Ah, 3, Bh, 3);
+     B3_MFMA(Ah, 0, Bl, 0);
+     B3_MFMA(Ah, 0, Bl, 1);
+     B3_MFMA(Ah, 0, Bl, 2);
+     B3_MFMA(Ah, 0, Bl, 3);
+     B3_MFMA(Ah, 1, Bl, 0);
+     B3_MFMA(Ah, 1, Bl, 1);
+     B3_MFMA(Ah, 1, Bl, 2);
+     B3_MFMA(Ah, 1, Bl, 3);
+     B3_MFMA(Ah, 2, Bl, 0);
+     B3_MFMA(Ah, 2, Bl, 1);
+     B3_MFMA(Ah, 2, Bl, 2);
+     B3_MFMA(Ah, 2, Bl, 3);
+     B3_MFMA(Ah, 3, Bl, 0);
+     B3_MFMA(Ah, 3, Bl, 1);
+     B3_MFMA(Ah, 3, Bl, 2);
+     B3_MFMA(Ah, 3, Bl, 3);
+     B3_MFMA(Al, 0, Bh, 0);
+     B3_MFMA(Al, 0, Bh, 1);
+     B3_MFMA(Al, 0, Bh, 2);
+     B3_MFMA(Al, 0, Bh, 3);
+     B3_MFMA(Al, 1, Bh, 0);
+     B3_MFMA(Al, 1, Bh, 1);
+     B3_MFMA(Al, 1, Bh, 2);
+     B3_MFMA(Al, 1, Bh, 3);
+     B3_MFMA(Al, 2, Bh, 0);
+     B3_MFMA(Al, 2, Bh, 1);
+     B3_MFMA(Al, 2, Bh, 2);
+     B3_MFMA(Al, 2, Bh, 3);
+     B3_MFMA(Al, 3, Bh, 0);
+     B3_MFMA(Al, 3, Bh, 1);
+     B3_MFMA(Al, 3, Bh, 2);
+     B3_MFMA(Al, 3, Bh, 3);
+    // Three slots, LDS-DMA two K-steps deep: iteration k reads the fragments of step k+1 from slot (k+1) % 3 while step k+2 is
+    // still landing in slot (k+2) % 3 and step k+3 is issued into slot k % 3 (step k lives in registers since iteration k-1).
+    int nxt = 1, fill = 0;
     for (int k = 0; k < nks; ++k) {
-      // (everything below is unconditional: past the end of the reduction the prepared addresses are the zero page, the
-      //  extra LDS-DMA fills and fragment reads touch slots nobody uses)
-      // One wave per SIMD issues in order, so a cluster of non-matrix instructions longer than an MFMA's 24 free issue cycles
-      // idles the matrix pipe.  The K-step is therefore written slot by slot: every MFMA carries at most one LDS-DMA piece,
-      // one fragment read or one piece of address arithmetic, pinned by scheduling fences.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my LDS-DMA of K-step k+1 has landed (issued a K-step ago)
-      __builtin_amdgcn_s_barrier();                      // ... everybody's; every wave has consumed the fragments of step k-1
+      // all but my newest 12 LDS-DMA pieces (= step k+2's, issued an iteration ago) have landed: step k+1 is there, issued TWO
+      // iterations ago (~5 us: with one iteration of distance the wait stalled on MALL / HBM misses, -10 %); every fragment read
+      // has returned (a real s_waitcnt the compiler can see, so that it does not wait for "unknown" loop-carried reads behind this
+      // iteration's first ones); the barrier: ... everybody's; every wave has consumed the fragments of step k
+      B3X_SYNC();
       asm volatile("" ::: "memory");
       const char* aa_ = smem + nxt * SLAB + ra0;
       const char* bb_ = smem + nxt * SLAB + rb0;
-      piece(fill, 0); B3_MFMA(Ah, 0, Bh, 0);
-       B3_MFMA(Ah, 0, Bh, 1);
-       B3_MFMA(Ah, 0, Bh, 2);
-      piece(fill, 1); B3_MFMA(Ah, 0, Bh, 3);
-       B3_MFMA(Ah, 1, Bh, 0);
-       B3_MFMA(Ah, 1, Bh, 1);
-      piece(fill, 2); B3_MFMA(Ah, 1, Bh, 2);
-       B3_MFMA(Ah, 1, Bh, 3);
-       B3_MFMA(Ah, 2, Bh, 0);
-      piece(fill, 3); B3_MFMA(Ah, 2, Bh, 1);
-       B3_MFMA(Ah, 2, Bh, 2);
-       B3_MFMA(Ah, 2, Bh, 3);
-      piece(fill, 4); B3_MFMA(Ah, 3, Bh, 0);
-       B3_MFMA(Ah, 3, Bh, 1);
-       B3_MFMA(Ah, 3, Bh, 2);
-      piece(fill, 5); B3_MFMA(Ah, 3, Bh, 3);
-       B3_MFMA(Ah, 0, Bl, 0);
-       B3_MFMA(Ah, 0, Bl, 1);
-      piece(fill, 6); B3_MFMA(Ah, 0, Bl, 2);
-       B3_MFMA(Ah, 0, Bl, 3);
-       B3_MFMA(Ah, 1, Bl, 0);
-      piece(fill, 7); B3_MFMA(Ah, 1, Bl, 1);
-       B3_MFMA(Ah, 1, Bl, 2);
-       B3_MFMA(Ah, 1, Bl, 3);
-      piece(fill, 8); B3_MFMA(Ah, 2, Bl, 0);
-       B3_MFMA(Ah, 2, Bl, 1);
-       B3_MFMA(Ah, 2, Bl, 2);
-      piece(fill, 9); B3_MFMA(Ah, 2, Bl, 3);
-       B3_MFMA(Ah, 3, Bl, 0);
-       B3_MFMA(Ah, 3, Bl, 1);
-      piece(fill, 10); B3_MFMA(Ah, 3, Bl, 2);
-       B3_MFMA(Ah, 3, Bl, 3);
-       B3_MFMA(Al, 0, Bh, 0);
-      piece(fill, 11); B3_MFMA(Al, 0, Bh, 1);
-       B3_MFMA(Al, 0, Bh, 2);
-       B3_MFMA(Al, 0, Bh, 3);
-      prepA(0); B3_MFMA(Al, 1, Bh, 0);
-       B3_MFMA(Al, 1, Bh, 1);
-      prepA(1); B3_MFMA(Al, 1, Bh, 2);
-       B3_MFMA(Al, 1, Bh, 3);
-      prepB(0); B3_MFMA(Al, 2, Bh, 0);
-       B3_MFMA(Al, 2, Bh, 1);
-      prepB(1); B3_MFMA(Al, 2, Bh, 2);
-       B3_MFMA(Al, 2, Bh, 3);
-      advance(); B3_MFMA(Al, 3, Bh, 0);
-       B3_MFMA(Al, 3, Bh, 1);
-       B3_MFMA(Al, 3, Bh, 2);
-       B3_MFMA(Al, 3, Bh, 3);
-      B3_MFMA(Ah, 0, Bm, 0);
-      B3_DS_READ(Al[0], aa_, 2 * PLANE_A + 0 * 1024); B3_MFMA(Ah, 0, Bm, 1);
-      B3_DS_READ(Al[1], aa_, 2 * PLANE_A + 1 * 1024); B3_MFMA(Ah, 0, Bm, 2);
-      B3_DS_READ(Al[2], aa_, 2 * PLANE_A + 2 * 1024); B3_MFMA(Ah, 0, Bm, 3);
-      B3_DS_READ(Al[3], aa_, 2 * PLANE_A + 3 * 1024); B3_MFMA(Ah, 1, Bm, 0);
-      B3_DS_READ(Bl[0], bb_, 2 * PLANE_B + 0 * 1024); B3_MFMA(Ah, 1, Bm, 1);
-      B3_DS_READ(Bl[1], bb_, 2 * PLANE_B + 1 * 1024); B3_MFMA(Ah, 1, Bm, 2);
-      B3_DS_READ(Bl[2], bb_, 2 * PLANE_B + 2 * 1024); B3_MFMA(Ah, 1, Bm, 3);
-      B3_DS_READ(Bl[3], bb_, 2 * PLANE_B + 3 * 1024); B3_MFMA(Ah, 2, Bm, 0);
-       B3_MFMA(Ah, 2, Bm, 1);
-       B3_MFMA(Ah, 2, Bm, 2);
-       B3_MFMA(Ah, 2, Bm, 3);
-       B3_MFMA(Ah, 3, Bm, 0);
-       B3_MFMA(Ah, 3, Bm, 1);
-       B3_MFMA(Ah, 3, Bm, 2);
-       B3_MFMA(Ah, 3, Bm, 3);
-      B3_DS_READ(Ah[0], aa_, 0 * PLANE_A + 0 * 1024); B3_MFMA(Am, 0, Bh, 0);
-      B3_DS_READ(Ah[1], aa_, 0 * PLANE_A + 1 * 1024); B3_MFMA(Am, 0, Bh, 1);
-      B3_DS_READ(Ah[2], aa_, 0 * PLANE_A + 2 * 1024); B3_MFMA(Am, 0, Bh, 2);
-      B3_DS_READ(Ah[3], aa_, 0 * PLANE_A + 3 * 1024); B3_MFMA(Am, 0, Bh, 3);
-       B3_MFMA(Am, 1, Bh, 0);
-       B3_MFMA(Am, 1, Bh, 1);
-       B3_MFMA(Am, 1, Bh, 2);
-       B3_MFMA(Am, 1, Bh, 3);
+      B3X_READ(Al[0], aa_, 2 * PLANE_A + 0 * 1024); B3_MFMA(Ah, 0, Bm, 0);
+      B3X_READ(Al[1], aa_, 2 * PLANE_A + 1 * 1024); B3_MFMA(Ah, 0, Bm, 1);
+      B3X_READ(Al[2], aa_, 2 * PLANE_A + 2 * 1024); B3_MFMA(Ah, 0, Bm, 2);
+      B3X_READ(Al[3], aa_, 2 * PLANE_A + 3 * 1024); B3_MFMA(Ah, 0, Bm, 3);
+      B3X_READ(Bl[0], bb_, 2 * PLANE_B + 0 * 1024); B3_MFMA(Ah, 1, Bm, 0);
+      B3X_READ(Bl[1], bb_, 2 * PLANE_B + 1 * 1024); B3_MFMA(Ah, 1, Bm, 1);
+      B3X_READ(Bl[2], bb_, 2 * PLANE_B + 2 * 1024); B3_MFMA(Ah, 1, Bm, 2);
+      B3X_READ(Bl[3], bb_, 2 * PLANE_B + 3 * 1024); B3_MFMA(Ah, 1, Bm, 3);
+      B3X_PIECE(fill, 0); B3_MFMA(Ah, 2, Bm, 0);
+      B3X_PIECE(fill, 1); B3_MFMA(Ah, 2, Bm, 1);
+      B3X_PIECE(fill, 2); B3_MFMA(Ah, 2, Bm, 2);
+      B3X_PIECE(fill, 3); B3_MFMA(Ah, 2, Bm, 3);
+      B3X_PIECE(fill, 4); B3_MFMA(Ah, 3, Bm, 0);
+      B3X_PIECE(fill, 5); B3_MFMA(Ah, 3, Bm, 1);
+      B3X_PIECE(fill, 6); B3_MFMA(Ah, 3, Bm, 2);
+      B3X_PIECE(fill, 7); B3_MFMA(Ah, 3, Bm, 3);
+      B3X_READ(Ah[0], aa_, 0 * PLANE_A + 0 * 1024); B3_MFMA(Am, 0, Bh, 0);
+      B3X_READ(Ah[1], aa_, 0 * PLANE_A + 1 * 1024); B3_MFMA(Am, 0, Bh, 1);
+      B3X_READ(Ah[2], aa_, 0 * PLANE_A + 2 * 1024); B3_MFMA(Am, 0, Bh, 2);
+      B3X_READ(Ah[3], aa_, 0 * PLANE_A + 3 * 1024); B3_MFMA(Am, 0, Bh, 3);
+      B3X_PIECE(fill, 8); B3_MFMA(Am, 1, Bh, 0);
+      B3X_PIECE(fill, 9); B3_MFMA(Am, 1, Bh, 1);
+      B3X_PIECE(fill, 10); B3_MFMA(Am, 1, Bh, 2);
+      B3X_PIECE(fill, 11); B3_MFMA(Am, 1, Bh, 3);
        B3_MFMA(Am, 2, Bh, 0);
        B3_MFMA(Am, 2, Bh, 1);
        B3_MFMA(Am, 2, Bh, 2);
@@ -609,27 +747,70 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
        B3_MFMA(Am, 3, Bh, 1);
        B3_MFMA(Am, 3, Bh, 2);
        B3_MFMA(Am, 3, Bh, 3);
-      B3_DS_READ(Bh[0], bb_, 0 * PLANE_B + 0 * 1024); B3_MFMA(Am, 0, Bm, 0);
-      B3_DS_READ(Bh[1], bb_, 0 * PLANE_B + 1 * 1024); B3_MFMA(Am, 0, Bm, 1);
-      B3_DS_READ(Bh[2], bb_, 0 * PLANE_B + 2 * 1024); B3_MFMA(Am, 0, Bm, 2);
-      B3_DS_READ(Bh[3], bb_, 0 * PLANE_B + 3 * 1024); B3_MFMA(Am, 0, Bm, 3);
-      B3_DS_READ(Am[0], aa_, 1 * PLANE_A + 0 * 1024); B3_MFMA(Am, 1, Bm, 0);
+      B3X_READ(Bh[0], bb_, 0 * PLANE_B + 0 * 1024); B3_MFMA(Am, 0, Bm, 0);
+      B3X_READ(Bh[1], bb_, 0 * PLANE_B + 1 * 1024); B3_MFMA(Am, 0, Bm, 1);
+      B3X_READ(Bh[2], bb_, 0 * PLANE_B + 2 * 1024); B3_MFMA(Am, 0, Bm, 2);
+      B3X_READ(Bh[3], bb_, 0 * PLANE_B + 3 * 1024); B3_MFMA(Am, 0, Bm, 3);
+       B3_MFMA(Am, 1, Bm, 0);
        B3_MFMA(Am, 1, Bm, 1);
        B3_MFMA(Am, 1, Bm, 2);
        B3_MFMA(Am, 1, Bm, 3);
-      B3_DS_READ(Am[1], aa_, 1 * PLANE_A + 1 * 1024); B3_MFMA(Am, 2, Bm, 0);
+       B3_MFMA(Am, 2, Bm, 0);
        B3_MFMA(Am, 2, Bm, 1);
        B3_MFMA(Am, 2, Bm, 2);
        B3_MFMA(Am, 2, Bm, 3);
-      B3_DS_READ(Am[2], aa_, 1 * PLANE_A + 2 * 1024); B3_MFMA(Am, 3, Bm, 0);
+       B3_MFMA(Am, 3, Bm, 0);
        B3_MFMA(Am, 3, Bm, 1);
        B3_MFMA(Am, 3, Bm, 2);
        B3_MFMA(Am, 3, Bm, 3);
-      B3_DS_READ(Am[3], aa_, 1 * PLANE_A + 3 * 1024);
-      B3_DS_READ(Bm[0], bb_, 1 * PLANE_B + 0 * 1024);
-      B3_DS_READ(Bm[1], bb_, 1 * PLANE_B + 1 * 1024);
-      B3_DS_READ(Bm[2], bb_, 1 * PLANE_B + 2 * 1024);
-      B3_DS_READ(Bm[3], bb_, 1 * PLANE_B + 3 * 1024);
+       B3_MFMA(Ah, 0, Bh, 0);
+      B3X_READ(Am[0], aa_, 1 * PLANE_A + 0 * 1024); B3_MFMA(Ah, 0, Bh, 1);
+      B3X_READ(Am[1], aa_, 1 * PLANE_A + 1 * 1024); B3_MFMA(Ah, 0, Bh, 2);
+      B3X_READ(Am[2], aa_, 1 * PLANE_A + 2 * 1024); B3_MFMA(Ah, 0, Bh, 3);
+      B3X_READ(Am[3], aa_, 1 * PLANE_A + 3 * 1024); B3_MFMA(Ah, 1, Bh, 0);
+      B3X_READ(Bm[0], bb_, 1 * PLANE_B + 0 * 1024); B3_MFMA(Ah, 1, Bh, 1);
+      B3X_READ(Bm[1], bb_, 1 * PLANE_B + 1 * 1024); B3_MFMA(Ah, 1, Bh, 2);
+      B3X_READ(Bm[2], bb_, 1 * PLANE_B + 2 * 1024); B3_MFMA(Ah, 1, Bh, 3);
+      B3X_READ(Bm[3], bb_, 1 * PLANE_B + 3 * 1024); B3_MFMA(Ah, 2, Bh, 0);
+       B3_MFMA(Ah, 2, Bh, 1);
+      B3X_PREPA(0); B3_MFMA(Ah, 2, Bh, 2);
+       B3_MFMA(Ah, 2, Bh, 3);
+       B3_MFMA(Ah, 3, Bh, 0);
+      B3X_PREPA(1); B3_MFMA(Ah, 3, Bh, 1);
+       B3_MFMA(Ah, 3, Bh, 2);
+       B3_MFMA(Ah, 3, Bh, 3);
+       B3_MFMA(Ah, 0, Bl, 0);
+      B3X_PREPB(0); B3_MFMA(Ah, 0, Bl, 1);
+       B3_MFMA(Ah, 0, Bl, 2);
+       B3_MFMA(Ah, 0, Bl, 3);
+       B3_MFMA(Ah, 1, Bl, 0);
+      B3X_PREPB(1); B3_MFMA(Ah, 1, Bl, 1);
+       B3_MFMA(Ah, 1, Bl, 2);
+       B3_MFMA(Ah, 1, Bl, 3);
+       B3_MFMA(Ah, 2, Bl, 0);
+      B3X_ADVANCE(); B3_MFMA(Ah, 2, Bl, 1);
+       B3_MFMA(Ah, 2, Bl, 2);
+       B3_MFMA(Ah, 2, Bl, 3);
+       B3_MFMA(Ah, 3, Bl, 0);
+       B3_MFMA(Ah, 3, Bl, 1);
+       B3_MFMA(Ah, 3, Bl, 2);
+       B3_MFMA(Ah, 3, Bl, 3);
+       B3_MFMA(Al, 0, Bh, 0);
+       B3_MFMA(Al, 0, Bh, 1);
+       B3_MFMA(Al, 0, Bh, 2);
+       B3_MFMA(Al, 0, Bh, 3);
+       B3_MFMA(Al, 1, Bh, 0);
+       B3_MFMA(Al, 1, Bh, 1);
+       B3_MFMA(Al, 1, Bh, 2);
+       B3_MFMA(Al, 1, Bh, 3);
+       B3_MFMA(Al, 2, Bh, 0);
+       B3_MFMA(Al, 2, Bh, 1);
+       B3_MFMA(Al, 2, Bh, 2);
+       B3_MFMA(Al, 2, Bh, 3);
+       B3_MFMA(Al, 3, Bh, 0);
+       B3_MFMA(Al, 3, Bh, 1);
+       B3_MFMA(Al, 3, Bh, 2);
+       B3_MFMA(Al, 3, Bh, 3);
       nxt = nxt == 2 ? 0 : nxt + 1;
       fill = fill == 2 ? 0 : fill + 1;
     }
@@ -1023,7 +1204,14 @@ int pick_b3_tile(int N) {
 }
 
 int run_b3(const B3Args& a, hipStream_t st) {
-  switch (pick_b3_tile(a.zero_to > a.N ? a.zero_to : a.N)) {
+  int tile = pick_b3_tile(a.zero_to > a.N ? a.zero_to : a.N);
+  // the register-pipelined kernel addresses each operand through one 32-bit-offset buffer resource over its three planes
+  if (tile == 9 && (a.a_plane * 6 >= (1ll << 32) - 64 || a.w_plane * 6 >= (1ll << 32) - 64)) tile = 1;
+  if (a.blocked) {
+    CS_REQUIRE(a.a_plane * 6 < (1ll << 32) - 64 && a.w_plane * 6 < (1ll << 32) - 64, "bf16x3 blocked planes: an operand's three planes must stay below 4 GB");
+    tile = 9;
+  }
+  switch (tile) {
     case 1: launch_b3<4, 2, 2, 4>(a, st); break;   // 256 x 256, wave tile 128 x 64
     case 2: launch_b3<2, 2, 4, 2, 2>(a, st); break;   // 256 x 128, wave tile 64 x 64 (two slots: two blocks per CU)
     case 7: launch_b3<2, 2, 4, 2, 3>(a, st); break;   // 256 x 128, three slots
@@ -1037,7 +1225,8 @@ int run_b3(const B3Args& a, hipStream_t st) {
       q.tilesM = (q.M + 255) / 256;
       q.tilesN = ((q.zero_to > q.N ? q.zero_to : q.N) + 255) / 256;
       q.zero = zero_page_b3();
-      hipLaunchKernelGGL(igemm_b3w_kernel, dim3(q.tilesM * q.tilesN), dim3(256), 0, st, q);
+      if (q.blocked) hipLaunchKernelGGL(igemm_b3w_kernel<true>, dim3(q.tilesM * q.tilesN), dim3(256), 0, st, q);
+      else hipLaunchKernelGGL(igemm_b3w_kernel<false>, dim3(q.tilesM * q.tilesN), dim3(256), 0, st, q);
       break;
     }
     default: catseg_set_error("bf16x3: unknown tile"); return CATSEG_EINVAL;
@@ -1128,6 +1317,97 @@ extern "C" int catseg_conv2d_bwd_data_bf16x3(const catseg_conv_desc* d, const vo
   const int cop = (d->Cout + 7) & ~7;
   B3Args a = {};
   a.a = (const u16*)dy_planes; a.lda = cop; a.a_plane = (long long)d->B * d->Ho * d->Wo * cop;
+  a.w = (const u16*)wt_planes; a.ldw = d->kh * d->kw * cop; a.w_plane = (long long)d->Cin * a.ldw;
+  a.C = dx; a.ldc = d->ldx; a.bias = nullptr;
+  a.M = d->B * d->H * d->W; a.N = d->Cin; a.Cin = cop; a.taps = d->kh * d->kw;
+  a.H = d->Ho; a.W = d->Wo; a.Ho = d->H; a.Wo = d->W; a.kw = d->kw; a.stride = 1; a.pad = d->pad; a.dil = d->dil;
+  a.sign = -1; a.accumulate = accumulate;
+  return run_b3(a, (hipStream_t)stream);
+}
+
+// ---- blocked operand planes (the 256 x 256 register-pipelined kernel reads whole cache lines per LDS-DMA instruction) ----------
+extern "C" size_t catseg_split3_blocked_elems(long long rows, int C) { return (size_t)3 * (size_t)((C + 15) / 16) * 16 * (size_t)rows; }
+
+// x [rows][ld] fp32 -> blocked planes [3][ceil(C/16)][rows][16]; planar_planes (may be null) additionally receives the layout of
+// catseg_split3 ([3][rows][roundup(C, 8)]) from the same pass over x
+extern "C" int catseg_split3_blocked(const float* x, long long rows, int C, int ld, void* blocked_planes, void* planar_planes,
+                                     catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && ld >= C && ld % 4 == 0 && cs_aligned16(x) && cs_aligned16(blocked_planes) && cs_aligned16(planar_planes),
+             "split3_blocked: bad args (ld must be a multiple of 4, pointers 16-byte aligned)");
+  const int ldp = (C + 7) & ~7;
+  const int c16 = (C + 15) / 16;
+  CS_REQUIRE((rows + 63) / 64 < (1ll << 31), "split3_blocked: too many rows");
+  hipLaunchKernelGGL(split3_blocked_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((c16 * 16 + 127) / 128)), dim3(256), 0, (hipStream_t)stream, x,
+                     ld, rows, C, ldp, (u16*)blocked_planes, (long long)c16 * rows * 16, (u16*)planar_planes, rows * ldp);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// OHWI weights viewed as [Cout][K = taps * Cin] -> blocked planes [3][K/16][Cout][16] (Cin % 16 == 0): B operand of the forward conv
+extern "C" int catseg_split3_weight_blocked(const float* w, int O, int taps, int Cin, void* planes, catseg_stream_t stream) {
+  CS_REQUIRE(O > 0 && taps > 0 && Cin > 0 && Cin % 16 == 0 && cs_aligned16(planes), "split3_weight_blocked: needs Cin % 16 == 0");
+  const int K = taps * Cin;
+  const long long n = (long long)O * K;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(split3_weight_blocked_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, O, K, O, O, taps, Cin, (u16*)planes, n);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// OHWI weights -> blocked planes of the transposed filter bank [3][taps * Opad / 16][Cin][16], Opad = roundup(O, 16): B operand of
+// backward-data
+extern "C" int catseg_split3_weight_t_blocked(const float* w, int O, int taps, int Cin, void* planes, catseg_stream_t stream) {
+  CS_REQUIRE(O > 0 && taps > 0 && Cin > 0 && cs_aligned16(planes), "split3_weight_t_blocked: bad args");
+  const int Opad = (O + 15) & ~15;
+  const int K = taps * Opad;
+  const long long n = (long long)Cin * K;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(split3_weight_blocked_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, Cin, K, O, Opad, taps, Cin, (u16*)planes, n);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// as catseg_conv2d_fwd_bf16x3 / _bnstats with BLOCKED planes: x_planes = catseg_split3_blocked of x (C = Cin, Cin % 16 == 0),
+// w_planes = catseg_split3_weight_blocked.  bn_part may be null (then tile_rows / n_tiles are not touched).
+extern "C" int catseg_conv2d_fwd_bf16x3_blocked(const catseg_conv_desc* d, const void* x_planes, const void* w_planes, const float* bias,
+                                                float* y, int zero_to, float* bn_part, size_t bn_part_floats, int* tile_rows, int* n_tiles,
+                                                catseg_stream_t stream) {
+  CS_REQUIRE(d && !d->stem4 && d->groups <= 1 && d->Cin % 16 == 0 && d->kh * d->kw <= 32, "conv fwd bf16x3 blocked: needs Cin % 16 == 0, <= 32 taps, dense");
+  CS_REQUIRE(cs_aligned16(x_planes) && cs_aligned16(w_planes) && cs_aligned16(y) && zero_to <= d->ldy, "conv fwd bf16x3 blocked: alignment");
+  B3Args a = {};
+  a.blocked = 1;
+  a.a_rows = d->B * d->H * d->W; a.w_rows = d->Cout;
+  a.a = (const u16*)x_planes; a.lda = d->Cin; a.a_plane = (long long)a.a_rows * d->Cin;
+  a.w = (const u16*)w_planes; a.ldw = d->kh * d->kw * d->Cin; a.w_plane = (long long)d->Cout * a.ldw;
+  a.C = y; a.ldc = d->ldy; a.bias = bias;
+  a.M = d->B * d->Ho * d->Wo; a.N = d->Cout; a.Cin = d->Cin; a.taps = d->kh * d->kw;
+  a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+  a.sign = 1; a.zero_to = zero_to;
+  if (bn_part != nullptr) {
+    CS_REQUIRE(tile_rows && n_tiles, "conv fwd bf16x3 blocked: tile_rows / n_tiles");
+    const int nt = (a.M + 255) / 256;
+    *tile_rows = 0; *n_tiles = 0;
+    if ((size_t)nt * 3 * d->Cout <= bn_part_floats) {
+      a.bn_part = bn_part;
+      *tile_rows = 256; *n_tiles = nt;
+    }
+  }
+  return run_b3(a, (hipStream_t)stream);
+}
+
+// as catseg_conv2d_bwd_data_bf16x3 with BLOCKED planes: dy_planes = catseg_split3_blocked of dy (C = Cout; the channel tail up to
+// roundup(Cout, 16) is zero), wt_planes = catseg_split3_weight_t_blocked
+extern "C" int catseg_conv2d_bwd_data_bf16x3_blocked(const catseg_conv_desc* d, const void* dy_planes, const void* wt_planes, float* dx,
+                                                     int accumulate, catseg_stream_t stream) {
+  CS_REQUIRE(d && !d->stem4 && d->groups <= 1 && d->stride == 1 && d->kh * d->kw <= 32, "conv bwd_data bf16x3 blocked: stride 1, <= 32 taps, dense");
+  CS_REQUIRE(cs_aligned16(dy_planes) && cs_aligned16(wt_planes) && cs_aligned16(dx), "conv bwd_data bf16x3 blocked: alignment");
+  const int cop = (d->Cout + 15) & ~15;
+  B3Args a = {};
+  a.blocked = 1;
+  a.a_rows = d->B * d->Ho * d->Wo; a.w_rows = d->Cin;
+  a.a = (const u16*)dy_planes; a.lda = cop; a.a_plane = (long long)a.a_rows * cop;
   a.w = (const u16*)wt_planes; a.ldw = d->kh * d->kw * cop; a.w_plane = (long long)d->Cin * a.ldw;
   a.C = dx; a.ldc = d->ldx; a.bias = nullptr;
   a.M = d->B * d->H * d->W; a.N = d->Cin; a.Cin = cop; a.taps = d->kh * d->kw;

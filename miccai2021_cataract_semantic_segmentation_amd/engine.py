@@ -331,7 +331,7 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
         return ops.conv_fwd_fused(x_in, wf, bf, residual, relu, Cout, kh, kw, s, p, d, out=out, stem4=conv.stem, groups=conv.groups)
     if cx.train:
         # batch statistics: per-tile partial sums come out of the convolution's epilogue (no separate pass over y)
-        y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups, bn_stats=FUSE_BN_STATS)
+        y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups, bn_stats=FUSE_BN_STATS, train=cx.record)
         y, partials = y if FUSE_BN_STATS else (y, None)
         if partials is not None:
             stats, scale = ops.bn_finalize(partials, ops.rows_of(y), Cout, bn.weight.data, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
@@ -340,7 +340,7 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
         bn._pending_batches += 1
         mean = stats[:Cout]
     else:
-        y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups)
+        y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups, train=cx.record)
         stats = None
         mean = bn.running_mean
         scale = ops.bn_eval_scale(bn.weight.data, bn.running_var, bn.eps)
@@ -389,7 +389,7 @@ def conv_bias(cx, x, conv, pad_to=32):
     s, p, d = conv.stride[0], conv.padding[0], conv.dilation[0]
     ld = max(pad_to, (Cout + 3) // 4 * 4)
     bias = conv.bias.data if conv.bias is not None else None
-    y = ops.conv_fwd(x, w.data, bias, Cout, kh, kw, s, p, d, zero_to=ld)
+    y = ops.conv_fwd(x, w.data, bias, Cout, kh, kw, s, p, d, zero_to=ld, train=cx.record)
     cx.claim(w, conv.bias)
     if cx.record:
         def bwd():

@@ -95,12 +95,12 @@ class _Timed:
 # the fp32 kernels.  CATSEG_PRECISION=fp32 selects the exact fp32 path everywhere.
 import os as _os
 PRECISION = _os.environ.get("CATSEG_PRECISION", "bf16x3")
-_b3_cache = {"key": None, "x": None, "planes": None}
+_b3_cache = {"key": None, "x": None, "planar": None, "blk": None}
 # thresholds of the layer selection (tests lower them to push small layers through the split-precision kernels)
 B3_MIN_TAPS, B3_MIN_K, B3_MIN_N, B3_MIN_TILES = 2, 2048, 192, 192
 B3_OPS = ("fwd", "dgrad", "wgrad")
 B3_MIN_WGRAD_ROWS = 32768
-_b3_cache_dy = {"key": None, "x": None, "planes": None}
+_b3_cache_dy = {"key": None, "x": None, "planar": None, "blk": None}
 
 
 # wide 1x1 layers (the 1024 -> 512 bottleneck of the OCR head at stride 4): both GEMM extents >= 512, their product >= 512 * 1024,
@@ -122,30 +122,49 @@ def _b3_eligible(rows, ncols, taps, cred, stride_ok=True):
     return _b3_wide_1x1(rows, ncols, taps, cred)
 
 
-def _split3_cached(x):
+# Layers that run the 256 x 256 register-pipelined kernel (> 192 output columns) read BLOCKED planes in forward / backward-data
+# (csrc/igemm_bf16x3.hip: whole cache lines per LDS-DMA instruction, 190 -> 248 TFLOP/s-equivalent on the 3x3 720 -> 512 layer);
+# the backward-weight kernel keeps the planar planes, written by the same split pass when a backward will follow.
+B3_BLOCKED = True
+
+
+def _b3_blocked_ok(ncols, cred):
+    return B3_BLOCKED and ncols > 192 and cred % 16 == 0
+
+
+def _split3_any(x, want, both):
+    """(planar, blocked) planes of x, at least the wanted one; `both`: produce the two layouts in ONE pass over x"""
+    if want == "blk" or both:
+        blk, planar = split3_blocked(x, with_planar=(want == "planar" or both))
+        return planar, blk
+    return split3(x), None
+
+
+def _cached(cache, x, key, want, both):
+    if cache["key"] == key and cache["x"] is x:
+        if cache[want] is None:
+            planar, blk = _split3_any(x, want, False)
+            cache[want] = planar if want == "planar" else blk
+        return cache[want]
+    planar, blk = _split3_any(x, want, both)
+    cache.update(key=key, x=x, planar=planar, blk=blk)
+    return cache[want]
+
+
+def _split3_cached(x, want="planar", both=False):
     """three-plane split of an activation; the last one is kept (the two 720-channel head convolutions of OCRNet-HRNet and the
-    ASPP branches read one tensor)"""
-    key = (x.data_ptr(), x._version, tuple(x.shape), ld_of(x))
-    if _b3_cache["key"] == key:
-        return _b3_cache["planes"]
-    planes = split3(x)
-    _b3_cache.update(key=key, x=x, planes=planes)
-    return planes
+    ASPP branches read one tensor; the backward-weight pass of a layer reads what its forward produced)"""
+    return _cached(_b3_cache, x, (x.data_ptr(), x._version, tuple(x.shape), ld_of(x)), want, both)
 
 
-def _split3_cached_dy(dy):
+def _split3_cached_dy(dy, want="planar", both=False):
     """the dy planes of a layer are used twice in its backward (backward-weight, then backward-data)"""
-    key = (dy.data_ptr(), tuple(dy.shape), ld_of(dy))
-    if _b3_cache_dy["key"] == key and _b3_cache_dy["x"] is dy:
-        return _b3_cache_dy["planes"]
-    planes = split3(dy)
-    _b3_cache_dy.update(key=key, x=dy, planes=planes)
-    return planes
+    return _cached(_b3_cache_dy, dy, (dy.data_ptr(), tuple(dy.shape), ld_of(dy)), want, both)
 
 
 def release_b3_cache():
-    _b3_cache.update(key=None, x=None, planes=None)
-    _b3_cache_dy.update(key=None, x=None, planes=None)
+    _b3_cache.update(key=None, x=None, planar=None, blk=None)
+    _b3_cache_dy.update(key=None, x=None, planar=None, blk=None)
 
 
 _bn_part = {}
@@ -162,7 +181,7 @@ def _bn_part_buffer(nfloats, device):
     return buf
 
 
-def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False, groups=1, bn_stats=False):
+def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False, groups=1, bn_stats=False, train=True):
     """bn_stats=True: returns (out, partials) where partials = (buffer, n_tiles, tile_rows) are the per-(M-tile, channel)
     BatchNorm partial sums written by the convolution's epilogue (for bn_finalize), or None if this layer's kernel has none"""
     B, H, W, Cin = x.shape
@@ -177,11 +196,16 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
         tr, nt = ctypes.c_int(0), ctypes.c_int(0)
     if "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(rows, Cout, kh * kw, Cin):
         d = make_desc(x.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
+        blk = _b3_blocked_ok(max(zero_to, Cout), Cin)
         with _Timed("split3", 0.0):
-            xp = _split3_cached(x)
-            wp = split3_weight(w_ptr_tensor)
+            xp = _split3_cached(x, "blk" if blk else "planar", both=blk and train)
+            wp = split3_weight_blocked(w_ptr_tensor) if blk else split3_weight(w_ptr_tensor)
         with _Timed("fwd_b3", flops):
-            if bn_stats:
+            if blk:
+                check(lib.catseg_conv2d_fwd_bf16x3_blocked(ctypes.byref(d), ptr(xp), ptr(wp), ptr(bias), ptr(out), zero_to, ptr(part),
+                                                           part.numel() if part is not None else 0,
+                                                           ctypes.byref(tr) if bn_stats else None, ctypes.byref(nt) if bn_stats else None, stream()))
+            elif bn_stats:
                 check(lib.catseg_conv2d_fwd_bf16x3_bnstats(ctypes.byref(d), ptr(xp), ptr(wp), ptr(bias), ptr(out), zero_to, ptr(part),
                                                            part.numel(), ctypes.byref(tr), ctypes.byref(nt), stream()))
             else:
@@ -218,11 +242,13 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
     flops = 2.0 * rows_of(dy) * Cout * (Cin // groups) * kh * kw
     if groups == 1 and "dgrad" in B3_OPS and _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1):
         d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
+        blk = _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16)
         with _Timed("split3", 0.0):
-            dyp = _split3_cached_dy(dy)
-            wtp = split3_weight_t(w)
+            dyp = _split3_cached_dy(dy, "blk" if blk else "planar")
+            wtp = split3_weight_t_blocked(w) if blk else split3_weight_t(w)
         with _Timed("dgrad_b3", flops):
-            check(lib.catseg_conv2d_bwd_data_bf16x3(ctypes.byref(d), ptr(dyp), ptr(wtp), ptr(out), 1 if accumulate else 0, stream()))
+            fn = lib.catseg_conv2d_bwd_data_bf16x3_blocked if blk else lib.catseg_conv2d_bwd_data_bf16x3
+            check(fn(ctypes.byref(d), ptr(dyp), ptr(wtp), ptr(out), 1 if accumulate else 0, stream()))
         return out
     d = make_desc(xshape, ld_of(out), Cout, ld_of(dy), kh, kw, stride, pad, dil, False, groups)
     with _Timed("dgrad", flops):
@@ -239,9 +265,11 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
              or (stride == 1 and _b3_wide_1x1(rows_of(dy), Cout, kh * kw, Cin)))):
         d = make_desc(x.shape, Cin, Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         ws = workspace(lib.catseg_conv2d_bwd_weight_bf16x3_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
+        dgrad_blk = (stride == 1 and "dgrad" in B3_OPS and _b3_eligible(rows_of(x), Cin, kh * kw, (Cout + 7) // 8 * 8)
+                     and _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16))
         with _Timed("split3", 0.0):
-            xp = _split3_cached(x)
-            dyp = _split3_cached_dy(dy)
+            xp = _split3_cached(x, "planar")
+            dyp = _split3_cached_dy(dy, "planar", both=dgrad_blk)
         with _Timed("wgrad_b3", flops):
             check(lib.catseg_conv2d_bwd_weight_bf16x3(ctypes.byref(d), ptr(xp), ptr(dyp), ptr(dw), ptr(ws), ws.numel(), stream()))
         if dbias is not None:
@@ -599,6 +627,31 @@ def split3(x):
     return planes
 
 
+def split3_blocked(x, with_planar=False):
+    """fp32 NHWC activation -> (blocked planes [3, ceil(C/16), rows, 16], planar planes [3, rows, roundup(C, 8)] or None), one pass"""
+    rows, C, ld = rows_of(x), x.shape[-1], ld_of(x)
+    blk = torch.empty((3, (C + 15) // 16, rows, 16), dtype=torch.int16, device=x.device)
+    planar = torch.empty((3, rows, (C + 7) // 8 * 8), dtype=torch.int16, device=x.device) if with_planar else None
+    check(lib.catseg_split3_blocked(ptr(x), rows, C, ld, ptr(blk), ptr(planar), stream()))
+    return blk, planar
+
+
+def split3_weight_blocked(w):
+    """[O, I, kh, kw] weights (physical OHWI, I % 16 == 0) -> blocked planes [3, kh*kw*I/16, O, 16] (forward operand)"""
+    O, I, kh, kw = w.shape
+    planes = torch.empty((3, kh * kw * I // 16, O, 16), dtype=torch.int16, device=w.device)
+    check(lib.catseg_split3_weight_blocked(ptr(w), O, kh * kw, I, ptr(planes), stream()))
+    return planes
+
+
+def split3_weight_t_blocked(w):
+    """OHWI weights -> blocked planes of the transposed bank [3, taps*roundup(O,16)/16, Cin, 16] (backward-data operand)"""
+    O, Cin, kh, kw = w.shape
+    planes = torch.empty((3, kh * kw * ((O + 15) // 16), Cin, 16), dtype=torch.int16, device=w.device)
+    check(lib.catseg_split3_weight_t_blocked(ptr(w), O, kh * kw, Cin, ptr(planes), stream()))
+    return planes
+
+
 def split3_weight(w):
     """[O, I, kh, kw] weights (physical OHWI) -> planes [3, O, kh*kw*I] (forward operand; I % 8 == 0)"""
     O, I, kh, kw = w.shape
@@ -634,4 +687,27 @@ def conv_bwd_data_b3(dyp, wtp, xshape, Cout, kh, kw, stride=1, pad=0, dil=1, out
     d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
     with _Timed("dgrad", 2.0 * B * d.Ho * d.Wo * Cout * Cin * kh * kw):
         check(lib.catseg_conv2d_bwd_data_bf16x3(ctypes.byref(d), ptr(dyp), ptr(wtp), ptr(out), 1 if accumulate else 0, stream()))
+    return out
+
+
+def conv_fwd_b3_blocked(xshape, xblk, wblk, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0):
+    """forward from BLOCKED planes (split3_blocked / split3_weight_blocked): always the 256 x 256 register-pipelined kernel"""
+    B, H, W, Cin = xshape
+    Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
+    if out is None:
+        out = new_act(B, Ho, Wo, Cout, xblk.device, ld=max(zero_to, (Cout + 3) // 4 * 4))
+    d = make_desc(xshape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
+    with _Timed("fwd", 2.0 * B * Ho * Wo * Cout * Cin * kh * kw):
+        check(lib.catseg_conv2d_fwd_bf16x3_blocked(ctypes.byref(d), ptr(xblk), ptr(wblk), ptr(bias), ptr(out), zero_to, None, 0, None, None, stream()))
+    return out
+
+
+def conv_bwd_data_b3_blocked(dyblk, wtblk, xshape, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, accumulate=False):
+    B, H, W, Cin = xshape
+    if out is None:
+        out = new_act(B, H, W, Cin, dyblk.device)
+        accumulate = False
+    d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
+    with _Timed("dgrad", 2.0 * B * d.Ho * d.Wo * Cout * Cin * kh * kw):
+        check(lib.catseg_conv2d_bwd_data_bf16x3_blocked(ctypes.byref(d), ptr(dyblk), ptr(wtblk), ptr(out), 1 if accumulate else 0, stream()))
     return out

@@ -465,6 +465,67 @@ def test_conv_bf16x3_split_precision(ops, case, tile):
         _lib.lib.catseg_debug_set_b3_tile(0)
 
 
+def test_split3_blocked_layout(ops):
+    """catseg_split3_blocked: blocked planes [3][ceil(C/16)][rows][16] and, from the same pass, the planar planes of catseg_split3 --
+    both bit-identical to the planar split (channel tail of the last chunk zero), for row / channel counts off the 64 x 128 block"""
+    for (rows_shape, C, ld) in [((3, 7, 11), 720, 720), ((2, 5, 13), 40, 44), ((1, 9, 9), 16, 16), ((2, 33, 4), 200, 200), ((1, 1, 70), 136, 140)]:
+        g = torch.Generator().manual_seed(C + ld)
+        full = torch.randn(rows_shape + (ld,), generator=g).cuda() * 3.0
+        x = full[..., :C] if ld != C else full
+        ref = ops.split3(x)                                  # [3, rows, roundup(C, 8)]
+        blk, planar = ops.split3_blocked(x, with_planar=True)
+        assert torch.equal(planar, ref)
+        rows = ref.shape[1]
+        c16 = (C + 15) // 16
+        want = torch.zeros((3, rows, c16 * 16), dtype=torch.int16, device="cuda")
+        want[:, :, :ref.shape[2]] = ref
+        want = want.view(3, rows, c16, 16).permute(0, 2, 1, 3).contiguous()
+        assert torch.equal(blk, want)
+        assert torch.equal(ops.split3_blocked(x)[0], want)
+    w = torch.randn(72, 48, 3, 3).cuda().contiguous(memory_format=torch.channels_last)
+    ref = ops.split3_weight(w)                               # [3, O, K]
+    want = ref.view(3, 72, 27, 16).permute(0, 2, 1, 3).contiguous()
+    assert torch.equal(ops.split3_weight_blocked(w), want)
+    w = torch.randn(40, 24, 3, 3).cuda().contiguous(memory_format=torch.channels_last)
+    ref = ops.split3_weight_t(w)                             # [3, Cin, taps, roundup(O, 8)]
+    pad = torch.zeros((3, 24, 9, 48), dtype=torch.int16, device="cuda")
+    pad[..., :40] = ref
+    want = pad.view(3, 24, 27, 16).permute(0, 2, 1, 3).contiguous()
+    assert torch.equal(ops.split3_weight_t_blocked(w), want)
+
+
+B3_BLOCKED_CASES = [(2, 19, 23, 720, 512, 3, 1, 1, 1), (2, 24, 24, 256, 256, 1, 1, 0, 1), (1, 17, 21, 64, 200, 3, 1, 1, 1), (2, 33, 29, 96, 320, 3, 2, 1, 1),
+                    (1, 40, 44, 16, 512, 3, 1, 1, 1), (1, 36, 40, 256, 256, 3, 1, 6, 6), (1, 16, 16, 1024, 512, 1, 1, 0, 1), (3, 9, 7, 32, 24, 3, 1, 1, 1)]
+
+
+@pytest.mark.parametrize("case", B3_BLOCKED_CASES)
+def test_conv_bf16x3_blocked_planes(ops, case):
+    """forward / backward-data of the 256 x 256 kernel from BLOCKED planes against an fp64 F.conv2d (as test_conv_bf16x3_split_precision)"""
+    B, H, W, Cin, Cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(sum(case) + 3)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(2 * torch.randn(1, Cin, 1, 1, generator=g))
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xr = x.double().requires_grad_()
+    y64 = F.conv2d(xr, w.double(), b.double(), s, p, d)
+    gy = torch.randn(y64.shape, generator=g)
+    y64.backward(gy.double())
+    xd, wd = nhwc(x), ohwi(w)
+    ld = (Cout + 3) // 4 * 4 + 4
+    y = ops.conv_fwd_b3_blocked(tuple(xd.shape), ops.split3_blocked(xd)[0], ops.split3_weight_blocked(wd), b.cuda(), Cout, k, k, s, p, d, zero_to=ld)
+    close(nchw(y), y64.detach(), atol=0, rtol=2e-5)
+    full = torch.as_strided(y, y.shape[:3] + (ld,), y.stride())
+    assert float(full[..., Cout:].abs().max()) == 0.0
+    if s == 1:
+        gyd = ops.new_act(B, y64.shape[2], y64.shape[3], Cout, xd.device, zero=True)
+        gyd.copy_(nhwc(gy))
+        dyb, wtb = ops.split3_blocked(gyd)[0], ops.split3_weight_t_blocked(wd)
+        dx = ops.conv_bwd_data_b3_blocked(dyb, wtb, tuple(xd.shape), Cout, k, k, s, p, d)
+        close(nchw(dx), xr.grad, atol=0, rtol=2e-5)
+        dx2 = ops.conv_bwd_data_b3_blocked(dyb, wtb, tuple(xd.shape), Cout, k, k, s, p, d, out=dx.clone(), accumulate=True)
+        close(nchw(dx2), 2 * xr.grad, atol=0, rtol=2e-5)
+
+
 B3_WGRAD_CASES = B3_CASES + [(2, 70, 90, 64, 64, 3, 1, 1, 1), (1, 68, 120, 720, 512, 3, 1, 1, 1), (3, 40, 40, 128, 300, 3, 2, 1, 1)]
 
 
