@@ -128,8 +128,11 @@ def _b3_eligible(rows, ncols, taps, cred, stride_ok=True):
 B3_BLOCKED = True
 
 
-def _b3_blocked_ok(ncols, cred):
-    return B3_BLOCKED and ncols > 192 and cred % 16 == 0
+def _b3_blocked_ok(ncols, cred, a_rows, w_rows, taps):
+    """cred: channels of the gathered operand (a multiple of 16); the three planes of an operand must stay below 4 GB (the
+    kernel addresses them through one 32-bit-offset buffer resource)"""
+    return (B3_BLOCKED and ncols > 192 and cred % 16 == 0 and 6 * a_rows * cred < (1 << 32) - 64
+            and 6 * w_rows * taps * cred < (1 << 32) - 64)
 
 
 def _split3_any(x, want, both):
@@ -196,7 +199,7 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
         tr, nt = ctypes.c_int(0), ctypes.c_int(0)
     if "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(rows, Cout, kh * kw, Cin):
         d = make_desc(x.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
-        blk = _b3_blocked_ok(max(zero_to, Cout), Cin)
+        blk = _b3_blocked_ok(max(zero_to, Cout), Cin, B * H * W, Cout, kh * kw)
         with _Timed("split3", 0.0):
             xp = _split3_cached(x, "blk" if blk else "planar", both=blk and train)
             wp = split3_weight_blocked(w_ptr_tensor) if blk else split3_weight(w_ptr_tensor)
@@ -242,7 +245,7 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
     flops = 2.0 * rows_of(dy) * Cout * (Cin // groups) * kh * kw
     if groups == 1 and "dgrad" in B3_OPS and _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1):
         d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
-        blk = _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16)
+        blk = _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16, rows_of(dy), Cin, kh * kw)
         with _Timed("split3", 0.0):
             dyp = _split3_cached_dy(dy, "blk" if blk else "planar")
             wtp = split3_weight_t_blocked(w) if blk else split3_weight_t(w)
@@ -266,7 +269,7 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
         d = make_desc(x.shape, Cin, Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         ws = workspace(lib.catseg_conv2d_bwd_weight_bf16x3_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
         dgrad_blk = (stride == 1 and "dgrad" in B3_OPS and _b3_eligible(rows_of(x), Cin, kh * kw, (Cout + 7) // 8 * 8)
-                     and _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16))
+                     and _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16, rows_of(dy), Cin, kh * kw))
         with _Timed("split3", 0.0):
             xp = _split3_cached(x, "planar")
             dyp = _split3_cached_dy(dy, "planar", both=dgrad_blk)
