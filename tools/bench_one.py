@@ -1,4 +1,4 @@
-"""Run one conv shape repeatedly (for rocprofv3 --pmc passes).  usage: bench_one.py [fwd|dgrad|wgrad|b3fwd|b3dgrad] [n] [B,H,W,Ci,Co,k,s,p,d] [b3 tile]"""
+"""Run one conv shape repeatedly (for rocprofv3 --pmc passes).  usage: bench_one.py [fwd|dgrad|wgrad|b3fwd|b3dgrad|b3fwdblk|b3dgradblk|b3wgrad] [n] [B,H,W,Ci,Co,k,s,p,d] [b3 tile]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,9 +18,13 @@ if kind.startswith("b3"):
     if len(sys.argv) > 4:
         _lib.lib.catseg_debug_set_b3_tile(int(sys.argv[4]))
     xp, wp, dyp, wtp = ops.split3(x), ops.split3_weight(w), ops.split3(dy), ops.split3_weight_t(w)
+    if kind.endswith("blk"):
+        xb, wb, dyb, wtb = ops.split3_blocked(x)[0], ops.split3_weight_blocked(w), ops.split3_blocked(dy)[0], ops.split3_weight_t_blocked(w)
 torch.cuda.synchronize()
 for _ in range(n):
     if kind == "b3fwd": ops.conv_fwd_b3(tuple(x.shape), xp, wp, None, Co, k, k, s, p, d, out=y)
+    elif kind == "b3fwdblk": ops.conv_fwd_b3_blocked(tuple(x.shape), xb, wb, None, Co, k, k, s, p, d, out=y)
+    elif kind == "b3dgradblk": ops.conv_bwd_data_b3_blocked(dyb, wtb, tuple(x.shape), Co, k, k, s, p, d, out=dx)
     elif kind == "b3dgrad": ops.conv_bwd_data_b3(dyp, wtp, tuple(x.shape), Co, k, k, s, p, d, out=dx)
     elif kind == "fwd": ops.conv_fwd(x, w, None, Co, k, k, s, p, d, out=y)
     elif kind == "dgrad": ops.conv_bwd_data(dy, w, tuple(x.shape), k, k, s, p, d, out=dx)
