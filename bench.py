@@ -127,6 +127,12 @@ def cpu_baseline(H, W, K, model_name):
                       % (timed, "cross entropy" if deeplab else "TwoScale-Lovasz", nb, H, W, K, dt, dt_anom)}
 
 
+def DTYPE_STRING():
+    from miccai2021_cataract_semantic_segmentation_amd import ops
+    return "f32" if ops.PRECISION == "fp32" else ("f32 (convolutions with K >= 2048 and >= 192 output columns: fp32 operands split "
+                                                  "exactly into 3 bf16 planes, 6 bf16 MFMA products, fp32 accumulate)")
+
+
 def infer_bench(args):
     """config 5: frames sharded over ranks, no exchange in the timed region (confusion matrices are summed once at
     the end of a real run); eval-mode BatchNorm, argmax + confusion matrix included in the step"""
@@ -201,7 +207,7 @@ def infer_bench(args):
         print(json.dumps({"metric": "inference frames/sec @1080x1920 UPerNet-ResNeXt101", "value": world * B * args.steps / dt,
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32", "data": "synthetic",
+                          "dtype": DTYPE_STRING(), "data": "synthetic",
                           "config": {"workload": "EncDec(ResNeXt101_32x8d + UPerNet), 25-class, bs=%d/GPU @3x%dx%d, eval-mode forward + "
                                                  "argmax + confusion matrix (BASELINE config 5)" % (B, H, W),
                                      "global_batch": world * B, "parallelism": "dp%d (frame sharded)" % world},
@@ -380,8 +386,7 @@ def main():
             "value": world * B * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if ops.PRECISION == "fp32" else "f32 (convolutions with K >= 2048 and >= 192 output columns: fp32 operands split "
-                                                            "exactly into 3 bf16 planes, 6 bf16 MFMA products, fp32 accumulate)",
+            "dtype": DTYPE_STRING(),
             "data": "synthetic",
             "config": {"workload": ("%s, 17-class (task 2), bs=%d/GPU @3x%dx%d, cross entropy (ignore 17), Adam lr 1e-4 (BASELINE config 2)"
                                     if deeplab else

@@ -124,6 +124,9 @@ int catseg_split3_weight_t_blocked(const float* w, int O, int taps, int Cin, voi
 int catseg_conv2d_fwd_bf16x3_blocked(const catseg_conv_desc* d, const void* x_planes, const void* w_planes, const float* bias,
                                      float* y, int zero_to, float* bn_part, size_t bn_part_floats, int* tile_rows, int* n_tiles,
                                      catseg_stream_t stream);
+/* inference: y = act(conv + bias (+ residual)) in one kernel, the bf16x3 counterpart of catseg_conv2d_fwd_fused */
+int catseg_conv2d_fwd_fused_bf16x3_blocked(const catseg_conv_desc* d, const void* x_planes, const void* w_planes, const float* bias,
+                                           const float* residual, int ldr, int relu, float* y, catseg_stream_t stream);
 int catseg_conv2d_bwd_data_bf16x3_blocked(const catseg_conv_desc* d, const void* dy_planes, const void* wt_planes, float* dx,
                                           int accumulate, catseg_stream_t stream);
 /* dbias[o] = sum_p dy[p, o] (the bias-gradient part of catseg_conv2d_bwd_weight on its own); workspace >= 256 * C floats */

@@ -56,6 +56,7 @@ _SIGS = {
     "catseg_split3_weight_t_blocked": (I, [P, I, I, I, P, P]),
     "catseg_conv2d_fwd_bf16x3_blocked": (I, [P, P, P, P, P, I, P, SZ, P, P, P]),
     "catseg_conv2d_bwd_data_bf16x3_blocked": (I, [P, P, P, P, I, P]),
+    "catseg_conv2d_fwd_fused_bf16x3_blocked": (I, [P, P, P, P, P, I, I, P, P]),
     "catseg_conv2d_fwd_bf16x3": (I, [P, P, P, P, P, I, P]),
     "catseg_conv2d_bwd_data_bf16x3": (I, [P, P, P, P, I, P]),
     "catseg_conv2d_bwd_weight_bf16x3_workspace": (SZ, [P]),

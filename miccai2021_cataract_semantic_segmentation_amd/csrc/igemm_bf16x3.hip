@@ -44,6 +44,9 @@ struct B3Args {
   float* bn_part;     // per (M-tile, channel) BatchNorm partials [tilesM][3][N], or nullptr
   // blocked operand planes (igemm_b3w_kernel<true> only): activations [Cin/16][a_rows][16], weights [taps*Cin/16][w_rows][16]
   int blocked, a_rows, w_rows;
+  // fused inference epilogue (igemm_b3w_kernel): v = act(v + bias (+ residual))
+  const float* residual;
+  int ldr, relu;
 };
 
 __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
@@ -848,6 +851,8 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
           if (col < p.N) {
             float v = acc[t][u][r] + bv;
             if (p.accumulate) v += *dst;
+            if (p.residual != nullptr) v += p.residual[(long long)row * p.ldr + col];
+            if (p.relu) v = fmaxf(v, 0.f);
             *dst = v;
           } else if (col < p.zero_to) {
             *dst = 0.f;
@@ -1394,6 +1399,25 @@ extern "C" int catseg_conv2d_fwd_bf16x3_blocked(const catseg_conv_desc* d, const
       *tile_rows = 256; *n_tiles = nt;
     }
   }
+  return run_b3(a, (hipStream_t)stream);
+}
+
+// inference: y = act(conv(x, w) + bias (+ residual)) from BLOCKED planes in one kernel (the bf16x3 counterpart of
+// catseg_conv2d_fwd_fused; w_planes = catseg_split3_weight_blocked of the BatchNorm-folded weights)
+extern "C" int catseg_conv2d_fwd_fused_bf16x3_blocked(const catseg_conv_desc* d, const void* x_planes, const void* w_planes, const float* bias,
+                                                      const float* residual, int ldr, int relu, float* y, catseg_stream_t stream) {
+  CS_REQUIRE(d && !d->stem4 && d->groups <= 1 && d->Cin % 16 == 0 && d->kh * d->kw <= 32, "conv fwd fused bf16x3: needs Cin % 16 == 0, <= 32 taps, dense");
+  CS_REQUIRE(cs_aligned16(x_planes) && cs_aligned16(w_planes) && cs_aligned16(y) && (residual == nullptr || ldr >= d->Cout), "conv fwd fused bf16x3: bad args");
+  B3Args a = {};
+  a.blocked = 1;
+  a.a_rows = d->B * d->H * d->W; a.w_rows = d->Cout;
+  a.a = (const u16*)x_planes; a.lda = d->Cin; a.a_plane = (long long)a.a_rows * d->Cin;
+  a.w = (const u16*)w_planes; a.ldw = d->kh * d->kw * d->Cin; a.w_plane = (long long)d->Cout * a.ldw;
+  a.C = y; a.ldc = d->ldy; a.bias = bias;
+  a.M = d->B * d->Ho * d->Wo; a.N = d->Cout; a.Cin = d->Cin; a.taps = d->kh * d->kw;
+  a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+  a.sign = 1;
+  a.residual = residual; a.ldr = ldr; a.relu = relu;
   return run_b3(a, (hipStream_t)stream);
 }
 

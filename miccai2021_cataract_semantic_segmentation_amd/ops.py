@@ -614,8 +614,30 @@ def conv_fwd_fused(x, w, bias, residual, relu, Cout, kh, kw, stride=1, pad=0, di
     Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
     if out is None:
         out = new_act(B, Ho, Wo, Cout, x.device)
+    flops = 2.0 * B * Ho * Wo * Cout * (3 if stem4 else Cin // groups) * kh * kw
+    if ("fwd" in B3_OPS and not stem4 and groups == 1 and w.numel() == Cout * kh * kw * Cin and _b3_eligible(B * Ho * Wo, Cout, kh * kw, Cin)
+            and B3_BLOCKED and Cout > 192 and Cin % 16 == 0 and 6 * Cout * kh * kw * Cin < (1 << 32) - 64):
+        # the bf16x3 kernel with the fused epilogue; the batch is cut so that the three blocked planes of a piece stay below 4 GB
+        # (UPerNet's 3x3 2048 -> 512 on a 4 x 272 x 480 map: 6.4 GB of planes in one piece)
+        per_img = 6 * H * W * Cin
+        nb = max(1, min(B, ((1 << 32) - 64) // per_img))
+        if per_img < (1 << 32) - 64:
+            wp = None
+            for b0 in range(0, B, nb):
+                xs, os_ = x[b0:b0 + nb], out[b0:b0 + nb]
+                rs = residual[b0:b0 + nb] if residual is not None else None
+                d = make_desc(xs.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
+                with _Timed("split3", 0.0):
+                    xp = _split3_cached(xs, "blk") if nb == B else split3_blocked(xs)[0]
+                    if wp is None:      # (w: OHWI weights, 4-D or the flat buffer catseg_fold_bn writes)
+                        wp = torch.empty((3, kh * kw * Cin // 16, Cout, 16), dtype=torch.int16, device=w.device)
+                        check(lib.catseg_split3_weight_blocked(ptr(w), Cout, kh * kw, Cin, ptr(wp), stream()))
+                with _Timed("fwd_b3", flops * xs.shape[0] / B):
+                    check(lib.catseg_conv2d_fwd_fused_bf16x3_blocked(ctypes.byref(d), ptr(xp), ptr(wp), ptr(bias), ptr(rs),
+                                                                     ld_of(residual) if residual is not None else 0, 1 if relu else 0, ptr(os_), stream()))
+            return out
     d = make_desc(x.shape, ld_of(x), Cout, ld_of(out), kh, kw, stride, pad, dil, stem4, groups)
-    with _Timed("fwd", 2.0 * B * Ho * Wo * Cout * (3 if stem4 else Cin // groups) * kh * kw):
+    with _Timed("fwd", flops):
         check(lib.catseg_conv2d_fwd_fused(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual),
                                           ld_of(residual) if residual is not None else 0, 1 if relu else 0, ptr(out), stream()))
     return out

@@ -526,6 +526,40 @@ def test_conv_bf16x3_blocked_planes(ops, case):
         close(nchw(dx2), 2 * xr.grad, atol=0, rtol=2e-5)
 
 
+@pytest.mark.parametrize("case", [(2, 19, 23, 64, 256, 3, 1, 1, 1, True, True), (1, 24, 24, 256, 320, 1, 1, 0, 1, False, True),
+                                  (3, 17, 21, 32, 200, 3, 2, 1, 1, True, False), (2, 16, 20, 48, 208, 3, 1, 2, 2, False, False)])
+def test_conv_fused_inference_bf16x3(ops, case):
+    """inference epilogue of the 256 x 256 bf16x3 kernel (bias + residual + ReLU, blocked planes) through ops.conv_fwd_fused with the
+    layer thresholds lowered, against fp64; the fp32 fused kernel must agree to fp32 rounding"""
+    B, H, W, Cin, Cout, k, s, p, d, use_res, relu = case
+    g = torch.Generator().manual_seed(sum(case[:9]) + 5)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    y64 = F.conv2d(x.double(), w.double(), b.double(), s, p, d)
+    res = torch.randn(y64.shape, generator=g) if use_res else None
+    if use_res:
+        y64 = y64 + res.double()
+    if relu:
+        y64 = y64.relu()
+    xd, wd = nhwc(x), ohwi(w)
+    resd = nhwc(res) if use_res else None
+    saved = (ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES)
+    try:
+        ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES = "bf16x3", 1, 16, 16, 1
+        prof, ops.PROFILE = ops.PROFILE, []
+        y = ops.conv_fwd_fused(xd, wd, b.cuda(), resd, relu, Cout, k, k, s, p, d)
+        kinds = [q[0] for q in ops.PROFILE]
+        ops.PROFILE = prof
+        assert "fwd_b3" in kinds, kinds                     # the split-precision kernel ran, not the fp32 one
+        ops.PRECISION = "fp32"
+        y32 = ops.conv_fwd_fused(xd, wd, b.cuda(), resd, relu, Cout, k, k, s, p, d)
+    finally:
+        ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES = saved
+    close(nchw(y), y64, atol=0, rtol=2e-5)
+    close(nchw(y32), y64, atol=0, rtol=2e-5)
+
+
 B3_WGRAD_CASES = B3_CASES + [(2, 70, 90, 64, 64, 3, 1, 1, 1), (1, 68, 120, 720, 512, 3, 1, 1, 1), (3, 40, 40, 128, 300, 3, 2, 1, 1)]
 
 
