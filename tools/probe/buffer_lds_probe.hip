@@ -38,3 +38,4 @@ int main() {
   printf(bad ? "PROBE FAIL (%d words)\n" : "PROBE OK: in-range lanes loaded, out-of-range lanes wrote zeros (%d bad)\n", bad);
   return bad != 0;
 }
+// build + run:  hipcc --offload-arch=gfx950 -O2 -o tools/probe/buffer_lds_probe tools/probe/buffer_lds_probe.hip && gpurun -- ./tools/probe/buffer_lds_probe
