@@ -279,13 +279,21 @@ __global__ __launch_bounds__(512, 2) void igemm_b3_kernel(const B3Args p) {
     for (int j = 0; j < NA; ++j) {
       const int c = achunk[j] * 8;
       const bool ok = tap_ok && ((amask[j] >> (ttap & 31)) & 1u) && (tck * 16 + c) < p.Cin;
+#ifdef B3G_BLOCKED   // address-only timing experiment (tools/ab_b3w.sh): activation planes [C/16][pixel][16]; values are garbage
+      pa[j] = ok ? p.a + ((long long)(tck * p.M + aoff[j] / p.lda + p.sign * (tky * p.dil * p.W + tkx * p.dil)) * 16 + (c & 8)) : zero;
+#else
       pa[j] = ok ? p.a + (aoff[j] + toff + c) : zero;
+#endif
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int c = bchunk[j] * 8;
       const bool ok = tap_ok && brow[j] < p.N && (tck * 16 + c) < p.Cin;
+#ifdef B3G_BLOCKED   // weight planes [K/16][N][16]
+      pb[j] = ok ? p.w + ((long long)((ttap * nck + tck) * p.N + brow[j]) * 16 + (c & 8)) : zero;
+#else
       pb[j] = ok ? p.w + ((long long)brow[j] * p.ldw + woff + c) : zero;
+#endif
     }
     if (++tck == nck) {
       tck = 0;

@@ -6,7 +6,7 @@ C=$R/miccai2021_cataract_semantic_segmentation_amd/csrc
 mkdir -p "$R/ab"
 for v in ${AB_VARIANTS:-base NO_PREP NO_DMA NO_READS NO_SYNC ALL TAP_INNER}; do
   D=""
-  case $v in base) ;; ALL) D="-DB3X_NO_PREP -DB3X_NO_DMA -DB3X_NO_READS -DB3X_NO_SYNC";; BLOCKED_AB) D="-DB3X_BLOCKED_A -DB3X_BLOCKED_B";; *) D="-DB3X_$v";; esac
+  case $v in base) ;; ALL) D="-DB3X_NO_PREP -DB3X_NO_DMA -DB3X_NO_READS -DB3X_NO_SYNC";; BLOCKED_AB) D="-DB3X_BLOCKED_A -DB3X_BLOCKED_B";; GEN_BLOCKED) D="-DB3G_BLOCKED";; *) D="-DB3X_$v";; esac
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R/include -Wno-comment $D -c $C/igemm_bf16x3.hip -o $R/ab/b3_$v.o
   OTHERS=$(ls $C/build/*.o | grep -v igemm_bf16x3.o)
   hipcc --offload-arch=gfx950 -shared -fPIC -o $R/ab/libcatseg_$v.so $OTHERS $R/ab/b3_$v.o
