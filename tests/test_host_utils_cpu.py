@@ -125,3 +125,27 @@ def test_second_backward_and_shared_module_are_rejected():
     with pytest.raises(NotImplementedError, match="applied twice"):
         cx.claim(p)
     engine.Ctx(train=False, record=False).claim(p, p)           # nothing is recorded in inference: no restriction
+
+
+def test_bf16x3_layer_selection():
+    """which convolutions take the split-precision kernels, and which of those read blocked planes (ops._b3_eligible /
+    _b3_blocked_ok: host logic of DESIGN 4.1c)"""
+    from miccai2021_cataract_semantic_segmentation_amd import ops
+    assert ops.PRECISION == "bf16x3" and ops.B3_BLOCKED
+    rows = 8 * 136 * 240
+    assert ops._b3_eligible(rows, 512, 9, 720)                         # OCRNet-HRNet head 3x3 720 -> 512
+    assert ops._b3_blocked_ok(512, 720, rows, 512, 9)
+    assert not ops._b3_eligible(rows, 48, 9, 48)                       # HRNet branch 3x3 48 -> 48: fp32 kernels
+    assert not ops._b3_eligible(8 * 17 * 30, 384, 9, 384)              # 384-channel branch: too few tiles
+    assert ops._b3_eligible(rows, 512, 1, 1024)                        # the wide 1x1 of the OCR head at stride 4 ...
+    assert ops._b3_eligible(rows, 1024, 1, 512)                        # ... and its backward-data (N = 1024, K = 512)
+    assert not ops._b3_eligible(8 * 68 * 120, 512, 1, 1024)            # the same layer at stride 8 (OCRNet-R50): fp32
+    assert not ops._b3_eligible(rows, 256, 1, 512)                     # smaller 1x1 layers: fp32
+    assert ops._b3_eligible(8 * 68 * 120, 512, 9, 2048)                # OCRNet-R50 conv_high_map
+    assert not ops._b3_eligible(8 * 68 * 120, 512, 9, 2044)            # Cin % 8
+    assert not ops._b3_blocked_ok(192, 720, rows, 192, 9)              # <= 192 columns: 8-wave tiles, planar planes
+    assert not ops._b3_blocked_ok(512, 712, rows, 512, 9)              # Cin % 16
+    big = 4 * 272 * 480
+    assert ops._b3_eligible(big, 512, 9, 2048)
+    assert not ops._b3_blocked_ok(512, 2048, big, 512, 9)              # three blocked planes = 6.4 GB > 4 GB: planar / cut batch
+    assert ops._b3_blocked_ok(512, 2048, big // 2, 512, 9)
