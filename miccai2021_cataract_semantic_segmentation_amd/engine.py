@@ -605,9 +605,11 @@ class EngineNet(nn.Module):
         return super().state_dict(*a, **k)
 
     def _run(self, x, record):
+        ops.release_b3_cache()          # (planes left over from a recorded forward that never saw its backward)
         cx = Ctx(self.training, record, None)
         outs = self._body(cx, x)
-        ops.release_b3_cache()
+        if not record:
+            ops.release_b3_cache()      # a recorded forward keeps its split planes for the backward-weight pass (_end_backward frees them)
         return cx, outs
 
     def zero_grad(self, set_to_none=True):

@@ -154,10 +154,23 @@ def _cached(cache, x, key, want, both):
     return cache[want]
 
 
-def _split3_cached(x, want="planar", both=False):
-    """three-plane split of an activation; the last one is kept (the two 720-channel head convolutions of OCRNet-HRNet and the
-    ASPP branches read one tensor; the backward-weight pass of a layer reads what its forward produced)"""
-    return _cached(_b3_cache, x, (x.data_ptr(), x._version, tuple(x.shape), ld_of(x)), want, both)
+_b3_kept = {}   # training step: planes of every split input, kept from the forward pass for its backward-weight pass
+
+
+def _split3_cached(x, want="planar", both=False, keep=False):
+    """three-plane split of an activation.  The last one is always kept (the two 720-channel head convolutions of OCRNet-HRNet and
+    the ASPP branches read one tensor); keep=True (a recorded training forward) holds on to the planes until release_b3_cache(),
+    so that the layer's backward-weight pass reads what its forward produced instead of splitting x again (the planes of all
+    bf16x3 layers of a step: 5.5 GB for OCRNet-HRNet-W48 at bs 8, of 288 GB)"""
+    key = (x.data_ptr(), x._version, tuple(x.shape), ld_of(x))
+    ent = _b3_kept.get(key)
+    if ent is not None and ent["x"] is x:
+        return _cached(ent, x, key, want, both)
+    if keep:
+        ent = {"key": None, "x": None, "planar": None, "blk": None}
+        _b3_kept[key] = ent
+        return _cached(ent, x, key, want, both)
+    return _cached(_b3_cache, x, key, want, both)
 
 
 def _split3_cached_dy(dy, want="planar", both=False):
@@ -168,6 +181,7 @@ def _split3_cached_dy(dy, want="planar", both=False):
 def release_b3_cache():
     _b3_cache.update(key=None, x=None, planar=None, blk=None)
     _b3_cache_dy.update(key=None, x=None, planar=None, blk=None)
+    _b3_kept.clear()
 
 
 _bn_part = {}
@@ -184,8 +198,10 @@ def _bn_part_buffer(nfloats, device):
     return buf
 
 
-def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False, groups=1, bn_stats=False, train=True):
-    """bn_stats=True: returns (out, partials) where partials = (buffer, n_tiles, tile_rows) are the per-(M-tile, channel)
+def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False, groups=1, bn_stats=False, train=False):
+    """train=True (the engine's recorded forward): a backward pass will follow -- the split planes of x are written in both layouts
+    and kept for it (release_b3_cache() frees them).
+    bn_stats=True: returns (out, partials) where partials = (buffer, n_tiles, tile_rows) are the per-(M-tile, channel)
     BatchNorm partial sums written by the convolution's epilogue (for bn_finalize), or None if this layer's kernel has none"""
     B, H, W, Cin = x.shape
     Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
@@ -201,7 +217,7 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
         d = make_desc(x.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
         blk = _b3_blocked_ok(max(zero_to, Cout), Cin, B * H * W, Cout, kh * kw)
         with _Timed("split3", 0.0):
-            xp = _split3_cached(x, "blk" if blk else "planar", both=blk and train)
+            xp = _split3_cached(x, "blk" if blk else "planar", both=blk and train, keep=train)
             wp = split3_weight_blocked(w_ptr_tensor) if blk else split3_weight(w_ptr_tensor)
         with _Timed("fwd_b3", flops):
             if blk:

@@ -29,6 +29,9 @@ for m in ocrnet_hrnet48 ocrnet_r50 deeplabv3plus_r50; do
   fi
 done
 python3 "$R/bench.py" --infer > "$O/bench_infer.json" 2> "$O/bench_infer.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_infer" -o p -- python3 "$R/bench.py" --infer --steps 3 --warmup 1 > "$O/bench_prof_infer.json" 2> "$O/bench_prof_infer.err"
+cp $(ls "$O"/prof_infer/*/p_kernel_stats.csv "$O"/prof_infer/p_kernel_stats.csv 2>/dev/null | head -1) "$O/kernel_stats_infer.csv"
+rm -rf "$O/prof_infer"
 # two ranks (gloo rendezvous) sharing the one GPU: the data-parallel path end to end (no 8-GPU node is available to the builder)
 CATSEG_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 "$R/bench.py" --gpus 2 --steps 5 --warmup 2 --batch 4 --no-cpu-baseline > "$O/bench_2rank_gloo_1gpu.json" 2> "$O/bench_2rank_gloo_1gpu.err"
 tail -c 300 "$O"/bench_ocrnet_hrnet48.json
