@@ -308,7 +308,9 @@ def main():
         # (the instrumented steps run the HRNet branches one after the other: with the branches overlapped on side streams, as
         #  in the timed region, the HIP events around one launch would also time its concurrent siblings)
         from miccai2021_cataract_semantic_segmentation_amd import engine
+        from miccai2021_cataract_semantic_segmentation_amd.losses import two_scale
         par, engine.PARALLEL_BRANCHES = engine.PARALLEL_BRANCHES, False
+        conc, two_scale.CONCURRENT = two_scale.CONCURRENT, False
         step()
         torch.cuda.synchronize()
         ops.PROFILE = [] if rank == 0 else None
@@ -316,6 +318,7 @@ def main():
             step()
         torch.cuda.synchronize()
         engine.PARALLEL_BRANCHES = par
+        two_scale.CONCURRENT = conc
     if not args.no_roofline and rank == 0:
         prof, ops.PROFILE = ops.PROFILE, None
         agg = {}

@@ -1,10 +1,22 @@
 """TwoScaleLoss — losses/TwoScaleLoss.py:8-52 of the reference: w_final * L(final) + w_interm * L(interm)."""
+import torch
 from torch import nn
 
 from ..utils import IGNORE_LABEL
 from .cross_entropy import CrossEntropyLoss
 from .lovasz import LovaszSoftmax
 from .ohem import OhemCrossEntropy
+
+CONCURRENT = True    # run the intermediate-scale loss on a side stream, concurrently with the final-scale loss
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device)
+    return _SIDE[key]
+
 
 _REGISTRY = {"LovaszSoftmax": LovaszSoftmax, "CrossEntropyLoss": CrossEntropyLoss, "OhemCrossEntropy": OhemCrossEntropy}
 
@@ -33,6 +45,19 @@ class TwoScaleLoss(nn.Module):
     def forward(self, logits_interm, logits_final, target):
         if logits_interm.shape[2:] != target.shape[1:]:
             raise NotImplementedError("intermediate logits must already be at label resolution (OCRNet upsamples them)")
-        loss_final = self.loss_final(logits_final, target)
-        loss_interm = self.loss_interm(logits_interm, target)
+        if CONCURRENT and logits_final.is_cuda:
+            # the two losses are independent: the intermediate one runs on a side stream (its sort / scan passes interleave with
+            # the final loss's; every kernel of a loss call is ordered on the stream it was issued to, workspaces are per stream)
+            main = torch.cuda.current_stream(logits_final.device)
+            side = _side_stream(logits_final.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                loss_interm = self.loss_interm(logits_interm, target)
+            loss_final = self.loss_final(logits_final, target)
+            main.wait_stream(side)
+            logits_interm.record_stream(side)
+            target.record_stream(side)
+        else:
+            loss_final = self.loss_final(logits_final, target)
+            loss_interm = self.loss_interm(logits_interm, target)
         return loss_final * self.w_final + loss_interm * self.w_interm
