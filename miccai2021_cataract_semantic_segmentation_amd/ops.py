@@ -126,13 +126,14 @@ def _b3_eligible(rows, ncols, taps, cred, stride_ok=True):
 # (csrc/igemm_bf16x3.hip: whole cache lines per LDS-DMA instruction, 190 -> 248 TFLOP/s-equivalent on the 3x3 720 -> 512 layer);
 # the backward-weight kernel keeps the planar planes, written by the same split pass when a backward will follow.
 B3_BLOCKED = True
+B3_PLANE_LIMIT = (1 << 32) - 64     # bytes of the three blocked planes of one operand (one 32-bit-offset buffer resource); tests lower it
 
 
 def _b3_blocked_ok(ncols, cred, a_rows, w_rows, taps):
     """cred: channels of the gathered operand (a multiple of 16); the three planes of an operand must stay below 4 GB (the
     kernel addresses them through one 32-bit-offset buffer resource)"""
-    return (B3_BLOCKED and ncols > 192 and cred % 16 == 0 and 6 * a_rows * cred < (1 << 32) - 64
-            and 6 * w_rows * taps * cred < (1 << 32) - 64)
+    return (B3_BLOCKED and ncols > 192 and cred % 16 == 0 and 6 * a_rows * cred < B3_PLANE_LIMIT
+            and 6 * w_rows * taps * cred < B3_PLANE_LIMIT)
 
 
 def _split3_any(x, want, both):
@@ -636,8 +637,8 @@ def conv_fwd_fused(x, w, bias, residual, relu, Cout, kh, kw, stride=1, pad=0, di
         # the bf16x3 kernel with the fused epilogue; the batch is cut so that the three blocked planes of a piece stay below 4 GB
         # (UPerNet's 3x3 2048 -> 512 on a 4 x 272 x 480 map: 6.4 GB of planes in one piece)
         per_img = 6 * H * W * Cin
-        nb = max(1, min(B, ((1 << 32) - 64) // per_img))
-        if per_img < (1 << 32) - 64:
+        nb = max(1, min(B, B3_PLANE_LIMIT // per_img))
+        if per_img < B3_PLANE_LIMIT:
             wp = None
             for b0 in range(0, B, nb):
                 xs, os_ = x[b0:b0 + nb], out[b0:b0 + nb]

@@ -558,6 +558,16 @@ def test_conv_fused_inference_bf16x3(ops, case):
         ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES = saved
     close(nchw(y), y64, atol=0, rtol=2e-5)
     close(nchw(y32), y64, atol=0, rtol=2e-5)
+    if B > 1:
+        # the batch cut that keeps a piece's three blocked planes below the buffer-resource limit (4 GB; here: one image per piece)
+        saved = (ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES, ops.B3_PLANE_LIMIT)
+        try:
+            ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES = "bf16x3", 1, 16, 16, 1
+            ops.B3_PLANE_LIMIT = 6 * H * W * Cin + 1
+            yc = ops.conv_fwd_fused(xd, wd, b.cuda(), resd, relu, Cout, k, k, s, p, d)
+        finally:
+            ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES, ops.B3_PLANE_LIMIT = saved
+        assert torch.equal(yc, y)
 
 
 B3_WGRAD_CASES = B3_CASES + [(2, 70, 90, 64, 64, 3, 1, 1, 1), (1, 68, 120, 720, 512, 3, 1, 1, 1), (3, 40, 40, 128, 300, 3, 2, 1, 1)]
