@@ -297,7 +297,12 @@ __device__ __forceinline__ void igemm_f32_body(const IgemmArgs& p) {
         const int toff = ((p.dy0 + tky * p.ddy) * p.g.W + (p.dx0 + tkx * p.ddx)) * p.g.ld + chunk * 4;
 #pragma unroll
         for (int j = 0; j < MI; ++j)
+#ifdef IGEMM_BLOCKED_AB   // address-only timing experiment (tools/ab_igemm.sh): activations laid out [C/16][pixel][16] fp32; values are garbage
+          pa[sub][j] = sel_ptr(cv && ((amask[j] >> (ttap & 31)) & 1u), gbase,
+                               (tck * p.M + aoff[j] / p.g.ld + (p.dy0 + tky * p.ddy) * p.g.W + (p.dx0 + tkx * p.ddx)) * 16 + kc_chunk * 4, p.zero);
+#else
           pa[sub][j] = sel_ptr(cv && ((amask[j] >> (ttap & 31)) & 1u), gbase, aoff[j] + toff, p.zero);
+#endif
       } else {
 #pragma unroll
         for (int j = 0; j < MI; ++j)
@@ -308,7 +313,11 @@ __device__ __forceinline__ void igemm_f32_body(const IgemmArgs& p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int n = n0 + j * 64 + kc_row;
+#ifdef IGEMM_BLOCKED_AB   // weights laid out [K/16][N][16]
+          pb[sub][j] = sel_ptr(n < p.N && cv, obase, ((wt * nck + tck) * p.N + n) * 16 + kc_chunk * 4, p.zero);
+#else
           pb[sub][j] = sel_ptr(n < p.N && cv, obase, n * p.ldo + boff, p.zero);
+#endif
         }
       } else {
         const int boff = wt * p.tap_stride + n0;
