@@ -262,6 +262,20 @@ int catseg_ingest_u8(const uint8_t* img, const uint8_t* lbl, int B, int H, int W
                      int pad_top, int pad_bottom, const float* mean, const float* stdv, float* x_nchw, float* x_nhwc4,
                      int64_t* labels, catseg_stream_t stream);
 
+/* PIL-based training augmentations on uint8 NHWC batches [B][H][W][3], bit-exact with Pillow (csrc/augment.hip; reference call
+ * sites utils/utils.py:412-417, utils/transforms.py:242-251):
+ *   catseg_aug_pad_flip_u8: FlipNP (bit 0 horizontal, bit 1 vertical) + PadNP reflect rows, uint8 -> uint8 (what precedes ToPILImage);
+ *   catseg_aug_box_blur: ONE extended box-blur pass along axis (0 = H, 1 = W) with per-image (radius, ww, fw) of BoxBlur.c
+ *     (radius[b] < 0: copy); ImageFilter.GaussianBlur(r) = 3 passes along W, then 3 along H, box radius from r (host side);
+ *   catseg_aug_color_op: ONE operation of torchvision ColorJitter per image, in place: op[b] = 0 brightness, 1 contrast,
+ *     2 saturation (factor[b] = the enhance factor), 3 hue (factor[b] = the integer H shift 0..255), < 0 none; workspace >= 8 B bytes. */
+int catseg_aug_pad_flip_u8(const uint8_t* in, uint8_t* out, int B, int H, int W, int C, const int32_t* flips, int pad_top,
+                           int pad_bottom, catseg_stream_t stream);
+int catseg_aug_box_blur(const uint8_t* in, uint8_t* out, int B, int H, int W, int axis, const int32_t* radius, const uint32_t* ww,
+                        const uint32_t* fw, catseg_stream_t stream);
+int catseg_aug_color_op(uint8_t* img, int B, int H, int W, const int32_t* op, const float* factor, void* workspace,
+                        size_t workspace_bytes, catseg_stream_t stream);
+
 /* Test-time augmentation plumbing (managers/BaseManager.py:652-660 wraps the model in ttach
  * HorizontalFlip x Scale(0.75, 1, 1.5, 1.75, 2), merge 'mean'; ttach is an un-vendored dependency: its Scale is
  * F.interpolate(mode='nearest', size=(int(h*s), int(w*s)))).  NHWC nearest resize:

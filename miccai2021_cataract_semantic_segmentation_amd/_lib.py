@@ -47,6 +47,9 @@ _SIGS = {
     "catseg_debug_set_wgrad_direct": (I, [I]),
     "catseg_debug_plan_conv": (I, [P, I, P]),
     "catseg_debug_set_b3_tile": (I, [I]),
+    "catseg_aug_pad_flip_u8": (I, [P, P, I, I, I, I, P, I, I, P]),
+    "catseg_aug_box_blur": (I, [P, P, I, I, I, I, P, P, P, P]),
+    "catseg_aug_color_op": (I, [P, I, I, I, P, P, P, SZ, P]),
     "catseg_split3_elems": (SZ, [L, I]),
     "catseg_split3": (I, [P, I, L, I, P, P]),
     "catseg_split3_weight_t": (I, [P, I, I, I, P, P]),

@@ -753,3 +753,33 @@ def conv_bwd_data_b3_blocked(dyblk, wtblk, xshape, Cout, kh, kw, stride=1, pad=0
     with _Timed("dgrad", 2.0 * B * d.Ho * d.Wo * Cout * Cin * kh * kw):
         check(lib.catseg_conv2d_bwd_data_bf16x3_blocked(ctypes.byref(d), ptr(dyblk), ptr(wtblk), ptr(out), 1 if accumulate else 0, stream()))
     return out
+
+
+# ---------------------------------------------------------------------------------------------- uint8 augmentation (csrc/augment.hip)
+def aug_pad_flip_u8(img, flips, pad_top, pad_bottom):
+    """uint8 [B,H,W,C] -> uint8 [B,H+pad,W,C]: FlipNP flags (bit 0 horizontal, bit 1 vertical) + PadNP reflect rows"""
+    assert img.dtype == torch.uint8 and img.is_contiguous() and img.is_cuda and img.dim() == 4
+    B, H, W, C = img.shape
+    out = torch.empty((B, H + pad_top + pad_bottom, W, C), dtype=torch.uint8, device=img.device)
+    check(lib.catseg_aug_pad_flip_u8(ptr(img), ptr(out), B, H, W, C, ptr(flips), pad_top, pad_bottom, stream()))
+    return out
+
+
+def aug_gaussian_blur(img, radius, ww, fw):
+    """ImageFilter.GaussianBlur per image: three box passes along W, then three along H; radius[b] < 0: image unchanged"""
+    assert img.dtype == torch.uint8 and img.is_contiguous() and img.is_cuda and img.shape[-1] == 3
+    B, H, W, _ = img.shape
+    a, b = img, torch.empty_like(img)
+    for axis in (1, 1, 1, 0, 0, 0):
+        check(lib.catseg_aug_box_blur(ptr(a), ptr(b), B, H, W, axis, ptr(radius), ptr(ww), ptr(fw), stream()))
+        a, b = b, (torch.empty_like(img) if a is img else a)
+    return a
+
+
+def aug_color_op(img, op, factor):
+    """one torchvision ColorJitter operation per image, IN PLACE (op 0 brightness, 1 contrast, 2 saturation, 3 hue with factor = H shift)"""
+    assert img.dtype == torch.uint8 and img.is_contiguous() and img.is_cuda and img.shape[-1] == 3
+    B, H, W, _ = img.shape
+    ws = workspace(8 * B + 256, img.device)
+    check(lib.catseg_aug_color_op(ptr(img), B, H, W, ptr(op), ptr(factor), ptr(ws), ws.numel(), stream()))
+    return img

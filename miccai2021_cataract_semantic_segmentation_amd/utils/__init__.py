@@ -1,4 +1,5 @@
 from .classes import CATEGORIES, CLASS_REMAP, IGNORE_LABEL, NUM_CLASSES, ce_ignore_index, num_classes  # noqa: F401
+from .augment import GpuAugment, gaussian_box_params, sample_blur, sample_color_jitter  # noqa: F401
 from .ingest import GpuIngest, remap_lut, sample_flips  # noqa: F401
 from .lr_functions import LRFcts  # noqa: F401
 from .sampling import RepeatFactorSampler, class_repeat_factors, image_repeat_factors  # noqa: F401

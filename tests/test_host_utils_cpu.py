@@ -149,3 +149,11 @@ def test_bf16x3_layer_selection():
     assert ops._b3_eligible(big, 512, 9, 2048)
     assert not ops._b3_blocked_ok(512, 2048, big, 512, 9)              # three blocked planes = 6.4 GB > 4 GB: planar / cut batch
     assert ops._b3_blocked_ok(512, 2048, big // 2, 512, 9)
+
+
+def test_gaussian_box_parameters_match_the_oracle():
+    """host side of the GPU blur: (radius, ww, fw) of Pillow's BoxBlur.c for ImageFilter.GaussianBlur(3..6)"""
+    from oracle import augment as A
+    from miccai2021_cataract_semantic_segmentation_amd.utils.augment import gaussian_box_params
+    for r in (1, 2, 3, 4, 5, 6, 9):
+        assert gaussian_box_params(r) == A.box_weights(A.gaussian_box_radius(r)), r
