@@ -19,16 +19,22 @@ import threading
 import numpy as np
 import torch
 
+from .augment import sample_blur, sample_color_jitter
 from .ingest import GpuIngest, sample_flips
 
 
 class PinnedFrameLoader:
     def __init__(self, dataset, batch_size, experiment, sampler=None, shuffle=True, drop_last=True, flip_probability=(0.0, 0.5),
-                 pad=(2, 2), normalise=False, nhwc4=False, device="cuda", prefetch=3, workers=4, seed=0, rank=0, world=1):
+                 pad=(2, 2), normalise=False, nhwc4=False, device="cuda", prefetch=3, workers=4, seed=0, rank=0, world=1,
+                 blur=False, colorjitter=False):
+        """blur / colorjitter: the 'blur' / 'colorjitter' entries of the reference's `transforms` config list (utils/utils.py:412-417):
+        BlurPIL(probability=.05, kernel_limits=(3, 7)) and ColorJitter((2/3, 1.5) x 3, hue (-.05, .05)) on the padded uint8 frames,
+        as GPU kernels (utils/augment.py)"""
         self.dataset, self.batch, self.drop_last = dataset, int(batch_size), drop_last
         self.device = torch.device(device)
         self.ingest = GpuIngest(experiment, pad=pad, normalise=normalise, device=device)
         self.flip_p, self.nhwc4 = flip_probability, nhwc4
+        self.blur, self.colorjitter = bool(blur), bool(colorjitter)
         self.prefetch, self.workers = max(int(prefetch), 1), max(int(workers), 1)
         self.seed, self.epoch, self.rank, self.world = seed, 0, rank, world
         self.sampler, self.shuffle = sampler, shuffle
@@ -65,6 +71,9 @@ class PinnedFrameLoader:
             batches.pop()
         rng = np.random.RandomState(self.seed * 1000003 + self.epoch)
         flips = [sample_flips(len(b), self.flip_p, rng) for b in batches]
+        gen = torch.Generator().manual_seed(self.seed * 1000003 + self.epoch)
+        blurs = [sample_blur(len(b), random=rng) if self.blur else None for b in batches]
+        jitters = [sample_color_jitter(len(b), generator=gen) if self.colorjitter else None for b in batches]
         ready = queue.Queue(maxsize=self.prefetch)
         free = queue.Queue()
         first = self.dataset[batches[0][0]] if batches else None
@@ -97,7 +106,7 @@ class PinnedFrameLoader:
                         return
                     slot = free.get()
                     fill(slot, ids)
-                    ready.put((slot, len(ids), flips[bi]))
+                    ready.put((slot, len(ids), flips[bi], blurs[bi], jitters[bi]))
             finally:
                 ready.put(None)
 
@@ -108,7 +117,7 @@ class PinnedFrameLoader:
                 item = ready.get()
                 if item is None:
                     break
-                slot, n, fl = item
+                slot, n, fl, br, jt = item
                 img_buf, lbl_buf = self._slots[slot]
                 with torch.cuda.stream(self.copy_stream):          # host -> device on the side stream (pinned: truly asynchronous)
                     img_d = img_buf[:n].to(self.device, non_blocking=True)
@@ -118,7 +127,7 @@ class PinnedFrameLoader:
                 torch.cuda.current_stream(self.device).wait_event(done)   # the ingest kernel waits for the copy, the host does not
                 img_d.record_stream(torch.cuda.current_stream(self.device))
                 lbl_d.record_stream(torch.cuda.current_stream(self.device))
-                x, labels = self.ingest(img_d, lbl_d, fl, nhwc4=self.nhwc4)
+                x, labels = self.ingest(img_d, lbl_d, fl, nhwc4=self.nhwc4, blur_radii=br, jitter=jt)
                 done.synchronize()                                         # the staging slot may be refilled once the copy has left it
                 free.put(slot)
                 yield x, labels

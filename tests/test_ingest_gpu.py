@@ -98,3 +98,39 @@ def test_pinned_frame_loader_matches_direct_ingest():
         # a second epoch reshuffles
         assert loader._indices() != idx
     assert not set(seen[0]) & set(seen[1])
+
+
+def test_pinned_frame_loader_with_blur_and_colour_jitter():
+    """the 'blur' / 'colorjitter' entries of the reference's transform list through the loader: the batches equal a direct GpuIngest
+    call with the same host draws (flips, then blur radii from one RandomState; jitter parameters from one torch Generator)"""
+    _need_gpu()
+    from miccai2021_cataract_semantic_segmentation_amd.utils import GpuIngest, PinnedFrameLoader, sample_blur, sample_color_jitter
+    from miccai2021_cataract_semantic_segmentation_amd.utils.ingest import sample_flips
+
+    class Frames:
+        def __len__(self):
+            return 8
+
+        def __getitem__(self, i):
+            rng = np.random.RandomState(100 + i)
+            return rng.randint(0, 256, (28, 40, 3)).astype(np.uint8), rng.randint(0, 36, (28, 40)).astype(np.uint8), {"index": i}
+
+    ds = Frames()
+    loader = PinnedFrameLoader(ds, batch_size=4, experiment=3, seed=3, shuffle=False, blur=True, colorjitter=True, workers=1)
+    out = list(loader)
+    rng = np.random.RandomState(3 * 1000003 + 1)
+    gen = torch.Generator().manual_seed(3 * 1000003 + 1)
+    flips = [sample_flips(4, (0.0, 0.5), rng) for _ in range(2)]
+    blurs = [sample_blur(4, random=rng) for _ in range(2)]
+    jit = [sample_color_jitter(4, generator=gen) for _ in range(2)]
+    plain = list(PinnedFrameLoader(ds, batch_size=4, experiment=3, seed=3, shuffle=False, workers=1))
+    changed = False
+    for bi, (x, labels) in enumerate(out):
+        ids = list(range(bi * 4, bi * 4 + 4))
+        img = torch.from_numpy(np.stack([ds[i][0] for i in ids]))
+        lbl = torch.from_numpy(np.stack([ds[i][1] for i in ids]))
+        xr, lr = GpuIngest(3)(img, lbl, flips[bi], blur_radii=blurs[bi], jitter=jit[bi])
+        assert torch.equal(x, xr) and torch.equal(labels, lr)
+        assert torch.equal(labels, plain[bi][1])
+        changed = changed or not torch.equal(x, plain[bi][0])
+    assert changed                                                      # the colour jitter did something
