@@ -324,7 +324,11 @@ __device__ __forceinline__ void igemm_f32_body(const IgemmArgs& p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int q = j * 256 + tid;
-          const int krow = q / (16 * NI), cc = q % (16 * NI);
+          const int krow = q / (16 * NI), cpos = q % (16 * NI);
+          // 16x16x4 forms: lanes 0-15 / 16-31 of a ds_read_b32 read rows k and k + 4 of this K-major image, 64 NI floats apart = the
+          // same banks.  Rows with (k >> 2) & 1 are therefore stored rotated by 16 floats (the LDS-DMA destination is lane-linear:
+          // the lane at position cpos fetches the column chunk that belongs there): conflict-free reads.
+          const int cc = (LAYOUT == L_NN && NARROW == 1) ? ((cpos - 4 * ((krow >> 2) & 1)) & (16 * NI - 1)) : cpos;
           const int k = tck * 16 + krow;
           const bool ok = live && k < p.Cred_b && (n0 + cc * 4) < ((p.N + 3) & ~3);
           pb[sub][j] = sel_ptr(ok, obase, k * p.ldo + boff + cc * 4, p.zero);
@@ -425,8 +429,9 @@ __device__ __forceinline__ void igemm_f32_body(const IgemmArgs& p) {
           const f32x4 v = *(const f32x4*)(sB + col * 16 + pos * 4);
           b[u][0] = v[0]; b[u][1] = v[1]; b[u][2] = v[2]; b[u][3] = v[3];
         } else {
+          const int colr = (LAYOUT == L_NN && NARROW == 1) ? ((col + 16 * (kq16 & 1)) & (BN - 1)) : col;   // rows 4 kq16 + e: (k >> 2) & 1 = kq16 & 1
 #pragma unroll
-          for (int e = 0; e < 4; ++e) b[u][e] = sB[(4 * kq16 + e) * BN + col];
+          for (int e = 0; e < 4; ++e) b[u][e] = sB[(4 * kq16 + e) * BN + colr];
         }
       }
       if (FAST || more) prep(sub);
