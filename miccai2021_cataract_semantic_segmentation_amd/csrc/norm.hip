@@ -365,6 +365,10 @@ extern "C" int catseg_bn_finalize(const float* partials, int n_blocks, long long
                  (long long)n_blocks * rows_per_block >= rows, "bn finalize: bad args");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, (hipStream_t)stream, partials, n_blocks, rows_per_block, rows, C,
                      gamma, eps, momentum, running_mean, running_var, stats_out, scale);
+#ifdef BN_AB_DOUBLE_FINALIZE
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, (hipStream_t)stream, partials, n_blocks, rows_per_block, rows, C,
+                     gamma, eps, momentum, running_mean, running_var, stats_out, scale);
+#endif
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
@@ -410,6 +414,9 @@ extern "C" int catseg_bn_backward(const float* dz, int lddz, const float* z, int
   float* coef = part + (size_t)kMaxRowBlocks * 3 * ((C + 3) & ~3);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma, beta, rows, C, relu, s, part);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
+#ifdef BN_AB_DOUBLE_FINALIZE   // (timing experiment, tools: the finalize launches issued twice -- same results; the added time = their cost in the step)
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
+#endif
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma,
                      beta, (const float*)coef, rows, C, relu, dy, lddy, dres, lddres, dres_accumulate);
   CS_LAUNCH_CHECK();
