@@ -460,6 +460,9 @@ __global__ __launch_bounds__(512, 2) void igemm_b3_kernel(const B3Args p) {
 // compiler's own wait-count insertion knows the counters' state (inline asm is opaque to it)
 constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
 
+#ifndef B3X_TAPS_INNER
+#define B3X_TAPS_INNER 1
+#endif
 template <bool BLK>
 __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
   constexpr int TM = 4, TN = 4, WGN = 2;
@@ -553,13 +556,25 @@ __global__ __launch_bounds__(256, 1) void igemm_b3w_kernel(const B3Args p) {
                            : (unsigned)(boff[j] + woff) * 2u;
     VB[j] = ok ? v : OOB;
   };
+  // K order.  BLK: 16-channel chunk outer, filter taps inner -- the nine taps of a chunk re-read the same contiguous run of a blocked
+  // plane shifted by a few pixels (L1 / L2 hits instead of nine passes over the whole plane through the fabric); planar planes keep
+  // taps outer, chunks inner (consecutive K-steps walk along a pixel row's cache lines).
   auto advance = [&]() {
-    const int nt = tck + 1, nx = tkx + 1;
-    const bool wrap = nt == nck, wrapx = wrap && (nx == p.kw);
-    tck = wrap ? 0 : nt;
-    ttap += wrap ? 1 : 0;
-    tkx = wrap ? (wrapx ? 0 : nx) : tkx;
-    tky += wrapx ? 1 : 0;
+    if (BLK && B3X_TAPS_INNER) {
+      const int nx = tkx + 1, nt = ttap + 1;
+      const bool wrapx = nx == p.kw, wrapt = nt == p.taps;
+      tkx = wrapx ? 0 : nx;
+      tky = wrapt ? 0 : (wrapx ? tky + 1 : tky);
+      ttap = wrapt ? 0 : nt;
+      tck += wrapt ? 1 : 0;
+    } else {
+      const int nt = tck + 1, nx = tkx + 1;
+      const bool wrap = nt == nck, wrapx = wrap && (nx == p.kw);
+      tck = wrap ? 0 : nt;
+      ttap += wrap ? 1 : 0;
+      tkx = wrap ? (wrapx ? 0 : nx) : tkx;
+      tky += wrapx ? 1 : 0;
+    }
   };
   auto prep = [&]() {
     prepA(0); prepA(1); prepB(0); prepB(1); advance();
