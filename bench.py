@@ -396,6 +396,7 @@ def main():
                                     "%s, 25-class (task 3), bs=%d/GPU @3x%dx%d, TwoScale Lovasz-Softmax (0.4 interm + 1.0 final), "
                                     "Adam lr 1e-4, loss/optimiser of reference configs/OCRNet_rf_lvsz.json") % (MODELS[args.model][1], B, H, W),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": final_loss,
+                       "peak_hbm_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
                        "inputs": "host (pinned) -> device copy inside every step" if args.with_h2d else "resident in HBM"},
             "roofline": roof, "cpu_baseline": cpu,
         }
