@@ -906,6 +906,29 @@ struct B3TArgs {
   const float* zero;
 };
 
+// (differential timing builds of the backward-weight kernel: -DB3T_NO_PREP / _NO_DMA / _NO_SYNC drop one ingredient of its K loop --
+//  wrong results, the time difference is that ingredient's cost)
+#ifdef B3T_NO_DMA
+#define B3T_PIECE(f, i) do {} while (0)
+#else
+#define B3T_PIECE(f, i) piece(f, i)
+#endif
+#ifdef B3T_NO_PREP
+#define B3T_PREPA() do {} while (0)
+#define B3T_PREPB(j) do {} while (0)
+#else
+#define B3T_PREPA() prepA()
+#define B3T_PREPB(j) prepB(j)
+#endif
+#ifdef B3T_NO_SYNC
+#define B3T_SYNC() do {} while (0)
+#else
+#define B3T_SYNC()                                           \
+  do {                                                       \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         \
+    __builtin_amdgcn_s_barrier();                            \
+  } while (0)
+#endif
 __global__ __launch_bounds__(256, 1) void igemm_b3t_kernel(const B3TArgs p) {
   constexpr int TM = 4, TN = 4;
   constexpr int PLANE = 16 * 256 * 2;             // bytes of one operand plane image: 16 pixel rows x 256 columns of bf16
@@ -1059,53 +1082,52 @@ __global__ __launch_bounds__(256, 1) void igemm_b3t_kernel(const B3TArgs p) {
     }
     int nxt = 1, fill = 2;
     for (int k = 0; k < nks; ++k) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my LDS-DMA of K-step k+1 has landed (issued a K-step ago)
-      __builtin_amdgcn_s_barrier();
+      B3T_SYNC();   // my LDS-DMA of K-step k+1 has landed (issued a K-step ago) + barrier
       asm volatile("" ::: "memory");
       const char* aa_[TM]; const char* bb_[TN];
 #pragma unroll
       for (int t = 0; t < TM; ++t) { aa_[t] = smem + nxt * SLAB + ra[t]; bb_[t] = smem + nxt * SLAB + rb[t]; }
-      piece(fill, 0); B3_MFMA(Ah, 0, Bh, 0);
+      B3T_PIECE(fill, 0); B3_MFMA(Ah, 0, Bh, 0);
        B3_MFMA(Ah, 0, Bh, 1);
        B3_MFMA(Ah, 0, Bh, 2);
-      piece(fill, 1); B3_MFMA(Ah, 0, Bh, 3);
+      B3T_PIECE(fill, 1); B3_MFMA(Ah, 0, Bh, 3);
        B3_MFMA(Ah, 1, Bh, 0);
        B3_MFMA(Ah, 1, Bh, 1);
-      piece(fill, 2); B3_MFMA(Ah, 1, Bh, 2);
+      B3T_PIECE(fill, 2); B3_MFMA(Ah, 1, Bh, 2);
        B3_MFMA(Ah, 1, Bh, 3);
        B3_MFMA(Ah, 2, Bh, 0);
-      piece(fill, 3); B3_MFMA(Ah, 2, Bh, 1);
+      B3T_PIECE(fill, 3); B3_MFMA(Ah, 2, Bh, 1);
        B3_MFMA(Ah, 2, Bh, 2);
        B3_MFMA(Ah, 2, Bh, 3);
-      piece(fill, 4); B3_MFMA(Ah, 3, Bh, 0);
+      B3T_PIECE(fill, 4); B3_MFMA(Ah, 3, Bh, 0);
        B3_MFMA(Ah, 3, Bh, 1);
        B3_MFMA(Ah, 3, Bh, 2);
-      piece(fill, 5); B3_MFMA(Ah, 3, Bh, 3);
+      B3T_PIECE(fill, 5); B3_MFMA(Ah, 3, Bh, 3);
        B3_MFMA(Ah, 0, Bl, 0);
        B3_MFMA(Ah, 0, Bl, 1);
-      piece(fill, 6); B3_MFMA(Ah, 0, Bl, 2);
+      B3T_PIECE(fill, 6); B3_MFMA(Ah, 0, Bl, 2);
        B3_MFMA(Ah, 0, Bl, 3);
        B3_MFMA(Ah, 1, Bl, 0);
-      piece(fill, 7); B3_MFMA(Ah, 1, Bl, 1);
+      B3T_PIECE(fill, 7); B3_MFMA(Ah, 1, Bl, 1);
        B3_MFMA(Ah, 1, Bl, 2);
        B3_MFMA(Ah, 1, Bl, 3);
-      piece(fill, 8); B3_MFMA(Ah, 2, Bl, 0);
+      B3T_PIECE(fill, 8); B3_MFMA(Ah, 2, Bl, 0);
        B3_MFMA(Ah, 2, Bl, 1);
        B3_MFMA(Ah, 2, Bl, 2);
-      piece(fill, 9); B3_MFMA(Ah, 2, Bl, 3);
+      B3T_PIECE(fill, 9); B3_MFMA(Ah, 2, Bl, 3);
        B3_MFMA(Ah, 3, Bl, 0);
        B3_MFMA(Ah, 3, Bl, 1);
-      piece(fill, 10); B3_MFMA(Ah, 3, Bl, 2);
+      B3T_PIECE(fill, 10); B3_MFMA(Ah, 3, Bl, 2);
        B3_MFMA(Ah, 3, Bl, 3);
        B3_MFMA(Al, 0, Bh, 0);
-      piece(fill, 11); B3_MFMA(Al, 0, Bh, 1);
+      B3T_PIECE(fill, 11); B3_MFMA(Al, 0, Bh, 1);
        B3_MFMA(Al, 0, Bh, 2);
        B3_MFMA(Al, 0, Bh, 3);
-      prepA(); B3_MFMA(Al, 1, Bh, 0);
+      B3T_PREPA(); B3_MFMA(Al, 1, Bh, 0);
        B3_MFMA(Al, 1, Bh, 1);
-      prepB(0); B3_MFMA(Al, 1, Bh, 2);
+      B3T_PREPB(0); B3_MFMA(Al, 1, Bh, 2);
        B3_MFMA(Al, 1, Bh, 3);
-      prepB(1); B3_MFMA(Al, 2, Bh, 0);
+      B3T_PREPB(1); B3_MFMA(Al, 2, Bh, 0);
        B3_MFMA(Al, 2, Bh, 1);
        B3_MFMA(Al, 2, Bh, 2);
        B3_MFMA(Al, 2, Bh, 3);
