@@ -133,6 +133,23 @@ int catseg_conv2d_bwd_data_bf16x3_blocked(const catseg_conv_desc* d, const void*
 int catseg_bias_grad(const float* dy, int ld, long long rows, int C, float* dbias, void* workspace, size_t workspace_bytes,
                      catseg_stream_t stream);
 
+/* ---- direct 3x3 / stride 1 / pad 1 convolution in split precision (csrc/dconv3_b3.hip) for the HRNet trunk: the BasicBlock
+ * convolutions conv3x3(planes, planes) at models/HRNetv2.py:22-25,41-44 (Cin = Cout = C in {48, 96}; catseg_dconv3_supported).
+ * Same F.conv2d call sites and same arithmetic as catseg_conv2d_fwd_bf16x3 (three exact bf16 planes per fp32 operand, six bf16
+ * MFMA products, fp32 accumulation), but the activation is read as fp32 and split inside the kernel: a block loads the halo
+ * tile of its pixel tile once and forms all nine taps from it.
+ *   catseg_dconv3_prep: OHWI fp32 weights [C][3][3][C] -> the kernel's pre-split weight image (catseg_dconv3_wimg_bytes bytes);
+ *                       backward_data != 0: the transposed, tap-mirrored bank, with which the same kernel run on dy computes dx.
+ *   catseg_dconv3:      y[p, o] (+)= sum_{ky,kx,c} x[pix(p,ky,kx), c] * w[o,ky,kx,c] (+ bias[o]).  bn_part != NULL: BatchNorm partials
+ *                       [n_tiles][3][C] (tile mean, s1, s2) + bn_counts[n_tiles] (valid pixels of each tile; n_tiles =
+ *                       catseg_dconv3_tiles) for catseg_bn_finalize_counts. */
+int catseg_dconv3_supported(int C);
+size_t catseg_dconv3_wimg_bytes(int C);
+int catseg_dconv3_tiles(int C, int B, int H, int W, int* tile_h, int* tile_w);
+int catseg_dconv3_prep(const float* w, int C, int backward_data, void* wimg, catseg_stream_t stream);
+int catseg_dconv3(int B, int H, int W, int C, const float* x, int ldx, const void* wimg, const float* bias, float* y, int ldy,
+                  int accumulate, float* bn_part, size_t bn_part_floats, int* bn_counts, catseg_stream_t stream);
+
 /* (tuning / measurement hooks live in catseg_debug.h: they are process-global and not part of the product surface) */
 
 /* ---- BatchNorm (+ReLU, +residual) — nn.BatchNorm2d/ReLU at e.g. models/OCR.py:74-75,
@@ -149,6 +166,10 @@ int catseg_bn_train_stats(const float* y, long long rows, int C, int ldy, const 
 int catseg_bn_finalize(const float* partials, int n_blocks, long long rows_per_block, long long rows, int C, const float* gamma,
                        float eps, float momentum, float* running_mean, float* running_var, float* stats_out, float* scale,
                        catseg_stream_t stream);
+/* the same merge for blocks with individual row counts (2-D pixel tiles with ragged edges: catseg_dconv3) */
+int catseg_bn_finalize_counts(const float* partials, int n_blocks, const int* counts, long long rows, int C, const float* gamma,
+                              float eps, float momentum, float* running_mean, float* running_var, float* stats_out, float* scale,
+                              catseg_stream_t stream);
 /* eval mode: scale = gamma / sqrt(running_var + eps) (use with mean = running_mean) */
 int catseg_bn_eval_scale(int C, const float* gamma, const float* running_var, float eps, float* scale,
                          catseg_stream_t stream);

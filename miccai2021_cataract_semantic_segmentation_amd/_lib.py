@@ -34,6 +34,12 @@ _SIGS = {
     "catseg_conv2d_fwd_bnstats": (I, [P, P, P, P, P, I, P, SZ, P, P, P]),
     "catseg_conv2d_fwd_bf16x3_bnstats": (I, [P, P, P, P, P, I, P, SZ, P, P, P]),
     "catseg_bn_finalize": (I, [P, I, L, L, I, P, F, F, P, P, P, P, P]),
+    "catseg_bn_finalize_counts": (I, [P, I, P, L, I, P, F, F, P, P, P, P, P]),
+    "catseg_dconv3_supported": (I, [I]),
+    "catseg_dconv3_wimg_bytes": (SZ, [I]),
+    "catseg_dconv3_tiles": (I, [I, I, I, I, P, P]),
+    "catseg_dconv3_prep": (I, [P, I, I, P, P]),
+    "catseg_dconv3": (I, [I, I, I, I, P, I, P, P, P, I, I, P, SZ, P, P]),
     "catseg_conv2d_fwd_fused": (I, [P, P, P, P, P, I, I, P, P]),
     "catseg_fold_bn": (I, [P, P, P, P, P, P, F, I, I, P, P, P]),
     "catseg_conv2d_bwd_data": (I, [P, P, P, P, I, P]),

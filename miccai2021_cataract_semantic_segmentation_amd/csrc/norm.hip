@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 // (the last subtraction cancels at most mean^2 / var digits of the 16 fp64 carries: exact to fp32 for |mean| / std < 1e4)
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nrb, long long rpb, long long rows, int C,
                                                            const float* __restrict__ gamma, float eps, float momentum, float* running_mean,
-                                                           float* running_var, float* __restrict__ stats, float* __restrict__ scale) {
+                                                           float* running_var, float* __restrict__ stats, float* __restrict__ scale,
+                                                           const int* __restrict__ counts) {
   const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
   const int c = blockIdx.x * 4 + cl;
   const bool live = c < C;
@@ -103,7 +104,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     auto one = [&](int b, double& s0, double& s1) {
       const float* o = part + ((long long)b * 3) * C;
       const bool last = b == nrb - 1;
-      const double nb = last ? n_last : n_full, inv = last ? inv_last : inv_full;
+      double nb = last ? n_last : n_full, inv = last ? inv_last : inv_full;
+      if (counts) {                         // per-block row counts (2-D pixel tiles with ragged edges: csrc/dconv3_b3.hip)
+        nb = (double)counts[b];
+        inv = 1.0 / nb;
+      }
       const double K = o[c], t1 = o[C + c], t2 = o[2 * C + c];
       const double mb = K + t1 * inv;
       s0 += nb * mb;
@@ -351,7 +356,7 @@ extern "C" int catseg_bn_train_stats(const float* y, long long rows, int C, int 
   float* part = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, y, ldy, rows, C, s, part);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, st, (const float*)part, s.nrb, s.rpb, rows, C,
-                     gamma, eps, momentum, running_mean, running_var, stats_out, scale);
+                     gamma, eps, momentum, running_mean, running_var, stats_out, scale, (const int*)nullptr);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
@@ -364,11 +369,22 @@ extern "C" int catseg_bn_finalize(const float* partials, int n_blocks, long long
   CS_REQUIRE(partials && n_blocks > 0 && rows > 0 && C > 0 && (long long)(n_blocks - 1) * rows_per_block < rows &&
                  (long long)n_blocks * rows_per_block >= rows, "bn finalize: bad args");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, (hipStream_t)stream, partials, n_blocks, rows_per_block, rows, C,
-                     gamma, eps, momentum, running_mean, running_var, stats_out, scale);
+                     gamma, eps, momentum, running_mean, running_var, stats_out, scale, (const int*)nullptr);
 #ifdef BN_AB_DOUBLE_FINALIZE
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, (hipStream_t)stream, partials, n_blocks, rows_per_block, rows, C,
-                     gamma, eps, momentum, running_mean, running_var, stats_out, scale);
+                     gamma, eps, momentum, running_mean, running_var, stats_out, scale, (const int*)nullptr);
 #endif
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// the same merge over blocks with individual row counts (counts[b] >= 1, sum = rows): the 2-D pixel tiles of catseg_dconv3
+extern "C" int catseg_bn_finalize_counts(const float* partials, int n_blocks, const int* counts, long long rows, int C, const float* gamma,
+                                         float eps, float momentum, float* running_mean, float* running_var, float* stats_out, float* scale,
+                                         catseg_stream_t stream) {
+  CS_REQUIRE(partials && counts && n_blocks > 0 && rows > 0 && C > 0, "bn finalize (counts): bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, (hipStream_t)stream, partials, n_blocks, (long long)1, rows, C,
+                     gamma, eps, momentum, running_mean, running_var, stats_out, scale, counts);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

@@ -183,6 +183,51 @@ def release_b3_cache():
     _b3_cache.update(key=None, x=None, planar=None, blk=None)
     _b3_cache_dy.update(key=None, x=None, planar=None, blk=None)
     _b3_kept.clear()
+    _d3_wimg.clear()
+
+
+# Direct 3x3 / stride 1 / pad 1 convolution of the HRNet trunk widths in split precision (csrc/dconv3_b3.hip): the fp32 activation is
+# split into bf16 planes inside the kernel, a block reads the halo tile of its pixel tile once.  DCONV3_MIN_ROWS: below that many
+# pixels the launch cannot fill the chip with its 128-pixel tiles and the fp32 implicit GEMM is as good (tests lower it).
+DCONV3 = True
+DCONV3_MIN_ROWS = 16384
+_d3_wimg = {}
+
+
+def _d3_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
+    return (DCONV3 and PRECISION == "bf16x3" and kh == 3 and kw == 3 and stride == 1 and pad == 1 and dil == 1 and groups == 1
+            and Cin == Cout and rows >= DCONV3_MIN_ROWS and lib.catseg_dconv3_supported(Cin))
+
+
+def dconv3_weight_image(w, backward_data=False):
+    """pre-split weight image of the direct kernel (cached until release_b3_cache(): one per layer and direction per step)"""
+    key = (w.data_ptr(), bool(backward_data))
+    img = _d3_wimg.get(key)
+    if img is None:
+        C = w.shape[0]
+        img = torch.empty(lib.catseg_dconv3_wimg_bytes(C), dtype=torch.uint8, device=w.device)
+        check(lib.catseg_dconv3_prep(ptr(w), C, 1 if backward_data else 0, ptr(img), stream()))
+        _d3_wimg[key] = img
+    return img
+
+
+def dconv3(x, wimg, bias=None, out=None, accumulate=False, bn_stats=False):
+    """y (+)= conv3x3(x) from a weight image; bn_stats: also returns (partials, n_tiles, 0, counts) for bn_finalize"""
+    B, H, W, C = x.shape
+    if out is None:
+        out = new_act(B, H, W, C, x.device)
+        accumulate = False
+    part = cnt = None
+    nt = 0
+    if bn_stats:
+        nt = lib.catseg_dconv3_tiles(C, B, H, W, None, None)
+        part = _bn_part_buffer(3 * nt * C + nt, x.device)
+        cnt = part[3 * nt * C:3 * nt * C + nt].view(torch.int32)
+    check(lib.catseg_dconv3(B, H, W, C, ptr(x), ld_of(x), ptr(wimg), ptr(bias), ptr(out), ld_of(out), 1 if accumulate else 0,
+                            ptr(part), 3 * nt * C, ptr(cnt), stream()))
+    if bn_stats:
+        return out, (part, nt, 0, cnt)
+    return out
 
 
 _bn_part = {}
@@ -214,6 +259,12 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
     if bn_stats:
         part = _bn_part_buffer(3 * ((rows + 63) // 64) * Cout, x.device)
         tr, nt = ctypes.c_int(0), ctypes.c_int(0)
+    if not stem4 and zero_to == 0 and w_ptr_tensor.dim() == 4 and _d3_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
+        with _Timed("split3", 0.0):
+            wimg = dconv3_weight_image(w_ptr_tensor)
+        with _Timed("fwd_d3", flops):
+            res = dconv3(x, wimg, bias, out=out, bn_stats=bn_stats)
+        return res
     if "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(rows, Cout, kh * kw, Cin):
         d = make_desc(x.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
         blk = _b3_blocked_ok(max(zero_to, Cout), Cin, B * H * W, Cout, kh * kw)
@@ -245,9 +296,13 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
 
 def bn_finalize(partials, rows, C, gamma, eps, momentum, running_mean, running_var):
     """batch statistics from the convolution epilogue's per-tile partials: (stats [mean(C), invstd(C)], scale)"""
-    part, n_tiles, tile_rows = partials
+    part, n_tiles, tile_rows = partials[:3]
     stats = torch.empty(2 * C, dtype=torch.float32, device=part.device)
     scale = torch.empty(C, dtype=torch.float32, device=part.device)
+    if len(partials) > 3:       # tiles with individual pixel counts (the direct 3x3 kernel's 2-D tiles)
+        check(lib.catseg_bn_finalize_counts(ptr(part), n_tiles, ptr(partials[3]), rows, C, ptr(gamma), eps, momentum, ptr(running_mean),
+                                            ptr(running_var), ptr(stats), ptr(scale), stream()))
+        return stats, scale
     check(lib.catseg_bn_finalize(ptr(part), n_tiles, tile_rows, rows, C, ptr(gamma), eps, momentum, ptr(running_mean), ptr(running_var),
                                  ptr(stats), ptr(scale), stream()))
     return stats, scale
@@ -260,6 +315,12 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
         out = new_act(B, H, W, Cin, dy.device)
         accumulate = False
     flops = 2.0 * rows_of(dy) * Cout * (Cin // groups) * kh * kw
+    if w.dim() == 4 and _d3_ok(B * H * W, Cin, Cout, kh, kw, stride, pad, dil, groups):
+        with _Timed("split3", 0.0):
+            wimg = dconv3_weight_image(w, backward_data=True)
+        with _Timed("dgrad_d3", flops):
+            dconv3(dy, wimg, None, out=out, accumulate=accumulate)
+        return out
     if groups == 1 and "dgrad" in B3_OPS and _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1):
         d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         blk = _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16, rows_of(dy), Cin, kh * kw)

@@ -1,0 +1,116 @@
+"""Direct split-precision 3x3 convolution of the HRNet trunk widths (csrc/dconv3_b3.hip, reference call sites models/HRNetv2.py:22-25,41-44)
+against an fp64 F.conv2d: forward (+bias, +BatchNorm partial statistics), backward-data (= the same kernel on dy with the mirrored
+weight image, write and accumulate), ragged tiles, tensors living inside wider concat buffers."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from miccai2021_cataract_semantic_segmentation_amd import ops as o
+    return o
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.cpu().permute(0, 3, 1, 2)
+
+
+def close(a, b, rtol):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    scale = b.abs().max().item() + 1e-12
+    assert err <= rtol * scale, "max abs err %g (ref scale %g)" % (err, scale)
+
+
+# B, H, W, C: tile-aligned, ragged in both directions, smaller than one tile, one pixel row / column
+CASES = [(2, 16, 32, 48), (1, 19, 37, 48), (2, 5, 7, 48), (1, 1, 50, 48), (3, 33, 1, 48),
+         (2, 8, 64, 96), (1, 19, 37, 96), (2, 3, 5, 96), (1, 1, 70, 96), (2, 41, 2, 96),
+         (1, 24, 40, 192), (2, 7, 9, 192), (1, 17, 30, 384), (1, 5, 3, 384)]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_dconv3_forward_backward_data_vs_fp64(ops, case):
+    """error of fp32 size (<= 2e-5 of the output scale, as for the other bf16x3 kernels) on inputs with a wide dynamic range"""
+    from miccai2021_cataract_semantic_segmentation_amd._lib import lib
+    B, H, W, C = case
+    if not lib.catseg_dconv3_supported(C):
+        pytest.skip("width not built")
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, C, H, W, generator=g) * torch.exp(2 * torch.randn(1, C, 1, 1, generator=g))
+    w = torch.randn(C, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5
+    b = torch.randn(C, generator=g)
+    xr = x.double().requires_grad_()
+    y64 = F.conv2d(xr, w.double(), b.double(), 1, 1, 1)
+    gy = torch.randn(y64.shape, generator=g)
+    y64.backward(gy.double())
+    xd, wd = nhwc(x), w.cuda().contiguous(memory_format=torch.channels_last)
+    wimg = ops.dconv3_weight_image(wd)
+    y, part = ops.dconv3(xd, wimg, b.cuda(), bn_stats=True)
+    close(nchw(y), y64.detach(), 2e-5)
+    # BatchNorm statistics from the epilogue's per-tile partials
+    gamma, rm, rv = torch.ones(C).cuda(), torch.zeros(C).cuda(), torch.ones(C).cuda()
+    stats, _ = ops.bn_finalize(part, B * H * W, C, gamma, 1e-5, 0.1, rm, rv)
+    y2 = y64.detach().permute(1, 0, 2, 3).reshape(C, -1)
+    mean, var = y2.mean(1), y2.var(1, unbiased=False)
+    assert float((stats[:C].cpu().double() - mean).abs().max()) <= 2e-5 * float(y2.abs().max())
+    assert float((stats[C:].cpu().double() * (var + 1e-5).sqrt() - 1).abs().max()) <= 1e-4
+    # backward-data: write, then accumulate on top
+    wimg_t = ops.dconv3_weight_image(wd, backward_data=True)
+    gyd = nhwc(gy)
+    dx = ops.dconv3(gyd, wimg_t)
+    close(nchw(dx), xr.grad, 2e-5)
+    dx2 = ops.dconv3(gyd, wimg_t, out=dx.clone(), accumulate=True)
+    close(nchw(dx2), 2 * xr.grad, 2e-5)
+    ops.release_b3_cache()
+
+
+def test_dconv3_inside_concat_buffers(ops):
+    """input and output as channel slices of wider buffers (row strides > C); neighbours of the output slice stay untouched"""
+    B, H, W, C = 2, 11, 21, 48
+    g = torch.Generator().manual_seed(5)
+    xin = torch.randn(B, H, W, 112, generator=g).cuda()
+    x = xin[..., 16:16 + C]
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last)
+    ybuf = torch.full((B, H, W, 96), 7.0).cuda()
+    y = ybuf[..., 32:32 + C]
+    ops.dconv3(x, ops.dconv3_weight_image(w), None, out=y)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1, 1).permute(0, 2, 3, 1)
+    close(y, ref, 2e-5)
+    assert float((ybuf[..., :32] - 7.0).abs().max()) == 0.0
+    assert float((ybuf[..., 32 + C:] - 7.0).abs().max()) == 0.0
+    ops.release_b3_cache()
+
+
+def test_conv_dispatch_uses_direct_kernel(ops):
+    """ops.conv_fwd / conv_bwd_data route eligible layers to the direct kernel and agree with the fp32 implicit GEMM"""
+    B, H, W, C = 2, 24, 40, 48
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, H, W, C, generator=g).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last)
+    saved = (ops.DCONV3_MIN_ROWS, ops.PRECISION)
+    try:
+        ops.PRECISION, ops.DCONV3_MIN_ROWS = "bf16x3", 1
+        ops.PROFILE = []
+        y, part = ops.conv_fwd(x, w, None, C, 3, 3, 1, 1, 1, bn_stats=True)
+        dx = ops.conv_bwd_data(y, w, tuple(x.shape), 3, 3, 1, 1, 1)
+        kinds = [k for k, *_ in ops.PROFILE]
+        assert "fwd_d3" in kinds and "dgrad_d3" in kinds and len(part) == 4
+        ops.PROFILE = None
+        ops.PRECISION = "fp32"
+        y0 = ops.conv_fwd(x, w, None, C, 3, 3, 1, 1, 1)
+        dx0 = ops.conv_bwd_data(y, w, tuple(x.shape), 3, 3, 1, 1, 1)
+        close(y, y0, 1e-5)
+        close(dx, dx0, 1e-5)
+    finally:
+        ops.PROFILE = None
+        ops.DCONV3_MIN_ROWS, ops.PRECISION = saved
+        ops.release_b3_cache()

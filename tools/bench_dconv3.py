@@ -1,0 +1,44 @@
+"""Direct split-precision 3x3 convolution (csrc/dconv3_b3.hip) against the fp32 implicit GEMM on the HRNet-W48 trunk shapes.
+usage: bench_dconv3.py [reps]"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from miccai2021_cataract_semantic_segmentation_amd import ops
+from miccai2021_cataract_semantic_segmentation_amd._lib import lib
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = torch.device("cuda")
+SHAPES = [(8, 136, 240, 48), (8, 68, 120, 96), (8, 34, 60, 192), (8, 17, 30, 384)]
+
+
+def timed(fn, n):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3   # us
+
+
+for (B, H, W, C) in SHAPES:
+    x = torch.randn(B, H, W, C, device=dev)
+    w = (torch.randn(C, C, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    y = torch.empty_like(x)
+    gf = 2.0 * B * H * W * C * C * 9 / 1e9
+    ops.PRECISION = "fp32"
+    t_f32 = timed(lambda: ops.conv_fwd(x, w, None, C, 3, 3, 1, 1, 1, out=y, bn_stats=True), reps)
+    t_f32d = timed(lambda: ops.conv_bwd_data(x, w, tuple(x.shape), 3, 3, 1, 1, 1, out=y), reps)
+    line = "C=%3d %dx%d  fp32 igemm fwd %7.1f us %6.1f TF  dgrad %7.1f us %6.1f TF" % (C, H, W, t_f32, gf / t_f32 * 1e3, t_f32d, gf / t_f32d * 1e3)
+    if lib.catseg_dconv3_supported(C):
+        wimg = ops.dconv3_weight_image(w)
+        wimg_t = ops.dconv3_weight_image(w, backward_data=True)
+        t_d = timed(lambda: ops.dconv3(x, wimg, None, out=y, bn_stats=True), reps)
+        t_dd = timed(lambda: ops.dconv3(x, wimg_t, None, out=y), reps)
+        t_prep = timed(lambda: lib.catseg_dconv3_prep(w.data_ptr(), C, 0, wimg.data_ptr(), torch.cuda.current_stream().cuda_stream), reps)
+        line += "  | direct fwd %7.1f us %6.1f TF  dgrad %7.1f us %6.1f TF  prep %5.1f us" % (t_d, gf / t_d * 1e3, t_dd, gf / t_dd * 1e3, t_prep)
+    print(line, flush=True)
+    ops.release_b3_cache()
