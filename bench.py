@@ -333,7 +333,8 @@ def main():
         mm = {k: v for k, v in agg.items() if not k.startswith("hbm:") and k != "split3" and v[1] > 0}
         # the dominant KERNEL (as rocprofv3 --stats names it): forward and backward-data of the bf16x3 layers are launches of one
         # kernel (igemm_b3w_kernel); the fp32 operations are the NT / NN / TN layouts of igemm_f32_kernel
-        KERNEL_OF = {"fwd_b3": "b3w", "dgrad_b3": "b3w", "wgrad_b3": "wgrad_b3", "fwd": "fwd", "dgrad": "dgrad", "wgrad": "wgrad"}
+        KERNEL_OF = {"fwd_b3": "b3w", "dgrad_b3": "b3w", "wgrad_b3": "wgrad_b3", "fwd": "fwd", "dgrad": "dgrad", "wgrad": "wgrad",
+                     "fwd_d3": "d3", "dgrad_d3": "d3"}
         groups = {}
         for k, v in mm.items():
             g = groups.setdefault(KERNEL_OF.get(k, k), [0.0, 0.0, 0])
@@ -341,12 +342,12 @@ def main():
         dom = max(groups, key=lambda k: groups[k][1])
         # (an fp32 layout is a union of 4-6 tile instantiations that rocprofv3 lists as separate kernels, the largest of them
         #  < 40 % of the layout's time: a single-symbol bf16x3 kernel with at least half of that time is the larger KERNEL)
-        for k in ("b3w", "wgrad_b3"):
-            if k in groups and dom not in ("b3w", "wgrad_b3") and groups[k][1] >= 0.5 * groups[dom][1]:
+        for k in ("b3w", "wgrad_b3", "d3"):
+            if k in groups and dom not in ("b3w", "wgrad_b3", "d3") and groups[k][1] >= 0.5 * groups[dom][1]:
                 dom = k
                 break
         fl, sec, n = groups[dom]
-        peak = PEAK_B3 if dom in ("b3w", "wgrad_b3") else PEAK_F32
+        peak = PEAK_B3 if dom in ("b3w", "wgrad_b3", "d3") else PEAK_F32
         traffic = traffic_src = None   # HBM bytes per launch from committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
         tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (PROFILE_ROUND, args.model))
         if os.path.exists(tpath) and (B, H, W) == (8, 544, 960):
@@ -357,7 +358,9 @@ def main():
         label = {"fwd": "igemm_f32_kernel<NT> (conv2d forward, fp32 MFMA)", "dgrad": "igemm_f32_kernel<NN> (conv2d backward-data, fp32 MFMA)",
                  "wgrad": "igemm_f32_kernel<TN> + wgrad_direct_kernel (conv2d backward-weight, fp32 MFMA, incl. slab reduction)",
                  "b3w": "igemm_b3w_kernel (conv2d forward and backward-data of the large layers, bf16x3 split precision)",
-                 "wgrad_b3": "igemm_b3t_kernel (conv2d backward-weight, bf16x3 split precision, incl. slab reduction)"}.get(dom, dom)
+                 "wgrad_b3": "igemm_b3t_kernel (conv2d backward-weight, bf16x3 split precision, incl. slab reduction)",
+                 "d3": "dconv3_b3_kernel (direct 3x3 conv2d forward and backward-data of the HRNet trunk, bf16x3 split precision, "
+                       "in-kernel split of the fp32 halo tile)"}.get(dom, dom)
         tot_fl = sum(v[0] for v in mm.values())
         tot_s = sum(v[1] for v in mm.values()) + agg.get("split3", [0, 0, 0])[1]
         hbm = {k[4:]: {"achieved_GBps": v[0] / v[1] / 1e9, "frac_of_8TBps": v[0] / v[1] / 8e12, "ms_per_step": v[1] / 2 * 1e3,
@@ -369,7 +372,7 @@ def main():
                 "avg_launch_ms": sec / n * 1e3, "algorithmic_gflop_per_launch": fl / n / 1e9,
                 "peak_note": "fp32 MFMA 157.3 TFLOP/s; bf16x3 kernels: dense bf16 MFMA 2500 TFLOP/s / 6 products = 416.7 TFLOP/s-equivalent "
                              "(achieved counts algorithmic fp32-equivalent FLOPs 2MNK; x6 for the bf16 MFMA FLOPs issued)",
-                "all_igemm": {k: {"tflops": v[0] / v[1] / 1e12, "frac": v[0] / v[1] / 1e12 / (PEAK_B3 if k.endswith("_b3") else PEAK_F32),
+                "all_igemm": {k: {"tflops": v[0] / v[1] / 1e12, "frac": v[0] / v[1] / 1e12 / (PEAK_B3 if k.endswith(("_b3", "_d3")) else PEAK_F32),
                                   "ms_per_step": v[1] / 2 * 1e3, "launches_per_step": v[2] // 2}
                               for k, v in mm.items()},
                 "all_matrix_ops": {"algorithmic_tflop_per_step": tot_fl / 2 / 1e12, "ms_per_step": tot_s / 2 * 1e3,

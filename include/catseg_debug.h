@@ -29,6 +29,9 @@ int catseg_debug_set_lovasz_prune(int on);
  * 1 = direct kernel (default); a value > 1 additionally sets the direct kernel's target block count (default 512) */
 int catseg_debug_set_wgrad_direct(int on);
 
+/* tuning hook: persistent blocks per launch of the direct 3x3 kernel (csrc/dconv3_b3.hip; 0 restores the default 512 = two per CU) */
+int catseg_debug_set_dconv3_blocks(int blocks);
+
 /* tuning hook: bf16x3 block tile: 0 = heuristic, 1 = 256x256, 2 = 256x128, 3 = 128x256, 4 = 256x192, 5 = 256x96, 6 = 256x64 */
 int catseg_debug_set_b3_tile(int t);
 /* planner query: which tile / split count would the library pick for this convolution?

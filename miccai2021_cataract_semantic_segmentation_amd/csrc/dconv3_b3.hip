@@ -38,8 +38,9 @@ __host__ __device__ constexpr Unit unit_of(int KC, int step, int half) {
 }
 __host__ __device__ constexpr int steps_of(int KC) { return KC == 32 ? 9 : 14; }
 
-template <int C_, int KC_, int NT_, int WC_, int WP_, int PB_, int TPH_, int TPW_, int PH_, int PW_>
+template <int C_, int KC_, int NT_, int WC_, int WP_, int PB_, int TPH_, int TPW_, int PH_, int PW_, bool XPF_>
 struct DcCfg {
+  static constexpr bool XPF = XPF_;                       // pixel fragments of step t + 1 read under the MFMAs of step t
   static constexpr int C = C_, KC = KC_, NT = NT_, WC = WC_, WP = WP_, PB = PB_, TPH = TPH_, TPW = TPW_, PH = PH_, PW = PW_;
   static_assert(KC == 32 || KC == 48, "channel chunk");
   static_assert(C % KC == 0 && C % NT == 0 && NT % (16 * WC) == 0 && PH * PW == 16 && TPH * TPW == WP * PB, "tiling");
@@ -57,13 +58,18 @@ struct DcCfg {
   static constexpr int WPS = 64 * NT;                      // bytes per plane of one K-step of weights: [4 k-groups][NT][16 B]
   static constexpr int WSTEP = 3 * WPS;
   static constexpr int NCHUNK = C / KC, NSTEP = steps_of(KC);
-  static constexpr int NITEM = HH * HW * NKG;              // staging items: (halo pixel, 8-channel group)
-  static constexpr int IPT = (NITEM + NTHR - 1) / NTHR;
+  // staging: one wave instruction = a unit of 16 consecutive halo pixels x 4 channel groups (lane = pixel + 16 * group): the
+  // 8-lane groups of a ds_write_b128 then hit 8 consecutive 16-byte slots (conflict-free; a lane order with the channel groups
+  // innermost wrote NKG-way conflicts: 32 % of all LDS cycles)
+  static constexpr int NPX = HH * HW;
+  static constexpr int NPG = (NPX + 15) / 16, NGB = (NKG + 3) / 4;
+  static constexpr int IPT = (NPG * NGB + NW - 1) / NW;    // units per wave
   static constexpr int WITEMS = WSTEP / 1024;              // LDS-DMA wave instructions per K-step
   static_assert(WSTEP % 1024 == 0, "weights of a K-step in whole 1 KB pieces");
   static constexpr int LDS = XBYTES + 2 * WSTEP;
   static constexpr int SCR = 3 * WP * NT * 4;              // epilogue scratch (floats -> bytes), inside the X image
   static_assert(SCR <= XBYTES, "epilogue scratch");
+  static_assert(IPT + 2 <= NSTEP, "the prefetch of the next halo tile is spread over the K-steps: item i is loaded in step i, split in step i + 2");
 };
 
 struct DcArgs {
@@ -85,6 +91,26 @@ __device__ __forceinline__ void dc_glds16(const void* src, void* lds_wave_base) 
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// sum over the 16 lanes of a DPP row (every lane gets the total): quad xor 1, xor 2, half-row mirror, row mirror
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
+// s_waitcnt through the builtin (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8]): unlike inline asm the
+// compiler's own wait insertion sees these, so it does not re-wait for what they have retired
+#define DC_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+#define DC_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | (n))
+
+// Persistent blocks (two per CU): a block walks a contiguous run of pixel tiles.  Per tile and channel chunk the prefetched fp32
+// halo tile is split and written to LDS (stash); then NSTEP K-steps run with ONE raw barrier each.  All operands of K-step t are in
+// registers when it starts: during step t a wave issues, in this order, the LDS-DMA of the weights of step t + 2 (into the slot whose
+// fragments it already holds), two global loads of the prefetch of the NEXT chunk / tile (spread over the steps, so that the counted
+// wait that ends the step -- vmcnt(2): everything but those two loads -- never waits for an HBM access), the LDS reads of the weight
+// and pixel fragments of step t + 1, and then the 6 CB PB MFMAs of step t, which depend on none of them.
 template <class G>
 __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
   __shared__ __attribute__((aligned(256))) unsigned char smem[G::LDS];
@@ -92,71 +118,110 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave / G::WP, wp = wave % G::WP;
   const int i16 = lane & 15, kg = lane >> 4;
-
-  // ---- tile of this block; each XCD (blockIdx.x % 8 labels the blocks that share one) gets a contiguous run of tiles ----------
-  const int ntile = gridDim.x;
-  int tile;
-  {
-    const int q = ntile >> 3, r = ntile & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
-  const int tx = tile % a.tiles_x;
-  const int ty = (tile / a.tiles_x) % a.tiles_y;
-  const int b = tile / (a.tiles_x * a.tiles_y);
-  const int y0 = ty * G::TH, x0 = tx * G::TW;
   const int cob = blockIdx.y;                       // output-channel block
-  const long long img0 = (long long)b * a.H * a.W;  // first pixel of the image
 
-  // ---- staging items: clamped source offset (always in bounds), validity, LDS destination -----------------------------------
-  int s_off[G::IPT], s_dst[G::IPT];
-  bool s_ok[G::IPT];
+  // ---- this block's run of tiles; the blocks that share an XCD (equal blockIdx.x % 8) get neighbouring runs ---------------------
+  const int ntile = a.B * a.tiles_y * a.tiles_x;
+  int t_begin, t_end;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    t_begin = (int)((long long)v * ntile / nb);
+    t_end = (int)((long long)(v + 1) * ntile / nb);
+  }
+  if (t_begin >= t_end) return;
+#ifdef DC_PRIO
+  // static priority: the two blocks that share a CU (dispatch order: block b and b + grid / 2) do not arbitrate step by step
+  if (blockIdx.x < (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(DC_PRIO);
+#endif
+
+  // ---- staging: unit u = wave + i NW covers 16 halo pixels x 4 channel groups, lane = pixel + 16 group ------------------------
+  // Prefetch of the next (tile, chunk): raw buffer loads over ONE image (rows above / below it are out of range: the hardware
+  // returns zeros = the convolution's padding; columns left / right of it get the out-of-range marker), item i in K-step i;
+  // two steps later the loaded fp32 values are split into the three bf16 planes (VALU work in the shadow of that step's MFMAs).
+  auto item_px = [&](int i) { return ((wave + i * G::NW) / G::NGB) * 16 + i16; };
+  auto item_g8 = [&](int i) { return ((wave + i * G::NW) % G::NGB) * 4 + kg; };
+  auto item_live = [&](int i) { return wave + i * G::NW < G::NPG * G::NGB && item_px(i) < G::NPX && item_g8(i) < G::NKG; };
+  int it_off[G::IPT], it_hx[G::IPT];     // byte offset of the item relative to the tile origin pixel (may be negative), halo column - 1
 #pragma unroll
   for (int i = 0; i < G::IPT; ++i) {
-    const int q = tid + i * G::NTHR;
-    const int hp = q / G::NKG, g8 = q % G::NKG;
-    const int hy = hp / G::HW, hx = hp % G::HW;
-    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-    s_ok[i] = q < G::NITEM && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-    const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
-    s_off[i] = (cy * a.W + cx) * a.ldx + g8 * 8;
-    s_dst[i] = q < G::NITEM ? g8 * G::KGS + (hy * G::RW + hx) * 16 : -1;
+    const int px = item_px(i);
+    it_hx[i] = px % G::HW - 1;
+    it_off[i] = (((px / G::HW - 1) * a.W + it_hx[i]) * a.ldx + (item_live(i) ? item_g8(i) * 8 : 0)) * 4;
   }
-  const float* xin = a.x + img0 * a.ldx;
-  f32x4 pre[G::IPT][2];
-  auto fetch = [&](int chunk) {
+  f32x4 pre[G::IPT][2];      // (whole-vector bit casts only: __builtin_bit_cast of ONE vector element reads element 0, hipcc 7.2)
+  bf16x8 pl[G::IPT][3];
+  const int img_bytes = ((a.H * a.W - 1) * a.ldx + G::KC) * 4;
+  __amdgpu_buffer_rsrc_t f_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, img_bytes, 0x00020000);
+  int f_x0 = 0, f_org = 0;           // fetch target: first column of the tile, byte offset of its origin pixel in the image
+  auto target = [&](int tile, int chunk) {
+    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+    f_x0 = tx * G::TW;
+    f_org = (ty * G::TH * a.W + f_x0) * a.ldx * 4;
+    f_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)b * a.H * a.W * a.ldx + chunk * G::KC), (short)0, img_bytes, 0x00020000);
+  };
+  auto fetch_item = [&](int i) {
+    const bool okx = (unsigned)(f_x0 + it_hx[i]) < (unsigned)a.W;
+    const int off = okx ? f_org + it_off[i] : (int)0xFFFFFFE0;
+#ifndef DC_NO_FETCH
+    pre[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rs, off, 0, 0));
+    pre[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rs, off + 16, 0, 0));
+#else
+    pre[i][0] = pre[i][1] = f32x4{(float)off, 0.f, 0.f, 0.f};
+#endif
+  };
+  auto convert_item = [&](int i) {
+#ifdef DC_NO_STASH
+    return;
+#endif
 #pragma unroll
-    for (int i = 0; i < G::IPT; ++i) {
-      const float* p = xin + s_off[i] + chunk * G::KC;
-      pre[i][0] = *(const f32x4*)p;
-      pre[i][1] = *(const f32x4*)(p + 4);
+    for (int j = 0; j < 8; ++j) {
+      const float v = pre[i][j >> 2][j & 3];
+      const __bf16 hh = (__bf16)v;
+      const float r1 = v - (float)hh;
+      const __bf16 mm = (__bf16)r1;
+      pl[i][0][j] = hh;
+      pl[i][1][j] = mm;
+      pl[i][2][j] = (__bf16)(r1 - (float)mm);
+    }
+    // pin the arithmetic to this K-step (LLVM would otherwise sink it to the stash, in front of the block-wide barrier)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      typedef int v4i __attribute__((ext_vector_type(4)));
+      v4i t = __builtin_bit_cast(v4i, pl[i][p]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int te = t[e];
+        asm volatile("" : "+v"(te));
+        t[e] = te;
+      }
+      pl[i][p] = __builtin_bit_cast(bf16x8, t);
     }
   };
   auto stash = [&]() {
+#ifdef DC_NO_STASH
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < G::IPT; ++i) {
-      if (s_dst[i] < 0) continue;
-      bf16x8 h, m, l;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = s_ok[i] ? pre[i][j >> 2][j & 3] : 0.f;
-        const __bf16 hh = (__bf16)v;
-        const float r1 = v - (float)hh;
-        const __bf16 mm = (__bf16)r1;
-        h[j] = hh;
-        m[j] = mm;
-        l[j] = (__bf16)(r1 - (float)mm);
+      const int px = item_px(i);
+      const int dst = item_g8(i) * G::KGS + ((px / G::HW) * G::RW + px % G::HW) * 16;
+      if (item_live(i)) {
+        *(bf16x8*)(smem + dst) = pl[i][0];
+        *(bf16x8*)(smem + dst + G::XPS) = pl[i][1];
+        *(bf16x8*)(smem + dst + 2 * G::XPS) = pl[i][2];
       }
-      *(bf16x8*)(smem + s_dst[i]) = h;
-      *(bf16x8*)(smem + s_dst[i] + G::XPS) = m;
-      *(bf16x8*)(smem + s_dst[i] + 2 * G::XPS) = l;
     }
   };
 
-  // ---- weight stream: K-step t (over all chunks) of this co block -> LDS slot t & 1 ------------------------------------------
+  // ---- weight stream: step q (0 .. NCHUNK NSTEP - 1, the same for every tile) of this co block -> LDS slot --------------------
   const unsigned char* wsrc = (const unsigned char*)a.wimg + (long long)cob * (G::NCHUNK * G::NSTEP) * G::WSTEP + lane * 16;
-  auto wfill = [&](int t) {
-    unsigned char* dst = smem + G::XBYTES + (t & 1) * G::WSTEP;
-    const unsigned char* src = wsrc + (long long)t * G::WSTEP;
+  auto wfill = [&](int q, int slot) {
+#ifdef DC_NO_DMA
+    return;
+#endif
+    unsigned char* dst = smem + G::XBYTES + slot * G::WSTEP;
+    const unsigned char* src = wsrc + (long long)q * G::WSTEP;
 #pragma unroll
     for (int i = 0; i < (G::WITEMS + G::NW - 1) / G::NW; ++i) {
       const int it = wave + i * G::NW;
@@ -164,174 +229,213 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
     }
   };
 
-  // ---- fragment addresses --------------------------------------------------------------------------------------------------
-  // pixel tile pt of this wave: lane i16 -> pixel (pr, pc) of the tile; halo coordinates of tap (ky, kx) = (row + ky, col + kx)
-  int xb[G::PB], xb2[G::PB];
-  bool p_ok[G::PB];
-  int p_row[G::PB], p_col[G::PB];
+  // ---- fragment addresses (tile independent) ----------------------------------------------------------------------------------
+  auto prow = [&](int pt) { return ((wp * G::PB + pt) / G::TPW) * G::PH + i16 / G::PW; };
+  auto pcol = [&](int pt) { return ((wp * G::PB + pt) % G::TPW) * G::PW + i16 % G::PW; };
+  int xb[G::PB];
 #pragma unroll
-  for (int pt = 0; pt < G::PB; ++pt) {
-    const int pl = wp * G::PB + pt;
-    const int row = (pl / G::TPW) * G::PH + i16 / G::PW, col = (pl % G::TPW) * G::PW + i16 % G::PW;
-    p_row[pt] = row;
-    p_col[pt] = col;
-    p_ok[pt] = y0 + row < a.H && x0 + col < a.W;
-    xb[pt] = kg * G::KGS + (row * G::RW + col) * 16;
-    xb2[pt] = (kg & 1) * G::KGS + (row * G::RW + col) * 16;
-  }
+  for (int pt = 0; pt < G::PB; ++pt) xb[pt] = kg * G::KGS + (prow(pt) * G::RW + pcol(pt)) * 16;
   const int wb = kg * (G::NT * 16) + (wc * G::CB * 16 + i16) * 16;
-
-  f32x4 acc[G::CB][G::PB];
-#pragma unroll
-  for (int ct = 0; ct < G::CB; ++ct)
-#pragma unroll
-    for (int pt = 0; pt < G::PB; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  auto kstep = [&](const int s, const unsigned char* wbuf) {     // (s is a compile-time constant after unrolling)
+  constexpr int XD = G::XPF ? 2 : 1;
+  bf16x8 xf[XD][G::PB][3], wf[G::CB][3];
+  auto xread1 = [&](const int s, const int set, const int pt) {   // pixel fragments of K-step s (current chunk image), pixel tile pt
     const Unit ua = unit_of(G::KC, s, 0), ub = unit_of(G::KC, s, 1);
     const int offa = ((ua.tap / 3) * G::RW + ua.tap % 3) * 16, offb = ((ub.tap / 3) * G::RW + ub.tap % 3) * 16;
-    bf16x8 wf[G::CB][3], xf[G::PB][3];
+    int o;
+    if (s < 9) o = xb[pt] + offa + 2 * ua.win * G::KGS;
+    else o = xb[pt] + (2 * ua.win - (kg & 2)) * G::KGS + (kg >> 1 ? offb : offa);   // group kg -> window 2, group kg & 1
 #pragma unroll
-    for (int ct = 0; ct < G::CB; ++ct)
+    for (int p = 0; p < 3; ++p) xf[set][pt][p] = *(const bf16x8*)(smem + p * G::XPS + o);
+  };
+  auto xread = [&](const int s, const int set) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wf[ct][p] = *(const bf16x8*)(wbuf + p * G::WPS + wb + ct * 256);
+    for (int pt = 0; pt < G::PB; ++pt) xread1(s, set, pt);
+  };
+  auto wread1 = [&](const int slot, const int ct) {
+    const unsigned char* wbuf = smem + G::XBYTES + slot * G::WSTEP;
 #pragma unroll
-    for (int pt = 0; pt < G::PB; ++pt) {
-      int o;
-      if (s < 9) o = xb[pt] + offa + 2 * ua.win * G::KGS;
-      else o = xb2[pt] + 2 * ua.win * G::KGS + (kg >> 1 ? offb : offa);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) xf[pt][p] = *(const bf16x8*)(smem + p * G::XPS + o);
-    }
-#pragma unroll
-    for (int ct = 0; ct < G::CB; ++ct)
-#pragma unroll
-      for (int pt = 0; pt < G::PB; ++pt) {
-        f32x4 c = acc[ct][pt];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][1], xf[pt][1], c, 0, 0, 0);   // m m
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[pt][2], c, 0, 0, 0);   // h l
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][2], xf[pt][0], c, 0, 0, 0);   // l h
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[pt][1], c, 0, 0, 0);   // h m
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][1], xf[pt][0], c, 0, 0, 0);   // m h
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[pt][0], c, 0, 0, 0);   // h h
-        acc[ct][pt] = c;
-      }
+    for (int p = 0; p < 3; ++p) wf[ct][p] = *(const bf16x8*)(wbuf + p * G::WPS + wb + ct * 256);
   };
 
-  // ---- main loop ------------------------------------------------------------------------------------------------------------
-  fetch(0);
-  wfill(0);
-  int t = 0;
-#pragma unroll 1
-  for (int chunk = 0; chunk < G::NCHUNK; ++chunk) {
-    stash();                                   // (the previous chunk's last reads are behind the barrier that closed its last K-step)
-    if (chunk + 1 < G::NCHUNK) fetch(chunk + 1);
-    __syncthreads();                           // chunk image + weights of K-step t visible (the barrier drains the LDS-DMA)
+  f32x4 acc[G::CB][G::PB];
+  constexpr int TSTEPS = G::NCHUNK * G::NSTEP;               // K-steps per tile
+  const int total = (t_end - t_begin) * TSTEPS;              // K-steps of this block
+  target(t_begin, 0);
 #pragma unroll
-    for (int s = 0; s < G::NSTEP; ++s) {
-      const bool more = !(s == G::NSTEP - 1 && chunk == G::NCHUNK - 1);
-      if (more) wfill(t + 1);
-      kstep(s, smem + G::XBYTES + (t & 1) * G::WSTEP);
-      ++t;
-      __syncthreads();
-    }
-  }
+  for (int i = 0; i < G::IPT; ++i) fetch_item(i);
+#pragma unroll
+  for (int i = 0; i < G::IPT; ++i) convert_item(i);
+  wfill(0, 0);
+  if (total > 1) wfill(1 % TSTEPS, 1);
+  int gs = 0;      // K-steps done: weights of step gs live in slot gs & 1
+  int qn = 2 % TSTEPS;   // step-in-tile index of the next weight DMA (step gs + 2)
 
-  // ---- epilogue: bias, store, BatchNorm partials ------------------------------------------------------------------------------
-  const int co0 = cob * G::NT + wc * G::CB * 16 + 4 * kg;   // + ct * 16 + r
-#pragma unroll
-  for (int ct = 0; ct < G::CB; ++ct) {
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias) bv = *(const f32x4*)(a.bias + co0 + ct * 16);
-#pragma unroll
-    for (int pt = 0; pt < G::PB; ++pt) {
-      acc[ct][pt] += bv;
-      if (p_ok[pt]) {
-        float* dst = a.y + (img0 + (long long)(y0 + p_row[pt]) * a.W + x0 + p_col[pt]) * a.ldy + co0 + ct * 16;
-        f32x4 v = acc[ct][pt];
-        if (a.accumulate) v += *(const f32x4*)dst;
-        *(f32x4*)dst = v;
-      }
-    }
-  }
-  if (a.bn_part) {
-    // (tile mean, sum(v - mean), sum((v - mean)^2)) per channel over the tile's valid pixels: two in-register passes; the 16 lanes
-    // of a k-group hold 16 pixels of the same four channels, the WP waves of a channel group the other pixels
-    float* scr = (float*)smem;    // [3][WP][NT]  (the K loop's last barrier is behind every LDS read)
-    const int nvalid = min(G::TH, a.H - y0) * min(G::TW, a.W - x0);
-    const float inv = 1.f / (float)nvalid;
-    const int cl = wc * G::CB * 16 + 4 * kg;   // block-local channel of (ct = 0, r = 0)
-    float s0[G::CB][4];
+#pragma unroll 1
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+    const int y0 = ty * G::TH, x0 = tx * G::TW;
+    const long long img0 = (long long)b * a.H * a.W;
 #pragma unroll
     for (int ct = 0; ct < G::CB; ++ct)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = 0.f;
+      for (int pt = 0; pt < G::PB; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < G::NCHUNK; ++chunk) {
+      stash();                                   // (every wave's reads of the previous image are behind the last K-step's barrier)
+      const bool last_chunk = chunk == G::NCHUNK - 1;
+      const bool have_next = !(last_chunk && tile + 1 == t_end);
+      if (have_next) target(last_chunk ? tile + 1 : tile, last_chunk ? 0 : chunk + 1);   // (no next: the current tile is fetched again, unused)
+      DC_WAIT_VM(0);
+      DC_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();
+      if (gs == 0) {                             // (afterwards: rolled in under the previous K-step's MFMAs)
 #pragma unroll
-        for (int pt = 0; pt < G::PB; ++pt) v += p_ok[pt] ? acc[ct][pt][r] : 0.f;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        s0[ct][r] = v;
+        for (int ct = 0; ct < G::CB; ++ct) wread1(0, ct);
       }
-    if (i16 == 0) {
+      xread(0, 0);
+#pragma unroll
+      for (int s = 0; s < G::NSTEP; ++s) {
+        if (gs + 2 < total) {
+          wfill(qn, gs & 1);
+          qn = qn + 1 == TSTEPS ? 0 : qn + 1;
+        }
+        if (s < G::IPT) fetch_item(s);
+        if (s >= 2 && s - 2 < G::IPT) convert_item(s - 2);
+        const int set = G::XPF ? (s & 1) : 0;
+#ifndef DC_NO_XREAD
+        if (G::XPF && s + 1 < G::NSTEP) xread(s + 1, (s + 1) & 1);
+#endif
+#pragma unroll
+        for (int ct = 0; ct < G::CB; ++ct) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int pt = 0; pt < G::PB; ++pt) {
+            f32x4 c = acc[ct][pt];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][1], xf[set][pt][1], c, 0, 0, 0);   // m m
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[set][pt][2], c, 0, 0, 0);   // h l
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][2], xf[set][pt][0], c, 0, 0, 0);   // l h
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[set][pt][1], c, 0, 0, 0);   // h m
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][1], xf[set][pt][0], c, 0, 0, 0);   // m h
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[set][pt][0], c, 0, 0, 0);   // h h
+            acc[ct][pt] = c;
+#ifndef DC_NO_XREAD
+            if (!G::XPF && ct == G::CB - 1 && s + 1 < G::NSTEP) {   // single fragment set: refilled behind its last use
+              __builtin_amdgcn_sched_barrier(0);
+              xread1(s + 1, 0, pt);
+            }
+#endif
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#ifndef DC_NO_WREAD
+          wread1((gs + 1) & 1, ct);     // the next step's weight fragments roll in behind the last use of these registers
+#endif
+        }
+        ++gs;
+        // the weights of step gs + 1 have landed (the two prefetch loads issued behind their DMA may stay in flight), every LDS
+        // read of this step has returned
+#ifndef DC_NO_SYNC
+        if (s < G::IPT) DC_WAIT_VM(2);
+        else DC_WAIT_VM(0);
+        DC_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+#endif
+      }
+    }
+
+    // ---- epilogue: bias, store, BatchNorm partials ----------------------------------------------------------------------------
+    bool p_ok[G::PB];
+#pragma unroll
+    for (int pt = 0; pt < G::PB; ++pt) p_ok[pt] = y0 + prow(pt) < a.H && x0 + pcol(pt) < a.W;
+    const int co0 = cob * G::NT + wc * G::CB * 16 + 4 * kg;   // + ct * 16 + r
+#pragma unroll
+    for (int ct = 0; ct < G::CB; ++ct) {
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) bv = *(const f32x4*)(a.bias + co0 + ct * 16);
+#pragma unroll
+      for (int pt = 0; pt < G::PB; ++pt) {
+        acc[ct][pt] += bv;
+#ifdef DC_NO_STORE
+        if (p_ok[pt] && acc[ct][pt][0] == 123.456f) {
+#else
+        if (p_ok[pt]) {
+#endif
+          float* dst = a.y + (img0 + (long long)(y0 + prow(pt)) * a.W + x0 + pcol(pt)) * a.ldy + co0 + ct * 16;
+          f32x4 v = acc[ct][pt];
+          if (a.accumulate) v += *(const f32x4*)dst;
+          *(f32x4*)dst = v;
+        }
+      }
+    }
+    if (a.bn_part) {
+      // (tile mean, sum(v - mean), sum((v - mean)^2)) per channel over the tile's valid pixels: two in-register passes; the 16 lanes
+      // of a k-group hold 16 pixels of the same four channels, the WP waves of a channel group the other pixels
+      float* scr = (float*)smem;    // [2 WP][NT]  (the K loop's last barrier is behind every LDS read of the image)
+      const int nvalid = min(G::TH, a.H - y0) * min(G::TW, a.W - x0);
+      const float inv = 1.f / (float)nvalid;
+      const int cl = wc * G::CB * 16 + 4 * kg;   // block-local channel of (ct = 0, r = 0)
 #pragma unroll
       for (int ct = 0; ct < G::CB; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) scr[wp * G::NT + cl + ct * 16 + r] = s0[ct][r];
-    }
-    __syncthreads();
-    float mean[G::CB][4];
+        for (int r = 0; r < 4; ++r) {
+          float v = 0.f;
 #pragma unroll
-    for (int ct = 0; ct < G::CB; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < G::WP; ++w) v += scr[w * G::NT + cl + ct * 16 + r];
-        mean[ct][r] = v * inv;
-      }
-    __syncthreads();
-#pragma unroll
-    for (int ct = 0; ct < G::CB; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float d1 = 0.f, d2 = 0.f;
-#pragma unroll
-        for (int pt = 0; pt < G::PB; ++pt) {
-          const float d = p_ok[pt] ? acc[ct][pt][r] - mean[ct][r] : 0.f;
-          d1 += d;
-          d2 += d * d;
+          for (int pt = 0; pt < G::PB; ++pt) v += p_ok[pt] ? acc[ct][pt][r] : 0.f;
+          v = row16_sum(v);
+          if (i16 == 0) scr[wp * G::NT + cl + ct * 16 + r] = v;
         }
+      __syncthreads();
+      float mean[G::CB][4];
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-          d1 += __shfl_xor(d1, o, 64);
-          d2 += __shfl_xor(d2, o, 64);
+      for (int ct = 0; ct < G::CB; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < G::WP; ++w) v += scr[w * G::NT + cl + ct * 16 + r];
+          mean[ct][r] = v * inv;
         }
-        if (i16 == 0) {
-          scr[wp * G::NT + cl + ct * 16 + r] = d1;
-          scr[(G::WP + wp) * G::NT + cl + ct * 16 + r] = d2;
-        }
-      }
-    __syncthreads();
-    if (wp == 0 && i16 == 0) {
-      float* part = a.bn_part + (long long)tile * 3 * G::C + cob * G::NT;
+      __syncthreads();
 #pragma unroll
       for (int ct = 0; ct < G::CB; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float d1 = 0.f, d2 = 0.f;
 #pragma unroll
-          for (int w = 0; w < G::WP; ++w) {
-            d1 += scr[w * G::NT + cl + ct * 16 + r];
-            d2 += scr[(G::WP + w) * G::NT + cl + ct * 16 + r];
+          for (int pt = 0; pt < G::PB; ++pt) {
+            const float d = p_ok[pt] ? acc[ct][pt][r] - mean[ct][r] : 0.f;
+            d1 += d;
+            d2 += d * d;
           }
-          const int c = cl + ct * 16 + r;
-          part[c] = mean[ct][r];
-          part[G::C + c] = d1;
-          part[2 * G::C + c] = d2;
+          d1 = row16_sum(d1);
+          d2 = row16_sum(d2);
+          if (i16 == 0) {
+            scr[wp * G::NT + cl + ct * 16 + r] = d1;
+            scr[(G::WP + wp) * G::NT + cl + ct * 16 + r] = d2;
+          }
         }
+      __syncthreads();
+      if (wp == 0 && i16 == 0) {
+        float* part = a.bn_part + (long long)tile * 3 * G::C + cob * G::NT;
+#pragma unroll
+        for (int ct = 0; ct < G::CB; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < G::WP; ++w) {
+              d1 += scr[w * G::NT + cl + ct * 16 + r];
+              d2 += scr[(G::WP + w) * G::NT + cl + ct * 16 + r];
+            }
+            const int c = cl + ct * 16 + r;
+            part[c] = mean[ct][r];
+            part[G::C + c] = d1;
+            part[2 * G::C + c] = d2;
+          }
+      }
+      if (tid == 0 && cob == 0) a.bn_cnt[tile] = nvalid;
+      __syncthreads();   // the scratch is read: the next tile's stash may overwrite it
     }
-    if (tid == 0 && cob == 0) a.bn_cnt[tile] = nvalid;
   }
 }
 
@@ -365,9 +469,9 @@ __global__ __launch_bounds__(256) void dconv3_prep_kernel(const float* __restric
   }
 }
 
-//                     C  KC  NT WC WP PB TPH TPW PH PW
-using Cfg48 = DcCfg<48, 48, 48, 1, 4, 2, 8, 1, 1, 16>;    // tile  8 x 16, wave = 48 co x 32 px
-using Cfg96 = DcCfg<96, 32, 96, 2, 2, 4, 4, 2, 1, 16>;    // tile  4 x 32, wave = 48 co x 64 px
+//                     C  KC  NT WC WP PB TPH TPW PH PW  XPF
+using Cfg48 = DcCfg<48, 48, 48, 1, 4, 2, 8, 1, 1, 16, true>;    // tile  8 x 16, wave = 48 co x 32 px
+using Cfg96 = DcCfg<96, 32, 96, 2, 2, 4, 4, 2, 1, 16, false>;    // tile  4 x 32, wave = 48 co x 64 px
 
 struct DcPlan { int kind, KC, NT, TH, TW; };
 
@@ -377,16 +481,25 @@ DcPlan dc_plan(int C) {
   return {0, 0, 0, 0, 0};
 }
 
+int g_dc_blocks = 512;   // persistent blocks per launch: two per CU
+
 template <class G>
 int dc_launch(const DcArgs& a, int C, hipStream_t st) {
-  static bool attr_done = false;
-  (void)attr_done;
   const int ntile = a.B * a.tiles_y * a.tiles_x;
-  hipLaunchKernelGGL((dconv3_b3_kernel<G>), dim3(ntile, C / G::NT), dim3(G::NTHR), 0, st, a);
+  // persistent blocks pay when a block gets >= 3 tiles (the next halo tile is prefetched under the current one: 2040 tiles of the
+  // 48-channel layer, 56.7 us with 512 blocks against 60.9 us with one block per tile); with fewer tiles per slot the uneven
+  // split costs more (544 tiles of the 96-channel layer: 79 us with 512 blocks, 65 us with 544)
+  const int nb = ntile > 3 * g_dc_blocks ? g_dc_blocks : ntile;
+  hipLaunchKernelGGL((dconv3_b3_kernel<G>), dim3(nb, C / G::NT), dim3(G::NTHR), 0, st, a);
   return 0;
 }
 
 }  // namespace
+
+extern "C" int catseg_debug_set_dconv3_blocks(int blocks) {
+  g_dc_blocks = blocks > 0 ? blocks : 512;
+  return CATSEG_OK;
+}
 
 extern "C" int catseg_dconv3_supported(int C) { return dc_plan(C).kind != 0; }
 
