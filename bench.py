@@ -334,7 +334,7 @@ def main():
         # the dominant KERNEL (as rocprofv3 --stats names it): forward and backward-data of the bf16x3 layers are launches of one
         # kernel (igemm_b3w_kernel); the fp32 operations are the NT / NN / TN layouts of igemm_f32_kernel
         KERNEL_OF = {"fwd_b3": "b3w", "dgrad_b3": "b3w", "wgrad_b3": "wgrad_b3", "fwd": "fwd", "dgrad": "dgrad", "wgrad": "wgrad",
-                     "fwd_d3": "d3", "dgrad_d3": "d3"}
+                     "fwd_d3": "d3", "dgrad_d3": "d3", "wgrad_d3": "wgrad_d3"}
         groups = {}
         for k, v in mm.items():
             g = groups.setdefault(KERNEL_OF.get(k, k), [0.0, 0.0, 0])
@@ -342,12 +342,12 @@ def main():
         dom = max(groups, key=lambda k: groups[k][1])
         # (an fp32 layout is a union of 4-6 tile instantiations that rocprofv3 lists as separate kernels, the largest of them
         #  < 40 % of the layout's time: a single-symbol bf16x3 kernel with at least half of that time is the larger KERNEL)
-        for k in ("b3w", "wgrad_b3", "d3"):
-            if k in groups and dom not in ("b3w", "wgrad_b3", "d3") and groups[k][1] >= 0.5 * groups[dom][1]:
+        for k in ("b3w", "wgrad_b3", "d3", "wgrad_d3"):
+            if k in groups and dom not in ("b3w", "wgrad_b3", "d3", "wgrad_d3") and groups[k][1] >= 0.5 * groups[dom][1]:
                 dom = k
                 break
         fl, sec, n = groups[dom]
-        peak = PEAK_B3 if dom in ("b3w", "wgrad_b3", "d3") else PEAK_F32
+        peak = PEAK_B3 if dom in ("b3w", "wgrad_b3", "d3", "wgrad_d3") else PEAK_F32
         traffic = traffic_src = None   # HBM bytes per launch from committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
         tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (PROFILE_ROUND, args.model))
         if os.path.exists(tpath) and (B, H, W) == (8, 544, 960):
@@ -359,6 +359,7 @@ def main():
                  "wgrad": "igemm_f32_kernel<TN> + wgrad_direct_kernel (conv2d backward-weight, fp32 MFMA, incl. slab reduction)",
                  "b3w": "igemm_b3w_kernel (conv2d forward and backward-data of the large layers, bf16x3 split precision)",
                  "wgrad_b3": "igemm_b3t_kernel (conv2d backward-weight, bf16x3 split precision, incl. slab reduction)",
+                 "wgrad_d3": "dwgrad3_b3_kernel (direct 3x3 conv2d backward-weight of the HRNet trunk, bf16x3 split precision, incl. slab reduction)",
                  "d3": "dconv3_b3_kernel (direct 3x3 conv2d forward and backward-data of the HRNet trunk, bf16x3 split precision, "
                        "in-kernel split of the fp32 halo tile)"}.get(dom, dom)
         tot_fl = sum(v[0] for v in mm.values())

@@ -147,8 +147,20 @@ int catseg_dconv3_supported(int C);
 size_t catseg_dconv3_wimg_bytes(int C);
 int catseg_dconv3_tiles(int C, int B, int H, int W, int* tile_h, int* tile_w);
 int catseg_dconv3_prep(const float* w, int C, int backward_data, void* wimg, catseg_stream_t stream);
+/* the weight images of ALL direct-kernel layers of a network in one launch (the parameters live in one flat buffer): `entries` is a
+ * DEVICE array of n records {int64 weight offset in floats from `flat`; int64 image offset in bytes from wimg_base; int32 C; int32 KC;
+ * int32 NT; int32 backward_data} with KC / NT from catseg_dconv3_layout(C) */
+int catseg_dconv3_layout(int C, int* kc, int* nt);
+int catseg_dconv3_prep_batch(const float* flat, int n, const void* entries, void* wimg_base, catseg_stream_t stream);
 int catseg_dconv3(int B, int H, int W, int C, const float* x, int ldx, const void* wimg, const float* bias, float* y, int ldy,
                   int accumulate, float* bn_part, size_t bn_part_floats, int* bn_counts, catseg_stream_t stream);
+/* backward-weight of the same layers (csrc/dwgrad3_b3.hip): dw[o,ky,kx,c] = sum_p dy[p, o] * x[pix(p,ky,kx), c], C in {48, 96, 192, 384};
+ * x and dy are read as fp32 and split inside the kernel, fragments by transposed LDS reads, per-block partial sums in
+ * `workspace` (catseg_dwgrad3_workspace bytes) added in a fixed order */
+int catseg_dwgrad3_supported(int C);
+size_t catseg_dwgrad3_workspace(int B, int H, int W, int C);
+int catseg_dwgrad3(int B, int H, int W, int C, const float* x, int ldx, const float* dy, int ldy, float* dw, void* workspace,
+                   size_t workspace_bytes, catseg_stream_t stream);
 
 /* (tuning / measurement hooks live in catseg_debug.h: they are process-global and not part of the product surface) */
 

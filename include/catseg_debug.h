@@ -31,6 +31,8 @@ int catseg_debug_set_wgrad_direct(int on);
 
 /* tuning hook: persistent blocks per launch of the direct 3x3 kernel (csrc/dconv3_b3.hip; 0 restores the default 512 = two per CU) */
 int catseg_debug_set_dconv3_blocks(int blocks);
+/* tuning hook: blocks per launch of the direct backward-weight kernel (csrc/dwgrad3_b3.hip; 0 restores the default 512) */
+int catseg_debug_set_dwgrad3_blocks(int blocks);
 
 /* tuning hook: bf16x3 block tile: 0 = heuristic, 1 = 256x256, 2 = 256x128, 3 = 128x256, 4 = 256x192, 5 = 256x96, 6 = 256x64 */
 int catseg_debug_set_b3_tile(int t);

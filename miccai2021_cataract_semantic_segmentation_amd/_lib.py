@@ -39,6 +39,12 @@ _SIGS = {
     "catseg_dconv3_wimg_bytes": (SZ, [I]),
     "catseg_dconv3_tiles": (I, [I, I, I, I, P, P]),
     "catseg_dconv3_prep": (I, [P, I, I, P, P]),
+    "catseg_dconv3_layout": (I, [I, P, P]),
+    "catseg_dwgrad3_supported": (I, [I]),
+    "catseg_dwgrad3_workspace": (SZ, [I, I, I, I]),
+    "catseg_dwgrad3": (I, [I, I, I, I, P, I, P, I, P, P, SZ, P]),
+    "catseg_debug_set_dwgrad3_blocks": (I, [I]),
+    "catseg_dconv3_prep_batch": (I, [P, I, P, P, P]),
     "catseg_dconv3": (I, [I, I, I, I, P, I, P, P, P, I, I, P, SZ, P, P]),
     "catseg_conv2d_fwd_fused": (I, [P, P, P, P, P, I, I, P, P]),
     "catseg_fold_bn": (I, [P, P, P, P, P, P, F, I, I, P, P, P]),

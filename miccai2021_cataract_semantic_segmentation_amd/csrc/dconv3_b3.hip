@@ -442,10 +442,11 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
 // OHWI fp32 weights [C][3][3][C] -> the kernel's weight image, split into three bf16 planes.
 //   forward:       A[co][k = (tap, c)]  = w[co][tap][c]
 //   backward-data: A[ci][k = (tap, o)]  = w[o][8 - tap][ci]      (dx = conv of dy with the transposed, tap-mirrored bank)
-__global__ __launch_bounds__(256) void dconv3_prep_kernel(const float* __restrict__ w, int C, int KC, int NT, int dgrad, u16* __restrict__ img) {
+__device__ __forceinline__ void dconv3_prep_body(const float* __restrict__ w, int C, int KC, int NT, int dgrad, u16* __restrict__ img,
+                                                 long long first, long long stride) {
   const int nstep = steps_of(KC), nchunk = C / KC;
   const long long total = (long long)(C / NT) * nchunk * nstep * NT * 32;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = first; i < total; i += stride) {
     const int j = (int)(i & 7);
     long long r = i >> 3;
     const int co = (int)(r % NT); r /= NT;
@@ -469,15 +470,34 @@ __global__ __launch_bounds__(256) void dconv3_prep_kernel(const float* __restric
   }
 }
 
+__global__ __launch_bounds__(256) void dconv3_prep_kernel(const float* __restrict__ w, int C, int KC, int NT, int dgrad, u16* __restrict__ img) {
+  dconv3_prep_body(w, C, KC, NT, dgrad, img, blockIdx.x * (long long)blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+}
+
+// all layers of a network in one launch: entry e = {weight offset (floats) in the flat parameter buffer, C, direction, image offset
+// (bytes)}, blockIdx.y = entry
+struct DcPrepEntry { long long w_off; long long img_off; int C, KC, NT, dgrad; };
+__global__ __launch_bounds__(256) void dconv3_prep_batch_kernel(const float* __restrict__ flat, const DcPrepEntry* __restrict__ ent,
+                                                                unsigned char* __restrict__ img_base) {
+  const DcPrepEntry e = ent[blockIdx.y];
+  dconv3_prep_body(flat + e.w_off, e.C, e.KC, e.NT, e.dgrad, (u16*)(img_base + e.img_off), blockIdx.x * (long long)blockDim.x + threadIdx.x,
+                   (long long)gridDim.x * blockDim.x);
+}
+
 //                     C  KC  NT WC WP PB TPH TPW PH PW  XPF
 using Cfg48 = DcCfg<48, 48, 48, 1, 4, 2, 8, 1, 1, 16, true>;    // tile  8 x 16, wave = 48 co x 32 px
 using Cfg96 = DcCfg<96, 32, 96, 2, 2, 4, 4, 2, 1, 16, false>;    // tile  4 x 32, wave = 48 co x 64 px
+
+using Cfg192 = DcCfg<192, 32, 96, 2, 2, 2, 2, 2, 1, 16, true>;  // tile 2 x 32, wave = 48 co x 32 px, two co blocks
+using Cfg384 = DcCfg<384, 32, 96, 2, 2, 2, 2, 2, 1, 16, true>;  // the same tile, four co blocks
 
 struct DcPlan { int kind, KC, NT, TH, TW; };
 
 DcPlan dc_plan(int C) {
   if (C == 48) return {1, Cfg48::KC, Cfg48::NT, Cfg48::TH, Cfg48::TW};
   if (C == 96) return {2, Cfg96::KC, Cfg96::NT, Cfg96::TH, Cfg96::TW};
+  if (C == 192) return {3, Cfg192::KC, Cfg192::NT, Cfg192::TH, Cfg192::TW};
+  if (C == 384) return {4, Cfg384::KC, Cfg384::NT, Cfg384::TH, Cfg384::TW};
   return {0, 0, 0, 0, 0};
 }
 
@@ -528,6 +548,24 @@ extern "C" int catseg_dconv3_prep(const float* w, int C, int backward_data, void
   return CATSEG_OK;
 }
 
+// entries: DEVICE array of n records {int64 weight offset (floats, relative to flat), int64 image offset (bytes, relative to
+// wimg_base), int32 C, int32 KC, int32 NT, int32 backward_data}; KC / NT as catseg_dconv3_layout reports them for C
+extern "C" int catseg_dconv3_prep_batch(const float* flat, int n, const void* entries, void* wimg_base, catseg_stream_t stream) {
+  CS_REQUIRE(flat && entries && wimg_base && n > 0, "dconv3 prep batch: bad args");
+  hipLaunchKernelGGL(dconv3_prep_batch_kernel, dim3(48, n), dim3(256), 0, (hipStream_t)stream, flat, (const DcPrepEntry*)entries,
+                     (unsigned char*)wimg_base);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+extern "C" int catseg_dconv3_layout(int C, int* kc, int* nt) {
+  const DcPlan p = dc_plan(C);
+  if (!p.kind) return 0;
+  if (kc) *kc = p.KC;
+  if (nt) *nt = p.NT;
+  return 1;
+}
+
 extern "C" int catseg_dconv3(int B, int H, int W, int C, const float* x, int ldx, const void* wimg, const float* bias, float* y, int ldy,
                              int accumulate, float* bn_part, size_t bn_part_floats, int* bn_counts, catseg_stream_t stream) {
   const DcPlan p = dc_plan(C);
@@ -547,7 +585,9 @@ extern "C" int catseg_dconv3(int B, int H, int W, int C, const float* x, int ldx
   const long long ntile = (long long)B * a.tiles_y * a.tiles_x;
   if (bn_part) CS_REQUIRE(bn_counts && bn_part_floats >= (size_t)ntile * 3 * C, "dconv3: BatchNorm partial buffer too small");
   if (p.kind == 1) dc_launch<Cfg48>(a, C, (hipStream_t)stream);
-  else dc_launch<Cfg96>(a, C, (hipStream_t)stream);
+  else if (p.kind == 2) dc_launch<Cfg96>(a, C, (hipStream_t)stream);
+  else if (p.kind == 3) dc_launch<Cfg192>(a, C, (hipStream_t)stream);
+  else dc_launch<Cfg384>(a, C, (hipStream_t)stream);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

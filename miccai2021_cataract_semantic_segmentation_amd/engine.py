@@ -604,8 +604,27 @@ class EngineNet(nn.Module):
         flush_bn_counters(self)
         return super().state_dict(*a, **k)
 
+    def _d3_bank(self):
+        """weight images of the direct 3x3 kernels (ops.Dconv3Bank): every eligible layer of the network, one launch per step"""
+        fp = self.flat()
+        bank = getattr(self, "_d3bank", None)
+        if bank is None or bank.flat is not fp.flat:
+            ws = []
+            for m in self.modules():
+                if (isinstance(m, Conv2d) and not m.stem and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
+                        and m.dilation == (1, 1) and m.groups == 1 and m.in_channels == m.out_channels
+                        and ops.lib.catseg_dconv3_supported(m.in_channels) and id(m.weight) in fp.offsets):
+                    ws.append((m.weight.data, fp.offsets[id(m.weight)]))
+            bank = ops.Dconv3Bank(fp.flat, ws) if ws else False
+            self._d3bank = bank
+        return bank
+
     def _run(self, x, record):
         ops.release_b3_cache()          # (planes left over from a recorded forward that never saw its backward)
+        if ops.DCONV3 and ops.PRECISION == "bf16x3" and self.training:
+            bank = self._d3_bank()
+            if bank:
+                bank.refresh()
         cx = Ctx(self.training, record, None)
         outs = self._body(cx, x)
         if not record:

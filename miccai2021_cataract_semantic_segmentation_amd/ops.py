@@ -190,7 +190,7 @@ def release_b3_cache():
 # split into bf16 planes inside the kernel, a block reads the halo tile of its pixel tile once.  DCONV3_MIN_ROWS: below that many
 # pixels the launch cannot fill the chip with its 128-pixel tiles and the fp32 implicit GEMM is as good (tests lower it).
 DCONV3 = True
-DCONV3_MIN_ROWS = 16384
+DCONV3_MIN_ROWS = 2048
 _d3_wimg = {}
 
 
@@ -209,6 +209,37 @@ def dconv3_weight_image(w, backward_data=False):
         check(lib.catseg_dconv3_prep(ptr(w), C, 1 if backward_data else 0, ptr(img), stream()))
         _d3_wimg[key] = img
     return img
+
+
+class Dconv3Bank:
+    """the weight images of every direct-kernel layer of one network, written by ONE launch per step
+    (catseg_dconv3_prep_batch over the flat parameter buffer) instead of two small launches per layer"""
+
+    def __init__(self, flat, weights):
+        """weights: [(parameter tensor (a view into flat), offset in floats)] of the eligible 3x3 layers"""
+        import numpy as np
+        self.flat = flat
+        rec = np.zeros(2 * len(weights), dtype=[("w", "<i8"), ("img", "<i8"), ("C", "<i4"), ("KC", "<i4"), ("NT", "<i4"), ("dg", "<i4")])
+        off = 0
+        self.slices = []
+        kc, nt = ctypes.c_int(0), ctypes.c_int(0)
+        for i, (w, woff) in enumerate(weights):
+            C = w.shape[0]
+            lib.catseg_dconv3_layout(C, ctypes.byref(kc), ctypes.byref(nt))
+            nbytes = lib.catseg_dconv3_wimg_bytes(C)
+            for dg in (0, 1):
+                rec[2 * i + dg] = (woff, off, C, kc.value, nt.value, dg)
+                self.slices.append((w, dg, off, nbytes))
+                off += (nbytes + 255) // 256 * 256
+        self.entries = torch.from_numpy(rec.view(np.uint8).copy()).to(flat.device)
+        self.n = len(rec)
+        self.images = torch.empty(max(off, 256), dtype=torch.uint8, device=flat.device)
+
+    def refresh(self):
+        """(re)write every image from the current parameters and publish them to dconv3_weight_image's cache"""
+        check(lib.catseg_dconv3_prep_batch(ptr(self.flat), self.n, ptr(self.entries), ptr(self.images), stream()))
+        for w, dg, off, nbytes in self.slices:
+            _d3_wimg[(w.data_ptr(), bool(dg))] = self.images[off:off + nbytes]
 
 
 def dconv3(x, wimg, bias=None, out=None, accumulate=False, bn_stats=False):
@@ -341,6 +372,10 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
     """dw: destination tensor (physical OHWI, or packed [O][7][8][4] for the stem)."""
     Cout, Cin = dy.shape[-1], x.shape[-1]
     flops = 2.0 * rows_of(dy) * Cout * (3 if stem4 else Cin // groups) * kh * kw
+    if (not stem4 and x.dim() == 4 and _d3_ok(rows_of(dy), Cin, Cout, kh, kw, stride, pad, dil, groups)
+            and lib.catseg_dwgrad3_supported(Cin)):
+        dwgrad3(x, dy, dw, dbias, flops)
+        return dw
     if (groups == 1 and "wgrad" in B3_OPS and not stem4 and PRECISION == "bf16x3" and Cin % 8 == 0 and
             ((B3_MIN_TAPS <= kh * kw and kh * kw * Cin >= B3_MIN_K and Cout >= B3_MIN_N and rows_of(dy) >= B3_MIN_WGRAD_ROWS)
              or (stride == 1 and _b3_wide_1x1(rows_of(dy), Cout, kh * kw, Cin)))):
@@ -361,6 +396,18 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
     ws = workspace(need, x.device)
     with _Timed("wgrad", flops):
         check(lib.catseg_conv2d_bwd_weight(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), stream()))
+    return dw
+
+
+def dwgrad3(x, dy, dw, dbias=None, flops=0.0):
+    """backward-weight of a 3x3 / stride 1 / pad 1 trunk convolution through the direct split-precision kernel"""
+    B, H, W, C = x.shape
+    need = lib.catseg_dwgrad3_workspace(B, H, W, C)
+    ws = workspace(need + 256 * C * 4, x.device)
+    with _Timed("wgrad_d3", flops or 2.0 * B * H * W * C * C * 9):
+        check(lib.catseg_dwgrad3(B, H, W, C, ptr(x), ld_of(x), ptr(dy), ld_of(dy), ptr(dw), ptr(ws), need, stream()))
+    if dbias is not None:
+        check(lib.catseg_bias_grad(ptr(dy), ld_of(dy), rows_of(dy), C, ptr(dbias), ptr(ws), ws.numel(), stream()))
     return dw
 
 

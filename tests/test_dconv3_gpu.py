@@ -114,3 +114,57 @@ def test_conv_dispatch_uses_direct_kernel(ops):
         ops.PROFILE = None
         ops.DCONV3_MIN_ROWS, ops.PRECISION = saved
         ops.release_b3_cache()
+
+
+def test_batched_weight_images_equal_single_prep(ops):
+    """ops.Dconv3Bank (one launch over the flat parameter buffer) writes the images catseg_dconv3_prep writes layer by layer"""
+    from miccai2021_cataract_semantic_segmentation_amd._lib import lib
+    g = torch.Generator().manual_seed(3)
+    widths = [48, 96, 48, 192]
+    sizes = [c * c * 9 for c in widths]
+    offs, o = [], 7 * 64
+    for n in sizes:
+        offs.append(o)
+        o += (n + 63) // 64 * 64 + 64
+    flat = torch.randn(o, generator=g).cuda()
+    ws = [flat[a:a + n].view(c, 3, 3, c).permute(0, 3, 1, 2) for a, n, c in zip(offs, sizes, widths)]
+    bank = ops.Dconv3Bank(flat, list(zip(ws, offs)))
+    ops.release_b3_cache()
+    bank.refresh()
+    got = {k: v.clone() for k, v in ops._d3_wimg.items()}
+    ops.release_b3_cache()
+    for w in ws:
+        for dg in (False, True):
+            assert torch.equal(got[(w.data_ptr(), dg)], ops.dconv3_weight_image(w, backward_data=dg))
+    ops.release_b3_cache()
+
+
+WG_CASES = [(2, 8, 32, 48), (1, 19, 37, 48), (3, 5, 7, 48), (1, 1, 50, 48), (2, 33, 1, 48),
+            (2, 8, 32, 96), (1, 19, 37, 96), (2, 3, 5, 96), (1, 11, 21, 192), (1, 17, 30, 384)]
+
+
+@pytest.mark.parametrize("case", WG_CASES)
+def test_dwgrad3_vs_fp64(ops, case):
+    """direct split-precision backward-weight (csrc/dwgrad3_b3.hip) against the fp64 autograd of F.conv2d, inputs with a wide dynamic
+    range, tensors inside wider buffers, every block count from one tile per block to one block"""
+    from miccai2021_cataract_semantic_segmentation_amd._lib import lib
+    B, H, W, C = case
+    g = torch.Generator().manual_seed(sum(case) + 7)
+    x = torch.randn(B, C, H, W, generator=g) * torch.exp(1.5 * torch.randn(1, C, 1, 1, generator=g))
+    gy = torch.randn(B, C, H, W, generator=g) * torch.exp(1.5 * torch.randn(1, C, 1, 1, generator=g))
+    wr = torch.zeros(C, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wr, None, 1, 1, 1).backward(gy.double())
+    xbuf = torch.zeros(B, H, W, C + 16).cuda()
+    xbuf[..., 8:8 + C] = nhwc(x)
+    xd = xbuf[..., 8:8 + C]
+    gyd = nhwc(gy)
+    try:
+        for blocks in (0, 1, 24, 100000):
+            lib.catseg_debug_set_dwgrad3_blocks(blocks)
+            dw = torch.full((C, C, 3, 3), 3.0).cuda().contiguous(memory_format=torch.channels_last)
+            db = torch.empty(C).cuda()
+            ops.dwgrad3(xd, gyd, dw, db)
+            close(dw, wr.grad, 2e-5)
+            close(db, gy.double().sum((0, 2, 3)), 2e-5)
+    finally:
+        lib.catseg_debug_set_dwgrad3_blocks(0)

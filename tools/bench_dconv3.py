@@ -32,7 +32,17 @@ for (B, H, W, C) in SHAPES:
     ops.PRECISION = "fp32"
     t_f32 = timed(lambda: ops.conv_fwd(x, w, None, C, 3, 3, 1, 1, 1, out=y, bn_stats=True), reps)
     t_f32d = timed(lambda: ops.conv_bwd_data(x, w, tuple(x.shape), 3, 3, 1, 1, 1, out=y), reps)
-    line = "C=%3d %dx%d  fp32 igemm fwd %7.1f us %6.1f TF  dgrad %7.1f us %6.1f TF" % (C, H, W, t_f32, gf / t_f32 * 1e3, t_f32d, gf / t_f32d * 1e3)
+    dw = torch.empty_like(w)
+    dyt = torch.randn_like(x)
+    t_f32w = timed(lambda: ops.conv_bwd_weight(x, dyt, dw, None, 3, 3, 1, 1, 1), reps)
+    line = "C=%3d %dx%d  fp32 igemm fwd %7.1f us %6.1f TF  dgrad %7.1f us %6.1f TF  wgrad %7.1f us %6.1f TF" % (
+        C, H, W, t_f32, gf / t_f32 * 1e3, t_f32d, gf / t_f32d * 1e3, t_f32w, gf / t_f32w * 1e3)
+    if lib.catseg_dwgrad3_supported(C):
+        for blocks in (512, 256, 1024):
+            lib.catseg_debug_set_dwgrad3_blocks(blocks)
+            t_w = timed(lambda: ops.dwgrad3(x, dyt, dw), reps)
+            line += "  | d3 wgrad[%d] %7.1f us %6.1f TF" % (blocks, t_w, gf / t_w * 1e3)
+        lib.catseg_debug_set_dwgrad3_blocks(0)
     if lib.catseg_dconv3_supported(C):
         wimg = ops.dconv3_weight_image(w)
         wimg_t = ops.dconv3_weight_image(w, backward_data=True)
