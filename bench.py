@@ -42,7 +42,7 @@ MODELS = {
     "deeplabv3plus_r50": ({"backbone": "resnet50", "out_stride": 8, "pretrained": False}, "DeepLabv3+-ResNet50-OS8"),
 }
 IS_DEEPLAB = lambda name: name.startswith("deeplab")   # noqa: E731
-PROFILE_ROUND = "r02"   # profiles/<round>_pmc_traffic_<model>.json feeds roofline.traffic
+PROFILE_ROUND = "r03"   # profiles/<round>_pmc_traffic_<model>.json feeds roofline.traffic
 
 
 def host_cpu_info():
@@ -72,7 +72,7 @@ def host_cpu_info():
     return model, (len(cores) or avail), avail
 
 
-def cpu_baseline(H, W, K, model_name):
+def cpu_baseline(H, W, K, model_name, threads=0):
     """the CPU oracle (port of the reference path) on this box's host cores -- the identical synthetic
     train step (zero_grad -> forward -> loss -> backward -> Adam), fp32, batch 2: 1 warm-up + 3 timed steps with anomaly
     detection off, then 1 step with torch.autograd.set_detect_anomaly(True) as the reference's main.py:8 sets it."""
@@ -80,7 +80,9 @@ def cpu_baseline(H, W, K, model_name):
     from oracle.state import fill_state, spec_of
     from miccai2021_cataract_semantic_segmentation_amd.models import DeepLabv3Plus, OCRNet
     cpu_model, physical, avail = host_cpu_info()
-    cores = max(1, min(avail, physical, 32))   # beyond ~32 threads the sort / BN phases of this step stop scaling
+    # threads: --cpu-threads, default = every physical core this process may use; the 32 / 64 / 128-thread sweep of this
+    # step on the GPU box's host is committed as profiles/r03_cpu_thread_sweep.json (tools/cpu_thread_sweep.py)
+    cores = max(1, min(avail, threads if threads > 0 else physical))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     deeplab = IS_DEEPLAB(model_name)
@@ -129,8 +131,9 @@ def cpu_baseline(H, W, K, model_name):
 
 def DTYPE_STRING():
     from miccai2021_cataract_semantic_segmentation_amd import ops
-    return "f32" if ops.PRECISION == "fp32" else ("f32 (convolutions with K >= 2048 and >= 192 output columns: fp32 operands split "
-                                                  "exactly into 3 bf16 planes, 6 bf16 MFMA products, fp32 accumulate)")
+    return "f32" if ops.PRECISION == "fp32" else ("f32 (convolutions with K >= 2048 and >= 192 output columns, and the 3x3 trunk convolutions "
+                                                  "of the HRNet widths: fp32 operands split exactly into 3 bf16 planes, 6 bf16 MFMA "
+                                                  "products, fp32 accumulate)")
 
 
 def infer_bench(args):
@@ -229,6 +232,9 @@ def main():
                     help="BASELINE config 5 instead: EncDec(ResNeXt101_32x8d + UPerNet) inference at 3x1080x1920, 4 frames per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all physical cores available to the process)")
+    ap.add_argument("--no-side-figures", action="store_true",
+                    help="skip the side figures measured after the timed region (exact-fp32 arithmetic, unpadded 540x960 frames, through the uint8 loader)")
     ap.add_argument("--with-h2d", action="store_true",
                     help="side measurement (never the reported `value` of the contract): every step also copies its batch from "
                          "pinned host memory, float32 image + int64 labels as the reference's loader hands them over")
@@ -268,17 +274,23 @@ def main():
     img, lbl = synth_batch(B, H, W, K, 1000 + rank, dev)
 
     host = (img.cpu().pin_memory(), lbl.cpu().pin_memory()) if args.with_h2d else None
+    from miccai2021_cataract_semantic_segmentation_amd.utils.metrics import t_get_confusion_matrix
+    cm = torch.zeros((K, K), dtype=torch.int32, device=dev)
 
-    def step():
-        if host is not None:
+    def step(batch=None):
+        """one training step as the reference's manager runs it (managers/OCRNet_Manager.py:80-113): zero_grad, forward, loss, backward,
+        (gradient exchange,) Adam, and the per-step training metric: the confusion matrix of the batch's predictions"""
+        x, y = batch if batch is not None else (img, lbl)
+        if host is not None and batch is None:
             img.copy_(host[0], non_blocking=True)
             lbl.copy_(host[1], non_blocking=True)
         opt.zero_grad()
-        out = model(img)
+        out = model(x)
         interm, final = (None, out) if deeplab else out
-        loss = crit(interm, final, lbl)
+        loss = crit(interm, final, y)
         loss.backward()
         opt.step()
+        t_get_confusion_matrix(final.detach(), y, cm)
         return loss
 
     def barrier():
@@ -380,9 +392,78 @@ def main():
                                    "tflops_equivalent": tot_fl / tot_s / 1e12, "frac_of_fp32_matrix_peak": tot_fl / tot_s / 1e12 / PEAK_F32,
                                    "split3_ms_per_step": agg.get("split3", [0, 0, 0])[1] / 2 * 1e3},
                 "hbm_kernels": hbm}
+        # whole-step view: the time the step's algorithmic work would take at the stated peaks (matrix work per arithmetic, the HBM-bound
+        # kernels' algorithmic bytes at 8 TB/s), against the measured step
+        lb_ms = (sum(v[0] for k, v in mm.items() if not k.endswith(("_b3", "_d3"))) / (PEAK_F32 * 1e12)
+                 + sum(v[0] for k, v in mm.items() if k.endswith(("_b3", "_d3"))) / (PEAK_B3 * 1e12)
+                 + sum(v[0] for k, v in agg.items() if k.startswith("hbm:")) / 8e12) / 2 * 1e3
+        roof["whole_step"] = {"lower_bound_ms": lb_ms, "measured_ms": dt / args.steps * 1e3, "frac": lb_ms / (dt / args.steps * 1e3),
+                              "bf16x3_tflop_per_step": sum(v[0] for k, v in mm.items() if k.endswith(("_b3", "_d3"))) / 2 / 1e12,
+                              "fp32_tflop_per_step": sum(v[0] for k, v in mm.items() if not k.endswith(("_b3", "_d3"))) / 2 / 1e12}
+    comm = None
+    if world > 1:
+        comm = model._grad_sync.stats()          # every rank (it synchronises its device); rank 0 prints
+        comm["payload_MB_per_step"] = round(comm["bytes_reduced_per_step"] / 1e6, 1)
+
+    def timed_steps(n, batches=None, warm=1):
+        for i in range(warm):
+            step(None if batches is None else next(batches))
+        barrier()
+        t0_ = time.perf_counter()
+        for i in range(n):
+            step(None if batches is None else next(batches))
+        barrier()
+        return (time.perf_counter() - t0_) / n
+
+    side = {}
+    if not args.no_side_figures and (B, H, W) == (8, 544, 960):
+        # (1) the same step with exact fp32 MFMA chains everywhere (CATSEG_PRECISION=fp32: no split-precision kernel)
+        if ops.PRECISION != "fp32":
+            saved = ops.PRECISION
+            ops.PRECISION = "fp32"
+            dt32 = timed_steps(3)
+            ops.PRECISION = saved
+            side["exact_fp32"] = {"frames_per_s": world * B / dt32, "ms_per_step": dt32 * 1e3, "steps": 3}
+        # (2) frames as the camera delivers them: 540 rows, no 'pad' transform
+        try:
+            g540 = torch.Generator().manual_seed(3000 + rank)
+            img540 = torch.rand(B, 3, 540, W, generator=g540).to(dev)
+            lbl540 = torch.randint(0, K + 1, (B, 18, W // 30), generator=g540).repeat_interleave(30, 1).repeat_interleave(30, 2).contiguous().to(dev)
+            dt540 = timed_steps(3, iter(lambda: (img540, lbl540), None))
+            side["unpadded_540x960"] = {"frames_per_s": world * B / dt540, "ms_per_step": dt540 * 1e3, "steps": 3,
+                                        "note": "labels 540 rows; the odd feature-map heights (135 / 68 / 34 / 17) run the same kernels"}
+        except Exception as e:   # noqa: BLE001
+            side["unpadded_540x960"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # (3) through the uint8 loader: pinned host frames -> side-stream copy -> GpuIngest(remap, flip, pad, blur, colour jitter) -> step
+        if True:
+            from miccai2021_cataract_semantic_segmentation_amd.utils.loader import PinnedFrameLoader
+
+            class _Frames(torch.utils.data.Dataset):
+                """64 raw uint8 frames 540 x 960 in host memory (the decode stays on the host in the reference too: datasets/Dataset_from_df.py:31-69)"""
+                def __init__(self):
+                    g = torch.Generator().manual_seed(7 + rank)
+                    self.img = torch.randint(0, 256, (64, 540, 960, 3), dtype=torch.uint8, generator=g).numpy()
+                    self.lbl = torch.randint(0, 36, (64, 540 // 30, 960 // 30), dtype=torch.uint8, generator=g).repeat_interleave(30, 1).repeat_interleave(30, 2).numpy()
+                def __len__(self):
+                    return 64
+                def __getitem__(self, i):
+                    return self.img[i], self.lbl[i]
+            loader = PinnedFrameLoader(_Frames(), batch_size=B, experiment=3, flip_probability=(0.0, 0.5), pad=(2, 2), normalise=False,
+                                       device=dev, blur=True, colorjitter=True, seed=rank)
+
+            def forever():
+                while True:
+                    for b_ in loader:
+                        yield b_
+            gen = forever()
+            dtl = timed_steps(6, gen, warm=2)
+            side["through_loader"] = {"frames_per_s": world * B / dtl, "ms_per_step": dtl * 1e3, "steps": 6,
+                                      "pipeline": "PinnedFrameLoader (64 host uint8 frames 540x960, 4 fill threads) -> pinned staging -> "
+                                                  "copy on a side stream -> GpuIngest(label remap, flip, pad to 544, BlurPIL, ColorJitter, ToTensor) -> train step",
+                                      "sustains_step_rate": bool(dtl <= 1.03 * dt / args.steps)}
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
-        cpu = cpu_baseline(H, W, K, args.model)
+        cpu = cpu_baseline(H, W, K, args.model, args.cpu_threads)
     if world > 1:
         dist.barrier()
 
@@ -404,6 +485,11 @@ def main():
                        "inputs": "host (pinned) -> device copy inside every step" if args.with_h2d else "resident in HBM"},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if comm is not None:
+            out["comm"] = comm
+        if side:
+            out["side_figures"] = side
+        out["config"]["step"] = "zero_grad, forward, loss, backward, Adam, confusion matrix of the batch (the reference's per-step training metric)"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -24,7 +24,11 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = os.environ.get("CATSEG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            env = os.environ.get("CATSEG_DIST_BACKEND")
+            backend = env or ("nccl" if torch.cuda.is_available() else "gloo")
+            if backend == "gloo" and torch.cuda.is_available() and env != "gloo":
+                raise RuntimeError("data parallel on GPUs runs over RCCL (backend 'nccl'); gloo stages every bucket through the host -- "
+                                   "set CATSEG_DIST_BACKEND=gloo to ask for it explicitly (functional tests)")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -33,35 +37,51 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
-class GradSync:
-    """Bucketed all-reduce(sum) of a flat gradient buffer, driven by per-parameter 'ready' events."""
+def default_bucket_bytes():
+    """CATSEG_BUCKET_MB (default 32): size of the gradient buckets.  xGMI is point to point (7 links x ~153 GB/s per GPU): a ring
+    all-reduce of a 32 MB bucket over 8 GPUs moves 2 * 7/8 * 32 MB per link ~ 0.4 ms -- long enough to run at link rate, short
+    enough that several buckets are in flight under the backward pass"""
+    return int(float(os.environ.get("CATSEG_BUCKET_MB", "32")) * (1 << 20))
 
-    def __init__(self, bucket_bytes=64 << 20, group=None):
-        self.bucket_bytes = bucket_bytes
+
+class GradSync:
+    """Bucketed all-reduce(sum) of a flat gradient buffer, driven by per-parameter 'ready' events.  The bucket that becomes ready
+    LAST (the lowest offsets: stem and first stage, whose gradients the backward pass writes at its very end) is kept small
+    (tail_bytes), because its all-reduce cannot overlap with anything."""
+
+    def __init__(self, bucket_bytes=None, group=None, tail_bytes=None):
+        self.bucket_bytes = int(bucket_bytes) if bucket_bytes else default_bucket_bytes()
+        self.tail_bytes = int(tail_bytes) if tail_bytes else min(self.bucket_bytes, int(float(os.environ.get("CATSEG_TAIL_BUCKET_MB", "4")) * (1 << 20)))
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._key = None
-        self.buckets = []       # [(start, end)] over the flat buffer, in REVERSE parameter order
+        self.buckets = []       # [(start, end, members)] over the flat buffer
         self.bucket_of = {}
         self.pending = []
         self.handles = []
         self.launched = []
         self.bytes_reduced = 0
+        self.steps = 0
+        self.exposed_ms = 0.0   # GPU time the launch stream spent waiting for the exchange after its last backward kernel
+        self.host_wait_ms = 0.0
+        self._ev = None
 
     def _plan(self, params, offsets, numel, align):
         self.buckets, self.bucket_of = [], {}
-        order = sorted(params, key=lambda p: offsets[id(p)], reverse=True)
-        cur_end, cur_start, members = None, None, []
+        order = sorted(params, key=lambda p: offsets[id(p)])          # ascending offsets: the first bucket is the tail bucket
+        cur_start, cur_end, members = None, None, []
+        limit = self.tail_bytes
         for p in order:
             o = offsets[id(p)]
             e = o + (p.numel() + align - 1) // align * align
-            if cur_end is None:
-                cur_end = e
-            cur_start = o
+            if cur_start is None:
+                cur_start = o
+            cur_end = e
             members.append(p)
-            if (cur_end - cur_start) * 4 >= self.bucket_bytes:
+            if (cur_end - cur_start) * 4 >= limit:
                 self._close(cur_start, cur_end, members)
-                cur_end, members = None, []
+                cur_start, members = None, []
+                limit = self.bucket_bytes
         if members:
             self._close(cur_start, cur_end, members)
 
@@ -99,14 +119,44 @@ class GradSync:
             self._launch(b)
 
     def finish(self):
+        import time
         for b in range(len(self.buckets)):   # parameters that received no gradient this step
             self._launch(b)
+        cuda = self.grad.is_cuda and self.world > 1
+        if cuda:
+            if self._ev is not None:         # (read last step's pair here: no synchronisation on the hot path)
+                e0, e1 = self._ev
+                if e1.query():
+                    self.exposed_ms += e0.elapsed_time(e1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        t0 = time.perf_counter()
         for h in self.handles:
             h.wait()
+        self.host_wait_ms += (time.perf_counter() - t0) * 1e3
+        if cuda:
+            e1.record()
+            self._ev = (e0, e1)
         self.handles = []
+        self.steps += 1
+
+    def stats(self):
+        """what a scaling run needs to interpret its number: which backend carried how many bytes in how many buckets, and how long the
+        launch stream waited for the exchange after the backward pass had nothing left to overlap it with"""
+        if self._ev is not None and self.grad.is_cuda:
+            torch.cuda.synchronize()
+            self.exposed_ms += self._ev[0].elapsed_time(self._ev[1])
+            self._ev = None
+        n = max(self.steps, 1)
+        return {"backend": dist.get_backend(self.group) if dist.is_initialized() else "none",
+                "world_seen_by_backend": self.world, "buckets": len(self.buckets), "bucket_MB": self.bucket_bytes / (1 << 20),
+                "tail_bucket_MB": self.tail_bytes / (1 << 20),
+                "bucket_sizes_MB": [round((e - s) * 4 / (1 << 20), 2) for (s, e, _) in self.buckets],
+                "bytes_reduced_per_step": self.bytes_reduced // n, "exposed_wait_ms": self.exposed_ms / n,
+                "host_wait_ms": self.host_wait_ms / n, "steps": self.steps}
 
 
-def attach(model, bucket_bytes=64 << 20):
+def attach(model, bucket_bytes=None):
     """Enable data-parallel gradient averaging on an EngineNet; returns 1/world for FusedAdam.grad_scale."""
     sync = GradSync(bucket_bytes)
     model._grad_sync = sync
@@ -129,6 +179,15 @@ def shard_indices(indices, rank, world, drop_last=True):
     return list(indices[rank:n:world])
 
 
+def check_unsharded(source):
+    """a sampler that already shards itself (utils.RepeatFactorSampler(rank=, world=)) must not be sharded again: every rank would
+    train on 1 / world^2 of the epoch and the step counts would be derived from the wrong total"""
+    if getattr(source, "world", 1) > 1:
+        raise ValueError("the sampler passed to a rank-sharding wrapper already shards its stream (world=%d): construct it with "
+                         "rank=0, world=1 and let ShardedSampler / PinnedFrameLoader / the manager take the rank's slice"
+                         % getattr(source, "world"))
+
+
 class ShardedSampler(torch.utils.data.Sampler):
     """Rank shard of an epoch's index stream.  ``source`` is either a dataset length (a fresh shared-seed permutation is
     drawn every epoch: ``seed + epoch``) or another sampler whose stream is identical on every rank (the repeat-factor
@@ -137,6 +196,7 @@ class ShardedSampler(torch.utils.data.Sampler):
     counts on every rank (a rank that ran one step more would dead-lock the gradient all-reduce)."""
 
     def __init__(self, source, rank, world, batch_size=1, seed=0):
+        check_unsharded(source)
         self.source, self.rank, self.world, self.batch, self.seed = source, rank, world, max(int(batch_size), 1), seed
         self.epoch = 0
 
@@ -162,21 +222,32 @@ class ShardedSampler(torch.utils.data.Sampler):
 
 def sync_bn_stats(model, how="mean"):
     """BatchNorm running statistics drift apart across ranks (each rank normalises with its LOCAL batch statistics; the
-    reference has no SyncBN).  Before validation / checkpointing every rank takes the mean over ranks
-    (``how='mean'``) or rank 0's values (``how='rank0'``), so that the sharded validation pass scores exactly the weights
-    that rank 0 saves.  One all-reduce of a flat buffer of all running means / variances."""
+    reference has no SyncBN).  Before validation / checkpointing every rank takes the POOLED statistics over ranks
+    (``how='mean'``: mean of the running means; variance = mean of the running variances + the variance of the running means, i.e.
+    the variance of the pooled population for equally sized shards) or rank 0's values (``how='rank0'``), so that the sharded
+    validation pass scores exactly the weights that rank 0 saves.  Only the running_mean / running_var buffers of BatchNorm
+    modules take part; one all-reduce of a flat buffer."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
-    bufs = [b for n, b in model.named_buffers() if b.dtype.is_floating_point]
-    if not bufs:
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.running_mean is not None]
+    if not bns:
         return
-    flat = torch.cat([b.reshape(-1) for b in bufs])
+    means = torch.cat([m.running_mean.reshape(-1) for m in bns])
+    vars_ = torch.cat([m.running_var.reshape(-1) for m in bns])
+    n = means.numel()
     if how == "rank0":
+        flat = torch.cat([means, vars_])
         dist.broadcast(flat, 0)
+        means, vars_ = flat[:n], flat[n:]
     else:
+        flat = torch.cat([means, vars_, means * means])
         dist.all_reduce(flat)
         flat /= dist.get_world_size()
+        means = flat[:n]
+        vars_ = flat[n:2 * n] + (flat[2 * n:] - means * means).clamp_min(0)
     o = 0
-    for b in bufs:
-        b.copy_(flat[o:o + b.numel()].view_as(b))
-        o += b.numel()
+    for m in bns:
+        k = m.running_mean.numel()
+        m.running_mean.copy_(means[o:o + k].view_as(m.running_mean))
+        m.running_var.copy_(vars_[o:o + k].view_as(m.running_var))
+        o += k

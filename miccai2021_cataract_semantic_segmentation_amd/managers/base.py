@@ -111,6 +111,8 @@ class BaseManager:
         self.shard_sampler = None
         if self.world > 1:
             src = self.train_sampler if self.train_sampler is not None else len(self.train_set)
+            if self.train_sampler is not None:
+                D.check_unsharded(self.train_sampler)
             self.shard_sampler = D.ShardedSampler(src, self.rank, self.world, bs, seed=self.config["seed"])
             tl = DataLoader(self.train_set, batch_size=bs, sampler=self.shard_sampler, drop_last=True,
                             num_workers=0 if self.train_sampler is not None else self.config["data"]["num_workers"])

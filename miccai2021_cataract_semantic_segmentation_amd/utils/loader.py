@@ -11,7 +11,7 @@ computes, and remap / flip / reflect-pad / ToTensor / Normalize happen in one ke
 
 ``dataset[i]`` returns ``(img uint8 [H,W,3] RGB, lbl uint8 [H,W] raw CaDIS ids)`` (numpy arrays or tensors; anything after the
 second element is ignored) -- e.g. ``cv2.imread`` + BGR->RGB as datasets/Dataset_from_df.py:36-44 does.  With WORLD_SIZE > 1
-the index stream is sharded by rank (dist.ShardedSampler).  Colour jitter / blur (PIL) are not applied (out of scope).
+the index stream is sharded by rank (dist.ShardedSampler).  blur= / colorjitter= apply BlurPIL / ColorJitter on the GPU (utils/augment.py).
 """
 import queue
 import threading
@@ -38,6 +38,9 @@ class PinnedFrameLoader:
         self.prefetch, self.workers = max(int(prefetch), 1), max(int(workers), 1)
         self.seed, self.epoch, self.rank, self.world = seed, 0, rank, world
         self.sampler, self.shuffle = sampler, shuffle
+        if world > 1 and sampler is not None:
+            from ..dist import check_unsharded
+            check_unsharded(sampler)        # (this loader takes the rank's slice itself)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self._slots = None
 
@@ -99,16 +102,31 @@ class PinnedFrameLoader:
                 for j in range(len(ids)):
                     one(j)
 
+        def put(q, item):                 # bounded queue: never block for good once the consumer has gone away
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
         def producer():
             try:
                 for bi, ids in enumerate(batches):
+                    slot = None
+                    while slot is None and not stop.is_set():
+                        try:
+                            slot = free.get(timeout=0.1)
+                        except queue.Empty:
+                            pass
                     if stop.is_set():
                         return
-                    slot = free.get()
                     fill(slot, ids)
-                    ready.put((slot, len(ids), flips[bi], blurs[bi], jitters[bi]))
+                    if not put(ready, (slot, len(ids), flips[bi], blurs[bi], jitters[bi])):
+                        return
             finally:
-                ready.put(None)
+                put(ready, None)
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
@@ -132,4 +150,12 @@ class PinnedFrameLoader:
                 free.put(slot)
                 yield x, labels
         finally:
+            # the consumer is done or has abandoned the iterator (break / exception): stop the producer and wait for it, so that it
+            # cannot write into the pinned staging slots while the NEXT iteration fills them
             stop.set()
+            while True:
+                try:
+                    ready.get_nowait()
+                except queue.Empty:
+                    break
+            th.join()

@@ -35,7 +35,7 @@ def _worker(rank, world, port, out):
     sizes = [1000, 37, 64, 5000, 3, 129, 2048, 77]
     fp = _FakeFlat(sizes, seed=100 + rank)
     local = fp.grad.clone()
-    sync = D.GradSync(bucket_bytes=8192)
+    sync = D.GradSync(bucket_bytes=8192, tail_bytes=1024)
     assert sync.world == world
     for step in range(2):
         sync.begin(fp)
@@ -48,6 +48,9 @@ def _worker(rank, world, port, out):
             first = fp.grad.clone()
             fp.grad.copy_(local)
     assert len(sync.buckets) > 2
+    # the bucket that is ready last (lowest offsets: it holds parameter 0) is the small tail bucket
+    tail = sync.buckets[sync.bucket_of[id(fp.params[0])]]
+    assert tail[0] == 0 and (tail[1] - tail[0]) * 4 <= 8192 and all((e - s_) * 4 >= 8192 for (s_, e, _) in sync.buckets[1:-1])
     torch.save({"local": local, "reduced": first, "again": fp.grad.clone()}, os.path.join(out, "r%d.pt" % rank))
     idx = list(range(23))
     assert D.shard_indices(idx, rank, world) == idx[rank:22:world]
@@ -66,8 +69,34 @@ def _worker(rank, world, port, out):
     bn.running_mean.fill_(float(rank))
     bn.running_var.fill_(1.0 + rank)
     D.sync_bn_stats(bn)
-    assert torch.allclose(bn.running_mean, torch.full((4,), 0.5)) and torch.allclose(bn.running_var, torch.full((4,), 1.5))
+    # pooled statistics: mean of the means; variance = mean of the variances (1.5) + variance of the means (0.25)
+    assert torch.allclose(bn.running_mean, torch.full((4,), 0.5)) and torch.allclose(bn.running_var, torch.full((4,), 1.75))
     assert int(bn.num_batches_tracked) == 0
+    # only BatchNorm statistics take part: any other floating-point buffer keeps its per-rank value
+    class _M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.bn = torch.nn.BatchNorm2d(2)
+            self.register_buffer("other", torch.full((3,), float(rank)))
+    m = _M()
+    m.bn.running_mean.fill_(2.0 * rank)
+    D.sync_bn_stats(m)
+    assert torch.equal(m.other, torch.full((3,), float(rank))) and torch.allclose(m.bn.running_mean, torch.full((2,), 1.0))
+    # a sampler that already shards itself must not be sharded again (advisor finding, round 2)
+    class _Self(torch.utils.data.Sampler):
+        world = 2
+        def __iter__(self):
+            return iter(range(4))
+        def __len__(self):
+            return 4
+    try:
+        D.ShardedSampler(_Self(), rank, world)
+        raise SystemExit("double sharding was accepted")
+    except ValueError:
+        pass
+    st = sync.stats()
+    assert st["backend"] == "gloo" and st["world_seen_by_backend"] == world and st["buckets"] == len(sync.buckets)
+    assert st["bytes_reduced_per_step"] == fp.grad.numel() * 4 and st["steps"] == 2
     torch.save({"epochs": epochs}, os.path.join(out, "s%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -87,3 +116,64 @@ def test_gradsync_gloo_world2(tmp_path):
     s0, s1 = torch.load(tmp_path / "s0.pt")["epochs"], torch.load(tmp_path / "s1.pt")["epochs"]
     for e0, e1 in zip(s0, s1):
         assert not set(e0) & set(e1) and len(e0) == len(e1) and len(set(e0) | set(e1)) == 20    # disjoint shards of one permutation
+
+
+def _worker8(rank, world, port, out):
+    """ShardedSampler(RepeatFactorSampler) at world 8: every rank draws the SAME epoch stream (private generator, seed 1) and keeps a
+    strided shard: disjoint frames, equal step counts, and the union is the stream truncated to a multiple of world x batch"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib.util
+    import numpy as np
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "miccai2021_cataract_semantic_segmentation_amd", rel))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    D = load("catseg_dist", "dist.py")
+    SM = load("catseg_sampling", os.path.join("utils", "sampling.py"))
+    rs = np.random.RandomState(3)
+    presence = rs.rand(301, 12) < np.linspace(0.02, 0.9, 12)[None, :]
+    presence[:, 0] = True
+    cmap = np.array([0, 1, 2, 3, 4, 5, 6, 7, 7, 8, 9, 9])
+    bs = 3
+    res = {"shards": [], "streams": []}
+    for ep in range(2):
+        rfs = SM.RepeatFactorSampler(presence, cmap, list(range(10)), 0.25)         # rank=0, world=1: unsharded source
+        for _ in range(ep + 1):                                                      # epoch ep of the private generator
+            stream = list(iter(rfs))
+        rfs2 = SM.RepeatFactorSampler(presence, cmap, list(range(10)), 0.25)
+        sh = D.ShardedSampler(rfs2, rank, world, batch_size=bs)
+        for _ in range(ep + 1):
+            shard = list(iter(sh))
+        assert len(shard) == len(stream) // (world * bs) * bs
+        gathered = [None] * world
+        dist.all_gather_object(gathered, shard)
+        streams = [None] * world
+        dist.all_gather_object(streams, stream)
+        assert all(s_ == streams[0] for s_ in streams), "ranks drew different epoch streams"
+        n = len(stream) // (world * bs) * (world * bs)
+        assert all(len(g_) == len(gathered[0]) for g_ in gathered)
+        inter = [v for i in range(n // world) for r in range(world) for v in [gathered[r][i]]]
+        assert inter == stream[:n], "the shards do not interleave to the epoch stream"
+        res["shards"].append(shard)
+    try:
+        D.ShardedSampler(SM.RepeatFactorSampler(presence, cmap, list(range(10)), 0.25, rank=rank, world=world), rank, world)
+        raise SystemExit("double sharding was accepted")
+    except ValueError:
+        pass
+    torch.save(res, os.path.join(out, "w8_%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_sharded_repeat_factor_sampler_gloo_world8(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    shards = [torch.load(tmp_path / ("w8_%d.pt" % r))["shards"] for r in range(8)]
+    assert all(len(sh[0]) == len(shards[0][0]) and len(sh[1]) == len(shards[0][1]) for sh in shards)
+    assert shards[0][0] != shards[0][1]          # a new draw every epoch

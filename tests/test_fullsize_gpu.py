@@ -68,7 +68,7 @@ def test_train_step_fullsize_is_deterministic_and_finite():
     model = OCRNet(dict(bench.MODELS["ocrnet_hrnet48"][0]), 3).to(dev).train()
     crit = TwoScaleLoss({"experiment": 3, "interm": {"name": "LovaszSoftmax", "args": [], "weight": 0.4},
                          "final": {"name": "LovaszSoftmax", "args": [], "weight": 1.0}})
-    img, lbl = bench.synth_batch(4, 544, 960, 25, 1, dev)
+    img, lbl = bench.synth_batch(8, 544, 960, 25, 1, dev)      # the configuration's batch
     state = {k: v.clone() for k, v in model.state_dict().items()}
     outs = []
     for _ in range(2):
