@@ -292,6 +292,10 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
       if (gs == 0) {                             // (afterwards: rolled in under the previous K-step's MFMAs)
 #pragma unroll
         for (int ct = 0; ct < G::CB; ++ct) wread1(0, ct);
+        // the first K-step issues the LDS-DMA of step 2 into slot 0: every wave must hold its fragments of step 0 before that
+        // (in the steady state the barrier that ends a K-step stands between a slot's last fragment read and its refill)
+        DC_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
       }
       xread(0, 0);
 #pragma unroll
@@ -301,6 +305,9 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
           qn = qn + 1 == TSTEPS ? 0 : qn + 1;
         }
         if (s < G::IPT) fetch_item(s);
+#ifdef DC_SGB
+        __builtin_amdgcn_sched_barrier(0);      // (region of the group barriers below: split arithmetic + fragment reads + MFMAs)
+#endif
         if (s >= 2 && s - 2 < G::IPT) convert_item(s - 2);
         const int set = G::XPF ? (s & 1) : 0;
 #ifndef DC_NO_XREAD
@@ -308,7 +315,12 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
 #endif
 #pragma unroll
         for (int ct = 0; ct < G::CB; ++ct) {
+#if !defined(DC_NOFENCE) && !defined(DC_SGB)
           __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef DC_SETPRIO
+          __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
           for (int pt = 0; pt < G::PB; ++pt) {
             f32x4 c = acc[ct][pt];
@@ -321,16 +333,39 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
             acc[ct][pt] = c;
 #ifndef DC_NO_XREAD
             if (!G::XPF && ct == G::CB - 1 && s + 1 < G::NSTEP) {   // single fragment set: refilled behind its last use
+#ifndef DC_SGB
               __builtin_amdgcn_sched_barrier(0);
+#endif
               xread1(s + 1, 0, pt);
             }
 #endif
           }
+#ifdef DC_SETPRIO
+          __builtin_amdgcn_s_setprio(0);
+#endif
+#if !defined(DC_NOFENCE) && !defined(DC_SGB)
           __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifndef DC_NO_WREAD
           wread1((gs + 1) & 1, ct);     // the next step's weight fragments roll in behind the last use of these registers
 #endif
         }
+#ifdef DC_SGB
+        // issue order of the step's region: the pixel-fragment prefetch first, then every MFMA followed by two of the VALU operations
+        // of the split arithmetic (they run in the shadow of the MFMA's own pipe time instead of as a block in front of the MFMAs),
+        // the weight fragments of the next step behind each output-channel tile's last MFMA
+        if (G::XPF && s + 1 < G::NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 3 * G::PB, 0);
+#pragma unroll
+        for (int ct = 0; ct < G::CB; ++ct) {
+#pragma unroll
+          for (int k = 0; k < 6 * G::PB; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         ++gs;
         // the weights of step gs + 1 have landed (the two prefetch loads issued behind their DMA may stay in flight), every LDS
         // read of this step has returned

@@ -943,12 +943,16 @@ __global__ __launch_bounds__(256, 1) void igemm_b3t_kernel(const B3TArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
 
+  // one-dimensional grid over (pixel slab, tile): the blocks that share an XCD (equal blockIdx.x % 8) get a contiguous run of it, so
+  // that all 2 x 26 tiles of a slab run on ONE XCD and re-read the slab's dy / x rows from that XCD's L2 (with the slab index in
+  // blockIdx.z the tiles of a slab were dealt round-robin over the eight XCDs: every L2 fetched every slab, 8x the operand bytes)
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tile_m = swz / p.tilesN, tile_n = swz - tile_m * p.tilesN;
+  const int ntile = p.tilesM * p.tilesN;
+  const int split = swz / ntile, tix = swz - split * ntile;
+  const int tile_m = tix / p.tilesN, tile_n = tix - tile_m * p.tilesN;
   const int m0 = tile_m * 256, n0 = tile_n * 256;
-  const int split = blockIdx.z;
   const int r_begin = split * p.rows_per_split;
   const int r_end = min(r_begin + p.rows_per_split, p.P);
   const int nks = (max(r_end - r_begin, 0) + 15) >> 4;
@@ -1365,6 +1369,8 @@ extern "C" int catseg_conv2d_bwd_data_bf16x3(const catseg_conv_desc* d, const vo
   CS_REQUIRE(d && !d->stem4 && d->groups <= 1 && d->stride == 1 && d->kh * d->kw <= 32, "conv bwd_data bf16x3: stride 1, <= 32 taps, dense");
   CS_REQUIRE(cs_aligned16(dy_planes) && cs_aligned16(wt_planes) && cs_aligned16(dx), "conv bwd_data bf16x3: alignment");
   const int cop = (d->Cout + 7) & ~7;
+  CS_REQUIRE((long long)d->B * d->Ho * d->Wo * cop < (1ll << 31) && (long long)d->Cin * d->kh * d->kw * cop < (1ll << 31),
+             "conv bwd_data bf16x3: 32-bit offsets");
   B3Args a = {};
   a.a = (const u16*)dy_planes; a.lda = cop; a.a_plane = (long long)d->B * d->Ho * d->Wo * cop;
   a.w = (const u16*)wt_planes; a.ldw = d->kh * d->kw * cop; a.w_plane = (long long)d->Cin * a.ldw;
@@ -1537,7 +1543,7 @@ extern "C" int catseg_conv2d_bwd_weight_bf16x3(const catseg_conv_desc* d, const 
   a.ldc = a.N; a.c_split_stride = (long long)a.M * a.N;
   a.C = sp > 1 ? (float*)workspace : dw;
   a.zero = zero_page_b3();
-  hipLaunchKernelGGL(igemm_b3t_kernel, dim3(a.tilesM * a.tilesN, 1, sp), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(igemm_b3t_kernel, dim3(a.tilesM * a.tilesN * sp), dim3(256), 0, st, a);
   CS_LAUNCH_CHECK();
   if (sp > 1) {
     const long long n4 = (long long)a.M * a.N / 4;

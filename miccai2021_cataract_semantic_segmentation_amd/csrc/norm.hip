@@ -430,7 +430,8 @@ extern "C" int catseg_bn_backward(const float* dz, int lddz, const float* z, int
   float* coef = part + (size_t)kMaxRowBlocks * 3 * ((C + 3) & ~3);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma, beta, rows, C, relu, s, part);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
-#ifdef BN_AB_DOUBLE_FINALIZE   // (timing experiment, tools: the finalize launches issued twice -- same results; the added time = their cost in the step)
+#ifdef BN_AB_DOUBLE_FINALIZE   // (TIMING-ONLY build: the finalize launches issued twice; the added time = their cost in the step.  NOT result
+                               //  preserving on the forward side: running_mean / running_var receive the momentum update twice)
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
 #endif
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma,

@@ -608,7 +608,7 @@ class EngineNet(nn.Module):
         """weight images of the direct 3x3 kernels (ops.Dconv3Bank): every eligible layer of the network, one launch per step"""
         fp = self.flat()
         bank = getattr(self, "_d3bank", None)
-        if bank is None or bank.flat is not fp.flat:
+        if bank is None or (bank is not False and bank.flat is not fp.flat):
             ws = []
             for m in self.modules():
                 if (isinstance(m, Conv2d) and not m.stem and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)

@@ -113,8 +113,13 @@ def _b3_wide_1x1(rows, ncols, taps, cred):
     return taps == 1 and min(cred, ncols) >= B3_1X1_MIN_DIM and cred * ncols >= B3_1X1_MIN_PROD and rows >= B3_1X1_MIN_ROWS
 
 
+B3_INDEX_LIMIT = 1 << 31     # the planar bf16x3 kernels index their operand planes with 32-bit element offsets
+
+
 def _b3_eligible(rows, ncols, taps, cred, stride_ok=True):
     if not (PRECISION == "bf16x3" and stride_ok and taps <= 32 and cred % 8 == 0):
+        return False
+    if rows * cred >= B3_INDEX_LIMIT or ncols * taps * cred >= B3_INDEX_LIMIT:      # oversized operands: the fp32 kernels (64-bit addressing)
         return False
     if (B3_MIN_TAPS <= taps and taps * cred >= B3_MIN_K and ncols >= B3_MIN_N
             and ((rows + 255) // 256) * ((ncols + 255) // 256) >= B3_MIN_TILES):
@@ -291,8 +296,7 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
         part = _bn_part_buffer(3 * ((rows + 63) // 64) * Cout, x.device)
         tr, nt = ctypes.c_int(0), ctypes.c_int(0)
     if not stem4 and zero_to == 0 and w_ptr_tensor.dim() == 4 and _d3_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
-        with _Timed("split3", 0.0):
-            wimg = dconv3_weight_image(w_ptr_tensor)
+        wimg = dconv3_weight_image(w_ptr_tensor)
         with _Timed("fwd_d3", flops):
             res = dconv3(x, wimg, bias, out=out, bn_stats=bn_stats)
         return res
@@ -347,8 +351,7 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
         accumulate = False
     flops = 2.0 * rows_of(dy) * Cout * (Cin // groups) * kh * kw
     if w.dim() == 4 and _d3_ok(B * H * W, Cin, Cout, kh, kw, stride, pad, dil, groups):
-        with _Timed("split3", 0.0):
-            wimg = dconv3_weight_image(w, backward_data=True)
+        wimg = dconv3_weight_image(w, backward_data=True)
         with _Timed("dgrad_d3", flops):
             dconv3(dy, wimg, None, out=out, accumulate=accumulate)
         return out
@@ -377,6 +380,7 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
         dwgrad3(x, dy, dw, dbias, flops)
         return dw
     if (groups == 1 and "wgrad" in B3_OPS and not stem4 and PRECISION == "bf16x3" and Cin % 8 == 0 and
+            rows_of(x) * Cin < B3_INDEX_LIMIT and rows_of(dy) * ((Cout + 7) // 8 * 8) < B3_INDEX_LIMIT and
             ((B3_MIN_TAPS <= kh * kw and kh * kw * Cin >= B3_MIN_K and Cout >= B3_MIN_N and rows_of(dy) >= B3_MIN_WGRAD_ROWS)
              or (stride == 1 and _b3_wide_1x1(rows_of(dy), Cout, kh * kw, Cin)))):
         d = make_desc(x.shape, Cin, Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
@@ -749,7 +753,7 @@ def conv_fwd_fused(x, w, bias, residual, relu, Cout, kh, kw, stride=1, pad=0, di
         if per_img < B3_PLANE_LIMIT:
             wp = None
             for b0 in range(0, B, nb):
-                xs, os_ = x[b0:b0 + nb], out[b0:b0 + nb]
+                xs, os_ = (x, out) if nb == B else (x[b0:b0 + nb], out[b0:b0 + nb])    # (x itself: the split-plane cache is keyed by identity)
                 rs = residual[b0:b0 + nb] if residual is not None else None
                 d = make_desc(xs.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
                 with _Timed("split3", 0.0):

@@ -729,3 +729,29 @@ def test_strided_backward_data_parity_classes(ops, case, multi):
     sc = float(ref.abs().max())
     assert float((dx.cpu() - ref).abs().max()) <= 2e-5 * sc + 2e-6
     assert float((acc.cpu() - ref - 0.5).abs().max()) <= 2e-5 * sc + 2e-6
+
+
+def test_fused_inference_convs_share_one_split_of_their_input(ops):
+    """two fused bf16x3 inference convolutions that read the same tensor (ASPP branches, the two OCR head convolutions, UPerNet)
+    split it once: the plane cache is keyed by the tensor's identity (advisor finding, round 2)"""
+    saved = (ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES)
+    calls = []
+    real = ops.split3_blocked
+    try:
+        ops.PRECISION = "bf16x3"
+        ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES = 1, 64, 32, 1
+        ops.split3_blocked = lambda x, with_planar=False: (calls.append(1), real(x, with_planar))[1]
+        g = torch.Generator().manual_seed(2)
+        x = torch.randn(2, 12, 20, 64, generator=g).cuda()
+        outs = []
+        for seed in (1, 2):
+            w = (torch.randn(208, 64, 3, 3, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last)
+            outs.append((w, ops.conv_fwd_fused(x, w, None, None, True, 208, 3, 3, 1, 1, 1)))
+        assert len(calls) == 1, "the shared input was split %d times" % len(calls)
+        for w, y in outs:
+            ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1, 1)).permute(0, 2, 3, 1)
+            close(y, ref, atol=0, rtol=2e-5)
+    finally:
+        ops.split3_blocked = real
+        ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES = saved
+        ops.release_b3_cache()

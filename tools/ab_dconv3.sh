@@ -5,7 +5,6 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/miccai2021_cataract_semantic_segmentation_amd/csrc
 mkdir -p "$R/ab"
-rm -f "$R"/ab/libcatseg_dc_*.so
 for v in ${AB_VARIANTS:-base NO_STASH NO_FETCH NO_DMA NO_SYNC NO_WREAD NO_XREAD NO_STORE ALL}; do
   D=""
   case $v in base) ;; ALL) D="-DDC_NO_STASH -DDC_NO_FETCH -DDC_NO_DMA -DDC_NO_SYNC -DDC_NO_WREAD -DDC_NO_XREAD -DDC_NO_STORE";; *) D="-DDC_$v";; esac

@@ -1,0 +1,33 @@
+"""race screen of the direct 3x3 kernels: the same launch repeated, alone and beside a concurrent stream of other kernels, every output
+compared bit for bit with the first (the kernels are deterministic by construction); dirty LDS / dirty output buffers between runs"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from miccai2021_cataract_semantic_segmentation_amd import ops
+dev = torch.device("cuda")
+side = torch.cuda.Stream()
+bad = 0
+for (B, H, W, C) in [(8, 136, 240, 48), (8, 68, 120, 96), (8, 34, 60, 192), (8, 17, 30, 384), (2, 136, 240, 48), (2, 68, 120, 96)]:
+    x = torch.randn(B, H, W, C, device=dev)
+    w = (torch.randn(C, C, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    big = torch.randn(64, 1024, 1024, device=dev)
+    wimg, wimg_t = ops.dconv3_weight_image(w), ops.dconv3_weight_image(w, backward_data=True)
+    ref, (part, nt, _, cnt) = ops.dconv3(x, wimg, None, bn_stats=True)
+    ref = ref.clone(); refp = part[:3 * nt * C].clone()
+    refd = ops.dconv3(x, wimg_t).clone()
+    dw0 = torch.empty_like(w); ops.dwgrad3(x, ref, dw0)
+    for it in range(60):
+        with torch.cuda.stream(side):
+            if it % 2:
+                big.mul_(1.0001)          # HBM-heavy neighbour
+        y = torch.full_like(x, float("nan"))
+        out, (part, nt, _, cnt) = ops.dconv3(x, wimg, None, out=y, bn_stats=True)
+        d = ops.dconv3(x, wimg_t, out=torch.full_like(x, float("nan")))
+        dw = torch.full_like(w, float("nan")); ops.dwgrad3(x, ref, dw)
+        if not torch.equal(out, ref) or not torch.equal(part[:3 * nt * C], refp) or not torch.equal(d, refd) or not torch.equal(dw, dw0):
+            bad += 1
+            print("MISMATCH", (B, H, W, C), it, float((out - ref).abs().max()), float((d - refd).abs().max()), float((dw - dw0).abs().max()), flush=True)
+    torch.cuda.synchronize()
+    print("shape", (B, H, W, C), "done, mismatches so far", bad, flush=True)
+    ops.release_b3_cache()
+print("RACE SCREEN", "FAILED" if bad else "clean")
