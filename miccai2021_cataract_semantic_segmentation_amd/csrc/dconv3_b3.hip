@@ -474,6 +474,320 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
   }
 }
 
+// ---- wave-specialised variant: 4 compute waves + 4 helper waves per block -------------------------------------------------------
+// In dconv3_b3_kernel every wave issues ~110 other instructions per K-step next to its 36 MFMAs (LDS-DMA, prefetch loads, the
+// split arithmetic, address arithmetic): as many issue cycles as the MFMAs themselves.  Here the helper waves (4 .. 7) do all of
+// that -- weight LDS-DMA, prefetch of the next halo tile, the fp32 -> 3 x bf16 split, the LDS image writes -- and the compute
+// waves (0 .. 3) only read fragments and issue MFMAs (+ the epilogue).  Both roles run the same sequence of block barriers.
+// 16 waves per CU (2 blocks): at most 128 registers per wave, which is why the two roles are separate code paths (no live range of
+// one role overlaps the other's) and the pixel fragments are single-buffered.
+template <class G>
+__global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const DcArgs a) {
+  __shared__ __attribute__((aligned(256))) unsigned char smem[G::LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kg = lane >> 4;
+  const int cob = blockIdx.y;
+  const int ntile = a.B * a.tiles_y * a.tiles_x;
+  int t_begin, t_end;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    t_begin = (int)((long long)v * ntile / nb);
+    t_end = (int)((long long)(v + 1) * ntile / nb);
+  }
+  if (t_begin >= t_end) return;
+  constexpr int TSTEPS = G::NCHUNK * G::NSTEP;
+  const int total = (t_end - t_begin) * TSTEPS;
+  const bool bn = a.bn_part != nullptr;
+
+  if (wave >= G::NW) {
+    // =========================================================== helper role ===========================================================
+    const int hw = wave - G::NW;
+    auto item_px = [&](int i) { return ((hw + i * G::NW) / G::NGB) * 16 + i16; };
+    auto item_g8 = [&](int i) { return ((hw + i * G::NW) % G::NGB) * 4 + kg; };
+    auto item_live = [&](int i) { return hw + i * G::NW < G::NPG * G::NGB && item_px(i) < G::NPX && item_g8(i) < G::NKG; };
+    int it_off[G::IPT], it_hx[G::IPT];
+#pragma unroll
+    for (int i = 0; i < G::IPT; ++i) {
+      const int px = item_px(i);
+      it_hx[i] = px % G::HW - 1;
+      it_off[i] = (((px / G::HW - 1) * a.W + it_hx[i]) * a.ldx + (item_live(i) ? item_g8(i) * 8 : 0)) * 4;
+    }
+    f32x4 pre[G::IPT][2];
+    bf16x8 pl[G::IPT][3];
+    const int img_bytes = ((a.H * a.W - 1) * a.ldx + G::KC) * 4;
+    __amdgpu_buffer_rsrc_t f_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, img_bytes, 0x00020000);
+    int f_x0 = 0, f_org = 0;
+    auto target = [&](int tile, int chunk) {
+      const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+      f_x0 = tx * G::TW;
+      f_org = (ty * G::TH * a.W + f_x0) * a.ldx * 4;
+      f_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)b * a.H * a.W * a.ldx + chunk * G::KC), (short)0, img_bytes, 0x00020000);
+    };
+    auto fetch_item = [&](int i) {
+      const bool okx = (unsigned)(f_x0 + it_hx[i]) < (unsigned)a.W;
+      const int off = okx ? f_org + it_off[i] : (int)0xFFFFFFE0;
+      pre[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rs, off, 0, 0));
+      pre[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rs, off + 16, 0, 0));
+    };
+    auto convert_item = [&](int i) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = pre[i][j >> 2][j & 3];
+        const __bf16 hh = (__bf16)v;
+        const float r1 = v - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        pl[i][0][j] = hh;
+        pl[i][1][j] = mm;
+        pl[i][2][j] = (__bf16)(r1 - (float)mm);
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {       // pin the arithmetic to this K-step
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        v4i t = __builtin_bit_cast(v4i, pl[i][p]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int te = t[e];
+          asm volatile("" : "+v"(te));
+          t[e] = te;
+        }
+        pl[i][p] = __builtin_bit_cast(bf16x8, t);
+      }
+    };
+    auto stash = [&]() {
+#pragma unroll
+      for (int i = 0; i < G::IPT; ++i) {
+        const int px = item_px(i);
+        const int dst = item_g8(i) * G::KGS + ((px / G::HW) * G::RW + px % G::HW) * 16;
+        if (item_live(i)) {
+          *(bf16x8*)(smem + dst) = pl[i][0];
+          *(bf16x8*)(smem + dst + G::XPS) = pl[i][1];
+          *(bf16x8*)(smem + dst + 2 * G::XPS) = pl[i][2];
+        }
+      }
+    };
+    const unsigned char* wsrc = (const unsigned char*)a.wimg + (long long)cob * (G::NCHUNK * G::NSTEP) * G::WSTEP + lane * 16;
+    auto wfill = [&](int q, int slot) {
+      unsigned char* dst = smem + G::XBYTES + slot * G::WSTEP;
+      const unsigned char* src = wsrc + (long long)q * G::WSTEP;
+#pragma unroll
+      for (int i = 0; i < (G::WITEMS + G::NW - 1) / G::NW; ++i) {
+        const int it = hw + i * G::NW;
+        if (it < G::WITEMS) dc_glds16(src + it * 1024, dst + it * 1024);
+      }
+    };
+    target(t_begin, 0);
+#pragma unroll
+    for (int i = 0; i < G::IPT; ++i) fetch_item(i);
+#pragma unroll
+    for (int i = 0; i < G::IPT; ++i) convert_item(i);
+    wfill(0, 0);
+    if (total > 1) wfill(1 % TSTEPS, 1);
+    int gs = 0, qn = 2 % TSTEPS;
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+#pragma unroll 1
+      for (int chunk = 0; chunk < G::NCHUNK; ++chunk) {
+        stash();
+        const bool last_chunk = chunk == G::NCHUNK - 1;
+        const bool have_next = !(last_chunk && tile + 1 == t_end);
+        if (have_next) target(last_chunk ? tile + 1 : tile, last_chunk ? 0 : chunk + 1);
+        DC_WAIT_VM(0);
+        DC_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        if (gs == 0) __builtin_amdgcn_s_barrier();          // (the compute waves hold their fragments of step 0: slot 0 may be refilled)
+#pragma unroll
+        for (int s = 0; s < G::NSTEP; ++s) {
+          if (gs + 2 < total) {
+            wfill(qn, gs & 1);
+            qn = qn + 1 == TSTEPS ? 0 : qn + 1;
+          }
+          if (s < G::IPT) fetch_item(s);
+          if (s >= 2 && s - 2 < G::IPT) convert_item(s - 2);
+          ++gs;
+          if (s < G::IPT) DC_WAIT_VM(2);
+          else DC_WAIT_VM(0);
+          __builtin_amdgcn_s_barrier();
+        }
+      }
+      if (bn) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    return;
+  }
+
+  // ============================================================= compute role =============================================================
+  const int wc = wave / G::WP, wp = wave % G::WP;
+  auto prow = [&](int pt) { return ((wp * G::PB + pt) / G::TPW) * G::PH + i16 / G::PW; };
+  auto pcol = [&](int pt) { return ((wp * G::PB + pt) % G::TPW) * G::PW + i16 % G::PW; };
+  int xb[G::PB];
+#pragma unroll
+  for (int pt = 0; pt < G::PB; ++pt) xb[pt] = kg * G::KGS + (prow(pt) * G::RW + pcol(pt)) * 16;
+  const int wb = kg * (G::NT * 16) + (wc * G::CB * 16 + i16) * 16;
+  bf16x8 xf[G::PB][3], wf[G::CB][3];
+  auto xread1 = [&](const int s, const int pt) {
+    const Unit ua = unit_of(G::KC, s, 0), ub = unit_of(G::KC, s, 1);
+    const int offa = ((ua.tap / 3) * G::RW + ua.tap % 3) * 16, offb = ((ub.tap / 3) * G::RW + ub.tap % 3) * 16;
+    int o;
+    if (s < 9) o = xb[pt] + offa + 2 * ua.win * G::KGS;
+    else o = xb[pt] + (2 * ua.win - (kg & 2)) * G::KGS + (kg >> 1 ? offb : offa);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) xf[pt][p] = *(const bf16x8*)(smem + p * G::XPS + o);
+  };
+  auto wread1 = [&](const int slot, const int ct) {
+    const unsigned char* wbuf = smem + G::XBYTES + slot * G::WSTEP;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) wf[ct][p] = *(const bf16x8*)(wbuf + p * G::WPS + wb + ct * 256);
+  };
+  f32x4 acc[G::CB][G::PB];
+  int gs = 0;
+#pragma unroll 1
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+    const int y0 = ty * G::TH, x0 = tx * G::TW;
+    const long long img0 = (long long)b * a.H * a.W;
+#pragma unroll
+    for (int ct = 0; ct < G::CB; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < G::PB; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int chunk = 0; chunk < G::NCHUNK; ++chunk) {
+      __builtin_amdgcn_s_barrier();
+      if (gs == 0) {
+#pragma unroll
+        for (int ct = 0; ct < G::CB; ++ct) wread1(0, ct);
+        DC_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+      }
+#pragma unroll
+      for (int pt = 0; pt < G::PB; ++pt) xread1(0, pt);
+#pragma unroll
+      for (int s = 0; s < G::NSTEP; ++s) {
+#pragma unroll
+        for (int ct = 0; ct < G::CB; ++ct) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int pt = 0; pt < G::PB; ++pt) {
+            f32x4 c = acc[ct][pt];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][1], xf[pt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[pt][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][2], xf[pt][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[pt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][1], xf[pt][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[pt][0], c, 0, 0, 0);
+            acc[ct][pt] = c;
+            if (ct == G::CB - 1 && s + 1 < G::NSTEP) {     // pixel fragments of the next step behind their last use
+              __builtin_amdgcn_sched_barrier(0);
+              xread1(s + 1, pt);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          wread1((gs + 1) & 1, ct);
+        }
+        ++gs;
+        DC_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------------
+    bool p_ok[G::PB];
+#pragma unroll
+    for (int pt = 0; pt < G::PB; ++pt) p_ok[pt] = y0 + prow(pt) < a.H && x0 + pcol(pt) < a.W;
+    const int co0 = cob * G::NT + wc * G::CB * 16 + 4 * kg;
+#pragma unroll
+    for (int ct = 0; ct < G::CB; ++ct) {
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) bv = *(const f32x4*)(a.bias + co0 + ct * 16);
+#pragma unroll
+      for (int pt = 0; pt < G::PB; ++pt) {
+        acc[ct][pt] += bv;
+        if (p_ok[pt]) {
+          float* dst = a.y + (img0 + (long long)(y0 + prow(pt)) * a.W + x0 + pcol(pt)) * a.ldy + co0 + ct * 16;
+          f32x4 v = acc[ct][pt];
+          if (a.accumulate) v += *(const f32x4*)dst;
+          *(f32x4*)dst = v;
+        }
+      }
+    }
+    if (bn) {
+      float* scr = (float*)smem;
+      const int nvalid = min(G::TH, a.H - y0) * min(G::TW, a.W - x0);
+      const float inv = 1.f / (float)nvalid;
+      const int cl = wc * G::CB * 16 + 4 * kg;
+#pragma unroll
+      for (int ct = 0; ct < G::CB; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = 0.f;
+#pragma unroll
+          for (int pt = 0; pt < G::PB; ++pt) v += p_ok[pt] ? acc[ct][pt][r] : 0.f;
+          v = row16_sum(v);
+          if (i16 == 0) scr[wp * G::NT + cl + ct * 16 + r] = v;
+        }
+      DC_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();
+      float mean[G::CB][4];
+#pragma unroll
+      for (int ct = 0; ct < G::CB; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < G::WP; ++w) v += scr[w * G::NT + cl + ct * 16 + r];
+          mean[ct][r] = v * inv;
+        }
+      DC_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int ct = 0; ct < G::CB; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+          for (int pt = 0; pt < G::PB; ++pt) {
+            const float d = p_ok[pt] ? acc[ct][pt][r] - mean[ct][r] : 0.f;
+            d1 += d;
+            d2 += d * d;
+          }
+          d1 = row16_sum(d1);
+          d2 = row16_sum(d2);
+          if (i16 == 0) {
+            scr[wp * G::NT + cl + ct * 16 + r] = d1;
+            scr[(G::WP + wp) * G::NT + cl + ct * 16 + r] = d2;
+          }
+        }
+      DC_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();
+      if (wp == 0 && i16 == 0) {
+        float* part = a.bn_part + (long long)tile * 3 * G::C + cob * G::NT;
+#pragma unroll
+        for (int ct = 0; ct < G::CB; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < G::WP; ++w) {
+              d1 += scr[w * G::NT + cl + ct * 16 + r];
+              d2 += scr[(G::WP + w) * G::NT + cl + ct * 16 + r];
+            }
+            const int c = cl + ct * 16 + r;
+            part[c] = mean[ct][r];
+            part[G::C + c] = d1;
+            part[2 * G::C + c] = d2;
+          }
+      }
+      if (tid == 0 && cob == 0) a.bn_cnt[tile] = nvalid;
+      DC_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+}
+
 // OHWI fp32 weights [C][3][3][C] -> the kernel's weight image, split into three bf16 planes.
 //   forward:       A[co][k = (tap, c)]  = w[co][tap][c]
 //   backward-data: A[ci][k = (tap, o)]  = w[o][8 - tap][ci]      (dx = conv of dy with the transposed, tap-mirrored bank)
@@ -538,6 +852,8 @@ DcPlan dc_plan(int C) {
 
 int g_dc_blocks = 512;   // persistent blocks per launch: two per CU
 
+int g_dc_spec = 0;       // 1: wave-specialised variant (4 compute + 4 helper waves per block)
+
 template <class G>
 int dc_launch(const DcArgs& a, int C, hipStream_t st) {
   const int ntile = a.B * a.tiles_y * a.tiles_x;
@@ -545,7 +861,8 @@ int dc_launch(const DcArgs& a, int C, hipStream_t st) {
   // 48-channel layer, 56.7 us with 512 blocks against 60.9 us with one block per tile); with fewer tiles per slot the uneven
   // split costs more (544 tiles of the 96-channel layer: 79 us with 512 blocks, 65 us with 544)
   const int nb = ntile > 3 * g_dc_blocks ? g_dc_blocks : ntile;
-  hipLaunchKernelGGL((dconv3_b3_kernel<G>), dim3(nb, C / G::NT), dim3(G::NTHR), 0, st, a);
+  if (g_dc_spec) hipLaunchKernelGGL((dconv3_b3_spec_kernel<G>), dim3(nb, C / G::NT), dim3(2 * G::NTHR), 0, st, a);
+  else hipLaunchKernelGGL((dconv3_b3_kernel<G>), dim3(nb, C / G::NT), dim3(G::NTHR), 0, st, a);
   return 0;
 }
 
@@ -553,6 +870,11 @@ int dc_launch(const DcArgs& a, int C, hipStream_t st) {
 
 extern "C" int catseg_debug_set_dconv3_blocks(int blocks) {
   g_dc_blocks = blocks > 0 ? blocks : 512;
+  return CATSEG_OK;
+}
+
+extern "C" int catseg_debug_set_dconv3_spec(int on) {
+  g_dc_spec = on ? 1 : 0;
   return CATSEG_OK;
 }
 

@@ -37,8 +37,17 @@ CASES = [(2, 16, 32, 48), (1, 19, 37, 48), (2, 5, 7, 48), (1, 1, 50, 48), (3, 33
          (1, 24, 40, 192), (2, 7, 9, 192), (1, 17, 30, 384), (1, 5, 3, 384)]
 
 
+@pytest.fixture(params=[0, 1], ids=["uniform", "specialised"])
+def spec(request):
+    """both variants of the direct kernel: uniform waves, and 4 compute + 4 helper waves per block"""
+    from miccai2021_cataract_semantic_segmentation_amd._lib import lib
+    lib.catseg_debug_set_dconv3_spec(request.param)
+    yield request.param
+    lib.catseg_debug_set_dconv3_spec(0)
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_dconv3_forward_backward_data_vs_fp64(ops, case):
+def test_dconv3_forward_backward_data_vs_fp64(ops, case, spec):
     """error of fp32 size (<= 2e-5 of the output scale, as for the other bf16x3 kernels) on inputs with a wide dynamic range"""
     from miccai2021_cataract_semantic_segmentation_amd._lib import lib
     B, H, W, C = case

@@ -27,7 +27,9 @@ def _close(a, b, atol, rtol):
     assert err <= atol + rtol * np.abs(b).max(), "max abs err %g (scale %g)" % (err, np.abs(b).max())
 
 
-@pytest.mark.parametrize("size", [(64, 96), (96, 160)], ids=["64x96", "96x160"])
+# (one CPU-checkable size here: the same model at the full 544 x 960 under the production plan is tests/test_fullres_gpu.py; a second
+#  small size, 96 x 160, cost 160 s of the GPU suite's budget for the same code paths)
+@pytest.mark.parametrize("size", [(64, 96)], ids=["64x96"])
 def test_ocrnet_hrnet48_bench_model_vs_oracle(size):
     _need_gpu()
     import bench

@@ -11,15 +11,21 @@ for (B, H, W, C) in [(8, 136, 240, 48), (8, 68, 120, 96), (8, 34, 60, 192), (8, 
     x = torch.randn(B, H, W, C, device=dev)
     w = (torch.randn(C, C, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
     big = torch.randn(64, 1024, 1024, device=dev)
+    x2 = torch.randn(8, 68, 120, 96, device=dev)
+    w2 = (torch.randn(96, 96, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    wimg2, y2 = ops.dconv3_weight_image(w2), torch.empty_like(x2)
     wimg, wimg_t = ops.dconv3_weight_image(w), ops.dconv3_weight_image(w, backward_data=True)
     ref, (part, nt, _, cnt) = ops.dconv3(x, wimg, None, bn_stats=True)
     ref = ref.clone(); refp = part[:3 * nt * C].clone()
     refd = ops.dconv3(x, wimg_t).clone()
     dw0 = torch.empty_like(w); ops.dwgrad3(x, ref, dw0)
-    for it in range(60):
+    for it in range(150):
         with torch.cuda.stream(side):
-            if it % 2:
+            if it % 3 == 1:
                 big.mul_(1.0001)          # HBM-heavy neighbour
+            elif it % 3 == 2:             # another direct kernel beside it (the HRNet branches run concurrently in a step)
+                for _ in range(3):
+                    ops.dconv3(x2, wimg2, None, out=y2)
         y = torch.full_like(x, float("nan"))
         out, (part, nt, _, cnt) = ops.dconv3(x, wimg, None, out=y, bn_stats=True)
         d = ops.dconv3(x, wimg_t, out=torch.full_like(x, float("nan")))
