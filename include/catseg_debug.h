@@ -31,7 +31,8 @@ int catseg_debug_set_wgrad_direct(int on);
 
 /* tuning hook: persistent blocks per launch of the direct 3x3 kernel (csrc/dconv3_b3.hip; 0 restores the default 512 = two per CU) */
 int catseg_debug_set_dconv3_blocks(int blocks);
-/* A/B hook: 1 = the wave-specialised variant of the direct 3x3 kernel (4 compute + 4 helper waves per block), 0 = uniform waves */
+/* A/B hook: 1 = the wave-specialised variant of the direct 3x3 kernel (4 compute + 4 helper waves per block), 0 = uniform waves,
+ * -1 (default) = the library's choice per channel count (specialised for 192 / 384 channels) */
 int catseg_debug_set_dconv3_spec(int on);
 /* tuning hook: blocks per launch of the direct backward-weight kernel (csrc/dwgrad3_b3.hip; 0 restores the default 512) */
 int catseg_debug_set_dwgrad3_blocks(int blocks);

@@ -38,8 +38,9 @@ __host__ __device__ constexpr Unit unit_of(int KC, int step, int half) {
 }
 __host__ __device__ constexpr int steps_of(int KC) { return KC == 32 ? 9 : 14; }
 
-template <int C_, int KC_, int NT_, int WC_, int WP_, int PB_, int TPH_, int TPW_, int PH_, int PW_, bool XPF_>
+template <int C_, int KC_, int NT_, int WC_, int WP_, int PB_, int TPH_, int TPW_, int PH_, int PW_, bool XPF_, bool SPEC_ = false>
 struct DcCfg {
+  static constexpr bool SPEC = SPEC_;                     // default variant: 4 compute + 4 helper waves per block (dconv3_b3_spec_kernel)
   static constexpr bool XPF = XPF_;                       // pixel fragments of step t + 1 read under the MFMAs of step t
   static constexpr int C = C_, KC = KC_, NT = NT_, WC = WC_, WP = WP_, PB = PB_, TPH = TPH_, TPW = TPW_, PH = PH_, PW = PW_;
   static_assert(KC == 32 || KC == 48, "channel chunk");
@@ -837,8 +838,8 @@ __global__ __launch_bounds__(256) void dconv3_prep_batch_kernel(const float* __r
 using Cfg48 = DcCfg<48, 48, 48, 1, 4, 2, 8, 1, 1, 16, true>;    // tile  8 x 16, wave = 48 co x 32 px
 using Cfg96 = DcCfg<96, 32, 96, 2, 2, 4, 4, 2, 1, 16, false>;    // tile  4 x 32, wave = 48 co x 64 px
 
-using Cfg192 = DcCfg<192, 32, 96, 2, 2, 2, 2, 2, 1, 16, true>;  // tile 2 x 32, wave = 48 co x 32 px, two co blocks
-using Cfg384 = DcCfg<384, 32, 96, 2, 2, 2, 2, 2, 1, 16, true>;  // the same tile, four co blocks
+using Cfg192 = DcCfg<192, 32, 96, 2, 2, 2, 2, 2, 1, 16, true, true>;  // tile 2 x 32, wave = 48 co x 32 px, two co blocks; specialised waves
+using Cfg384 = DcCfg<384, 32, 96, 2, 2, 2, 2, 2, 1, 16, true, true>;  // the same tile, four co blocks
 
 struct DcPlan { int kind, KC, NT, TH, TW; };
 
@@ -852,7 +853,7 @@ DcPlan dc_plan(int C) {
 
 int g_dc_blocks = 512;   // persistent blocks per launch: two per CU
 
-int g_dc_spec = 0;       // 1: wave-specialised variant (4 compute + 4 helper waves per block)
+int g_dc_spec = -1;      // -1: per configuration (Cfg::SPEC), 0 / 1: force the uniform / the wave-specialised kernel
 
 template <class G>
 int dc_launch(const DcArgs& a, int C, hipStream_t st) {
@@ -861,7 +862,9 @@ int dc_launch(const DcArgs& a, int C, hipStream_t st) {
   // 48-channel layer, 56.7 us with 512 blocks against 60.9 us with one block per tile); with fewer tiles per slot the uneven
   // split costs more (544 tiles of the 96-channel layer: 79 us with 512 blocks, 65 us with 544)
   const int nb = ntile > 3 * g_dc_blocks ? g_dc_blocks : ntile;
-  if (g_dc_spec) hipLaunchKernelGGL((dconv3_b3_spec_kernel<G>), dim3(nb, C / G::NT), dim3(2 * G::NTHR), 0, st, a);
+  // specialised waves: 192 / 384 channels 82 -> 73 us, 90 -> 79 us; 48 channels 65 -> 70 us (its helper waves carry six staging items per
+  // 14-step tile and the role needs 9 spilled registers), 96 channels: the 48 x 64 wave tile does not fit 128 registers
+  if (g_dc_spec < 0 ? G::SPEC : g_dc_spec != 0) hipLaunchKernelGGL((dconv3_b3_spec_kernel<G>), dim3(nb, C / G::NT), dim3(2 * G::NTHR), 0, st, a);
   else hipLaunchKernelGGL((dconv3_b3_kernel<G>), dim3(nb, C / G::NT), dim3(G::NTHR), 0, st, a);
   return 0;
 }
@@ -874,7 +877,7 @@ extern "C" int catseg_debug_set_dconv3_blocks(int blocks) {
 }
 
 extern "C" int catseg_debug_set_dconv3_spec(int on) {
-  g_dc_spec = on ? 1 : 0;
+  g_dc_spec = on < 0 ? -1 : (on ? 1 : 0);
   return CATSEG_OK;
 }
 

@@ -144,25 +144,24 @@ class HighResolutionModule(nn.Module):
     def run(self, cx, xs):
         if self.num_branches == 1:
             return [_run_seq(cx, self.branches[0], xs[0])]
-        # the branches are independent until the fuse layers: one HIP stream each (engine.Ctx.parallel)
+        # The branches are independent until the fuse layers: one HIP stream each (engine.Ctx.parallel).  The fuse chains
+        # (models/HRNetv2.py:237-261: out_i = relu(sum_j f_ij(x_j)); 12 independent chains f_ij) run grouped by their SOURCE branch j ON
+        # THAT BRANCH'S STREAM, right behind the branch: chain f_ij needs nothing but x_j, so the region joins only once per module
+        # (a join + fork between branches and fuse chains cost one cross-stream hand-over more: 252 -> ~130 idle gaps of ~24 us per
+        # step); the gradient of x_j is accumulated by one stream, in a fixed order.  The sums follow on the main stream.
         xs = list(xs)
-        with cx.parallel(xs[0].device, self.num_branches) as par:
-            for i in range(self.num_branches):
-                with par.branch(i):
-                    xs[i] = _run_seq(cx, self.branches[i], xs[i])
-        # fuse (models/HRNetv2.py:237-261): out_i = relu(sum_j f_ij(x_j)).  The 12 chains f_ij are independent; they run grouped by
-        # their SOURCE branch j, one stream per j (the gradient of x_j is then accumulated by one stream, in a fixed order);
-        # the sums follow on the main stream
         n_out = len(self.fuse_layers)
         terms = [[None] * self.num_branches for _ in range(n_out)]
+        shapes = [tuple(x.shape) for x in xs]       # (branch outputs keep their input's spatial size)
         with cx.parallel(xs[0].device, self.num_branches) as par:
             for j in range(self.num_branches):
                 with par.branch(j):
+                    xs[j] = _run_seq(cx, self.branches[j], xs[j])
                     for i in range(n_out):
                         if j == i:
                             continue
                         t = _run_seq(cx, self.fuse_layers[i][j], xs[j])
-                        terms[i][j] = bilinear(cx, t, xs[i].shape[1], xs[i].shape[2], False) if j > i else t
+                        terms[i][j] = bilinear(cx, t, shapes[i][1], shapes[i][2], False) if j > i else t
         outs = []
         for i in range(n_out):
             terms[i][i] = xs[i]

@@ -52,6 +52,9 @@ for (B, H, W, C) in SHAPES:
         t_s = timed(lambda: ops.dconv3(x, wimg, None, out=y, bn_stats=True), reps)
         t_sd = timed(lambda: ops.dconv3(x, wimg_t, None, out=y), reps)
         lib.catseg_debug_set_dconv3_spec(0)
+        t_d = timed(lambda: ops.dconv3(x, wimg, None, out=y, bn_stats=True), reps)
+        t_dd = timed(lambda: ops.dconv3(x, wimg_t, None, out=y), reps)
+        lib.catseg_debug_set_dconv3_spec(-1)
         line += "  | SPEC fwd %7.1f us %6.1f TF  dgrad %7.1f us %6.1f TF" % (t_s, gf / t_s * 1e3, t_sd, gf / t_sd * 1e3)
         t_prep = timed(lambda: lib.catseg_dconv3_prep(w.data_ptr(), C, 0, wimg.data_ptr(), torch.cuda.current_stream().cuda_stream), reps)
         line += "  | direct fwd %7.1f us %6.1f TF  dgrad %7.1f us %6.1f TF  prep %5.1f us" % (t_d, gf / t_d * 1e3, t_dd, gf / t_dd * 1e3, t_prep)
