@@ -224,22 +224,28 @@ __global__ __launch_bounds__(G::NTHR, 2) void dwgrad3_b3_kernel(const WgArgs a) 
     }
 }
 
-// dw = sum over the slabs, in a fixed order: 16 float4 columns x 16 slab lanes per block, tree over the lanes
+// dw = sum over the slabs, in a fixed order: 64 float4 columns (1 KB contiguous per slab row) x 4 slab lanes per block, each lane adds
+// every 4th slab with four independent load chains, fixed-order combine over the lanes
 __global__ __launch_bounds__(256) void dwgrad3_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long long n4, int splits,
                                                              long long slab_stride4) {
-  __shared__ f32x4 sh[16][17];
-  const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const long long col = (long long)blockIdx.x * 16 + c;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (col < n4)
-    for (int k = sl; k < splits; k += 16) s += ((const f32x4*)slabs)[k * slab_stride4 + col];
-  sh[sl][c] = s;
-  __syncthreads();
-  for (int st = 8; st >= 1; st >>= 1) {
-    if (sl < st) sh[sl][c] += sh[sl + st][c];
-    __syncthreads();
+  __shared__ f32x4 sh[4][64];
+  const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long long col = (long long)blockIdx.x * 64 + c;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  if (col < n4) {
+    const f32x4* p = (const f32x4*)slabs + col;
+    int k = sl;
+    for (; k + 12 < splits; k += 16) {
+      s0 += p[(long long)k * slab_stride4];
+      s1 += p[(long long)(k + 4) * slab_stride4];
+      s2 += p[(long long)(k + 8) * slab_stride4];
+      s3 += p[(long long)(k + 12) * slab_stride4];
+    }
+    for (; k < splits; k += 4) s0 += p[(long long)k * slab_stride4];
   }
-  if (sl == 0 && col < n4) ((f32x4*)dw)[col] = sh[0][c];
+  sh[sl][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && col < n4) ((f32x4*)dw)[col] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
 }
 
 using Wg48 = WgCfg<48, 48, 3, 1, 4>;   // one block: all 48 x 432 accumulators (wave = 48 co x 7 of the 27 (tap, ci) tiles)
@@ -300,7 +306,7 @@ extern "C" int catseg_dwgrad3(int B, int H, int W, int C, const float* x, int ld
   if (p.kind == 1) hipLaunchKernelGGL((dwgrad3_b3_kernel<Wg48>), dim3(p.splits, p.variants), dim3(Wg48::NTHR), 0, st, a);
   else hipLaunchKernelGGL((dwgrad3_b3_kernel<Wg96>), dim3(p.splits, p.variants), dim3(Wg96::NTHR), 0, st, a);
   const long long n4 = wel / 4;
-  hipLaunchKernelGGL(dwgrad3_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float*)workspace, dw, n4, p.splits, n4);
+  hipLaunchKernelGGL(dwgrad3_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, (const float*)workspace, dw, n4, p.splits, n4);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
