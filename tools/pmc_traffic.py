@@ -22,6 +22,12 @@ def group(name):
         return "b3w"            # bf16x3 forward AND backward-data (one kernel serves both)
     if "igemm_b3t_kernel" in name or "b3_reduce_slabs" in name:
         return "wgrad_b3"
+    if "dconv3_b3" in name:
+        return "d3"             # direct 3x3 forward / backward-data of the HRNet trunk (dconv3_b3_kernel, dconv3_b3_spec_kernel)
+    if "dwgrad3" in name:
+        return "wgrad_d3"       # direct backward-weight + its slab reduction
+    if "dconv3_prep" in name:
+        return "d3_prep"
     if "split3" in name:
         return "split3"
     if "wgrad_direct_kernel" in name or "reduce_slabs" in name or "colsum_" in name:

@@ -12,18 +12,18 @@ mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 for m in ocrnet_hrnet48 ocrnet_r50 deeplabv3plus_r50; do
   if [ "$m" != "deeplabv3plus_r50" ]; then
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch_$m" -- python3 "$R/bench.py" --model $m --steps 1 --warmup 1 --no-roofline --no-cpu-baseline > "$O/pmc_fetch_$m.log" 2>&1
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write_$m" -- python3 "$R/bench.py" --model $m --steps 1 --warmup 1 --no-roofline --no-cpu-baseline > "$O/pmc_write_$m.log" 2>&1
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch_$m" -- python3 "$R/bench.py" --model $m --steps 1 --warmup 1 --no-roofline --no-cpu-baseline --no-side-figures > "$O/pmc_fetch_$m.log" 2>&1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write_$m" -- python3 "$R/bench.py" --model $m --steps 1 --warmup 1 --no-roofline --no-cpu-baseline --no-side-figures > "$O/pmc_write_$m.log" 2>&1
     python3 "$R/tools/pmc_traffic.py" "$O/pmc_fetch_$m" "$O/pmc_write_$m" $m > "$O/pmc_traffic_$m.json"
-    mkdir -p "$R/profiles" && cp "$O/pmc_traffic_$m.json" "$R/profiles/r02_pmc_traffic_$m.json"     # bench.py reads it for roofline.traffic
+    mkdir -p "$R/profiles" && cp "$O/pmc_traffic_$m.json" "$R/profiles/r03_pmc_traffic_$m.json"     # bench.py reads it for roofline.traffic
     rm -rf "$O"/pmc_fetch_$m "$O"/pmc_write_$m
   fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$m" -o p -- python3 "$R/bench.py" --model $m --steps 3 --warmup 1 --no-cpu-baseline > "$O/bench_prof_$m.json" 2> "$O/bench_prof_$m.err"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$m" -o p -- python3 "$R/bench.py" --model $m --steps 3 --warmup 1 --no-cpu-baseline --no-side-figures > "$O/bench_prof_$m.json" 2> "$O/bench_prof_$m.err"
   cp $(ls "$O"/prof_$m/*/p_kernel_stats.csv "$O"/prof_$m/p_kernel_stats.csv 2>/dev/null | head -1) "$O/kernel_stats_$m.csv"
   rm -rf "$O/prof_$m"
   if [ "$m" = "ocrnet_hrnet48" ]; then
     python3 "$R/bench.py" --model $m --steps 20 --warmup 5 > "$O/bench_$m.json" 2> "$O/bench_$m.err"
-    CATSEG_PRECISION=fp32 python3 "$R/bench.py" --model $m --steps 10 --warmup 3 --no-cpu-baseline > "$O/bench_${m}_fp32only.json" 2> /dev/null
+    CATSEG_PRECISION=fp32 python3 "$R/bench.py" --model $m --steps 10 --warmup 3 --no-cpu-baseline --no-side-figures > "$O/bench_${m}_fp32only.json" 2> /dev/null
   else
     python3 "$R/bench.py" --model $m --steps 10 --warmup 3 --no-cpu-baseline > "$O/bench_$m.json" 2> "$O/bench_$m.err"
   fi
