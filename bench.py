@@ -80,9 +80,10 @@ def cpu_baseline(H, W, K, model_name, threads=0):
     from oracle.state import fill_state, spec_of
     from miccai2021_cataract_semantic_segmentation_amd.models import DeepLabv3Plus, OCRNet
     cpu_model, physical, avail = host_cpu_info()
-    # threads: --cpu-threads, default = every physical core this process may use; the 32 / 64 / 128-thread sweep of this
-    # step on the GPU box's host is committed as profiles/r03_cpu_thread_sweep.json (tools/cpu_thread_sweep.py)
-    cores = max(1, min(avail, threads if threads > 0 else physical))
+    # threads: --cpu-threads; default 32.  The sweep of this very step on the GPU box's host (128-core EPYC 9575F, tools/cpu_thread_sweep.py,
+    # profiles/r03_cpu_thread_sweep.json): 16 threads 0.260 frames/s, 32: 0.249, 48: 0.160, 64: 0.129, 128 (all physical cores): 0.052 --
+    # beyond 32 threads the oracle's torch CPU ops (sort, BatchNorm, small convolutions) get SLOWER, so all cores would understate the CPU
+    cores = max(1, min(avail, physical, threads if threads > 0 else 32))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     deeplab = IS_DEEPLAB(model_name)
@@ -232,7 +233,8 @@ def main():
                     help="BASELINE config 5 instead: EncDec(ResNeXt101_32x8d + UPerNet) inference at 3x1080x1920, 4 frames per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all physical cores available to the process)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = 32: the fastest region of the committed sweep, "
+                                                                 "profiles/r03_cpu_thread_sweep.json; all 128 cores are 5x slower)")
     ap.add_argument("--no-side-figures", action="store_true",
                     help="skip the side figures measured after the timed region (exact-fp32 arithmetic, unpadded 540x960 frames, through the uint8 loader)")
     ap.add_argument("--with-h2d", action="store_true",

@@ -61,6 +61,7 @@ _SIGS = {
     "catseg_debug_set_b3_tile": (I, [I]),
     "catseg_debug_set_dconv3_blocks": (I, [I]),
     "catseg_debug_set_dconv3_spec": (I, [I]),
+    "catseg_debug_set_dconv3_alt96": (I, [I]),
     "catseg_aug_pad_flip_u8": (I, [P, P, I, I, I, I, P, I, I, P]),
     "catseg_aug_box_blur": (I, [P, P, I, I, I, I, P, P, P, P]),
     "catseg_aug_color_op": (I, [P, I, I, I, P, P, P, SZ, P]),

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void dwgrad3_reduce_kernel(const float* __rest
 }
 
 using Wg48 = WgCfg<48, 48, 3, 1, 4>;   // one block: all 48 x 432 accumulators (wave = 48 co x 7 of the 27 (tap, ci) tiles)
+using Wg64 = WgCfg<64, 64, 1, 1, 4>;   // 64 x 64 (stage-1 bottlenecks): block = 64 co x (one filter row x 64 ci)
 using Wg96 = WgCfg<96, 48, 1, 2, 2>;   // block = 96 co x (one filter row x 48 ci); variants over (co tile, ci chunk, filter row)
 
 int g_wg_blocks = 512;
@@ -258,6 +259,7 @@ struct WgPlan { int kind, variants, splits; };
 WgPlan wg_plan(int C, int B, int H, int W) {
   WgPlan p = {0, 0, 0};
   if (C == 48) { p.kind = 1; p.variants = 1; }
+  else if (C == 64) { p.kind = 3; p.variants = 3; }
   else if (C == 96 || C == 192 || C == 384) { p.kind = 2; p.variants = (C / 96) * (C / 48) * 3; }
   else return p;
   const int ntile = B * ((H + 3) / 4) * ((W + 15) / 16);
@@ -275,7 +277,7 @@ extern "C" int catseg_debug_set_dwgrad3_blocks(int blocks) {
   return CATSEG_OK;
 }
 
-extern "C" int catseg_dwgrad3_supported(int C) { return C == 48 || C == 96 || C == 192 || C == 384; }
+extern "C" int catseg_dwgrad3_supported(int C) { return C == 48 || C == 64 || C == 96 || C == 192 || C == 384; }
 
 extern "C" size_t catseg_dwgrad3_workspace(int B, int H, int W, int C) {
   const WgPlan p = wg_plan(C, B, H, W);
@@ -304,6 +306,7 @@ extern "C" int catseg_dwgrad3(int B, int H, int W, int C, const float* x, int ld
   a.slab_stride = wel;
   hipStream_t st = (hipStream_t)stream;
   if (p.kind == 1) hipLaunchKernelGGL((dwgrad3_b3_kernel<Wg48>), dim3(p.splits, p.variants), dim3(Wg48::NTHR), 0, st, a);
+  else if (p.kind == 3) hipLaunchKernelGGL((dwgrad3_b3_kernel<Wg64>), dim3(p.splits, p.variants), dim3(Wg64::NTHR), 0, st, a);
   else hipLaunchKernelGGL((dwgrad3_b3_kernel<Wg96>), dim3(p.splits, p.variants), dim3(Wg96::NTHR), 0, st, a);
   const long long n4 = wel / 4;
   hipLaunchKernelGGL(dwgrad3_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, (const float*)workspace, dw, n4, p.splits, n4);

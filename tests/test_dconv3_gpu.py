@@ -34,7 +34,7 @@ def close(a, b, rtol):
 # B, H, W, C: tile-aligned, ragged in both directions, smaller than one tile, one pixel row / column
 CASES = [(2, 16, 32, 48), (1, 19, 37, 48), (2, 5, 7, 48), (1, 1, 50, 48), (3, 33, 1, 48),
          (2, 8, 64, 96), (1, 19, 37, 96), (2, 3, 5, 96), (1, 1, 70, 96), (2, 41, 2, 96),
-         (1, 24, 40, 192), (2, 7, 9, 192), (1, 17, 30, 384), (1, 5, 3, 384)]
+         (1, 24, 40, 192), (2, 7, 9, 192), (1, 17, 30, 384), (1, 5, 3, 384), (2, 16, 32, 64), (1, 19, 37, 64)]
 
 
 @pytest.fixture(params=[0, 1], ids=["uniform", "specialised"])
@@ -149,7 +149,7 @@ def test_batched_weight_images_equal_single_prep(ops):
 
 
 WG_CASES = [(2, 8, 32, 48), (1, 19, 37, 48), (3, 5, 7, 48), (1, 1, 50, 48), (2, 33, 1, 48),
-            (2, 8, 32, 96), (1, 19, 37, 96), (2, 3, 5, 96), (1, 11, 21, 192), (1, 17, 30, 384)]
+            (2, 8, 32, 96), (1, 19, 37, 96), (2, 3, 5, 96), (1, 11, 21, 192), (1, 17, 30, 384), (2, 8, 32, 64), (1, 19, 37, 64)]
 
 
 @pytest.mark.parametrize("case", WG_CASES)

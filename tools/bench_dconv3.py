@@ -9,7 +9,7 @@ from miccai2021_cataract_semantic_segmentation_amd._lib import lib
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = torch.device("cuda")
-SHAPES = [(8, 136, 240, 48), (8, 68, 120, 96), (8, 34, 60, 192), (8, 17, 30, 384)]
+SHAPES = [(8, 136, 240, 48), (8, 68, 120, 96), (8, 34, 60, 192), (8, 17, 30, 384), (8, 136, 240, 64)]
 
 
 def timed(fn, n):
@@ -56,6 +56,12 @@ for (B, H, W, C) in SHAPES:
         t_dd = timed(lambda: ops.dconv3(x, wimg_t, None, out=y), reps)
         lib.catseg_debug_set_dconv3_spec(-1)
         line += "  | SPEC fwd %7.1f us %6.1f TF  dgrad %7.1f us %6.1f TF" % (t_s, gf / t_s * 1e3, t_sd, gf / t_sd * 1e3)
+        if C == 96:
+            lib.catseg_debug_set_dconv3_alt96(1)
+            t_a = timed(lambda: ops.dconv3(x, wimg, None, out=y, bn_stats=True), reps)
+            t_ad = timed(lambda: ops.dconv3(x, wimg_t, None, out=y), reps)
+            lib.catseg_debug_set_dconv3_alt96(0)
+            line += "  | ALT96 fwd %7.1f us dgrad %7.1f us" % (t_a, t_ad)
         t_prep = timed(lambda: lib.catseg_dconv3_prep(w.data_ptr(), C, 0, wimg.data_ptr(), torch.cuda.current_stream().cuda_stream), reps)
         line += "  | direct fwd %7.1f us %6.1f TF  dgrad %7.1f us %6.1f TF  prep %5.1f us" % (t_d, gf / t_d * 1e3, t_dd, gf / t_dd * 1e3, t_prep)
     print(line, flush=True)
