@@ -34,7 +34,7 @@ int catseg_debug_set_dconv3_blocks(int blocks);
 /* A/B hook: 1 = the wave-specialised variant of the direct 3x3 kernel (4 compute + 4 helper waves per block), 0 = uniform waves,
  * -1 (default) = the library's choice per channel count (specialised for 192 / 384 channels) */
 int catseg_debug_set_dconv3_spec(int on);
-/* A/B hook: 1 = 96-channel layers on 4 x 16-pixel tiles with specialised waves instead of 4 x 32 tiles with uniform waves */
+/* A/B hook: 1 = 96-channel layers on 4 x 32-pixel tiles with uniform waves instead of the default 4 x 16 tiles with specialised waves */
 int catseg_debug_set_dconv3_alt96(int on);
 /* tuning hook: blocks per launch of the direct backward-weight kernel (csrc/dwgrad3_b3.hip; 0 restores the default 512) */
 int catseg_debug_set_dwgrad3_blocks(int blocks);

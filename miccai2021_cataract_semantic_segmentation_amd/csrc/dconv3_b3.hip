@@ -837,9 +837,9 @@ __global__ __launch_bounds__(256) void dconv3_prep_batch_kernel(const float* __r
 //                     C  KC  NT WC WP PB TPH TPW PH PW  XPF
 using Cfg48 = DcCfg<48, 48, 48, 1, 4, 2, 8, 1, 1, 16, true>;    // tile  8 x 16, wave = 48 co x 32 px
 using Cfg64 = DcCfg<64, 32, 64, 1, 4, 2, 8, 1, 1, 16, true>;    // tile  8 x 16, wave = 64 co x 32 px (the stage-1 bottlenecks' 3x3)
-using Cfg96 = DcCfg<96, 32, 96, 2, 2, 4, 4, 2, 1, 16, false>;    // tile  4 x 32, wave = 48 co x 64 px
+using Cfg96 = DcCfg<96, 32, 96, 2, 2, 4, 4, 2, 1, 16, false>;    // tile  4 x 32, wave = 48 co x 64 px (A/B alternative)
 
-using Cfg96s = DcCfg<96, 32, 96, 2, 2, 2, 4, 1, 1, 16, true, true>;   // A/B: tile 4 x 16, wave = 48 co x 32 px, specialised waves
+using Cfg96s = DcCfg<96, 32, 96, 2, 2, 2, 4, 1, 1, 16, true, true>;   // tile 4 x 16, wave = 48 co x 32 px, specialised waves (the default for 96)
 using Cfg192 = DcCfg<192, 32, 96, 2, 2, 2, 2, 2, 1, 16, true, true>;  // tile 2 x 32, wave = 48 co x 32 px, two co blocks; specialised waves
 using Cfg384 = DcCfg<384, 32, 96, 2, 2, 2, 2, 2, 1, 16, true, true>;  // the same tile, four co blocks
 
@@ -849,8 +849,8 @@ extern int g_dc_alt96;
 DcPlan dc_plan(int C) {
   if (C == 48) return {1, Cfg48::KC, Cfg48::NT, Cfg48::TH, Cfg48::TW};
   if (C == 64) return {5, Cfg64::KC, Cfg64::NT, Cfg64::TH, Cfg64::TW};
-  if (C == 96 && g_dc_alt96) return {6, Cfg96s::KC, Cfg96s::NT, Cfg96s::TH, Cfg96s::TW};
-  if (C == 96) return {2, Cfg96::KC, Cfg96::NT, Cfg96::TH, Cfg96::TW};
+  if (C == 96 && g_dc_alt96) return {2, Cfg96::KC, Cfg96::NT, Cfg96::TH, Cfg96::TW};
+  if (C == 96) return {6, Cfg96s::KC, Cfg96s::NT, Cfg96s::TH, Cfg96s::TW};     // 65 / 62 us against 71 / 68 us for the 4 x 32 tile with uniform waves
   if (C == 192) return {3, Cfg192::KC, Cfg192::NT, Cfg192::TH, Cfg192::TW};
   if (C == 384) return {4, Cfg384::KC, Cfg384::NT, Cfg384::TH, Cfg384::TW};
   return {0, 0, 0, 0, 0};
@@ -858,7 +858,7 @@ DcPlan dc_plan(int C) {
 
 int g_dc_blocks = 512;   // persistent blocks per launch: two per CU
 
-int g_dc_alt96 = 0;      // A/B: 1 = the 4 x 16-pixel specialised configuration for 96 channels
+int g_dc_alt96 = 0;      // A/B: 1 = the 4 x 32-pixel configuration with uniform waves for 96 channels (default: 4 x 16, specialised waves)
 int g_dc_spec = -1;      // -1: per configuration (Cfg::SPEC), 0 / 1: force the uniform / the wave-specialised kernel
 
 template <class G>

@@ -61,7 +61,7 @@ for (B, H, W, C) in SHAPES:
             t_a = timed(lambda: ops.dconv3(x, wimg, None, out=y, bn_stats=True), reps)
             t_ad = timed(lambda: ops.dconv3(x, wimg_t, None, out=y), reps)
             lib.catseg_debug_set_dconv3_alt96(0)
-            line += "  | ALT96 fwd %7.1f us dgrad %7.1f us" % (t_a, t_ad)
+            line += "  | 4x32-uniform fwd %7.1f us dgrad %7.1f us" % (t_a, t_ad)
         t_prep = timed(lambda: lib.catseg_dconv3_prep(w.data_ptr(), C, 0, wimg.data_ptr(), torch.cuda.current_stream().cuda_stream), reps)
         line += "  | direct fwd %7.1f us %6.1f TF  dgrad %7.1f us %6.1f TF  prep %5.1f us" % (t_d, gf / t_d * 1e3, t_dd, gf / t_dd * 1e3, t_prep)
     print(line, flush=True)
