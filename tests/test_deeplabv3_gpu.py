@@ -75,10 +75,17 @@ def test_deeplabv3_matches_reference_fixture(golden):
             P = dict(model.named_parameters())
             norms = np.array([float(P[k].grad.double().norm()) for k in names])
             np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-2, atol=1e-7)
-            for i in (2, 3, 4):   # dilated branches: filter gradients tap by tap (d = 12, 24, 36)
+            # dilated branches: filter gradients tap by tap (d = 12, 24, 36).  The Lovasz gradient is a function of the RANK of
+            # every pixel's error and BatchNorm here normalises over 2 x 38 x 40 values, so rounding-level differences in the
+            # logits move these entries by ~1 %: the exact-fp32 kernels measure 0.6 - 1.0 % of max (0.5 - 0.7 % L2) against
+            # the CPU fixture, the split-precision ones 0.8 - 2.1 % (tools/diag_deeplab_grad.py prints both); the bound is
+            # twice the worst of those, and a wrong tap (a whole entry missing or misplaced) is ~100 %
+            for i in (2, 3, 4):
                 ref = g["g:aspp.aspp%d.weight[0:2]" % i]
                 got = P["aspp.aspp%d.weight" % i].grad[0:2].cpu().numpy()
-                assert np.abs(got - ref).max() <= 2e-2 * np.abs(ref).max(), (i, np.abs(got - ref).max(), np.abs(ref).max())
+                assert np.abs(got - ref).max() <= 4e-2 * np.abs(ref).max(), (i, np.abs(got - ref).max(), np.abs(ref).max())
+                l2 = np.linalg.norm((got - ref).ravel().astype(np.float64)) / np.linalg.norm(ref.ravel().astype(np.float64))
+                assert l2 <= 3e-2, (i, l2)
             sd = model.state_dict()
             for k in g.files:
                 if k.startswith("rs:"):
