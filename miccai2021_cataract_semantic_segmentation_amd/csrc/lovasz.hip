@@ -64,13 +64,62 @@ size_t lv_layout(long long P, int K, char* base, LvWs* w) {
   return off;
 }
 
-// ---- stage a block of PIX pixels x K logits into LDS (coalesced), row stride KS (odd)
+// ---- stage a block of PIX pixels x K logits into LDS, row stride KS (odd).  The block's span starts at p0 * K floats with
+// p0 a multiple of PIX, so it is 16-byte aligned whenever the tensor is: 16-byte global accesses (a scalar dword per lane
+// moves ~1/4 of the bytes per request), one integer division per four elements instead of one each.
 __device__ __forceinline__ void stage_rows(const float* __restrict__ logits, long long p0, int np, int K, int KS, float* sh) {
   const int n = np * K;
   const float* src = logits + p0 * K;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  int done = 0;
+  if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    const int n4 = n >> 2;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    for (int i4 = threadIdx.x; i4 < n4; i4 += blockDim.x) {
+      const float4 v = s4[i4];
+      const float e[4] = {v.x, v.y, v.z, v.w};
+      int r = (4 * i4) / K, c = 4 * i4 - r * K;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sh[r * KS + c] = e[u];
+        if (++c == K) { c = 0; ++r; }
+      }
+    }
+    done = n4 << 2;
+  }
+  for (int i = done + threadIdx.x; i < n; i += blockDim.x) {
     const int r = i / K, c = i - r * K;
     sh[r * KS + c] = src[i];
+  }
+}
+// the reverse: rows of the LDS image to global (acc: added to what is there)
+__device__ __forceinline__ void unstage_rows(float* __restrict__ out, long long p0, int np, int K, int KS, const float* sh, bool acc) {
+  const int n = np * K;
+  float* dst = out + p0 * K;
+  int done = 0;
+  if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    const int n4 = n >> 2;
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int i4 = threadIdx.x; i4 < n4; i4 += blockDim.x) {
+      float e[4];
+      int r = (4 * i4) / K, c = 4 * i4 - r * K;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        e[u] = sh[r * KS + c];
+        if (++c == K) { c = 0; ++r; }
+      }
+      float4 v = make_float4(e[0], e[1], e[2], e[3]);
+      if (acc) {
+        const float4 o = d4[i4];
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      d4[i4] = v;
+    }
+    done = n4 << 2;
+  }
+  for (int i = done + threadIdx.x; i < n; i += blockDim.x) {
+    const int r = i / K, c = i - r * K;
+    const float v = sh[r * KS + c];
+    dst[i] = acc ? dst[i] + v : v;
   }
 }
 
@@ -598,13 +647,7 @@ __global__ __launch_bounds__(PIX) void lv_backward_kernel(const float* __restric
     for (int c = 0; c < K; ++c) row[c] = row[c] * (grow[c] - dot);
   }
   __syncthreads();
-  const int n = np * K;
-  float* dst = dlogits + p0 * K;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int r = i / K, c = i - r * K;
-    const float v = sh[r * KS + c];
-    dst[i] = acc ? dst[i] + v : v;
-  }
+  unstage_rows(dlogits, p0, np, K, KS, sh, acc != 0);
 }
 
 // ---- cross entropy ----------------------------------------------------------------------------
@@ -681,12 +724,7 @@ __global__ __launch_bounds__(PIX) void ce_bwd_kernel(const float* __restrict__ l
     }
   }
   __syncthreads();
-  const int n = np * K;
-  float* dst = dlogits + p0 * K;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int r = i / K, c = i - r * K;
-    dst[i] = sh[r * KS + c];
-  }
+  unstage_rows(dlogits, p0, np, K, KS, sh, false);
 }
 
 // ---- confusion matrix ---------------------------------------------------------------------------
