@@ -208,7 +208,7 @@ def infer_bench(args):
                     "conv_ms_per_step": sum(v[1] for v in mm.values()) / 2 * 1e3,
                     "algorithmic_tflop_per_step": sum(v[0] for v in mm.values()) / 2 / 1e12}
     if rank == 0:
-        print(json.dumps({"metric": "inference frames/sec @1080x1920 UPerNet-ResNeXt101", "value": world * B * args.steps / dt,
+        _emit(json.dumps({"metric": "inference frames/sec @1080x1920 UPerNet-ResNeXt101", "value": world * B * args.steps / dt,
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": DTYPE_STRING(), "data": "synthetic",
@@ -218,6 +218,25 @@ def infer_bench(args):
                           "roofline": roof, "cpu_baseline": None}))
     if world > 1:
         dist.destroy_process_group()
+
+
+_RESULT_OUT = None
+
+
+def _claim_stdout():
+    """the contract is ONE JSON line on stdout: keep the real stdout for that line and point fd 1 at stderr for everything else
+    (gloo prints its connection report to stdout; RCCL does with NCCL_DEBUG set)"""
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def _emit(line):
+    _claim_stdout()
+    _RESULT_OUT.write(line + "\n")
+    _RESULT_OUT.flush()
 
 
 def main():
@@ -241,6 +260,7 @@ def main():
                     help="side measurement (never the reported `value` of the contract): every step also copies its batch from "
                          "pinned host memory, float32 image + int64 labels as the reference's loader hands them over")
     args = ap.parse_args()
+    _claim_stdout()
 
     if args.infer:
         return infer_bench(args)
@@ -492,7 +512,7 @@ def main():
         if side:
             out["side_figures"] = side
         out["config"]["step"] = "zero_grad, forward, loss, backward, Adam, confusion matrix of the batch (the reference's per-step training metric)"
-        print(json.dumps(out))
+        _emit(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

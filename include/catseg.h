@@ -154,6 +154,13 @@ int catseg_dconv3_layout(int C, int* kc, int* nt);
 int catseg_dconv3_prep_batch(const float* flat, int n, const void* entries, void* wimg_base, catseg_stream_t stream);
 int catseg_dconv3(int B, int H, int W, int C, const float* x, int ldx, const void* wimg, const float* bias, float* y, int ldy,
                   int accumulate, float* bn_part, size_t bn_part_floats, int* bn_counts, catseg_stream_t stream);
+/* backward-data of a BasicBlock's SECOND convolution fused with the first pass of the backward of the relu(bn1(q)) that produced
+ * its input (models/HRNetv2.py:36-47: out = relu(bn1(conv1(x))); conv2(out)): g = (dy (*) w^T) where relu(bn1(q)) > 0 (the mask is
+ * recomputed from q, stats = [mean(C), invstd(C)], gamma, beta with the forward's exact expression), and part[n_tiles][2][C] = per
+ * tile sum of g and of g * xhat -- what the first pass of catseg_bn_backward computes from (dz, q).  catseg_bn_backward_pre finishes. */
+int catseg_dconv3_bnbwd(int B, int H, int W, int C, const float* dy, int lddy, const void* wimg_bwd, float* g, int ldg, const float* q,
+                        int ldq, const float* stats, const float* gamma, const float* beta, float* part, size_t part_floats,
+                        catseg_stream_t stream);
 /* backward-weight of the same layers (csrc/dwgrad3_b3.hip): dw[o,ky,kx,c] = sum_p dy[p, o] * x[pix(p,ky,kx), c], C in {48, 96, 192, 384};
  * x and dy are read as fp32 and split inside the kernel, fragments by transposed LDS reads, per-block partial sums in
  * `workspace` (catseg_dwgrad3_workspace bytes) added in a fixed order */
@@ -199,6 +206,12 @@ int catseg_bn_backward(const float* dz, int lddz, const float* z, int ldz, const
                        float* dy, int lddy, float* dgamma, float* dbeta, float* dres, int lddres,
                        int dres_accumulate, void* workspace, size_t workspace_bytes,
                        catseg_stream_t stream);
+/* the rest of catseg_bn_backward when g (already masked) and the per-block sums [n_blocks][2][C] of g and g * xhat come from
+ * catseg_dconv3_bnbwd: merges the sums (dgamma, dbeta) and writes dq = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)).
+ * workspace >= 2 * C floats (rounded up to 256 bytes). */
+int catseg_bn_backward_pre(const float* g, int ldg, const float* q, int ldq, const float* stats, const float* gamma,
+                           const float* partials, int n_blocks, long long rows, int C, float* dq, int lddq, float* dgamma,
+                           float* dbeta, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
 /* eval-mode / frozen-statistics backward is not on the training path and is not provided. */
 
 /* ---- layout / pointwise helpers ---------------------------------------------------------- */

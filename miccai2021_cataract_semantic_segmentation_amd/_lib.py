@@ -46,6 +46,7 @@ _SIGS = {
     "catseg_debug_set_dwgrad3_blocks": (I, [I]),
     "catseg_dconv3_prep_batch": (I, [P, I, P, P, P]),
     "catseg_dconv3": (I, [I, I, I, I, P, I, P, P, P, I, I, P, SZ, P, P]),
+    "catseg_dconv3_bnbwd": (I, [I, I, I, I, P, I, P, P, I, P, I, P, P, P, P, SZ, P]),
     "catseg_conv2d_fwd_fused": (I, [P, P, P, P, P, I, I, P, P]),
     "catseg_fold_bn": (I, [P, P, P, P, P, P, F, I, I, P, P, P]),
     "catseg_conv2d_bwd_data": (I, [P, P, P, P, I, P]),
@@ -85,6 +86,7 @@ _SIGS = {
     "catseg_bn_eval_scale": (I, [I, P, P, F, P, P]),
     "catseg_bn_apply": (I, [P, I, P, P, P, P, I, P, I, L, I, I, P]),
     "catseg_bn_backward": (I, [P, I, P, I, P, I, P, P, P, L, I, I, P, I, P, P, P, I, I, P, SZ, P]),
+    "catseg_bn_backward_pre": (I, [P, I, P, I, P, P, P, I, L, I, P, I, P, P, P, SZ, P]),
     "catseg_nchw3_to_nhwc4": (I, [P, P, I, I, I, P]),
     "catseg_stem_pack_weight": (I, [P, P, I, P]),
     "catseg_stem_unpack_grad": (I, [P, P, I, P]),

@@ -85,6 +85,15 @@ struct DcArgs {
   int accumulate;
   float* bn_part;   // [tile][3][C] or nullptr
   int* bn_cnt;      // [tile] valid pixels
+  // backward through the ReLU + BatchNorm that produced this convolution's INPUT (backward-data launches, catseg_dconv3_bnbwd):
+  // the output is the gradient of z = relu(bn(q)); the epilogue masks it with z > 0 (z recomputed from q exactly as bn_apply_kernel
+  // evaluates it) and leaves the per-tile sums of g and g * xhat that bn_bwd_partial_kernel would have needed another pass for
+  const float* bq_y;      // q, the pre-normalisation tensor [B][H][W][ld]
+  int bq_ldy;
+  const float* bq_stats;  // [mean(C), invstd(C)]
+  const float* bq_gamma;
+  const float* bq_beta;
+  float* bq_part;         // [tile][2][C] or nullptr
 };
 
 __device__ __forceinline__ void dc_glds16(const void* src, void* lds_wave_base) {
@@ -112,7 +121,74 @@ __device__ __forceinline__ float row16_sum(float v) {
 // fragments it already holds), two global loads of the prefetch of the NEXT chunk / tile (spread over the steps, so that the counted
 // wait that ends the step -- vmcnt(2): everything but those two loads -- never waits for an HBM access), the LDS reads of the weight
 // and pixel fragments of step t + 1, and then the 6 CB PB MFMAs of step t, which depend on none of them.
-template <class G>
+// Epilogue of a backward-data launch whose output feeds the backward of relu(bn(q)) (see DcArgs::bq_*): g = acc where z > 0,
+// stored; per (tile, channel) sum g and sum g * xhat over the tile's valid pixels (DPP row sums over the 16 pixels of a k-group,
+// the WP waves of a channel group through LDS), in the [block][2][C] layout bn_bwd_finalize_kernel merges.
+template <class G, class PRow, class PCol>
+__device__ __forceinline__ void dc_bnbwd_epilogue(const DcArgs& a, f32x4 (&acc)[G::CB][G::PB], const bool (&p_ok)[G::PB], long long img0, int y0,
+                                                  int x0, int co0, int cl, int wp, int i16, int tile, int cob, unsigned char* smem,
+                                                  PRow prow, PCol pcol) {
+  f32x4 q[G::CB][G::PB];
+#pragma unroll
+  for (int ct = 0; ct < G::CB; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < G::PB; ++pt) {
+      const long long px = img0 + (long long)(y0 + prow(pt)) * a.W + x0 + pcol(pt);
+      q[ct][pt] = p_ok[pt] ? *(const f32x4*)(a.bq_y + px * a.bq_ldy + co0 + ct * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  float* scr = (float*)smem;    // [2 WP][NT]  (the K loop's last barrier is behind every LDS read of the image)
+#pragma unroll
+  for (int ct = 0; ct < G::CB; ++ct) {
+    const int c = co0 + ct * 16;
+    const f32x4 mean = *(const f32x4*)(a.bq_stats + c), inv = *(const f32x4*)(a.bq_stats + G::C + c);
+    const f32x4 sc = *(const f32x4*)(a.bq_gamma + c) * inv;   // scale exactly as bn_finalize_kernel stored it
+    const f32x4 be = *(const f32x4*)(a.bq_beta + c);
+    f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pt = 0; pt < G::PB; ++pt) {
+      f32x4 g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z = __builtin_fmaf(q[ct][pt][r] - mean[r], sc[r], be[r]);   // = bn_affine (norm.hip), the forward's own expression
+        g[r] = (p_ok[pt] && z > 0.f) ? acc[ct][pt][r] : 0.f;
+      }
+      if (p_ok[pt]) *(f32x4*)(a.y + (img0 + (long long)(y0 + prow(pt)) * a.W + x0 + pcol(pt)) * a.ldy + c) = g;
+      const f32x4 xh = (q[ct][pt] - mean) * inv;
+      sg += g;
+      sgx += g * xh;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v1 = row16_sum(sg[r]), v2 = row16_sum(sgx[r]);
+      if (i16 == 0) {
+        scr[wp * G::NT + cl + ct * 16 + r] = v1;
+        scr[(G::WP + wp) * G::NT + cl + ct * 16 + r] = v2;
+      }
+    }
+  }
+  DC_WAIT_LGKM0();
+  __builtin_amdgcn_s_barrier();
+  if (wp == 0 && i16 == 0) {
+    float* part = a.bq_part + (long long)tile * 2 * G::C + cob * G::NT;
+#pragma unroll
+    for (int ct = 0; ct < G::CB; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < G::WP; ++w) {
+          d1 += scr[w * G::NT + cl + ct * 16 + r];
+          d2 += scr[(G::WP + w) * G::NT + cl + ct * 16 + r];
+        }
+        part[cl + ct * 16 + r] = d1;
+        part[G::C + cl + ct * 16 + r] = d2;
+      }
+  }
+  DC_WAIT_LGKM0();
+  __builtin_amdgcn_s_barrier();   // the scratch is read: the next tile's stash may overwrite it
+}
+
+template <class G, bool BQ = false>   // BQ: the catseg_dconv3_bnbwd epilogue (a separate instantiation: the plain kernels keep their registers)
 __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
   __shared__ __attribute__((aligned(256))) unsigned char smem[G::LDS];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -384,6 +460,10 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
 #pragma unroll
     for (int pt = 0; pt < G::PB; ++pt) p_ok[pt] = y0 + prow(pt) < a.H && x0 + pcol(pt) < a.W;
     const int co0 = cob * G::NT + wc * G::CB * 16 + 4 * kg;   // + ct * 16 + r
+    if constexpr (BQ) {
+      dc_bnbwd_epilogue<G>(a, acc, p_ok, img0, y0, x0, co0, wc * G::CB * 16 + 4 * kg, wp, i16, tile, cob, smem, prow, pcol);
+      continue;
+    }
 #pragma unroll
     for (int ct = 0; ct < G::CB; ++ct) {
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -482,7 +562,7 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
 // waves (0 .. 3) only read fragments and issue MFMAs (+ the epilogue).  Both roles run the same sequence of block barriers.
 // 16 waves per CU (2 blocks): at most 128 registers per wave, which is why the two roles are separate code paths (no live range of
 // one role overlaps the other's) and the pixel fragments are single-buffered.
-template <class G>
+template <class G, bool BQ = false>
 __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const DcArgs a) {
   __shared__ __attribute__((aligned(256))) unsigned char smem[G::LDS];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -612,7 +692,10 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
           __builtin_amdgcn_s_barrier();
         }
       }
-      if (bn) {
+      if constexpr (BQ) {         // the two barriers of dc_bnbwd_epilogue
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+      } else if (bn) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_barrier();
@@ -700,6 +783,10 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
 #pragma unroll
     for (int pt = 0; pt < G::PB; ++pt) p_ok[pt] = y0 + prow(pt) < a.H && x0 + pcol(pt) < a.W;
     const int co0 = cob * G::NT + wc * G::CB * 16 + 4 * kg;
+    if constexpr (BQ) {
+      dc_bnbwd_epilogue<G>(a, acc, p_ok, img0, y0, x0, co0, wc * G::CB * 16 + 4 * kg, wp, i16, tile, cob, smem, prow, pcol);
+      continue;
+    }
 #pragma unroll
     for (int ct = 0; ct < G::CB; ++ct) {
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -870,7 +957,11 @@ int dc_launch(const DcArgs& a, int C, hipStream_t st) {
   const int nb = ntile > 3 * g_dc_blocks ? g_dc_blocks : ntile;
   // specialised waves: 192 / 384 channels 82 -> 73 us, 90 -> 79 us; 48 channels 65 -> 70 us (its helper waves carry six staging items per
   // 14-step tile and the role needs 9 spilled registers), 96 channels: the 48 x 64 wave tile does not fit 128 registers
-  if (g_dc_spec < 0 ? G::SPEC : g_dc_spec != 0) hipLaunchKernelGGL((dconv3_b3_spec_kernel<G>), dim3(nb, C / G::NT), dim3(2 * G::NTHR), 0, st, a);
+  const bool spec = g_dc_spec < 0 ? G::SPEC : g_dc_spec != 0;
+  if (a.bq_part) {
+    if (spec) hipLaunchKernelGGL((dconv3_b3_spec_kernel<G, true>), dim3(nb, C / G::NT), dim3(2 * G::NTHR), 0, st, a);
+    else hipLaunchKernelGGL((dconv3_b3_kernel<G, true>), dim3(nb, C / G::NT), dim3(G::NTHR), 0, st, a);
+  } else if (spec) hipLaunchKernelGGL((dconv3_b3_spec_kernel<G>), dim3(nb, C / G::NT), dim3(2 * G::NTHR), 0, st, a);
   else hipLaunchKernelGGL((dconv3_b3_kernel<G>), dim3(nb, C / G::NT), dim3(G::NTHR), 0, st, a);
   return 0;
 }
@@ -937,8 +1028,32 @@ extern "C" int catseg_dconv3_layout(int C, int* kc, int* nt) {
   return 1;
 }
 
+namespace {
+int dc_run(int B, int H, int W, int C, const float* x, int ldx, const void* wimg, const float* bias, float* y, int ldy, int accumulate,
+           float* bn_part, size_t bn_part_floats, int* bn_counts, const float* bq_y, int bq_ldy, const float* bq_stats,
+           const float* bq_gamma, const float* bq_beta, float* bq_part, size_t bq_part_floats, catseg_stream_t stream);
+}
+
 extern "C" int catseg_dconv3(int B, int H, int W, int C, const float* x, int ldx, const void* wimg, const float* bias, float* y, int ldy,
                              int accumulate, float* bn_part, size_t bn_part_floats, int* bn_counts, catseg_stream_t stream) {
+  return dc_run(B, H, W, C, x, ldx, wimg, bias, y, ldy, accumulate, bn_part, bn_part_floats, bn_counts, nullptr, 0, nullptr, nullptr, nullptr,
+                nullptr, 0, stream);
+}
+
+extern "C" int catseg_dconv3_bnbwd(int B, int H, int W, int C, const float* dy, int lddy, const void* wimg_bwd, float* g, int ldg,
+                                   const float* q, int ldq, const float* stats, const float* gamma, const float* beta, float* part,
+                                   size_t part_floats, catseg_stream_t stream) {
+  CS_REQUIRE(q && stats && gamma && beta && part, "dconv3 bnbwd: bad args");
+  CS_REQUIRE(ldq >= C && ldq % 4 == 0 && cs_aligned16(q) && cs_aligned16(stats) && cs_aligned16(gamma) && cs_aligned16(beta) &&
+                 cs_aligned16(part), "dconv3 bnbwd: alignment / row strides");
+  CS_REQUIRE((long long)H * W * (long long)ldq < (1LL << 31), "dconv3 bnbwd: image too large for 32-bit offsets");
+  return dc_run(B, H, W, C, dy, lddy, wimg_bwd, nullptr, g, ldg, 0, nullptr, 0, nullptr, q, ldq, stats, gamma, beta, part, part_floats, stream);
+}
+
+namespace {
+int dc_run(int B, int H, int W, int C, const float* x, int ldx, const void* wimg, const float* bias, float* y, int ldy, int accumulate,
+           float* bn_part, size_t bn_part_floats, int* bn_counts, const float* bq_y, int bq_ldy, const float* bq_stats,
+           const float* bq_gamma, const float* bq_beta, float* bq_part, size_t bq_part_floats, catseg_stream_t stream) {
   const DcPlan p = dc_plan(C);
   CS_REQUIRE(p.kind, "dconv3: unsupported channel count %d", C);
   CS_REQUIRE(B > 0 && H > 0 && W > 0 && x && wimg && y, "dconv3: bad args");
@@ -953,8 +1068,10 @@ extern "C" int catseg_dconv3(int B, int H, int W, int C, const float* x, int ldx
   a.accumulate = accumulate;
   a.bn_part = bn_part;
   a.bn_cnt = bn_counts;
+  a.bq_y = bq_y; a.bq_ldy = bq_ldy; a.bq_stats = bq_stats; a.bq_gamma = bq_gamma; a.bq_beta = bq_beta; a.bq_part = bq_part;
   const long long ntile = (long long)B * a.tiles_y * a.tiles_x;
   if (bn_part) CS_REQUIRE(bn_counts && bn_part_floats >= (size_t)ntile * 3 * C, "dconv3: BatchNorm partial buffer too small");
+  if (bq_part) CS_REQUIRE(bq_part_floats >= (size_t)ntile * 2 * C, "dconv3 bnbwd: partial buffer too small");
   if (p.kind == 1) dc_launch<Cfg48>(a, C, (hipStream_t)stream);
   else if (p.kind == 2) dc_launch<Cfg96>(a, C, (hipStream_t)stream);
   else if (p.kind == 3) dc_launch<Cfg192>(a, C, (hipStream_t)stream);
@@ -964,3 +1081,4 @@ extern "C" int catseg_dconv3(int B, int H, int W, int C, const float* x, int ldx
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
+}  // namespace

@@ -255,23 +255,25 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   }
 }
 
+// 16 channels x 64 row lanes per block: up to 2040 partial rows (one per pixel tile of the direct kernels) are ~8 loads deep per
+// thread (with 64 channels x 16 row lanes they were 32 deep: a latency chain of ~10 us on 1 - 6 blocks); fixed summation order
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nrb, long long rows, int C,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double sg = 0, sgx = 0;
   if (c < C)
 #pragma unroll 4
-    for (int b = rl; b < nrb; b += 16) {
+    for (int b = rl; b < nrb; b += 64) {
       const float* o = part + ((long long)b * 2) * C;
       sg += o[c];
       sgx += o[C + c];
     }
-  __shared__ double s1[16][64], s2[16][64];
+  __shared__ double s1[64][16], s2[64][16];
   s1[rl][cl] = sg; s2[rl][cl] = sgx;
   __syncthreads();
   if (rl != 0 || c >= C) return;
-  for (int k = 1; k < 16; ++k) { sg += s1[k][cl]; sgx += s2[k][cl]; }
+  for (int k = 1; k < 64; ++k) { sg += s1[k][cl]; sgx += s2[k][cl]; }
   if (dbeta) dbeta[c] = (float)sg;
   if (dgamma) dgamma[c] = (float)sgx;
   coef[c] = (float)(sg / (double)rows);
@@ -429,13 +431,36 @@ extern "C" int catseg_bn_backward(const float* dz, int lddz, const float* z, int
   float* part = (float*)workspace;
   float* coef = part + (size_t)kMaxRowBlocks * 3 * ((C + 3) & ~3);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma, beta, rows, C, relu, s, part);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
 #ifdef BN_AB_DOUBLE_FINALIZE   // (TIMING-ONLY build: the finalize launches issued twice; the added time = their cost in the step.  NOT result
                                //  preserving on the forward side: running_mean / running_var receive the momentum update twice)
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
 #endif
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma,
                      beta, (const float*)coef, rows, C, relu, dy, lddy, dres, lddres, dres_accumulate);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// backward of z = relu(bn(q)) when the producer of dz has already masked it (g = dz where z > 0) and left the per-block sums
+// [n_blocks][2][C] of g and g * xhat (catseg_dconv3_bnbwd): the merge of the sums and the apply pass, i.e. catseg_bn_backward
+// without its first pass over (dz, q)
+extern "C" int catseg_bn_backward_pre(const float* g, int ldg, const float* q, int ldq, const float* stats, const float* gamma,
+                                      const float* partials, int n_blocks, long long rows, int C, float* dq, int lddq, float* dgamma,
+                                      float* dbeta, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && ldg % 4 == 0 && ldq % 4 == 0 && lddq % 4 == 0 && n_blocks > 0 && partials,
+             "bn bwd (pre): C and ld must be multiples of 4");
+  CS_REQUIRE(cs_aligned16(g) && cs_aligned16(q) && cs_aligned16(dq) && cs_aligned16(stats) && cs_aligned16(gamma), "bn bwd (pre): alignment");
+  const size_t need = cs_align_up((size_t)2 * ((C + 3) & ~3) * 4, 256);
+  if (workspace_bytes < need || !workspace) {
+    catseg_set_error("bn bwd (pre): workspace too small");
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* coef = (float*)workspace;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partials, n_blocks, rows, C, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, st, g, ldg, (const float*)nullptr, 0, q, ldq, stats,
+                     gamma, (const float*)nullptr, (const float*)coef, rows, C, 0, dq, lddq, (float*)nullptr, 0, 0);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

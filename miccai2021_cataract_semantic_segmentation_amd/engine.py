@@ -126,6 +126,8 @@ class Ctx:
         self.region = None
         self._region_depth = 0         # backward: parallel regions entered and not yet joined
         self._deferred = []            # backward: parameters whose 'gradient ready' signal waits for the join
+        self.bn_src = {}               # id(z) -> (y, stats, gamma, beta) of a conv_bn_act output z = relu(bn(y))
+        self.bn_pre = {}               # backward: id(z) -> per-tile sums of the already masked gradient of z (conv_bn_act private_in)
 
     def claim(self, *params):
         """every parameter may feed exactly one recorded layer: the backward tape WRITES (does not accumulate) parameter
@@ -221,6 +223,7 @@ class Ctx:
         return self.grads[k]
 
     def give(self, t, g, shared=False):
+        assert id(t) not in self.bn_pre, "conv_bn_act(private_in=True): the input has a second consumer"
         if id(t) not in self.grads:
             self.grads[id(t)] = g
             if shared:
@@ -230,6 +233,7 @@ class Ctx:
 
     def dest(self, t):
         """buffer the gradient of activation t must be written to: (buffer, accumulate?)"""
+        assert id(t) not in self.bn_pre, "conv_bn_act(private_in=True): the input has a second consumer"
         if id(t) in self.grads:
             return self._own(t), True
         C = t.shape[-1]
@@ -289,6 +293,8 @@ class Ctx:
                     fn()
         self.grads.clear()
         self.shared.clear()
+        self.bn_src.clear()
+        self.bn_pre.clear()
 
 
 # --------------------------------------------------------------------------- fused layers
@@ -305,9 +311,12 @@ FUSE_BN_STATS = True  # training forward: BatchNorm batch statistics from the co
 FUSE_EVAL_BN = True   # eval-mode forward: fold BatchNorm into the conv and fuse bias/residual/ReLU into its epilogue
 
 
-def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=True):
+def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=True, private_in=False):
     """conv -> BatchNorm (batch stats in training) -> (+residual) -> (ReLU).  x NHWC (or the raw
-    NCHW image for the stem).  Returns z (NHWC)."""
+    NCHW image for the stem).  Returns z (NHWC).
+    private_in: the caller states that x is the output of the preceding conv_bn_act (ReLU, no residual) and has NO other consumer
+    (the first half of a BasicBlock).  The backward-data kernel of this layer may then run the first pass of that BatchNorm's
+    backward in its epilogue (ops.conv_bwd_data(bn_src=...))."""
     w = conv.weight
     Cout = w.shape[0]
     kh, kw = conv.kernel_size
@@ -349,17 +358,25 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
         if not cx.train:
             raise NotImplementedError("backward through eval-mode BatchNorm is not on the training path")
 
+        if relu and residual is None and out is None:
+            cx.bn_src[id(z)] = (y, stats, bn.weight.data, bn.bias.data)     # for a private_in consumer of z
+
         def bwd():
             dz = cx.take(z)
+            pre = cx.bn_pre.pop(id(z), None)
             if dz is None:
                 return
             dres, acc = (None, False)
             if residual is not None:
                 dres, acc = cx.dest(residual)
-            # without a residual branch the ReLU mask is recomputed from y (z is not read: 1 of 3 tensor reads saved)
-            z_mask = z if (residual is not None or not relu) else None
-            dy = ops.bn_backward(dz, z_mask, y, stats, bn.weight.data, relu, cx.pgrad(bn.weight), cx.pgrad(bn.bias), dres, acc,
-                                 beta=bn.bias.data)
+            if pre is not None:
+                # dz is already masked and its per-tile sums exist (the consumer's backward-data epilogue): merge + apply only
+                dy = ops.bn_backward_pre(dz, y, stats, bn.weight.data, pre, cx.pgrad(bn.weight), cx.pgrad(bn.bias))
+            else:
+                # without a residual branch the ReLU mask is recomputed from y (z is not read: 1 of 3 tensor reads saved)
+                z_mask = z if (residual is not None or not relu) else None
+                dy = ops.bn_backward(dz, z_mask, y, stats, bn.weight.data, relu, cx.pgrad(bn.weight), cx.pgrad(bn.bias), dres, acc,
+                                     beta=bn.bias.data)
             del dz
             dbias = cx.pgrad(conv.bias) if conv.bias is not None else None
             if conv.stem:
@@ -374,7 +391,10 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
                 ops.conv_bwd_weight(x_in, dy, cx.pgrad(w), dbias, kh, kw, s, p, d, groups=conv.groups)
                 if need_dx:
                     dx, accx = cx.dest(x)
-                    ops.conv_bwd_data(dy, w.data, tuple(x.shape), kh, kw, s, p, d, out=dx, accumulate=accx, groups=conv.groups)
+                    src = cx.bn_src.get(id(x)) if (private_in and not accx) else None
+                    r = ops.conv_bwd_data(dy, w.data, tuple(x.shape), kh, kw, s, p, d, out=dx, accumulate=accx, groups=conv.groups, bn_src=src)
+                    if isinstance(r, tuple):
+                        cx.bn_pre[id(x)] = r[1]
             cx.done(bn.weight, bn.bias, w, conv.bias)
         cx.push(bwd)
     return z

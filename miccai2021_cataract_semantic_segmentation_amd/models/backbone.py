@@ -35,7 +35,7 @@ class Bottleneck(nn.Module):
 
     def run(self, cx, x):
         o = conv_bn_act(cx, x, self.conv1, self.bn1)
-        o = conv_bn_act(cx, o, self.conv2, self.bn2)
+        o = conv_bn_act(cx, o, self.conv2, self.bn2, private_in=True)
         idt = x if self.downsample is None else conv_bn_act(cx, x, self.downsample[0], self.downsample[1], relu=False)
         return conv_bn_act(cx, o, self.conv3, self.bn3, relu=True, residual=idt)
 
@@ -58,7 +58,7 @@ class BasicBlock(nn.Module):
     def run(self, cx, x):
         o = conv_bn_act(cx, x, self.conv1, self.bn1)
         idt = x if self.downsample is None else conv_bn_act(cx, x, self.downsample[0], self.downsample[1], relu=False)
-        return conv_bn_act(cx, o, self.conv2, self.bn2, relu=True, residual=idt)
+        return conv_bn_act(cx, o, self.conv2, self.bn2, relu=True, residual=idt, private_in=True)
 
 
 _CFG = {"resnet18": (BasicBlock, [2, 2, 2, 2]), "resnet34": (BasicBlock, [3, 4, 6, 3]),

@@ -343,7 +343,13 @@ def bn_finalize(partials, rows, C, gamma, eps, momentum, running_mean, running_v
     return stats, scale
 
 
-def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accumulate=False, groups=1):
+BN_BWD_FUSE = True    # first pass of the backward of relu(bn1(.)) in the epilogue of the backward-data kernel that produces its dz
+
+
+def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accumulate=False, groups=1, bn_src=None):
+    """bn_src = (q, stats, gamma, beta): the convolution's input was relu(bn(q)) and this call is the ONLY contribution to its
+    gradient.  When the direct kernel takes the layer, the result is then already masked (g = dx where relu(bn(q)) > 0) and the
+    call returns (g, (partials, n_tiles)) for bn_backward_pre; otherwise it returns dx alone, as without bn_src."""
     B, H, W, Cin = xshape
     Cout = dy.shape[-1]
     if out is None:
@@ -352,6 +358,14 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
     flops = 2.0 * rows_of(dy) * Cout * (Cin // groups) * kh * kw
     if w.dim() == 4 and _d3_ok(B * H * W, Cin, Cout, kh, kw, stride, pad, dil, groups):
         wimg = dconv3_weight_image(w, backward_data=True)
+        if bn_src is not None and BN_BWD_FUSE and not accumulate:
+            q, stats, gamma, beta = bn_src
+            nt = lib.catseg_dconv3_tiles(Cin, B, H, W, None, None)
+            part = torch.empty(2 * nt * Cin, dtype=torch.float32, device=dy.device)
+            with _Timed("dgrad_d3", flops):
+                check(lib.catseg_dconv3_bnbwd(B, H, W, Cin, ptr(dy), ld_of(dy), ptr(wimg), ptr(out), ld_of(out), ptr(q), ld_of(q),
+                                              ptr(stats), ptr(gamma), ptr(beta), ptr(part), part.numel(), stream()))
+            return out, (part, nt)
         with _Timed("dgrad_d3", flops):
             dconv3(dy, wimg, None, out=out, accumulate=accumulate)
         return out
@@ -467,6 +481,21 @@ def bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres=None, dres_acc
     with _Timed("hbm:bn_backward", 4.0 * y.numel() * (5 + (1 if dres is not None else 0))):
         _bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres, dres_accumulate, dy_out, beta, rows, C, ws)
     return dy_out
+
+
+def bn_backward_pre(g, q, stats, gamma, partials, dgamma, dbeta, dq_out=None):
+    """backward of relu(bn(q)) from the masked gradient g and the per-tile sums (partials, n_tiles) that conv_bwd_data(bn_src=...)
+    returned: merge + apply pass only"""
+    C = q.shape[-1]
+    rows = rows_of(q)
+    part, nt = partials
+    if dq_out is None:
+        dq_out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    ws = workspace(lib.catseg_bn_workspace(rows, C), q.device)
+    with _Timed("hbm:bn_backward", 4.0 * q.numel() * 3):      # one pass: g and q read, dq written
+        check(lib.catseg_bn_backward_pre(ptr(g), ld_of(g), ptr(q), ld_of(q), ptr(stats), ptr(gamma), ptr(part), nt, rows, C, ptr(dq_out),
+                                         ld_of(dq_out), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), stream()))
+    return dq_out
 
 
 def _bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres, dres_accumulate, dy_out, beta, rows, C, ws):

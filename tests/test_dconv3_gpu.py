@@ -82,6 +82,62 @@ def test_dconv3_forward_backward_data_vs_fp64(ops, case, spec):
     ops.release_b3_cache()
 
 
+BQ_CASES = [(2, 16, 32, 48), (1, 19, 37, 48), (2, 5, 7, 48), (2, 8, 64, 96), (1, 19, 37, 96), (1, 24, 40, 192), (2, 7, 9, 192),
+            (1, 17, 30, 384), (2, 16, 32, 64), (1, 19, 37, 64)]
+
+
+@pytest.mark.parametrize("case", BQ_CASES)
+def test_backward_data_with_fused_bn_backward_pass(ops, case, spec):
+    """out = relu(bn1(q)); y = conv2(out) (models/HRNetv2.py:36-47): the backward-data launch of conv2 masks its result with
+    relu(bn1(q)) > 0 and leaves the per-tile sums of the first pass of bn1's backward (catseg_dconv3_bnbwd), catseg_bn_backward_pre
+    finishes.  dq, dgamma, dbeta against fp64 autograd through relu(batch_norm(q)) -> conv2d, and against the two-pass route
+    (plain backward-data + catseg_bn_backward): the masked gradient must be bit-identical (same products, same mask expression)."""
+    from miccai2021_cataract_semantic_segmentation_amd._lib import lib
+    B, H, W, C = case
+    if not lib.catseg_dconv3_supported(C):
+        pytest.skip("width not built")
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    q = torch.randn(B, C, H, W, generator=g) * torch.exp(torch.randn(1, C, 1, 1, generator=g)) + torch.randn(1, C, 1, 1, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, 0.3 * torch.randn(C, generator=g)
+    gy = torch.randn(B, C, H, W, generator=g)
+    q64, g64, b64 = q.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    out = F.relu(F.batch_norm(q64, None, None, g64, b64, True, 0.1, 1e-5))
+    F.conv2d(out, w.double(), None, 1, 1, 1).backward(gy.double())
+    qd, gyd = nhwc(q), nhwc(gy)
+    gd, bd = gamma.cuda(), beta.cuda()
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    stats, _ = ops.bn_train_stats(qd, gd, 1e-5, 0.1, torch.zeros(C).cuda(), torch.ones(C).cuda())
+    saved = (ops.PRECISION, ops.DCONV3_MIN_ROWS)
+    ops.PRECISION, ops.DCONV3_MIN_ROWS = "bf16x3", 1
+    try:
+        # fused: one backward-data launch + merge + apply
+        gbuf = torch.full((B, H, W, C), float("nan")).cuda()
+        r = ops.conv_bwd_data(gyd, wd, (B, H, W, C), 3, 3, 1, 1, 1, out=gbuf, bn_src=(qd, stats, gd, bd))
+        assert isinstance(r, tuple), "the direct kernel did not take the layer"
+        dgam, dbet = torch.empty(C).cuda(), torch.empty(C).cuda()
+        dq = ops.bn_backward_pre(r[0], qd, stats, gd, r[1], dgam, dbet)
+        # two-pass route
+        dz = ops.conv_bwd_data(gyd, wd, (B, H, W, C), 3, 3, 1, 1, 1)
+        dgam2, dbet2 = torch.empty(C).cuda(), torch.empty(C).cuda()
+        dq2 = ops.bn_backward(dz, None, qd, stats, gd, True, dgam2, dbet2, beta=bd)
+    finally:
+        ops.PRECISION, ops.DCONV3_MIN_ROWS = saved
+        ops.release_b3_cache()
+    zpos = nhwc(out.detach().float()) > 0
+    # (a pixel whose fp32 z is within rounding of 0 may be masked differently from the fp64 reference; both GPU routes agree exactly)
+    zd = torch.addcmul(bd, qd - stats[:C], gd * stats[C:])
+    differs = r[0] != torch.where(zd > 0, dz, torch.zeros_like(dz))
+    assert not bool((differs & (zd.abs() > 1e-6)).any())       # (torch's own z may round differently from the kernels' fma at |z| ~ 0)
+    assert int((zpos != (zd > 0)).sum()) <= 2 + zpos.numel() // 20000
+    close(nchw(dq), q64.grad, 5e-5)
+    close(dgam, g64.grad, 5e-5)
+    close(dbet, b64.grad, 5e-5)
+    close(dq, dq2, 1e-5)
+    close(dgam, dgam2, 1e-5)
+    close(dbet, dbet2, 1e-5)
+
+
 def test_dconv3_inside_concat_buffers(ops):
     """input and output as channel slices of wider buffers (row strides > C); neighbours of the output slice stay untouched"""
     B, H, W, C = 2, 11, 21, 48
