@@ -132,9 +132,12 @@ def cpu_baseline(H, W, K, model_name, threads=0):
 
 def DTYPE_STRING():
     from miccai2021_cataract_semantic_segmentation_amd import ops
-    return "f32" if ops.PRECISION == "fp32" else ("f32 (convolutions with K >= 2048 and >= 192 output columns, and the 3x3 trunk convolutions "
-                                                  "of the HRNet widths: fp32 operands split exactly into 3 bf16 planes, 6 bf16 MFMA "
-                                                  "products, fp32 accumulate)")
+    if ops.PRECISION == "fp32":
+        return "f32"
+    heads = ("forward / backward-data of those with > 192 output columns: operands scaled by a per-tensor power of two and split into 2 fp16 "
+             "planes (22 significant bits), 3 fp16 MFMA products; " if ops.HEADS == "f16x2" else "")
+    return ("f32 (convolutions with K >= 2048 and >= 192 output columns, and the 3x3 trunk convolutions of the HRNet widths: " + heads +
+            "otherwise fp32 operands split exactly into 3 bf16 planes, 6 bf16 MFMA products; fp32 accumulate everywhere)")
 
 
 def infer_bench(args):
@@ -194,13 +197,14 @@ def infer_bench(args):
             a[0] += work
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
-        mm = {k: v for k, v in agg.items() if k in ("fwd", "fwd_b3") and v[1] > 0}
+        mm = {k: v for k, v in agg.items() if k in ("fwd", "fwd_b3", "fwd_h2") and v[1] > 0}
         if mm:
             dom = max(mm, key=lambda k: mm[k][1])
             fl, sec, n = mm[dom]
-            peak = 2500.0 / 6.0 if dom == "fwd_b3" else 157.3
-            roof = {"bound": "mfma", "kernel": "igemm_f32_kernel<NT> (conv2d forward + folded BatchNorm / residual / ReLU epilogue, fp32 MFMA)"
-                    if dom == "fwd" else "igemm_b3w_kernel (conv2d forward, bf16x3 split precision)",
+            peak = {"fwd_b3": 2500.0 / 6.0, "fwd_h2": 2500.0 / 3.0}.get(dom, 157.3)
+            roof = {"bound": "mfma", "kernel": {"fwd": "igemm_f32_kernel<NT> (conv2d forward + folded BatchNorm / residual / ReLU epilogue, fp32 MFMA)",
+                                                "fwd_b3": "igemm_b3w_kernel (conv2d forward, bf16x3 split precision)",
+                                                "fwd_h2": "igemm_h2w_kernel (conv2d forward + fused epilogue, f16x2 split precision: 3 fp16 MFMA products)"}[dom],
                     "achieved": fl / sec / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak, "traffic": None,
                     "launches_per_step": n // 2, "avg_launch_ms": sec / n * 1e3, "algorithmic_gflop_per_launch": fl / n / 1e9,
                     "all_igemm": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / 2 * 1e3, "launches_per_step": v[2] // 2}
@@ -363,12 +367,16 @@ def main():
             a[2] += 1
         # matrix-core operations: three ops x two arithmetics.  "*_b3" = the bf16x3 split-precision kernels (six bf16 MFMA
         # products per fp32-equivalent product: their peak is the dense bf16 peak / 6); the rest = exact fp32 MFMA.
-        PEAK_F32, PEAK_B3 = 157.3, 2500.0 / 6.0
+        # "*_h2" = the f16x2 kernels (three fp16 MFMA products per fp32-equivalent product: dense fp16 peak / 3)
+        PEAK_F32, PEAK_B3, PEAK_H2 = 157.3, 2500.0 / 6.0, 2500.0 / 3.0
+
+        def peak_of(kind):
+            return PEAK_H2 if kind.endswith("_h2") or kind == "h2w" else (PEAK_B3 if kind.endswith(("_b3", "_d3")) or kind in ("b3w", "d3") else PEAK_F32)
         mm = {k: v for k, v in agg.items() if not k.startswith("hbm:") and k != "split3" and v[1] > 0}
         # the dominant KERNEL (as rocprofv3 --stats names it): forward and backward-data of the bf16x3 layers are launches of one
         # kernel (igemm_b3w_kernel); the fp32 operations are the NT / NN / TN layouts of igemm_f32_kernel
         KERNEL_OF = {"fwd_b3": "b3w", "dgrad_b3": "b3w", "wgrad_b3": "wgrad_b3", "fwd": "fwd", "dgrad": "dgrad", "wgrad": "wgrad",
-                     "fwd_d3": "d3", "dgrad_d3": "d3", "wgrad_d3": "wgrad_d3"}
+                     "fwd_d3": "d3", "dgrad_d3": "d3", "wgrad_d3": "wgrad_d3", "fwd_h2": "h2w", "dgrad_h2": "h2w"}
         groups = {}
         for k, v in mm.items():
             g = groups.setdefault(KERNEL_OF.get(k, k), [0.0, 0.0, 0])
@@ -376,12 +384,12 @@ def main():
         dom = max(groups, key=lambda k: groups[k][1])
         # (an fp32 layout is a union of 4-6 tile instantiations that rocprofv3 lists as separate kernels, the largest of them
         #  < 40 % of the layout's time: a single-symbol bf16x3 kernel with at least half of that time is the larger KERNEL)
-        for k in ("b3w", "wgrad_b3", "d3", "wgrad_d3"):
-            if k in groups and dom not in ("b3w", "wgrad_b3", "d3", "wgrad_d3") and groups[k][1] >= 0.5 * groups[dom][1]:
+        for k in ("h2w", "b3w", "wgrad_b3", "d3", "wgrad_d3"):
+            if k in groups and dom not in ("h2w", "b3w", "wgrad_b3", "d3", "wgrad_d3") and groups[k][1] >= 0.5 * groups[dom][1]:
                 dom = k
                 break
         fl, sec, n = groups[dom]
-        peak = PEAK_B3 if dom in ("b3w", "wgrad_b3", "d3", "wgrad_d3") else PEAK_F32
+        peak = peak_of(dom)
         traffic = traffic_src = None   # HBM bytes per launch from committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
         tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (PROFILE_ROUND, args.model))
         if os.path.exists(tpath) and (B, H, W) == (8, 544, 960):
@@ -392,6 +400,8 @@ def main():
         label = {"fwd": "igemm_f32_kernel<NT> (conv2d forward, fp32 MFMA)", "dgrad": "igemm_f32_kernel<NN> (conv2d backward-data, fp32 MFMA)",
                  "wgrad": "igemm_f32_kernel<TN> + wgrad_direct_kernel (conv2d backward-weight, fp32 MFMA, incl. slab reduction)",
                  "b3w": "igemm_b3w_kernel (conv2d forward and backward-data of the large layers, bf16x3 split precision)",
+                 "h2w": "igemm_h2w_kernel (conv2d forward and backward-data of the large layers, f16x2 split precision: two fp16 planes "
+                        "per operand, three MFMA products)",
                  "wgrad_b3": "igemm_b3t_kernel (conv2d backward-weight, bf16x3 split precision, incl. slab reduction)",
                  "wgrad_d3": "dwgrad3_b3_kernel (direct 3x3 conv2d backward-weight of the HRNet trunk, bf16x3 split precision, incl. slab reduction)",
                  "d3": "dconv3_b3_kernel (direct 3x3 conv2d forward and backward-data of the HRNet trunk, bf16x3 split precision, "
@@ -405,9 +415,10 @@ def main():
                 "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": n // 2,
                 "avg_launch_ms": sec / n * 1e3, "algorithmic_gflop_per_launch": fl / n / 1e9,
-                "peak_note": "fp32 MFMA 157.3 TFLOP/s; bf16x3 kernels: dense bf16 MFMA 2500 TFLOP/s / 6 products = 416.7 TFLOP/s-equivalent "
-                             "(achieved counts algorithmic fp32-equivalent FLOPs 2MNK; x6 for the bf16 MFMA FLOPs issued)",
-                "all_igemm": {k: {"tflops": v[0] / v[1] / 1e12, "frac": v[0] / v[1] / 1e12 / (PEAK_B3 if k.endswith(("_b3", "_d3")) else PEAK_F32),
+                "peak_note": "fp32 MFMA 157.3 TFLOP/s; bf16x3 kernels: dense bf16 MFMA 2500 TFLOP/s / 6 products = 416.7 TFLOP/s-equivalent; "
+                             "f16x2 kernels: dense fp16 MFMA 2500 TFLOP/s / 3 products = 833.3 "
+                             "(achieved counts algorithmic fp32-equivalent FLOPs 2MNK; x6 / x3 for the MFMA FLOPs issued)",
+                "all_igemm": {k: {"tflops": v[0] / v[1] / 1e12, "frac": v[0] / v[1] / 1e12 / peak_of(k),
                                   "ms_per_step": v[1] / 2 * 1e3, "launches_per_step": v[2] // 2}
                               for k, v in mm.items()},
                 "all_matrix_ops": {"algorithmic_tflop_per_step": tot_fl / 2 / 1e12, "ms_per_step": tot_s / 2 * 1e3,
@@ -416,12 +427,12 @@ def main():
                 "hbm_kernels": hbm}
         # whole-step view: the time the step's algorithmic work would take at the stated peaks (matrix work per arithmetic, the HBM-bound
         # kernels' algorithmic bytes at 8 TB/s), against the measured step
-        lb_ms = (sum(v[0] for k, v in mm.items() if not k.endswith(("_b3", "_d3"))) / (PEAK_F32 * 1e12)
-                 + sum(v[0] for k, v in mm.items() if k.endswith(("_b3", "_d3"))) / (PEAK_B3 * 1e12)
+        lb_ms = (sum(v[0] / (peak_of(k) * 1e12) for k, v in mm.items())
                  + sum(v[0] for k, v in agg.items() if k.startswith("hbm:")) / 8e12) / 2 * 1e3
         roof["whole_step"] = {"lower_bound_ms": lb_ms, "measured_ms": dt / args.steps * 1e3, "frac": lb_ms / (dt / args.steps * 1e3),
+                              "f16x2_tflop_per_step": sum(v[0] for k, v in mm.items() if k.endswith("_h2")) / 2 / 1e12,
                               "bf16x3_tflop_per_step": sum(v[0] for k, v in mm.items() if k.endswith(("_b3", "_d3"))) / 2 / 1e12,
-                              "fp32_tflop_per_step": sum(v[0] for k, v in mm.items() if not k.endswith(("_b3", "_d3"))) / 2 / 1e12}
+                              "fp32_tflop_per_step": sum(v[0] for k, v in mm.items() if not k.endswith(("_b3", "_d3", "_h2"))) / 2 / 1e12}
     comm = None
     if world > 1:
         comm = model._grad_sync.stats()          # every rank (it synchronises its device); rank 0 prints

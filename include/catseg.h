@@ -133,6 +133,25 @@ int catseg_conv2d_bwd_data_bf16x3_blocked(const catseg_conv_desc* d, const void*
 int catseg_bias_grad(const float* dy, int ld, long long rows, int C, float* dbias, void* workspace, size_t workspace_bytes,
                      catseg_stream_t stream);
 
+/* ---- two-plane fp16 split precision (csrc/igemm_f16x2.hip): the same F.conv2d call sites as the bf16x3 blocked entry points above
+ * (the OCR / auxiliary head convolutions 3x3 720 -> 512 and the 1x1 1024 -> 512 of models/OCR.py:88-104, UPerNet's fusion layers), half
+ * the matrix work.  Every operand tensor is scaled by 2^e, e = 14 - floor(log2(max|x|)), and split into h = fp16(x 2^e),
+ * l = fp16(x 2^e - h) (22 significant bits); the kernel accumulates hh + hl + lh in fp32 and scales the result by 2^-(e_x + e_w).
+ *   `scale`: 8 bytes of DEVICE memory per operand, {uint32 bits of max|x|, int32 e}, written by the split call (two launches: amax,
+ *   split) and read by the convolution -- no host round trip. */
+size_t catseg_split2h_blocked_elems(long long rows, int C);
+int catseg_split2h_blocked(const float* x, long long rows, int C, int ld, void* planes, void* scale, catseg_stream_t stream);
+int catseg_split2h_weight_blocked(const float* w, int O, int taps, int Cin, void* planes, void* scale, catseg_stream_t stream);
+int catseg_split2h_weight_t_blocked(const float* w, int O, int taps, int Cin, void* planes, void* scale, catseg_stream_t stream);
+int catseg_conv2d_fwd_f16x2_blocked(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* w_planes,
+                                    const void* w_scale, const float* bias, float* y, int zero_to, float* bn_part, size_t bn_part_floats,
+                                    int* tile_rows, int* n_tiles, catseg_stream_t stream);
+int catseg_conv2d_fwd_fused_f16x2_blocked(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* w_planes,
+                                          const void* w_scale, const float* bias, const float* residual, int ldr, int relu, float* y,
+                                          catseg_stream_t stream);
+int catseg_conv2d_bwd_data_f16x2_blocked(const catseg_conv_desc* d, const void* dy_planes, const void* dy_scale, const void* wt_planes,
+                                         const void* wt_scale, float* dx, int accumulate, catseg_stream_t stream);
+
 /* ---- direct 3x3 / stride 1 / pad 1 convolution in split precision (csrc/dconv3_b3.hip) for the HRNet trunk: the BasicBlock
  * convolutions conv3x3(planes, planes) at models/HRNetv2.py:22-25,41-44 (Cin = Cout = C in {48, 96}; catseg_dconv3_supported).
  * Same F.conv2d call sites and same arithmetic as catseg_conv2d_fwd_bf16x3 (three exact bf16 planes per fp32 operand, six bf16

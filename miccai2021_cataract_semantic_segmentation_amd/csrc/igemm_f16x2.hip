@@ -1,0 +1,590 @@
+// Split-precision implicit-GEMM convolution on the fp16 matrix cores of gfx950: TWO planes, THREE products.
+//
+// igemm_bf16x3.hip reproduces an fp32 product from three bf16 planes per operand and six MFMA products; under that load the chip is
+// power-limited (1.54 - 1.67 GHz) and the large head layers sit at 0.85 of what the sustained clock allows -- the matrix work itself is
+// the floor.  fp16 carries 11 significant bits per piece instead of 8:
+//   xs = x * 2^e (exact; e chosen per TENSOR so that max|xs| is in [2^14, 2^15)),  h = fp16(xs),  l = fp16(xs - h)
+//   xs = h + l + r,  |r| <= 2^-22 |xs|   (for |xs| >= 2^-3; smaller elements lose relative, not absolute precision: |r| <= 2^-25,
+//                                          i.e. 2^-39 of the tensor's largest element)
+// and a product of two such operands is  hh + hl + lh  (+ ll + ..., relative 2^-22) -- three v_mfma_f32_32x32x16_f16 per 32x32x16
+// block, all into ONE fp32 accumulator; every fp16 x fp16 product is exact in fp32.  Representation error 2^-22 per operand (a fourth
+// of an fp32 ulp of the operand is lost, about one ulp of the result), accumulation in fp32 as before.  What fp16 needs and bf16 does
+// not is the range: 5 exponent bits, so every operand tensor is scaled by a power of two derived from its amax (gradients are ~1e-6)
+// and the epilogue scales the result back by 2^-(e_a + e_w).
+//
+// This file: amax, the two-plane blocked split of activations and weights, and igemm_h2w_kernel -- the 256 x 256 register-pipelined
+// kernel of igemm_bf16x3.hip (blocked planes, LDS-DMA through buffer resources, one wave per SIMD) with 48 MFMAs per K-step in the
+// order  lh | hh | hl  and four 32 KB LDS slots.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+// ---- amax -----------------------------------------------------------------------------------------------------------------------
+// bits of max |x| over [rows][C] (row stride ld), atomicMax on the unsigned bit pattern (non-negative floats order like their bits;
+// a NaN is larger than everything and is kept: the split then falls back to e = 0 and NaNs propagate as they would in fp32)
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int ld, long long rows, int C, unsigned* __restrict__ out) {
+  const int c4n = (C + 3) >> 2;
+  const long long n = rows * c4n;
+  unsigned m = 0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    const float* src = x + r * ld + c;
+    if (c + 3 < C) {
+      const f32x4 v = *(const f32x4*)src;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m = max(m, __float_as_uint(v[j]) & 0x7FFFFFFFu);
+    } else {
+      for (int j = 0; c + j < C; ++j) m = max(m, __float_as_uint(src[j]) & 0x7FFFFFFFu);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  __shared__ unsigned sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+    if (m) atomicMax(out, m);
+  }
+}
+
+// exponent e of the prescale 2^e: amax * 2^e in [2^14, 2^15) (fp16's largest finite value is 65504); 0 for an all-zero tensor, for
+// denormal amax and for inf / NaN; clamped so that 2^e and 2^-e stay normal floats
+__device__ __forceinline__ int h2_exponent(unsigned amax_bits) {
+  const int ex = (int)((amax_bits >> 23) & 0xFF);
+  if (ex == 0 || ex == 255) return 0;
+  const int e = 14 - (ex - 127);
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+
+__device__ __forceinline__ void split2h_one(float v, int e, u16& h, u16& l) {
+  const float xs = __builtin_ldexpf(v, e);
+  const _Float16 hh = (_Float16)xs;
+  const float r = xs - (float)hh;
+  h = __builtin_bit_cast(u16, hh);
+  l = __builtin_bit_cast(u16, (_Float16)r);
+}
+
+// fp32 [rows][ld] -> two fp16 planes in the BLOCKED layout [C16][rows][16] (C16 = ceil(C / 16), channel tail zero), prescaled by 2^e
+// (e from amax_bits, written to *e_out).  Block = 64 rows x 128 channels through LDS, as split3_blocked_kernel.
+__global__ __launch_bounds__(256) void split2h_blocked_kernel(const float* __restrict__ x, int ld, long long rows, int C,
+                                                              const unsigned* __restrict__ amax_bits, u16* __restrict__ blk, long long blk_plane,
+                                                              int* __restrict__ e_out) {
+  constexpr int RS = 128 + 8;
+  __shared__ __attribute__((aligned(16))) u16 sh[2][64 * RS];
+  const int e = h2_exponent(*amax_bits);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *e_out = e;
+  const long long r0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 128;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = i * 256 + t, row = q >> 5, c4 = (q & 31) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r0 + row < rows) {
+      const float* src = x + (r0 + row) * ld + c0 + c4;
+      if (c0 + c4 + 3 < C) {
+        const f32x4 f = *(const f32x4*)src;
+        v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (c0 + c4 + j < C) ? src[j] : 0.f;
+      }
+    }
+    u16 h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2h_one(v[j], e, h[j], l[j]);
+    u16* d = &sh[0][row * RS + c4];
+    *(unsigned long long*)d = (unsigned long long)h[0] | ((unsigned long long)h[1] << 16) | ((unsigned long long)h[2] << 32) | ((unsigned long long)h[3] << 48);
+    *(unsigned long long*)(d + 64 * RS) = (unsigned long long)l[0] | ((unsigned long long)l[1] << 16) | ((unsigned long long)l[2] << 32) | ((unsigned long long)l[3] << 48);
+  }
+  __syncthreads();
+  const int c16 = (C + 15) >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 256 + t, cc = q >> 7, row = (q & 127) >> 1, half = (q & 1) * 8;
+    const int chunk = (c0 >> 4) + cc;
+    if (r0 + row < rows && chunk < c16) {
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        *(half8*)(blk + pl * blk_plane + ((long long)chunk * rows + r0 + row) * 16 + half) = *(const half8*)&sh[pl][row * RS + cc * 16 + half];
+    }
+  }
+}
+
+// fp32 weights viewed as [N][K] -> blocked fp16 planes [K/16][N][16], prescaled; T = the transposed filter bank of backward-data
+// (row n = input channel c, k = tap * Opad + o, source w[(o * taps + tap) * Cin + c], zero for o >= O)
+template <bool T>
+__global__ __launch_bounds__(256) void split2h_weight_blocked_kernel(const float* __restrict__ w, int N, int K, int O, int Opad, int taps, int Cin,
+                                                                     const unsigned* __restrict__ amax_bits, u16* __restrict__ out, long long plane,
+                                                                     int* __restrict__ e_out) {
+  const int e = h2_exponent(*amax_bits);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *e_out = e;
+  const long long n_el = (long long)N * K;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_el; i += (long long)gridDim.x * blockDim.x) {
+    const int kk = (int)(i & 15);
+    const long long rest = i >> 4;
+    const int n = (int)(rest % N), k16 = (int)(rest / N);
+    const int k = k16 * 16 + kk;
+    float v;
+    if (T) {
+      const int tap = k / Opad, o = k - tap * Opad;
+      v = o < O ? w[((long long)o * taps + tap) * Cin + n] : 0.f;
+    } else {
+      v = w[(long long)n * K + k];
+    }
+    u16 h, l;
+    split2h_one(v, e, h, l);
+    out[i] = h;
+    out[i + plane] = l;
+  }
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------------------------------------------
+struct H2Args {
+  const u16* a;       // activation planes, blocked [2][Cin/16][a_rows][16]
+  long long a_plane;  // elements between planes
+  const u16* w;       // weight planes, blocked [2][taps * Cin / 16][w_rows][16]
+  long long w_plane;
+  const int* ea;      // device: prescale exponents of the two operands
+  const int* ew;
+  float* C;
+  int ldc;
+  const float* bias;
+  int M, N, Cin, taps;
+  int H, W, Ho, Wo;   // H, W: source image of the gather; Ho, Wo: the grid the GEMM rows decode over
+  int kw, stride, pad, dil;
+  int sign;           // +1: forward gather; -1: stride-1 backward-data gather
+  int tilesM, tilesN;
+  int zero_to, accumulate;
+  float* bn_part;     // per (M-tile, channel) BatchNorm partials [tilesM][3][N], or nullptr
+  int a_rows, w_rows;
+  const float* residual;   // fused inference epilogue: v = act(v + bias (+ residual))
+  int ldr, relu;
+};
+
+constexpr int h2_waitcnt(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
+
+// 4 waves (one per SIMD), block tile 256 x 256, wave tile 128 x 128 (4 x 4 MFMA tiles of 32 x 32), K-step = 16.
+// Per K-step 48 MFMAs (1536 cycles): products in the order  lh | hh | hl.  An iteration of the K loop is  hh(k), hl(k), lh(k+1):
+// every fragment set is re-read for step k+1 right behind its last use in step k --
+//   Al behind lh(k) [read under hh(k)],  Bh behind hh(k) [under hl(k)],  Ah and Bl behind hl(k) [under lh(k+1), which needs Al, Bh] --
+// so all fragment reads of an iteration come from ONE slot (k+1), nothing is double buffered (64 fragment registers + 256
+// accumulators) and each read has >= 8 MFMAs (256 cycles) before its first use.
+// LDS: four 32 KB slots.  Iteration k reads slot (k+1) % 4 while steps k+2, k+3 are landing and the LDS-DMA of step k+4 is issued
+// into slot k % 4 (last read in iteration k-1: the barrier at the top of the iteration separates them).  One barrier per K-step;
+// a load has three K-steps (4608 cycles) of latency budget.
+__global__ __launch_bounds__(256, 1) void igemm_h2w_kernel(const H2Args p) {
+  constexpr int TM = 4, TN = 4, WGN = 2;
+  constexpr int BM = 256, BN = 256;
+  constexpr int PLANE_A = BM * 32, PLANE_B = BN * 32;
+  constexpr int SLAB = 2 * (PLANE_A + PLANE_B);
+  constexpr int NSLOT = 4;
+  constexpr int NA = 2, NB = 2;   // 16-byte chunks per thread per plane
+  __shared__ __attribute__((aligned(16))) char smem[NSLOT * SLAB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_m = swz / p.tilesN, tile_n = swz - tile_m * p.tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int aoff[NA], achunk[NA], bchunk[NB], brow[NB];
+  unsigned amask[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int q = j * 256 + tid, row = q >> 1;
+    achunk[j] = ((q & 1) ^ ((row >> 3) & 1)) * 8;
+    const int r = m0 + row;
+    aoff[j] = 0;
+    amask[j] = 0;
+    if (r < p.M) {
+      const int hw = p.Ho * p.Wo;
+      const int b = r / hw, rem = r - b * hw;
+      const int y = rem / p.Wo, x = rem - y * p.Wo;
+      const int y0 = p.sign > 0 ? y * p.stride - p.pad : y + p.pad;
+      const int x0 = p.sign > 0 ? x * p.stride - p.pad : x + p.pad;
+      aoff[j] = (b * p.H + y0) * p.W + x0;   // pixel index of tap (0, 0)
+      const int kh = p.taps / p.kw;
+      int t = 0;
+      for (int ky = 0; ky < kh; ++ky)
+        for (int kx = 0; kx < p.kw; ++kx, ++t) {
+          const int yy = y0 + p.sign * ky * p.dil, xx = x0 + p.sign * kx * p.dil;
+          if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) amask[j] |= 1u << t;
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int q = j * 256 + tid, row = q >> 1;
+    bchunk[j] = ((q & 1) ^ ((row >> 3) & 1)) * 8;
+    brow[j] = n0 + row;
+  }
+
+  const int nck = (p.Cin + 15) >> 4;
+  const int nks = p.taps * nck;
+  int ttap = 0, tky = 0, tkx = 0, tck = 0;
+  // LDS-DMA sources through two raw buffer resources (one per operand, both planes inside; the host checks 2 planes < 4 GB): a lane's
+  // source = 32-bit BYTE offset; padding taps, channel tails and rows past M / N get an out-of-range offset = zeros in LDS
+  const unsigned apl_b = (unsigned)(p.a_plane * 2), wpl_b = (unsigned)(p.w_plane * 2);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, (short)0, (int)(2u * apl_b), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)(2u * wpl_b), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  unsigned VA[NA], VB[NB];   // byte offsets of one K-step's pieces inside plane 0 (the plane offset rides in the instruction's soffset)
+  auto prepA = [&](const int j) {
+    const bool ok = (int)(ttap < p.taps) & (int)((amask[j] >> (ttap & 31)) & 1u) & (int)((tck * 16 + achunk[j]) < p.Cin);
+    const unsigned v = (unsigned)((tck * p.a_rows + aoff[j] + p.sign * (tky * p.dil * p.W + tkx * p.dil)) * 16 + achunk[j]) * 2u;
+    VA[j] = ok ? v : OOB;
+  };
+  auto prepB = [&](const int j) {
+    const bool ok = (int)(ttap < p.taps) & (int)(brow[j] < p.N) & (int)((tck * 16 + bchunk[j]) < p.Cin);
+    const unsigned v = (unsigned)(((ttap * nck + tck) * p.w_rows + brow[j]) * 16 + bchunk[j]) * 2u;   // [K/16][N][16]
+    VB[j] = ok ? v : OOB;
+  };
+  // K order: 16-channel chunk outer, filter taps inner (the nine taps of a chunk re-read the same contiguous run of a blocked plane
+  // shifted by a few pixels: L1 / L2 hits instead of nine passes over the whole plane through the fabric)
+  auto advance = [&]() {
+    const int nx = tkx + 1, nt = ttap + 1;
+    const bool wrapx = nx == p.kw, wrapt = nt == p.taps;
+    tkx = wrapx ? 0 : nx;
+    tky = wrapt ? 0 : (wrapx ? tky + 1 : tky);
+    ttap = wrapt ? 0 : nt;
+    tck += wrapt ? 1 : 0;
+  };
+  auto prep = [&]() {
+    prepA(0); prepA(1); prepB(0); prepB(1); advance();
+  };
+  // LDS-DMA piece i of a K-step: i = 4 * plane + {A0, A1, B0, B1}
+  auto piece = [&](const int buf, const int i) {
+    char* s = smem + buf * SLAB;
+    const int pl = i >> 2, w = i & 3;
+    if (w < 2)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(s + pl * PLANE_A + (w * 256 + wave * 64) * 16), 16,
+                                               VA[w], pl * apl_b, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(s + 2 * PLANE_A + pl * PLANE_B + ((w - 2) * 256 + wave * 64) * 16),
+                                               16, VB[w - 2], pl * wpl_b, 0, 0);
+  };
+  auto issue = [&](const int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) piece(buf, i);
+  };
+
+  half8 Ah[TM], Bh[TN], Al[TM], Bl[TN];
+  int ra0, rb0;
+  {
+    const int rowa = wm * 128 + l31, rowb = wn * 128 + l31;   // (row + 32 t keeps (row >> 3) & 1: one swizzle per lane)
+    ra0 = rowa * 32 + ((h ^ ((rowa >> 3) & 1)) << 4);
+    rb0 = 2 * PLANE_A + rowb * 32 + ((h ^ ((rowb >> 3) & 1)) << 4);
+  }
+#define H2_READ(dst, base, off) dst = *(const half8*)((base) + (off))
+#define H2_MFMA(A_, t_, B_, u_)                                                                              \
+  do {                                                                                                        \
+    acc[t_][u_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[t_], B_[u_], acc[t_][u_], 0, 0, 0);                \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  } while (0)
+#define H2_SYNC()                                        \
+  do {                                                   \
+    __builtin_amdgcn_s_waitcnt(h2_waitcnt(16, 0));       \
+    __builtin_amdgcn_s_barrier();                        \
+  } while (0)
+
+  if (nks > 0) {
+    prep();
+    issue(0);
+    prep();
+    issue(1);                       // (unconditional: past the end of the reduction every offset is out of range = zeros)
+    prep();
+    issue(2);
+    prep();
+    issue(3);
+    prep();
+    __builtin_amdgcn_s_waitcnt(h2_waitcnt(24, 0));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      const char* aa_ = smem + ra0;
+      const char* bb_ = smem + rb0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        H2_READ(Al[t], aa_, 1 * PLANE_A + t * 1024);
+        H2_READ(Bh[t], bb_, 0 * PLANE_B + t * 1024);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        H2_READ(Ah[t], aa_, 0 * PLANE_A + t * 1024);
+        H2_READ(Bl[t], bb_, 1 * PLANE_B + t * 1024);
+      }
+    }
+    // lh(0)
+    H2_MFMA(Al, 0, Bh, 0); H2_MFMA(Al, 0, Bh, 1); H2_MFMA(Al, 0, Bh, 2); H2_MFMA(Al, 0, Bh, 3);
+    H2_MFMA(Al, 1, Bh, 0); H2_MFMA(Al, 1, Bh, 1); H2_MFMA(Al, 1, Bh, 2); H2_MFMA(Al, 1, Bh, 3);
+    H2_MFMA(Al, 2, Bh, 0); H2_MFMA(Al, 2, Bh, 1); H2_MFMA(Al, 2, Bh, 2); H2_MFMA(Al, 2, Bh, 3);
+    H2_MFMA(Al, 3, Bh, 0); H2_MFMA(Al, 3, Bh, 1); H2_MFMA(Al, 3, Bh, 2); H2_MFMA(Al, 3, Bh, 3);
+    int nxt = 1, fill = 0;
+    for (int k = 0; k < nks; ++k) {
+      // all but my newest 16 LDS-DMA pieces (steps k+2, k+3) have landed: step k+1 is there; every fragment read has returned; the
+      // barrier: ... everybody's, and every wave has read the fragments of step k out of slot k % 4, which step k+4 now overwrites
+      H2_SYNC();
+      asm volatile("" ::: "memory");
+      const char* aa_ = smem + nxt * SLAB + ra0;
+      const char* bb_ = smem + nxt * SLAB + rb0;
+      // hh(k); Al(k+1) read; the eight pieces of step k+4
+      H2_READ(Al[0], aa_, PLANE_A + 0 * 1024); H2_MFMA(Ah, 0, Bh, 0);
+      H2_READ(Al[1], aa_, PLANE_A + 1 * 1024); H2_MFMA(Ah, 0, Bh, 1);
+      H2_READ(Al[2], aa_, PLANE_A + 2 * 1024); H2_MFMA(Ah, 0, Bh, 2);
+      H2_READ(Al[3], aa_, PLANE_A + 3 * 1024); H2_MFMA(Ah, 0, Bh, 3);
+      piece(fill, 0); H2_MFMA(Ah, 1, Bh, 0);
+      piece(fill, 1); H2_MFMA(Ah, 1, Bh, 1);
+      piece(fill, 2); H2_MFMA(Ah, 1, Bh, 2);
+      piece(fill, 3); H2_MFMA(Ah, 1, Bh, 3);
+      piece(fill, 4); H2_MFMA(Ah, 2, Bh, 0);
+      piece(fill, 5); H2_MFMA(Ah, 2, Bh, 1);
+      piece(fill, 6); H2_MFMA(Ah, 2, Bh, 2);
+      piece(fill, 7); H2_MFMA(Ah, 2, Bh, 3);
+      H2_MFMA(Ah, 3, Bh, 0); H2_MFMA(Ah, 3, Bh, 1); H2_MFMA(Ah, 3, Bh, 2); H2_MFMA(Ah, 3, Bh, 3);
+      // hl(k); Bh(k+1) read; the addresses of step k+5
+      H2_READ(Bh[0], bb_, 0 * 1024); H2_MFMA(Ah, 0, Bl, 0);
+      H2_READ(Bh[1], bb_, 1 * 1024); H2_MFMA(Ah, 0, Bl, 1);
+      H2_READ(Bh[2], bb_, 2 * 1024); H2_MFMA(Ah, 0, Bl, 2);
+      H2_READ(Bh[3], bb_, 3 * 1024); H2_MFMA(Ah, 0, Bl, 3);
+      H2_MFMA(Ah, 1, Bl, 0);
+      prepA(0); H2_MFMA(Ah, 1, Bl, 1);
+      H2_MFMA(Ah, 1, Bl, 2);
+      prepA(1); H2_MFMA(Ah, 1, Bl, 3);
+      H2_MFMA(Ah, 2, Bl, 0);
+      prepB(0); H2_MFMA(Ah, 2, Bl, 1);
+      H2_MFMA(Ah, 2, Bl, 2);
+      prepB(1); H2_MFMA(Ah, 2, Bl, 3);
+      H2_MFMA(Ah, 3, Bl, 0);
+      advance(); H2_MFMA(Ah, 3, Bl, 1);
+      H2_MFMA(Ah, 3, Bl, 2); H2_MFMA(Ah, 3, Bl, 3);
+      // lh(k+1) (step nks is all zeros); Ah(k+1), Bl(k+1) read
+      H2_READ(Ah[0], aa_, 0 * 1024); H2_MFMA(Al, 0, Bh, 0);
+      H2_READ(Ah[1], aa_, 1 * 1024); H2_MFMA(Al, 0, Bh, 1);
+      H2_READ(Ah[2], aa_, 2 * 1024); H2_MFMA(Al, 0, Bh, 2);
+      H2_READ(Ah[3], aa_, 3 * 1024); H2_MFMA(Al, 0, Bh, 3);
+      H2_READ(Bl[0], bb_, PLANE_B + 0 * 1024); H2_MFMA(Al, 1, Bh, 0);
+      H2_READ(Bl[1], bb_, PLANE_B + 1 * 1024); H2_MFMA(Al, 1, Bh, 1);
+      H2_READ(Bl[2], bb_, PLANE_B + 2 * 1024); H2_MFMA(Al, 1, Bh, 2);
+      H2_READ(Bl[3], bb_, PLANE_B + 3 * 1024); H2_MFMA(Al, 1, Bh, 3);
+      H2_MFMA(Al, 2, Bh, 0); H2_MFMA(Al, 2, Bh, 1); H2_MFMA(Al, 2, Bh, 2); H2_MFMA(Al, 2, Bh, 3);
+      H2_MFMA(Al, 3, Bh, 0); H2_MFMA(Al, 3, Bh, 1); H2_MFMA(Al, 3, Bh, 2); H2_MFMA(Al, 3, Bh, 3);
+      nxt = (nxt + 1) & 3;
+      fill = (fill + 1) & 3;
+    }
+  }
+#undef H2_READ
+#undef H2_MFMA
+#undef H2_SYNC
+
+  // back to the operands' scale: 2^-(e_a + e_w) in two exact steps (each exponent is within [-100, 100])
+  {
+    const int ea = -*p.ea, ew = -*p.ew;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int u = 0; u < TN; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][u][r] = __builtin_ldexpf(__builtin_ldexpf(acc[t][u][r], ea), ew);
+  }
+
+  if (p.bn_part != nullptr) {   // BatchNorm batch statistics of this tile (common.h: cs_tile_bn_partials)
+    __syncthreads();
+    int colv[TN];
+    float bvv[TN];
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      colv[u] = wn * 128 + u * 32 + l31;
+      bvv[u] = (p.bias != nullptr && n0 + colv[u] < p.N) ? p.bias[n0 + colv[u]] : 0.f;
+    }
+    const int rbase = m0 + wm * 128 + 4 * h;
+    cs_tile_bn_partials<TN, TM * 16, 2, false>(
+        (float*)smem, BN, colv, h == 0, wm, min(BM, p.M - m0),
+        [&](int j, int i) { return acc[i >> 4][j][i & 15] + bvv[j]; },
+        [&](int i) { return rbase + (i >> 4) * 32 + (i & 3) + 8 * ((i & 15) >> 2) < p.M; }, p.bn_part + (long long)tile_m * 3 * p.N, p.N, n0);
+  }
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      const int col = n0 + wn * 128 + u * 32 + l31;
+      const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 128 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < p.M) {
+          float* dst = p.C + (long long)row * p.ldc + col;
+          if (col < p.N) {
+            float v = acc[t][u][r] + bv;
+            if (p.accumulate) v += *dst;
+            if (p.residual != nullptr) v += p.residual[(long long)row * p.ldr + col];
+            if (p.relu) v = fmaxf(v, 0.f);
+            *dst = v;
+          } else if (col < p.zero_to) {
+            *dst = 0.f;
+          }
+        }
+      }
+    }
+}
+
+int run_h2(H2Args a, hipStream_t st) {
+  CS_REQUIRE(a.a_plane * 4 < (1ll << 32) - 64 && a.w_plane * 4 < (1ll << 32) - 64, "f16x2 blocked planes: an operand's two planes must stay below 4 GB");
+  CS_REQUIRE(a.ea && a.ew, "f16x2: prescale exponents missing");
+  a.tilesM = (a.M + 255) / 256;
+  a.tilesN = ((a.zero_to > a.N ? a.zero_to : a.N) + 255) / 256;
+  hipLaunchKernelGGL(igemm_h2w_kernel, dim3(a.tilesM * a.tilesN), dim3(256), 0, st, a);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+int amax_launch(const float* x, int ld, long long rows, int C, unsigned* amax_bits, hipStream_t st) {
+  if (hipMemsetAsync(amax_bits, 0, 4, st) != hipSuccess) { catseg_set_error("amax: memset failed"); return CATSEG_EHIP; }
+  const long long n = rows * ((C + 3) / 4);
+  long long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ld, rows, C, amax_bits);
+  return CATSEG_OK;
+}
+
+}  // namespace
+
+// scale[0] (device, 8 bytes: {uint32 amax bits, int32 exponent}) is working storage + result of the split calls below
+extern "C" size_t catseg_split2h_blocked_elems(long long rows, int C) { return (size_t)2 * (size_t)((C + 15) / 16) * 16 * (size_t)rows; }
+
+// x [rows][ld] fp32 -> two fp16 planes [2][ceil(C/16)][rows][16] of x * 2^e, e = 14 - floor(log2(max|x|)); scale[0] receives
+// {bits of max|x|, e}.  Two launches (amax, split).
+extern "C" int catseg_split2h_blocked(const float* x, long long rows, int C, int ld, void* planes, void* scale, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && ld >= C && ld % 4 == 0 && cs_aligned16(x) && cs_aligned16(planes) && scale && (((uintptr_t)scale) & 7) == 0,
+             "split2h_blocked: bad args (ld must be a multiple of 4, pointers 16-byte aligned)");
+  CS_REQUIRE((rows + 63) / 64 < (1ll << 31), "split2h_blocked: too many rows");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* ab = (unsigned*)scale;
+  if (int rc = amax_launch(x, ld, rows, C, ab, st)) return rc;
+  const int c16 = (C + 15) / 16;
+  hipLaunchKernelGGL(split2h_blocked_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((c16 * 16 + 127) / 128)), dim3(256), 0, st, x, ld, rows, C,
+                     (const unsigned*)ab, (u16*)planes, (long long)c16 * rows * 16, (int*)(ab + 1));
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// OHWI weights viewed as [Cout][K = taps * Cin] -> blocked fp16 planes [2][K/16][Cout][16] (Cin % 16 == 0): B operand of the forward conv
+extern "C" int catseg_split2h_weight_blocked(const float* w, int O, int taps, int Cin, void* planes, void* scale, catseg_stream_t stream) {
+  CS_REQUIRE(O > 0 && taps > 0 && Cin > 0 && Cin % 16 == 0 && cs_aligned16(planes) && cs_aligned16(w) && scale, "split2h_weight_blocked: needs Cin % 16 == 0");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* ab = (unsigned*)scale;
+  const int K = taps * Cin;
+  if (int rc = amax_launch(w, K, O, K, ab, st)) return rc;
+  const long long n = (long long)O * K;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(split2h_weight_blocked_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, w, O, K, O, O, taps, Cin, (const unsigned*)ab,
+                     (u16*)planes, n, (int*)(ab + 1));
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// OHWI weights -> blocked fp16 planes of the transposed filter bank [2][taps * Opad / 16][Cin][16], Opad = roundup(O, 16): B operand of
+// backward-data
+extern "C" int catseg_split2h_weight_t_blocked(const float* w, int O, int taps, int Cin, void* planes, void* scale, catseg_stream_t stream) {
+  CS_REQUIRE(O > 0 && taps > 0 && Cin > 0 && Cin % 4 == 0 && cs_aligned16(planes) && cs_aligned16(w) && scale, "split2h_weight_t_blocked: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* ab = (unsigned*)scale;
+  if (int rc = amax_launch(w, taps * Cin, O, taps * Cin, ab, st)) return rc;
+  const int Opad = (O + 15) & ~15;
+  const int K = taps * Opad;
+  const long long n = (long long)Cin * K;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(split2h_weight_blocked_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, w, Cin, K, O, Opad, taps, Cin, (const unsigned*)ab,
+                     (u16*)planes, n, (int*)(ab + 1));
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+namespace {
+H2Args h2_fwd_args(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* w_planes, const void* w_scale,
+                   const float* bias, float* y) {
+  H2Args a = {};
+  a.a_rows = d->B * d->H * d->W; a.w_rows = d->Cout;
+  a.a = (const u16*)x_planes; a.a_plane = (long long)a.a_rows * d->Cin;
+  a.w = (const u16*)w_planes; a.w_plane = (long long)d->Cout * d->kh * d->kw * d->Cin;
+  a.ea = (const int*)x_scale + 1; a.ew = (const int*)w_scale + 1;
+  a.C = y; a.ldc = d->ldy; a.bias = bias;
+  a.M = d->B * d->Ho * d->Wo; a.N = d->Cout; a.Cin = d->Cin; a.taps = d->kh * d->kw;
+  a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+  a.sign = 1;
+  return a;
+}
+}  // namespace
+
+// y = conv(x, w) (+ bias) from two-plane fp16 operands: x_planes / x_scale = catseg_split2h_blocked of x (C = Cin, Cin % 16 == 0),
+// w_planes / w_scale = catseg_split2h_weight_blocked.  bn_part may be null (then tile_rows / n_tiles are not touched).
+extern "C" int catseg_conv2d_fwd_f16x2_blocked(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* w_planes,
+                                               const void* w_scale, const float* bias, float* y, int zero_to, float* bn_part,
+                                               size_t bn_part_floats, int* tile_rows, int* n_tiles, catseg_stream_t stream) {
+  CS_REQUIRE(d && !d->stem4 && d->groups <= 1 && d->Cin % 16 == 0 && d->kh * d->kw <= 32, "conv fwd f16x2: needs Cin % 16 == 0, <= 32 taps, dense");
+  CS_REQUIRE(cs_aligned16(x_planes) && cs_aligned16(w_planes) && cs_aligned16(y) && zero_to <= d->ldy && x_scale && w_scale, "conv fwd f16x2: alignment");
+  H2Args a = h2_fwd_args(d, x_planes, x_scale, w_planes, w_scale, bias, y);
+  a.zero_to = zero_to;
+  if (bn_part != nullptr) {
+    CS_REQUIRE(tile_rows && n_tiles, "conv fwd f16x2: tile_rows / n_tiles");
+    const int nt = (a.M + 255) / 256;
+    *tile_rows = 0; *n_tiles = 0;
+    if ((size_t)nt * 3 * d->Cout <= bn_part_floats) {
+      a.bn_part = bn_part;
+      *tile_rows = 256; *n_tiles = nt;
+    }
+  }
+  return run_h2(a, (hipStream_t)stream);
+}
+
+// inference: y = act(conv(x, w) + bias (+ residual)) in one kernel (the counterpart of catseg_conv2d_fwd_fused_bf16x3_blocked)
+extern "C" int catseg_conv2d_fwd_fused_f16x2_blocked(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* w_planes,
+                                                     const void* w_scale, const float* bias, const float* residual, int ldr, int relu, float* y,
+                                                     catseg_stream_t stream) {
+  CS_REQUIRE(d && !d->stem4 && d->groups <= 1 && d->Cin % 16 == 0 && d->kh * d->kw <= 32, "conv fwd fused f16x2: needs Cin % 16 == 0, <= 32 taps, dense");
+  CS_REQUIRE(cs_aligned16(x_planes) && cs_aligned16(w_planes) && cs_aligned16(y) && (residual == nullptr || ldr >= d->Cout) && x_scale && w_scale,
+             "conv fwd fused f16x2: bad args");
+  H2Args a = h2_fwd_args(d, x_planes, x_scale, w_planes, w_scale, bias, y);
+  a.residual = residual; a.ldr = ldr; a.relu = relu;
+  return run_h2(a, (hipStream_t)stream);
+}
+
+// dx (+)= conv_transpose(dy, w), stride 1: dy_planes / dy_scale = catseg_split2h_blocked of dy (C = Cout; the channel tail up to
+// roundup(Cout, 16) is zero), wt_planes / wt_scale = catseg_split2h_weight_t_blocked
+extern "C" int catseg_conv2d_bwd_data_f16x2_blocked(const catseg_conv_desc* d, const void* dy_planes, const void* dy_scale, const void* wt_planes,
+                                                    const void* wt_scale, float* dx, int accumulate, catseg_stream_t stream) {
+  CS_REQUIRE(d && !d->stem4 && d->groups <= 1 && d->stride == 1 && d->kh * d->kw <= 32, "conv bwd_data f16x2: stride 1, <= 32 taps, dense");
+  CS_REQUIRE(cs_aligned16(dy_planes) && cs_aligned16(wt_planes) && cs_aligned16(dx) && dy_scale && wt_scale, "conv bwd_data f16x2: alignment");
+  const int cop = (d->Cout + 15) & ~15;
+  H2Args a = {};
+  a.a_rows = d->B * d->Ho * d->Wo; a.w_rows = d->Cin;
+  a.a = (const u16*)dy_planes; a.a_plane = (long long)a.a_rows * cop;
+  a.w = (const u16*)wt_planes; a.w_plane = (long long)d->Cin * d->kh * d->kw * cop;
+  a.ea = (const int*)dy_scale + 1; a.ew = (const int*)wt_scale + 1;
+  a.C = dx; a.ldc = d->ldx; a.bias = nullptr;
+  a.M = d->B * d->H * d->W; a.N = d->Cin; a.Cin = cop; a.taps = d->kh * d->kw;
+  a.H = d->Ho; a.W = d->Wo; a.Ho = d->H; a.Wo = d->W; a.kw = d->kw; a.stride = 1; a.pad = d->pad; a.dil = d->dil;
+  a.sign = -1; a.accumulate = accumulate;
+  return run_h2(a, (hipStream_t)stream);
+}

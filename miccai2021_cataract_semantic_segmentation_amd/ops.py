@@ -141,6 +141,16 @@ def _b3_blocked_ok(ncols, cred, a_rows, w_rows, taps):
             and 6 * w_rows * taps * cred < B3_PLANE_LIMIT)
 
 
+# Arithmetic of the layers on the blocked 256 x 256 path (forward / backward-data of the head convolutions): "f16x2" = two fp16 planes
+# per operand after a per-tensor power-of-two prescale, three MFMA products (csrc/igemm_f16x2.hip: 22 significant bits per operand,
+# half the matrix work of bf16x3); "bf16x3" = three exact bf16 planes, six products.  CATSEG_HEADS selects.
+HEADS = _os.environ.get("CATSEG_HEADS", "f16x2")
+
+
+def _h2():
+    return HEADS == "f16x2"
+
+
 def _split3_any(x, want, both):
     """(planar, blocked) planes of x, at least the wanted one; `both`: produce the two layouts in ONE pass over x"""
     if want == "blk" or both:
@@ -150,13 +160,19 @@ def _split3_any(x, want, both):
 
 
 def _cached(cache, x, key, want, both):
-    if cache["key"] == key and cache["x"] is x:
-        if cache[want] is None:
-            planar, blk = _split3_any(x, want, False)
-            cache[want] = planar if want == "planar" else blk
-        return cache[want]
-    planar, blk = _split3_any(x, want, both)
-    cache.update(key=key, x=x, planar=planar, blk=blk)
+    """want: "planar" / "blk" (bf16 x 3 planes) or "h2" ((fp16 x 2 blocked planes, device scale record))"""
+    hit = cache["key"] == key and cache["x"] is x
+    if not hit:
+        cache.update(key=key, x=x, planar=None, blk=None, h2=None)
+    if cache.get(want) is None:
+        if want == "h2":
+            cache["h2"] = split2h_blocked(x)
+        else:
+            planar, blk = _split3_any(x, want, both and not hit)
+            if planar is not None:
+                cache["planar"] = planar
+            if blk is not None:
+                cache["blk"] = blk
     return cache[want]
 
 
@@ -173,7 +189,7 @@ def _split3_cached(x, want="planar", both=False, keep=False):
     if ent is not None and ent["x"] is x:
         return _cached(ent, x, key, want, both)
     if keep:
-        ent = {"key": None, "x": None, "planar": None, "blk": None}
+        ent = {"key": None, "x": None, "planar": None, "blk": None, "h2": None}
         _b3_kept[key] = ent
         return _cached(ent, x, key, want, both)
     return _cached(_b3_cache, x, key, want, both)
@@ -185,8 +201,8 @@ def _split3_cached_dy(dy, want="planar", both=False):
 
 
 def release_b3_cache():
-    _b3_cache.update(key=None, x=None, planar=None, blk=None)
-    _b3_cache_dy.update(key=None, x=None, planar=None, blk=None)
+    _b3_cache.update(key=None, x=None, planar=None, blk=None, h2=None)
+    _b3_cache_dy.update(key=None, x=None, planar=None, blk=None, h2=None)
     _b3_kept.clear()
     _d3_wimg.clear()
 
@@ -303,6 +319,17 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
     if "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(rows, Cout, kh * kw, Cin):
         d = make_desc(x.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
         blk = _b3_blocked_ok(max(zero_to, Cout), Cin, B * H * W, Cout, kh * kw)
+        if blk and _h2():
+            with _Timed("split3", 0.0):
+                xp, xsc = _split3_cached(x, "h2", keep=train)
+                wp, wsc = split2h_weight_blocked(w_ptr_tensor)
+            with _Timed("fwd_h2", flops):
+                check(lib.catseg_conv2d_fwd_f16x2_blocked(ctypes.byref(d), ptr(xp), ptr(xsc), ptr(wp), ptr(wsc), ptr(bias), ptr(out), zero_to,
+                                                          ptr(part), part.numel() if part is not None else 0,
+                                                          ctypes.byref(tr) if bn_stats else None, ctypes.byref(nt) if bn_stats else None, stream()))
+            if bn_stats:
+                return out, ((part, nt.value, tr.value) if tr.value > 0 else None)
+            return out
         with _Timed("split3", 0.0):
             xp = _split3_cached(x, "blk" if blk else "planar", both=blk and train, keep=train)
             wp = split3_weight_blocked(w_ptr_tensor) if blk else split3_weight(w_ptr_tensor)
@@ -372,6 +399,14 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
     if groups == 1 and "dgrad" in B3_OPS and _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1):
         d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         blk = _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16, rows_of(dy), Cin, kh * kw)
+        if blk and _h2():
+            with _Timed("split3", 0.0):
+                dyp, dysc = _split3_cached_dy(dy, "h2")
+                wtp, wtsc = split2h_weight_t_blocked(w)
+            with _Timed("dgrad_h2", flops):
+                check(lib.catseg_conv2d_bwd_data_f16x2_blocked(ctypes.byref(d), ptr(dyp), ptr(dysc), ptr(wtp), ptr(wtsc), ptr(out),
+                                                               1 if accumulate else 0, stream()))
+            return out
         with _Timed("split3", 0.0):
             dyp = _split3_cached_dy(dy, "blk" if blk else "planar")
             wtp = split3_weight_t_blocked(w) if blk else split3_weight_t(w)
@@ -399,7 +434,7 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
              or (stride == 1 and _b3_wide_1x1(rows_of(dy), Cout, kh * kw, Cin)))):
         d = make_desc(x.shape, Cin, Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         ws = workspace(lib.catseg_conv2d_bwd_weight_bf16x3_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
-        dgrad_blk = (stride == 1 and "dgrad" in B3_OPS and _b3_eligible(rows_of(x), Cin, kh * kw, (Cout + 7) // 8 * 8)
+        dgrad_blk = (not _h2() and stride == 1 and "dgrad" in B3_OPS and _b3_eligible(rows_of(x), Cin, kh * kw, (Cout + 7) // 8 * 8)
                      and _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16, rows_of(dy), Cin, kh * kw))
         with _Timed("split3", 0.0):
             xp = _split3_cached(x, "planar")
@@ -785,6 +820,18 @@ def conv_fwd_fused(x, w, bias, residual, relu, Cout, kh, kw, stride=1, pad=0, di
                 xs, os_ = (x, out) if nb == B else (x[b0:b0 + nb], out[b0:b0 + nb])    # (x itself: the split-plane cache is keyed by identity)
                 rs = residual[b0:b0 + nb] if residual is not None else None
                 d = make_desc(xs.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
+                if _h2():
+                    with _Timed("split3", 0.0):
+                        xp, xsc = _split3_cached(xs, "h2") if nb == B else split2h_blocked(xs)
+                        if wp is None:      # (w: OHWI weights, 4-D or the flat buffer catseg_fold_bn writes)
+                            wp = torch.empty((2, kh * kw * Cin // 16, Cout, 16), dtype=torch.int16, device=w.device)
+                            wsc = torch.empty(2, dtype=torch.int32, device=w.device)
+                            check(lib.catseg_split2h_weight_blocked(ptr(w), Cout, kh * kw, Cin, ptr(wp), ptr(wsc), stream()))
+                    with _Timed("fwd_h2", flops * xs.shape[0] / B):
+                        check(lib.catseg_conv2d_fwd_fused_f16x2_blocked(ctypes.byref(d), ptr(xp), ptr(xsc), ptr(wp), ptr(wsc), ptr(bias), ptr(rs),
+                                                                        ld_of(residual) if residual is not None else 0, 1 if relu else 0,
+                                                                        ptr(os_), stream()))
+                    continue
                 with _Timed("split3", 0.0):
                     xp = _split3_cached(xs, "blk") if nb == B else split3_blocked(xs)[0]
                     if wp is None:      # (w: OHWI weights, 4-D or the flat buffer catseg_fold_bn writes)
@@ -817,6 +864,33 @@ def split3_blocked(x, with_planar=False):
     planar = torch.empty((3, rows, (C + 7) // 8 * 8), dtype=torch.int16, device=x.device) if with_planar else None
     check(lib.catseg_split3_blocked(ptr(x), rows, C, ld, ptr(blk), ptr(planar), stream()))
     return blk, planar
+
+
+def split2h_blocked(x):
+    """fp32 NHWC activation -> (fp16 planes [2, ceil(C/16), rows, 16] of x * 2^e, device record int32[2] = {bits of max|x|, e})"""
+    rows, C, ld = rows_of(x), x.shape[-1], ld_of(x)
+    planes = torch.empty((2, (C + 15) // 16, rows, 16), dtype=torch.int16, device=x.device)
+    scale = torch.empty(2, dtype=torch.int32, device=x.device)
+    check(lib.catseg_split2h_blocked(ptr(x), rows, C, ld, ptr(planes), ptr(scale), stream()))
+    return planes, scale
+
+
+def split2h_weight_blocked(w):
+    """[O, I, kh, kw] weights (physical OHWI, I % 16 == 0) -> (fp16 planes [2, kh*kw*I/16, O, 16], scale record): forward operand"""
+    O, I, kh, kw = w.shape
+    planes = torch.empty((2, kh * kw * I // 16, O, 16), dtype=torch.int16, device=w.device)
+    scale = torch.empty(2, dtype=torch.int32, device=w.device)
+    check(lib.catseg_split2h_weight_blocked(ptr(w), O, kh * kw, I, ptr(planes), ptr(scale), stream()))
+    return planes, scale
+
+
+def split2h_weight_t_blocked(w):
+    """OHWI weights -> (fp16 planes of the transposed bank [2, taps*roundup(O,16)/16, Cin, 16], scale record): backward-data operand"""
+    O, Cin, kh, kw = w.shape
+    planes = torch.empty((2, kh * kw * ((O + 15) // 16), Cin, 16), dtype=torch.int16, device=w.device)
+    scale = torch.empty(2, dtype=torch.int32, device=w.device)
+    check(lib.catseg_split2h_weight_t_blocked(ptr(w), O, kh * kw, Cin, ptr(planes), ptr(scale), stream()))
+    return planes, scale
 
 
 def split3_weight_blocked(w):

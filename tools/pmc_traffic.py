@@ -18,6 +18,10 @@ def group(name):
     m = re.search(r"igemm_f32_kernel<(\d)", name)
     if m:
         return LAY[m.group(1)]
+    if "igemm_h2w_kernel" in name:
+        return "h2w"            # f16x2 forward AND backward-data
+    if "split2h" in name or "amax_kernel" in name:
+        return "split3"
     if "igemm_b3w_kernel" in name or "igemm_b3_kernel" in name:
         return "b3w"            # bf16x3 forward AND backward-data (one kernel serves both)
     if "igemm_b3t_kernel" in name or "b3_reduce_slabs" in name:
