@@ -376,7 +376,7 @@ def main():
         # the dominant KERNEL (as rocprofv3 --stats names it): forward and backward-data of the bf16x3 layers are launches of one
         # kernel (igemm_b3w_kernel); the fp32 operations are the NT / NN / TN layouts of igemm_f32_kernel
         KERNEL_OF = {"fwd_b3": "b3w", "dgrad_b3": "b3w", "wgrad_b3": "wgrad_b3", "fwd": "fwd", "dgrad": "dgrad", "wgrad": "wgrad",
-                     "fwd_d3": "d3", "dgrad_d3": "d3", "wgrad_d3": "wgrad_d3", "fwd_h2": "h2w", "dgrad_h2": "h2w"}
+                     "fwd_d3": "d3", "dgrad_d3": "d3", "wgrad_d3": "wgrad_d3", "fwd_h2": "h2w", "dgrad_h2": "h2w", "wgrad_h2": "wgrad_h2"}
         groups = {}
         for k, v in mm.items():
             g = groups.setdefault(KERNEL_OF.get(k, k), [0.0, 0.0, 0])
@@ -384,8 +384,8 @@ def main():
         dom = max(groups, key=lambda k: groups[k][1])
         # (an fp32 layout is a union of 4-6 tile instantiations that rocprofv3 lists as separate kernels, the largest of them
         #  < 40 % of the layout's time: a single-symbol bf16x3 kernel with at least half of that time is the larger KERNEL)
-        for k in ("h2w", "b3w", "wgrad_b3", "d3", "wgrad_d3"):
-            if k in groups and dom not in ("h2w", "b3w", "wgrad_b3", "d3", "wgrad_d3") and groups[k][1] >= 0.5 * groups[dom][1]:
+        for k in ("h2w", "wgrad_h2", "b3w", "wgrad_b3", "d3", "wgrad_d3"):
+            if k in groups and dom not in ("h2w", "wgrad_h2", "b3w", "wgrad_b3", "d3", "wgrad_d3") and groups[k][1] >= 0.5 * groups[dom][1]:
                 dom = k
                 break
         fl, sec, n = groups[dom]
@@ -403,6 +403,7 @@ def main():
                  "h2w": "igemm_h2w_kernel (conv2d forward and backward-data of the large layers, f16x2 split precision: two fp16 planes "
                         "per operand, three MFMA products)",
                  "wgrad_b3": "igemm_b3t_kernel (conv2d backward-weight, bf16x3 split precision, incl. slab reduction)",
+                 "wgrad_h2": "igemm_h2t_kernel (conv2d backward-weight of the large layers, f16x2 split precision, incl. slab reduction)",
                  "wgrad_d3": "dwgrad3_b3_kernel (direct 3x3 conv2d backward-weight of the HRNet trunk, bf16x3 split precision, incl. slab reduction)",
                  "d3": "dconv3_b3_kernel (direct 3x3 conv2d forward and backward-data of the HRNet trunk, bf16x3 split precision, "
                        "in-kernel split of the fp32 halo tile)"}.get(dom, dom)

@@ -139,8 +139,10 @@ int catseg_bias_grad(const float* dy, int ld, long long rows, int C, float* dbia
  * l = fp16(x 2^e - h) (22 significant bits); the kernel accumulates hh + hl + lh in fp32 and scales the result by 2^-(e_x + e_w).
  *   `scale`: 8 bytes of DEVICE memory per operand, {uint32 bits of max|x|, int32 e}, written by the split call (two launches: amax,
  *   split) and read by the convolution -- no host round trip. */
-size_t catseg_split2h_blocked_elems(long long rows, int C);
-int catseg_split2h_blocked(const float* x, long long rows, int C, int ld, void* planes, void* scale, catseg_stream_t stream);
+size_t catseg_split2h_blocked_elems(long long rows, int C);   /* [2][ceil(C/16)][rows][16]: forward / backward-data operand */
+size_t catseg_split2h_planar_elems(long long rows, int C);    /* [2][rows][roundup(C, 8)]: backward-weight operand */
+int catseg_split2h(const float* x, long long rows, int C, int ld, void* blocked_planes, void* planar_planes, void* scale,
+                   catseg_stream_t stream);                   /* either layout may be NULL; one pass over x for both */
 int catseg_split2h_weight_blocked(const float* w, int O, int taps, int Cin, void* planes, void* scale, catseg_stream_t stream);
 int catseg_split2h_weight_t_blocked(const float* w, int O, int taps, int Cin, void* planes, void* scale, catseg_stream_t stream);
 int catseg_conv2d_fwd_f16x2_blocked(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* w_planes,
@@ -151,6 +153,9 @@ int catseg_conv2d_fwd_fused_f16x2_blocked(const catseg_conv_desc* d, const void*
                                           catseg_stream_t stream);
 int catseg_conv2d_bwd_data_f16x2_blocked(const catseg_conv_desc* d, const void* dy_planes, const void* dy_scale, const void* wt_planes,
                                          const void* wt_scale, float* dx, int accumulate, catseg_stream_t stream);
+size_t catseg_conv2d_bwd_weight_f16x2_workspace(const catseg_conv_desc* d);
+int catseg_conv2d_bwd_weight_f16x2(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* dy_planes,
+                                   const void* dy_scale, float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
 
 /* ---- direct 3x3 / stride 1 / pad 1 convolution in split precision (csrc/dconv3_b3.hip) for the HRNet trunk: the BasicBlock
  * convolutions conv3x3(planes, planes) at models/HRNetv2.py:22-25,41-44 (Cin = Cout = C in {48, 96}; catseg_dconv3_supported).

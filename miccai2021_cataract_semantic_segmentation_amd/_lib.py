@@ -77,7 +77,10 @@ _SIGS = {
     "catseg_conv2d_bwd_data_bf16x3_blocked": (I, [P, P, P, P, I, P]),
     "catseg_conv2d_fwd_fused_bf16x3_blocked": (I, [P, P, P, P, P, I, I, P, P]),
     "catseg_split2h_blocked_elems": (SZ, [L, I]),
-    "catseg_split2h_blocked": (I, [P, L, I, I, P, P, P]),
+    "catseg_split2h_planar_elems": (SZ, [L, I]),
+    "catseg_split2h": (I, [P, L, I, I, P, P, P, P]),
+    "catseg_conv2d_bwd_weight_f16x2_workspace": (SZ, [P]),
+    "catseg_conv2d_bwd_weight_f16x2": (I, [P, P, P, P, P, P, P, SZ, P]),
     "catseg_split2h_weight_blocked": (I, [P, I, I, I, P, P, P]),
     "catseg_split2h_weight_t_blocked": (I, [P, I, I, I, P, P, P]),
     "catseg_conv2d_fwd_f16x2_blocked": (I, [P, P, P, P, P, P, P, I, P, SZ, P, P, P]),

@@ -12,9 +12,10 @@
 // not is the range: 5 exponent bits, so every operand tensor is scaled by a power of two derived from its amax (gradients are ~1e-6)
 // and the epilogue scales the result back by 2^-(e_a + e_w).
 //
-// This file: amax, the two-plane blocked split of activations and weights, and igemm_h2w_kernel -- the 256 x 256 register-pipelined
-// kernel of igemm_bf16x3.hip (blocked planes, LDS-DMA through buffer resources, one wave per SIMD) with 48 MFMAs per K-step in the
-// order  lh | hh | hl  and four 32 KB LDS slots.
+// This file: amax, the two-plane split of activations (blocked and / or planar layout) and weights, igemm_h2w_kernel -- the 256 x 256
+// register-pipelined forward / backward-data kernel of igemm_bf16x3.hip (blocked planes, LDS-DMA through buffer resources, one wave
+// per SIMD) with 48 MFMAs per K-step in the order  lh | hh | hl  and four 32 KB LDS slots -- and igemm_h2t_kernel, its backward-weight
+// counterpart (planar planes, transposed LDS reads).
 #include "common.h"
 
 namespace {
@@ -69,11 +70,12 @@ __device__ __forceinline__ void split2h_one(float v, int e, u16& h, u16& l) {
   l = __builtin_bit_cast(u16, (_Float16)r);
 }
 
-// fp32 [rows][ld] -> two fp16 planes in the BLOCKED layout [C16][rows][16] (C16 = ceil(C / 16), channel tail zero), prescaled by 2^e
-// (e from amax_bits, written to *e_out).  Block = 64 rows x 128 channels through LDS, as split3_blocked_kernel.
-__global__ __launch_bounds__(256) void split2h_blocked_kernel(const float* __restrict__ x, int ld, long long rows, int C,
-                                                              const unsigned* __restrict__ amax_bits, u16* __restrict__ blk, long long blk_plane,
-                                                              int* __restrict__ e_out) {
+// fp32 [rows][ld] -> two fp16 planes, prescaled by 2^e (e from amax_bits, written to *e_out), in the BLOCKED layout [C16][rows][16]
+// (C16 = ceil(C / 16), channel tail zero; operand of igemm_h2w_kernel) and / or the planar layout [rows][ldp], ldp = roundup(C, 8)
+// (operand of igemm_h2t_kernel), from ONE pass over x.  Block = 64 rows x 128 channels through LDS, as split3_blocked_kernel.
+__global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ x, int ld, long long rows, int C, int ldp,
+                                                      const unsigned* __restrict__ amax_bits, u16* __restrict__ blk, long long blk_plane,
+                                                      u16* __restrict__ planar, long long planar_plane, int* __restrict__ e_out) {
   constexpr int RS = 128 + 8;
   __shared__ __attribute__((aligned(16))) u16 sh[2][64 * RS];
   const int e = h2_exponent(*amax_bits);
@@ -103,6 +105,18 @@ __global__ __launch_bounds__(256) void split2h_blocked_kernel(const float* __res
     *(unsigned long long*)(d + 64 * RS) = (unsigned long long)l[0] | ((unsigned long long)l[1] << 16) | ((unsigned long long)l[2] << 32) | ((unsigned long long)l[3] << 48);
   }
   __syncthreads();
+  if (planar != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = i * 256 + t, row = q >> 4, c8 = (q & 15) * 8;
+      if (r0 + row < rows && c0 + c8 < ldp) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          *(half8*)(planar + pl * planar_plane + (r0 + row) * ldp + c0 + c8) = *(const half8*)&sh[pl][row * RS + c8];
+      }
+    }
+  }
+  if (blk == nullptr) return;
   const int c16 = (C + 15) >> 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -447,6 +461,284 @@ __global__ __launch_bounds__(256, 1) void igemm_h2w_kernel(const H2Args p) {
     }
 }
 
+
+// ---- backward-weight: dW[o][tap][c] = sum_p dy[p][o] * x[pix(p, tap)][c] as a "TN" GEMM (M = Cout, N = taps * Cin, reduction over the
+// output pixels, split over blocks, partial slabs reduced afterwards): igemm_b3t_kernel of igemm_bf16x3.hip with two fp16 planes.
+// Planar planes [pixel][channels]; LDS images [16 pixels][256 columns] per plane, chunks swizzled by (pixel & 3) << 2, fragments by
+// the hardware transpose ds_read_b64_tr_b16.  48 MFMAs per K-step in the order lh | hh | hl, iteration = hh(k), hl(k), lh(k+1) with
+// every fragment set re-read for step k+1 behind its last use (all from slot (k+1) % 3); LDS-DMA two K-steps ahead (step k+3 into
+// the slot of step k, behind the barrier that ends its reads).
+__device__ __attribute__((aligned(256))) float g_zero_page_h2[64];
+
+struct H2TArgs {
+  const u16* dy;  long long dy_plane; int ldo;     // [P][ldo] planes, ldo = roundup(Cout, 8)
+  const u16* x;   long long x_plane;  int ldx;     // [B*H*W][ldx] planes
+  const int* edy; const int* ex;                   // device: prescale exponents
+  float* C;       int ldc; long long c_split_stride;
+  int M, N, Cin, taps;                             // M = Cout, N = taps * Cin
+  int P, rows_per_split;                           // output pixels; multiple of 16 per split
+  int H, W, Ho, Wo, kw, stride, pad, dil;
+  int step_b, step_qy, step_rx;                    // 16 pixels = step_b images + step_qy rows + step_rx pixels
+  int tilesM, tilesN;
+  const float* zero;
+};
+
+__device__ __forceinline__ void h2_glds16(const void* src, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
+  constexpr int TM = 4, TN = 4;
+  constexpr int PLANE = 16 * 256 * 2;             // bytes of one operand plane image: 16 pixel rows x 256 columns of fp16
+  constexpr int SLAB = 4 * PLANE;                 // A planes 0..1, then B planes 0..1
+  __shared__ __attribute__((aligned(16))) char smem[3 * SLAB];
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // one-dimensional grid over (pixel slab, tile): the blocks that share an XCD get a contiguous run of it (all tiles of a slab on one L2)
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ntile = p.tilesM * p.tilesN;
+  const int split = swz / ntile, tix = swz - split * ntile;
+  const int tile_m = tix / p.tilesN, tile_n = tix - tile_m * p.tilesN;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const int r_begin = split * p.rows_per_split;
+  const int r_end = min(r_begin + p.rows_per_split, p.P);
+  const int nks = (max(r_end - r_begin, 0) + 15) >> 4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging: chunk q = j * 256 + tid of a plane image: pixel row krow = q >> 5, position q & 31 (lane-linear LDS-DMA), logical
+  // 8-column chunk = position ^ ((krow & 3) << 2)
+  const u16* zero = (const u16*)p.zero;
+  int arow[2], acol[2];
+  int brow[2], tb[2], ty[2], tx[2], bky[2], bkx[2], bch[2];
+  bool bcv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = j * 256 + tid, krow = q >> 5, cl = (q & 31) ^ ((krow & 3) << 2);
+    arow[j] = r_begin + krow;
+    acol[j] = (m0 + cl * 8) < p.ldo ? m0 + cl * 8 : -1;
+    brow[j] = r_begin + krow;
+    const int n = n0 + cl * 8;
+    bcv[j] = n < p.N;
+    const int tap = bcv[j] ? n / p.Cin : 0;
+    bch[j] = n - tap * p.Cin;
+    bky[j] = tap / p.kw;
+    bkx[j] = tap - bky[j] * p.kw;
+    const int r = brow[j] < p.P ? brow[j] : 0;
+    const int hw = p.Ho * p.Wo;
+    tb[j] = r / hw;
+    const int rem = r - tb[j] * hw;
+    ty[j] = rem / p.Wo;
+    tx[j] = rem - ty[j] * p.Wo;
+  }
+  const u16* PA[2][2];
+  const u16* PB[2][2];
+  const long long apl = p.dy_plane, xpl = p.x_plane;
+  auto prepA = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = (int)(arow[j] < r_end) & (int)(acol[j] >= 0);
+      const u16* q = p.dy + ((long long)(ok ? arow[j] : 0) * p.ldo + (ok ? acol[j] : 0));
+      PA[j][0] = ok ? q : zero;
+      PA[j][1] = PA[j][0] + (ok ? apl : 0);
+      arow[j] += 16;
+    }
+  };
+  auto prepB = [&](const int j) {
+    const int iy = ty[j] * p.stride - p.pad + bky[j] * p.dil;
+    const int ix = tx[j] * p.stride - p.pad + bkx[j] * p.dil;
+    const bool ok = (int)(brow[j] < r_end) & (int)bcv[j] & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W);
+    const u16* q = p.x + (unsigned)(ok ? ((tb[j] * p.H + iy) * p.W + ix) * p.ldx + bch[j] : 0);
+    PB[j][0] = ok ? q : zero;
+    PB[j][1] = PB[j][0] + (ok ? xpl : 0);
+    brow[j] += 16;                                   // advance this row by 16 pixels
+    tx[j] += p.step_rx;
+    ty[j] += p.step_qy;
+    const bool cx = tx[j] >= p.Wo;
+    tx[j] -= cx ? p.Wo : 0;
+    ty[j] += cx ? 1 : 0;
+    const bool cy = ty[j] >= p.Ho;
+    ty[j] -= cy ? p.Ho : 0;
+    tb[j] += p.step_b + (cy ? 1 : 0);
+  };
+  auto prep = [&]() { prepA(); prepB(0); prepB(1); };
+  auto piece = [&](const int buf, const int i) {     // i = 4 * plane + {A0, A1, B0, B1}
+    char* s = smem + buf * SLAB;
+    const int pl = i >> 2, w = i & 3;
+    if (w < 2) h2_glds16(PA[w][pl], s + pl * PLANE + (w * 256 + wave * 64) * 16);
+    else h2_glds16(PB[w - 2][pl], s + (2 + pl) * PLANE + ((w - 2) * 256 + wave * 64) * 16);
+  };
+  auto issue = [&](const int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) piece(buf, i);
+  };
+
+  // fragment addresses (transposed reads): lane = 16 g + 4 q + pp inside its 32-lane half
+  int ra[TM], rb[TN];
+  {
+    const int g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+    const int rowb = (8 * h + q) * 512;               // pixel row 8h + q (+ 4 for the second read: + 2048 bytes)
+#pragma unroll
+    for (int t = 0; t < TM; ++t) ra[t] = rowb + ((wm * 16 + ((t ^ q) << 2) + 2 * g1 + (pp >> 1)) << 4) + ((pp & 1) << 3);
+#pragma unroll
+    for (int u = 0; u < TN; ++u) rb[u] = 2 * PLANE + rowb + ((wn * 16 + ((u ^ q) << 2) + 2 * g1 + (pp >> 1)) << 4) + ((pp & 1) << 3);
+  }
+  half8 Ah[TM], Bh[TN], Al[TM], Bl[TN];
+#define T_READ(dst, base, off)                                                                              \
+  do {                                                                                                      \
+    const s16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)((base) + (off)));                \
+    const s16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)((base) + (off) + 2048));         \
+    typedef short s16x8_ __attribute__((ext_vector_type(8)));                                               \
+    const s16x8_ v_ = {lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};                       \
+    dst = __builtin_bit_cast(half8, v_);                                                                    \
+  } while (0)
+#define H2_MFMA(A_, t_, B_, u_)                                                                              \
+  do {                                                                                                        \
+    acc[t_][u_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[t_], B_[u_], acc[t_][u_], 0, 0, 0);                \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  } while (0)
+
+  if (nks > 0) {
+    prep();
+    issue(0);
+    prep();
+    issue(1);                       // (past the end of the slab every source is the zero page)
+    prep();
+    issue(2);
+    prep();
+    __builtin_amdgcn_s_waitcnt(h2_waitcnt(16, 0));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+#pragma unroll
+      for (int t = 0; t < TM; ++t) { T_READ(Al[t], smem + ra[t], 1 * PLANE); T_READ(Bh[t], smem + rb[t], 0 * PLANE); }
+#pragma unroll
+      for (int t = 0; t < TM; ++t) { T_READ(Ah[t], smem + ra[t], 0 * PLANE); T_READ(Bl[t], smem + rb[t], 1 * PLANE); }
+    }
+    // lh(0)
+    H2_MFMA(Al, 0, Bh, 0); H2_MFMA(Al, 0, Bh, 1); H2_MFMA(Al, 0, Bh, 2); H2_MFMA(Al, 0, Bh, 3);
+    H2_MFMA(Al, 1, Bh, 0); H2_MFMA(Al, 1, Bh, 1); H2_MFMA(Al, 1, Bh, 2); H2_MFMA(Al, 1, Bh, 3);
+    H2_MFMA(Al, 2, Bh, 0); H2_MFMA(Al, 2, Bh, 1); H2_MFMA(Al, 2, Bh, 2); H2_MFMA(Al, 2, Bh, 3);
+    H2_MFMA(Al, 3, Bh, 0); H2_MFMA(Al, 3, Bh, 1); H2_MFMA(Al, 3, Bh, 2); H2_MFMA(Al, 3, Bh, 3);
+    int nxt = 1, fill = 0;
+    for (int k = 0; k < nks; ++k) {
+      // all but my newest 8 LDS-DMA pieces (step k+2) have landed: step k+1 is there; every fragment read has returned; barrier:
+      // ... everybody's, and every wave has read the fragments of step k out of slot k % 3, which step k+3 now overwrites
+      __builtin_amdgcn_s_waitcnt(h2_waitcnt(8, 0));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* aa_[TM]; const char* bb_[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) { aa_[t] = smem + nxt * SLAB + ra[t]; bb_[t] = smem + nxt * SLAB + rb[t]; }
+      // hh(k); Al(k+1); the eight pieces of step k+3
+      T_READ(Al[0], aa_[0], PLANE); H2_MFMA(Ah, 0, Bh, 0);
+      T_READ(Al[1], aa_[1], PLANE); H2_MFMA(Ah, 0, Bh, 1);
+      T_READ(Al[2], aa_[2], PLANE); H2_MFMA(Ah, 0, Bh, 2);
+      T_READ(Al[3], aa_[3], PLANE); H2_MFMA(Ah, 0, Bh, 3);
+      piece(fill, 0); H2_MFMA(Ah, 1, Bh, 0);
+      piece(fill, 1); H2_MFMA(Ah, 1, Bh, 1);
+      piece(fill, 2); H2_MFMA(Ah, 1, Bh, 2);
+      piece(fill, 3); H2_MFMA(Ah, 1, Bh, 3);
+      piece(fill, 4); H2_MFMA(Ah, 2, Bh, 0);
+      piece(fill, 5); H2_MFMA(Ah, 2, Bh, 1);
+      piece(fill, 6); H2_MFMA(Ah, 2, Bh, 2);
+      piece(fill, 7); H2_MFMA(Ah, 2, Bh, 3);
+      H2_MFMA(Ah, 3, Bh, 0); H2_MFMA(Ah, 3, Bh, 1); H2_MFMA(Ah, 3, Bh, 2); H2_MFMA(Ah, 3, Bh, 3);
+      // hl(k); Bh(k+1); the addresses of step k+4
+      T_READ(Bh[0], bb_[0], 0); H2_MFMA(Ah, 0, Bl, 0);
+      T_READ(Bh[1], bb_[1], 0); H2_MFMA(Ah, 0, Bl, 1);
+      T_READ(Bh[2], bb_[2], 0); H2_MFMA(Ah, 0, Bl, 2);
+      T_READ(Bh[3], bb_[3], 0); H2_MFMA(Ah, 0, Bl, 3);
+      H2_MFMA(Ah, 1, Bl, 0);
+      prepA(); H2_MFMA(Ah, 1, Bl, 1);
+      H2_MFMA(Ah, 1, Bl, 2); H2_MFMA(Ah, 1, Bl, 3);
+      prepB(0); H2_MFMA(Ah, 2, Bl, 0);
+      H2_MFMA(Ah, 2, Bl, 1); H2_MFMA(Ah, 2, Bl, 2);
+      prepB(1); H2_MFMA(Ah, 2, Bl, 3);
+      H2_MFMA(Ah, 3, Bl, 0); H2_MFMA(Ah, 3, Bl, 1); H2_MFMA(Ah, 3, Bl, 2); H2_MFMA(Ah, 3, Bl, 3);
+      // lh(k+1) (step nks is all zeros); Ah(k+1), Bl(k+1)
+      T_READ(Ah[0], aa_[0], 0); H2_MFMA(Al, 0, Bh, 0);
+      T_READ(Ah[1], aa_[1], 0); H2_MFMA(Al, 0, Bh, 1);
+      T_READ(Ah[2], aa_[2], 0); H2_MFMA(Al, 0, Bh, 2);
+      T_READ(Ah[3], aa_[3], 0); H2_MFMA(Al, 0, Bh, 3);
+      T_READ(Bl[0], bb_[0], PLANE); H2_MFMA(Al, 1, Bh, 0);
+      T_READ(Bl[1], bb_[1], PLANE); H2_MFMA(Al, 1, Bh, 1);
+      T_READ(Bl[2], bb_[2], PLANE); H2_MFMA(Al, 1, Bh, 2);
+      T_READ(Bl[3], bb_[3], PLANE); H2_MFMA(Al, 1, Bh, 3);
+      H2_MFMA(Al, 2, Bh, 0); H2_MFMA(Al, 2, Bh, 1); H2_MFMA(Al, 2, Bh, 2); H2_MFMA(Al, 2, Bh, 3);
+      H2_MFMA(Al, 3, Bh, 0); H2_MFMA(Al, 3, Bh, 1); H2_MFMA(Al, 3, Bh, 2); H2_MFMA(Al, 3, Bh, 3);
+      nxt = nxt == 2 ? 0 : nxt + 1;
+      fill = fill == 2 ? 0 : fill + 1;
+    }
+  }
+#undef T_READ
+#undef H2_MFMA
+
+  const int ea = -*p.edy, eb = -*p.ex;
+  float* cout = p.C + (long long)split * p.c_split_stride;
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      const int col = n0 + wn * 128 + u * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 128 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < p.M && col < p.N) cout[(long long)row * p.ldc + col] = __builtin_ldexpf(__builtin_ldexpf(acc[t][u][r], ea), eb);
+      }
+    }
+}
+
+// out[i] = sum_s slab[s][i]  (fixed order: deterministic)
+__global__ void h2_reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n4, int splits, long long stride4) {
+  const f32x4* s = (const f32x4*)slabs;
+  f32x4* o = (f32x4*)out;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 a = s[i];
+    for (int k = 1; k < splits; ++k) a += s[i + k * stride4];
+    o[i] = a;
+  }
+}
+
+const float* zero_page_h2() {
+  static const float* z[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!z[dev]) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_page_h2)) == hipSuccess) z[dev] = (const float*)q;
+  }
+  return z[dev];
+}
+
+int h2t_splits(int tiles, long long P) {
+  int best = 1;
+  double best_fill = 0.0;
+  for (int sp = 1; sp <= 64; ++sp) {
+    if (P / sp < 2048 && sp > 1) break;                 // at least 128 K-steps per block
+    const double rounds = (double)tiles * sp / 256.0;
+    const double fill = rounds / (double)(long long)(rounds + 0.999999);
+    if (fill > best_fill + 0.01) { best_fill = fill; best = sp; }
+  }
+  return best;
+}
+
 int run_h2(H2Args a, hipStream_t st) {
   CS_REQUIRE(a.a_plane * 4 < (1ll << 32) - 64 && a.w_plane * 4 < (1ll << 32) - 64, "f16x2 blocked planes: an operand's two planes must stay below 4 GB");
   CS_REQUIRE(a.ea && a.ew, "f16x2: prescale exponents missing");
@@ -468,21 +760,24 @@ int amax_launch(const float* x, int ld, long long rows, int C, unsigned* amax_bi
 
 }  // namespace
 
-// scale[0] (device, 8 bytes: {uint32 amax bits, int32 exponent}) is working storage + result of the split calls below
+// scale (device, 8 bytes: {uint32 amax bits, int32 exponent}) is working storage + result of the split calls below
 extern "C" size_t catseg_split2h_blocked_elems(long long rows, int C) { return (size_t)2 * (size_t)((C + 15) / 16) * 16 * (size_t)rows; }
+extern "C" size_t catseg_split2h_planar_elems(long long rows, int C) { return (size_t)2 * (size_t)rows * ((C + 7) & ~7); }
 
-// x [rows][ld] fp32 -> two fp16 planes [2][ceil(C/16)][rows][16] of x * 2^e, e = 14 - floor(log2(max|x|)); scale[0] receives
-// {bits of max|x|, e}.  Two launches (amax, split).
-extern "C" int catseg_split2h_blocked(const float* x, long long rows, int C, int ld, void* planes, void* scale, catseg_stream_t stream) {
-  CS_REQUIRE(rows > 0 && C > 0 && ld >= C && ld % 4 == 0 && cs_aligned16(x) && cs_aligned16(planes) && scale && (((uintptr_t)scale) & 7) == 0,
-             "split2h_blocked: bad args (ld must be a multiple of 4, pointers 16-byte aligned)");
-  CS_REQUIRE((rows + 63) / 64 < (1ll << 31), "split2h_blocked: too many rows");
+// x [rows][ld] fp32 -> two fp16 planes of x * 2^e, e = 14 - floor(log2(max|x|)): blocked_planes [2][ceil(C/16)][rows][16] and / or
+// planar_planes [2][rows][roundup(C, 8)] (either may be null); scale receives {bits of max|x|, e}.  Two launches (amax, split).
+extern "C" int catseg_split2h(const float* x, long long rows, int C, int ld, void* blocked_planes, void* planar_planes, void* scale,
+                              catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && ld >= C && ld % 4 == 0 && cs_aligned16(x) && cs_aligned16(blocked_planes) && cs_aligned16(planar_planes) &&
+                 (blocked_planes || planar_planes) && scale && (((uintptr_t)scale) & 7) == 0,
+             "split2h: bad args (ld must be a multiple of 4, pointers 16-byte aligned)");
+  CS_REQUIRE((rows + 63) / 64 < (1ll << 31), "split2h: too many rows");
   hipStream_t st = (hipStream_t)stream;
   unsigned* ab = (unsigned*)scale;
   if (int rc = amax_launch(x, ld, rows, C, ab, st)) return rc;
-  const int c16 = (C + 15) / 16;
-  hipLaunchKernelGGL(split2h_blocked_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((c16 * 16 + 127) / 128)), dim3(256), 0, st, x, ld, rows, C,
-                     (const unsigned*)ab, (u16*)planes, (long long)c16 * rows * 16, (int*)(ab + 1));
+  const int c16 = (C + 15) / 16, ldp = (C + 7) & ~7;
+  hipLaunchKernelGGL(split2h_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((c16 * 16 + 127) / 128)), dim3(256), 0, st, x, ld, rows, C, ldp,
+                     (const unsigned*)ab, (u16*)blocked_planes, (long long)c16 * rows * 16, (u16*)planar_planes, rows * ldp, (int*)(ab + 1));
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
@@ -537,7 +832,7 @@ H2Args h2_fwd_args(const catseg_conv_desc* d, const void* x_planes, const void* 
 }
 }  // namespace
 
-// y = conv(x, w) (+ bias) from two-plane fp16 operands: x_planes / x_scale = catseg_split2h_blocked of x (C = Cin, Cin % 16 == 0),
+// y = conv(x, w) (+ bias) from two-plane fp16 operands: x_planes / x_scale = the blocked planes of catseg_split2h of x (C = Cin, Cin % 16 == 0),
 // w_planes / w_scale = catseg_split2h_weight_blocked.  bn_part may be null (then tile_rows / n_tiles are not touched).
 extern "C" int catseg_conv2d_fwd_f16x2_blocked(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* w_planes,
                                                const void* w_scale, const float* bias, float* y, int zero_to, float* bn_part,
@@ -570,7 +865,7 @@ extern "C" int catseg_conv2d_fwd_fused_f16x2_blocked(const catseg_conv_desc* d, 
   return run_h2(a, (hipStream_t)stream);
 }
 
-// dx (+)= conv_transpose(dy, w), stride 1: dy_planes / dy_scale = catseg_split2h_blocked of dy (C = Cout; the channel tail up to
+// dx (+)= conv_transpose(dy, w), stride 1: dy_planes / dy_scale = the blocked planes of catseg_split2h of dy (C = Cout; the channel tail up to
 // roundup(Cout, 16) is zero), wt_planes / wt_scale = catseg_split2h_weight_t_blocked
 extern "C" int catseg_conv2d_bwd_data_f16x2_blocked(const catseg_conv_desc* d, const void* dy_planes, const void* dy_scale, const void* wt_planes,
                                                     const void* wt_scale, float* dx, int accumulate, catseg_stream_t stream) {
@@ -587,4 +882,54 @@ extern "C" int catseg_conv2d_bwd_data_f16x2_blocked(const catseg_conv_desc* d, c
   a.H = d->Ho; a.W = d->Wo; a.Ho = d->H; a.Wo = d->W; a.kw = d->kw; a.stride = 1; a.pad = d->pad; a.dil = d->dil;
   a.sign = -1; a.accumulate = accumulate;
   return run_h2(a, (hipStream_t)stream);
+}
+
+// workspace: split-reduction slabs (only when more than one split is planned)
+extern "C" size_t catseg_conv2d_bwd_weight_f16x2_workspace(const catseg_conv_desc* d) {
+  if (!d) return 0;
+  const long long P = (long long)d->B * d->Ho * d->Wo;
+  const int N = d->kh * d->kw * d->Cin;
+  const int tiles = ((d->Cout + 255) / 256) * ((N + 255) / 256);
+  const int sp = h2t_splits(tiles, P);
+  return sp > 1 ? cs_align_up((size_t)sp * d->Cout * N * 4, 256) : 0;
+}
+
+// dw[o][ky][kx][c] = sum_p dy[p][o] x[pix(p,ky,kx)][c] from two-plane fp16 operands in the PLANAR layout of catseg_split2h:
+// dy_planes / dy_scale of dy (C = Cout), x_planes / x_scale of x (C = Cin, Cin % 8 == 0)
+extern "C" int catseg_conv2d_bwd_weight_f16x2(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* dy_planes,
+                                              const void* dy_scale, float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(d && !d->stem4 && d->groups <= 1 && d->Cin % 8 == 0, "conv bwd_weight f16x2: dense, Cin % 8 == 0");
+  CS_REQUIRE(cs_aligned16(x_planes) && cs_aligned16(dy_planes) && cs_aligned16(dw) && x_scale && dy_scale, "conv bwd_weight f16x2: alignment");
+  CS_REQUIRE((long long)d->B * d->H * d->W * d->Cin < (1ll << 31), "conv bwd_weight f16x2: 32-bit offsets");
+  const size_t need = catseg_conv2d_bwd_weight_f16x2_workspace(d);
+  if (workspace_bytes < need || (need && !workspace)) {
+    catseg_set_error("conv bwd_weight f16x2: workspace %zu < %zu", workspace_bytes, need);
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  H2TArgs a = {};
+  a.P = d->B * d->Ho * d->Wo;
+  a.M = d->Cout; a.Cin = d->Cin; a.taps = d->kh * d->kw; a.N = a.taps * d->Cin;
+  a.ldo = (d->Cout + 7) & ~7; a.dy = (const u16*)dy_planes; a.dy_plane = (long long)a.P * a.ldo;
+  a.ldx = d->Cin; a.x = (const u16*)x_planes; a.x_plane = (long long)d->B * d->H * d->W * d->Cin;
+  a.edy = (const int*)dy_scale + 1; a.ex = (const int*)x_scale + 1;
+  a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+  const int img = d->Ho * d->Wo;
+  a.step_b = 16 / img; a.step_qy = (16 % img) / d->Wo; a.step_rx = (16 % img) % d->Wo;
+  a.tilesM = (a.M + 255) / 256; a.tilesN = (a.N + 255) / 256;
+  const int sp0 = h2t_splits(a.tilesM * a.tilesN, a.P);
+  a.rows_per_split = (int)((((long long)a.P + sp0 - 1) / sp0 + 15) / 16 * 16);
+  const int sp = (a.P + a.rows_per_split - 1) / a.rows_per_split;
+  a.ldc = a.N; a.c_split_stride = (long long)a.M * a.N;
+  a.C = sp > 1 ? (float*)workspace : dw;
+  a.zero = zero_page_h2();
+  hipLaunchKernelGGL(igemm_h2t_kernel, dim3(a.tilesM * a.tilesN * sp), dim3(256), 0, st, a);
+  CS_LAUNCH_CHECK();
+  if (sp > 1) {
+    const long long n4 = (long long)a.M * a.N / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(h2_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n4, sp, n4);
+    CS_LAUNCH_CHECK();
+  }
+  return CATSEG_OK;
 }

@@ -160,13 +160,18 @@ def _split3_any(x, want, both):
 
 
 def _cached(cache, x, key, want, both):
-    """want: "planar" / "blk" (bf16 x 3 planes) or "h2" ((fp16 x 2 blocked planes, device scale record))"""
+    """want: "planar" / "blk" (bf16 x 3 planes), or "h2" / "h2p" ((fp16 x 2 planes in the blocked / planar layout, device scale record));
+    both: on a miss produce the sibling layout in the same pass over x"""
     hit = cache["key"] == key and cache["x"] is x
     if not hit:
-        cache.update(key=key, x=x, planar=None, blk=None, h2=None)
+        cache.update(key=key, x=x, planar=None, blk=None, h2=None, h2p=None)
     if cache.get(want) is None:
-        if want == "h2":
-            cache["h2"] = split2h_blocked(x)
+        if want in ("h2", "h2p"):
+            blk, pl, sc = split2h(x, blocked=(want == "h2" or both), planar=(want == "h2p" or both))
+            if blk is not None:
+                cache["h2"] = (blk, sc)
+            if pl is not None:
+                cache["h2p"] = (pl, sc)
         else:
             planar, blk = _split3_any(x, want, both and not hit)
             if planar is not None:
@@ -189,7 +194,7 @@ def _split3_cached(x, want="planar", both=False, keep=False):
     if ent is not None and ent["x"] is x:
         return _cached(ent, x, key, want, both)
     if keep:
-        ent = {"key": None, "x": None, "planar": None, "blk": None, "h2": None}
+        ent = {"key": None, "x": None, "planar": None, "blk": None, "h2": None, "h2p": None}
         _b3_kept[key] = ent
         return _cached(ent, x, key, want, both)
     return _cached(_b3_cache, x, key, want, both)
@@ -201,8 +206,8 @@ def _split3_cached_dy(dy, want="planar", both=False):
 
 
 def release_b3_cache():
-    _b3_cache.update(key=None, x=None, planar=None, blk=None, h2=None)
-    _b3_cache_dy.update(key=None, x=None, planar=None, blk=None, h2=None)
+    _b3_cache.update(key=None, x=None, planar=None, blk=None, h2=None, h2p=None)
+    _b3_cache_dy.update(key=None, x=None, planar=None, blk=None, h2=None, h2p=None)
     _b3_kept.clear()
     _d3_wimg.clear()
 
@@ -321,7 +326,7 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
         blk = _b3_blocked_ok(max(zero_to, Cout), Cin, B * H * W, Cout, kh * kw)
         if blk and _h2():
             with _Timed("split3", 0.0):
-                xp, xsc = _split3_cached(x, "h2", keep=train)
+                xp, xsc = _split3_cached(x, "h2", both=train, keep=train)
                 wp, wsc = split2h_weight_blocked(w_ptr_tensor)
             with _Timed("fwd_h2", flops):
                 check(lib.catseg_conv2d_fwd_f16x2_blocked(ctypes.byref(d), ptr(xp), ptr(xsc), ptr(wp), ptr(wsc), ptr(bias), ptr(out), zero_to,
@@ -434,8 +439,20 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
              or (stride == 1 and _b3_wide_1x1(rows_of(dy), Cout, kh * kw, Cin)))):
         d = make_desc(x.shape, Cin, Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         ws = workspace(lib.catseg_conv2d_bwd_weight_bf16x3_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
-        dgrad_blk = (not _h2() and stride == 1 and "dgrad" in B3_OPS and _b3_eligible(rows_of(x), Cin, kh * kw, (Cout + 7) // 8 * 8)
+        dgrad_blk = (stride == 1 and "dgrad" in B3_OPS and _b3_eligible(rows_of(x), Cin, kh * kw, (Cout + 7) // 8 * 8)
                      and _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16, rows_of(dy), Cin, kh * kw))
+        if _h2():
+            # two fp16 planes per operand (csrc/igemm_f16x2.hip); dy's blocked planes for this layer's backward-data from the same pass
+            wsb = workspace(lib.catseg_conv2d_bwd_weight_f16x2_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
+            with _Timed("split3", 0.0):
+                xp, xsc = _split3_cached(x, "h2p")
+                dyp, dysc = _split3_cached_dy(dy, "h2p", both=dgrad_blk)
+            with _Timed("wgrad_h2", flops):
+                check(lib.catseg_conv2d_bwd_weight_f16x2(ctypes.byref(d), ptr(xp), ptr(xsc), ptr(dyp), ptr(dysc), ptr(dw), ptr(wsb), wsb.numel(),
+                                                         stream()))
+            if dbias is not None:
+                check(lib.catseg_bias_grad(ptr(dy), ld_of(dy), rows_of(dy), Cout, ptr(dbias), ptr(wsb), wsb.numel(), stream()))
+            return dw
         with _Timed("split3", 0.0):
             xp = _split3_cached(x, "planar")
             dyp = _split3_cached_dy(dy, "planar", both=dgrad_blk)
@@ -866,13 +883,20 @@ def split3_blocked(x, with_planar=False):
     return blk, planar
 
 
-def split2h_blocked(x):
-    """fp32 NHWC activation -> (fp16 planes [2, ceil(C/16), rows, 16] of x * 2^e, device record int32[2] = {bits of max|x|, e})"""
+def split2h(x, blocked=True, planar=False):
+    """fp32 NHWC activation -> fp16 planes of x * 2^e in the blocked layout [2, ceil(C/16), rows, 16] and / or the planar layout
+    [2, rows, roundup(C, 8)] (one pass for both) + the device record int32[2] = {bits of max|x|, e}: (blocked or None, planar or None, scale)"""
     rows, C, ld = rows_of(x), x.shape[-1], ld_of(x)
-    planes = torch.empty((2, (C + 15) // 16, rows, 16), dtype=torch.int16, device=x.device)
+    blk = torch.empty((2, (C + 15) // 16, rows, 16), dtype=torch.int16, device=x.device) if blocked else None
+    pl = torch.empty((2, rows, (C + 7) // 8 * 8), dtype=torch.int16, device=x.device) if planar else None
     scale = torch.empty(2, dtype=torch.int32, device=x.device)
-    check(lib.catseg_split2h_blocked(ptr(x), rows, C, ld, ptr(planes), ptr(scale), stream()))
-    return planes, scale
+    check(lib.catseg_split2h(ptr(x), rows, C, ld, ptr(blk), ptr(pl), ptr(scale), stream()))
+    return blk, pl, scale
+
+
+def split2h_blocked(x):
+    blk, _, scale = split2h(x, True, False)
+    return blk, scale
 
 
 def split2h_weight_blocked(w):

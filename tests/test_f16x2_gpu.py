@@ -138,6 +138,20 @@ def test_forward_and_backward_data_vs_fp64(ops, case):
                                                            ops.stream()))
         close(nchw(dx), 2 * xr.grad, 2e-5)
         print("f16x2 %s: forward %.2g, backward-data %.2g of the output scale" % (case, e, e2))
+    # backward-weight from the planar planes (written by the same pass as the blocked ones)
+    w64 = w.double().requires_grad_()
+    F.conv2d(x.double(), w64, None, s, p, d).backward(gy.double())
+    gyd = nhwc(gy)
+    xb, xpl, xsc = ops.split2h(xd, blocked=True, planar=True)
+    assert torch.equal(xb, xp)
+    _, gpl, gsc = ops.split2h(gyd, blocked=False, planar=True)
+    dsc = ops.make_desc(xd.shape, Ci, Co, (Co + 7) // 8 * 8, k, k, s, p, d)
+    ws = torch.empty(max(lib.catseg_conv2d_bwd_weight_f16x2_workspace(ctypes.byref(dsc)), 256), dtype=torch.uint8).cuda()
+    dw = torch.full((Co, Ci, k, k), float("nan")).cuda().contiguous(memory_format=torch.channels_last)
+    ops.check(lib.catseg_conv2d_bwd_weight_f16x2(ctypes.byref(dsc), ops.ptr(xpl), ops.ptr(xsc), ops.ptr(gpl), ops.ptr(gsc), ops.ptr(dw),
+                                                 ops.ptr(ws), ws.numel(), ops.stream()))
+    e3 = close(dw, w64.grad, 2e-5)
+    print("f16x2 %s: backward-weight %.2g of the output scale" % (case, e3))
 
 
 def test_dispatch_takes_the_f16x2_kernels_and_matches_bf16x3(ops):
@@ -148,24 +162,28 @@ def test_dispatch_takes_the_f16x2_kernels_and_matches_bf16x3(ops):
     x = nhwc(torch.randn(B, Ci, H, W, generator=g))
     w = ohwi(torch.randn(Co, Ci, 3, 3, generator=g) * 0.04)
     dy = nhwc(torch.randn(B, Co, H, W, generator=g) * 1e-5)
-    saved = (ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES, ops.HEADS)
+    saved = (ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES, ops.B3_MIN_WGRAD_ROWS, ops.HEADS)
     res = {}
     try:
-        ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES = "bf16x3", 1, 16, 16, 1
+        ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES, ops.B3_MIN_WGRAD_ROWS = "bf16x3", 1, 16, 16, 1, 1
         for heads in ("f16x2", "bf16x3"):
             ops.HEADS = heads
             ops.release_b3_cache()
             ops.PROFILE = []
             y, part = ops.conv_fwd(x, w, None, Co, 3, 3, 1, 1, 1, bn_stats=True, train=True)
+            dw = torch.empty_like(w)
+            ops.conv_bwd_weight(x, dy, dw, None, 3, 3, 1, 1, 1)
             dx = ops.conv_bwd_data(dy, w, tuple(x.shape), 3, 3, 1, 1, 1)
             kinds = [q[0] for q in ops.PROFILE]
             ops.PROFILE = None
-            assert ("fwd_h2" in kinds and "dgrad_h2" in kinds) if heads == "f16x2" else ("fwd_b3" in kinds and "dgrad_b3" in kinds), kinds
+            want = ("fwd_h2", "dgrad_h2", "wgrad_h2") if heads == "f16x2" else ("fwd_b3", "dgrad_b3", "wgrad_b3")
+            assert all(k in kinds for k in want), kinds
             assert part is not None
-            res[heads] = (y.clone(), dx.clone())
+            res[heads] = (y.clone(), dx.clone(), dw.clone())
     finally:
-        ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES, ops.HEADS = saved
+        ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES, ops.B3_MIN_WGRAD_ROWS, ops.HEADS = saved
         ops.PROFILE = None
         ops.release_b3_cache()
     close(res["f16x2"][0], res["bf16x3"][0], 5e-6)      # (each is ~1e-6 from fp64: fp32 accumulation over K = 1872)
     close(res["f16x2"][1], res["bf16x3"][1], 5e-6)
+    close(res["f16x2"][2], res["bf16x3"][2], 5e-6)

@@ -736,11 +736,12 @@ def test_fused_inference_convs_share_one_split_of_their_input(ops):
     split it once: the plane cache is keyed by the tensor's identity (advisor finding, round 2)"""
     saved = (ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES)
     calls = []
-    real = ops.split3_blocked
+    real, real2 = ops.split3_blocked, ops.split2h
     try:
         ops.PRECISION = "bf16x3"
         ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES = 1, 64, 32, 1
         ops.split3_blocked = lambda x, with_planar=False: (calls.append(1), real(x, with_planar))[1]
+        ops.split2h = lambda x, blocked=True, planar=False: (calls.append(1), real2(x, blocked, planar))[1]     # (CATSEG_HEADS=f16x2, the default)
         g = torch.Generator().manual_seed(2)
         x = torch.randn(2, 12, 20, 64, generator=g).cuda()
         outs = []
@@ -752,6 +753,6 @@ def test_fused_inference_convs_share_one_split_of_their_input(ops):
             ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1, 1)).permute(0, 2, 3, 1)
             close(y, ref, atol=0, rtol=2e-5)
     finally:
-        ops.split3_blocked = real
+        ops.split3_blocked, ops.split2h = real, real2
         ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES = saved
         ops.release_b3_cache()

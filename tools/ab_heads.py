@@ -21,21 +21,22 @@ for (B, H, W, Ci, Co, k, p) in [(8, 136, 240, 720, 512, 3, 1), (8, 136, 240, 102
     x = torch.randn(B, H, W, Ci, device=dev)
     w = (torch.randn(Co, Ci, k, k, device=dev) * 0.02).contiguous(memory_format=torch.channels_last)
     dy = torch.randn(B, H, W, Co, device=dev) * 1e-4
-    y = torch.empty(B, H, W, Co, device=dev); dx = torch.empty_like(x)
+    y = torch.empty(B, H, W, Co, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
     for heads in ("bf16x3", "f16x2", "bf16x3", "f16x2"):
         ops.HEADS = heads
         ops.release_b3_cache()
         ops.PROFILE = []
         for _ in range(6):
             ops.release_b3_cache()
-            ops.conv_fwd(x, w, None, Co, k, k, 1, p, 1, out=y)
+            ops.conv_fwd(x, w, None, Co, k, k, 1, p, 1, out=y, train=True)
+            ops.conv_bwd_weight(x, dy, dw, None, k, k, 1, p, 1)
             ops.conv_bwd_data(dy, w, tuple(x.shape), k, k, 1, p, 1, out=dx)
         torch.cuda.synchronize()
         agg = {}
         for kind, fl, e0, e1 in ops.PROFILE[len(ops.PROFILE) // 3:]:
             a = agg.setdefault(kind, [0.0, 0]); a[0] += e0.elapsed_time(e1); a[1] += 1
         ops.PROFILE = None
-        print("%dx%d %d->%d k%d %-7s " % (H, W, Ci, Co, k, heads) + "  ".join("%s %.2f ms" % (kk, v[0] / v[1] * (2 if kk == "split3" else 1)) for kk, v in sorted(agg.items())), flush=True)
+        print("%dx%d %d->%d k%d %-7s " % (H, W, Ci, Co, k, heads) + "  ".join("%s %.2f ms" % (kk, v[0] / v[1] * (3 if kk == "split3" else 1)) for kk, v in sorted(agg.items())), flush=True)
 torch.manual_seed(0)
 model = OCRNet(dict(bench.MODELS["ocrnet_hrnet48"][0]), 3).to(dev).train()
 crit = TwoScaleLoss({"experiment": 3, "interm": {"name": "LovaszSoftmax", "args": [], "weight": 0.4}, "final": {"name": "LovaszSoftmax", "args": [], "weight": 1.0}})

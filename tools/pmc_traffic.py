@@ -18,6 +18,8 @@ def group(name):
     m = re.search(r"igemm_f32_kernel<(\d)", name)
     if m:
         return LAY[m.group(1)]
+    if "igemm_h2t_kernel" in name or "h2_reduce_slabs" in name:
+        return "wgrad_h2"
     if "igemm_h2w_kernel" in name:
         return "h2w"            # f16x2 forward AND backward-data
     if "split2h" in name or "amax_kernel" in name:
