@@ -466,8 +466,8 @@ __global__ __launch_bounds__(256, 1) void igemm_h2w_kernel(const H2Args p) {
 // output pixels, split over blocks, partial slabs reduced afterwards): igemm_b3t_kernel of igemm_bf16x3.hip with two fp16 planes.
 // Planar planes [pixel][channels]; LDS images [16 pixels][256 columns] per plane, chunks swizzled by (pixel & 3) << 2, fragments by
 // the hardware transpose ds_read_b64_tr_b16.  48 MFMAs per K-step in the order lh | hh | hl, iteration = hh(k), hl(k), lh(k+1) with
-// every fragment set re-read for step k+1 behind its last use (all from slot (k+1) % 3); LDS-DMA two K-steps ahead (step k+3 into
-// the slot of step k, behind the barrier that ends its reads).
+// every fragment set re-read for step k+1 behind its last use (all from the slot of step k+1); NSLOT slots, LDS-DMA NSLOT - 1 K-steps
+// ahead (step k+NSLOT into the slot of step k, behind the barrier that ends its reads).
 __device__ __attribute__((aligned(256))) float g_zero_page_h2[64];
 
 struct H2TArgs {
@@ -492,7 +492,11 @@ __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
   constexpr int TM = 4, TN = 4;
   constexpr int PLANE = 16 * 256 * 2;             // bytes of one operand plane image: 16 pixel rows x 256 columns of fp16
   constexpr int SLAB = 4 * PLANE;                 // A planes 0..1, then B planes 0..1
-  __shared__ __attribute__((aligned(16))) char smem[3 * SLAB];
+#ifndef H2T_NSLOT
+#define H2T_NSLOT 4
+#endif
+  constexpr int NSLOT = H2T_NSLOT;                // LDS-DMA runs NSLOT - 1 K-steps ahead
+  __shared__ __attribute__((aligned(16))) char smem[NSLOT * SLAB];
   typedef short s16x4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
@@ -615,14 +619,13 @@ __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
   } while (0)
 
   if (nks > 0) {
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {    // (past the end of the slab every source is the zero page)
+      prep();
+      issue(sl);
+    }
     prep();
-    issue(0);
-    prep();
-    issue(1);                       // (past the end of the slab every source is the zero page)
-    prep();
-    issue(2);
-    prep();
-    __builtin_amdgcn_s_waitcnt(h2_waitcnt(16, 0));
+    __builtin_amdgcn_s_waitcnt(h2_waitcnt(8 * (NSLOT - 1), 0));
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     {
@@ -638,15 +641,15 @@ __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
     H2_MFMA(Al, 3, Bh, 0); H2_MFMA(Al, 3, Bh, 1); H2_MFMA(Al, 3, Bh, 2); H2_MFMA(Al, 3, Bh, 3);
     int nxt = 1, fill = 0;
     for (int k = 0; k < nks; ++k) {
-      // all but my newest 8 LDS-DMA pieces (step k+2) have landed: step k+1 is there; every fragment read has returned; barrier:
-      // ... everybody's, and every wave has read the fragments of step k out of slot k % 3, which step k+3 now overwrites
-      __builtin_amdgcn_s_waitcnt(h2_waitcnt(8, 0));
+      // all but my newest 8 (NSLOT - 2) LDS-DMA pieces have landed: step k+1 is there; every fragment read has returned; barrier:
+      // ... everybody's, and every wave has read the fragments of step k out of its slot, which step k+NSLOT now overwrites
+      __builtin_amdgcn_s_waitcnt(h2_waitcnt(8 * (NSLOT - 2), 0));
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const char* aa_[TM]; const char* bb_[TN];
 #pragma unroll
       for (int t = 0; t < TM; ++t) { aa_[t] = smem + nxt * SLAB + ra[t]; bb_[t] = smem + nxt * SLAB + rb[t]; }
-      // hh(k); Al(k+1); the eight pieces of step k+3
+      // hh(k); Al(k+1); the eight pieces of step k+NSLOT
       T_READ(Al[0], aa_[0], PLANE); H2_MFMA(Ah, 0, Bh, 0);
       T_READ(Al[1], aa_[1], PLANE); H2_MFMA(Ah, 0, Bh, 1);
       T_READ(Al[2], aa_[2], PLANE); H2_MFMA(Ah, 0, Bh, 2);
@@ -683,8 +686,8 @@ __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
       T_READ(Bl[3], bb_[3], PLANE); H2_MFMA(Al, 1, Bh, 3);
       H2_MFMA(Al, 2, Bh, 0); H2_MFMA(Al, 2, Bh, 1); H2_MFMA(Al, 2, Bh, 2); H2_MFMA(Al, 2, Bh, 3);
       H2_MFMA(Al, 3, Bh, 0); H2_MFMA(Al, 3, Bh, 1); H2_MFMA(Al, 3, Bh, 2); H2_MFMA(Al, 3, Bh, 3);
-      nxt = nxt == 2 ? 0 : nxt + 1;
-      fill = fill == 2 ? 0 : fill + 1;
+      nxt = nxt == NSLOT - 1 ? 0 : nxt + 1;
+      fill = fill == NSLOT - 1 ? 0 : fill + 1;
     }
   }
 #undef T_READ
