@@ -528,7 +528,6 @@ __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
 
   // staging: chunk q = j * 256 + tid of a plane image: pixel row krow = q >> 5, position q & 31 (lane-linear LDS-DMA), logical
   // 8-column chunk = position ^ ((krow & 3) << 2)
-  const u16* zero = (const u16*)p.zero;
   int arow[2], acol[2];
   int brow[2], tb[2], ty[2], tx[2], bky[2], bkx[2], bch[2];
   bool bcv[2];
@@ -551,16 +550,18 @@ __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
     ty[j] = rem / p.Wo;
     tx[j] = rem - ty[j] * p.Wo;
   }
-  const u16* PA[2][2];
-  const u16* PB[2][2];
-  const long long apl = p.dy_plane, xpl = p.x_plane;
+  // LDS-DMA sources through two raw buffer resources (one per operand, both planes inside; the host checks 2 planes < 4 GB): a lane's
+  // source = 32-bit BYTE offset inside plane 0, the plane offset rides in the instruction's soffset; rows past the slab, padding taps
+  // and column tails get an out-of-range offset = zeros in LDS.  (With global_load_lds + 64-bit pointers the compiler put an
+  // s_waitcnt vmcnt(0) in front of the first fragment read behind the issue -- every K-step waited for its own fresh loads.)
+  const unsigned apl_b = (unsigned)(p.dy_plane * 2), xpl_b = (unsigned)(p.x_plane * 2);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  unsigned VA[2], VB[2];
   auto prepA = [&]() {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const bool ok = (int)(arow[j] < r_end) & (int)(acol[j] >= 0);
-      const u16* q = p.dy + ((long long)(ok ? arow[j] : 0) * p.ldo + (ok ? acol[j] : 0));
-      PA[j][0] = ok ? q : zero;
-      PA[j][1] = PA[j][0] + (ok ? apl : 0);
+      VA[j] = ok ? (unsigned)(arow[j] * p.ldo + acol[j]) * 2u : OOB;
       arow[j] += 16;
     }
   };
@@ -568,9 +569,7 @@ __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
     const int iy = ty[j] * p.stride - p.pad + bky[j] * p.dil;
     const int ix = tx[j] * p.stride - p.pad + bkx[j] * p.dil;
     const bool ok = (int)(brow[j] < r_end) & (int)bcv[j] & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W);
-    const u16* q = p.x + (unsigned)(ok ? ((tb[j] * p.H + iy) * p.W + ix) * p.ldx + bch[j] : 0);
-    PB[j][0] = ok ? q : zero;
-    PB[j][1] = PB[j][0] + (ok ? xpl : 0);
+    VB[j] = ok ? (unsigned)(((tb[j] * p.H + iy) * p.W + ix) * p.ldx + bch[j]) * 2u : OOB;
     brow[j] += 16;                                   // advance this row by 16 pixels
     tx[j] += p.step_rx;
     ty[j] += p.step_qy;
@@ -582,11 +581,29 @@ __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
     tb[j] += p.step_b + (cy ? 1 : 0);
   };
   auto prep = [&]() { prepA(); prepB(0); prepB(1); };
+  // The LDS-DMA is issued from inline asm: behind an LDS-DMA it can see (builtin), hipcc puts an s_waitcnt vmcnt(0) in front of the next
+  // ds_read_b64_tr_b16 (it cannot prove that the transposed read does not alias the DMA's destination) -- every K-step then waited
+  // for the loads it had just issued.  Hidden, the DMA is retired by the counted s_waitcnt at the top of the K loop alone (there is
+  // no other vector-memory load in the loop for the compiler to count).  M0 = the wave's LDS destination; saved and restored.
+  const unsigned lds0 = (unsigned)reinterpret_cast<size_t>(smem) + (unsigned)wave * 1024u;
+  typedef int i32x4_ __attribute__((ext_vector_type(4)));
+  auto rsrc_words = [](const void* base, unsigned bytes) {    // raw buffer descriptor: base, stride 0, num_records = bytes, flags as above
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    return i32x4_{(int)(unsigned)b, (int)(unsigned)((b >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+  };
+  const i32x4_ rA = rsrc_words(p.dy, 2u * apl_b), rB = rsrc_words(p.x, 2u * xpl_b);
+  auto dma16 = [&](const i32x4_ rs, const unsigned voff, const unsigned soff, const unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rs), "s"(soff), "s"(dst)
+                 : "memory");
+  };
   auto piece = [&](const int buf, const int i) {     // i = 4 * plane + {A0, A1, B0, B1}
-    char* s = smem + buf * SLAB;
     const int pl = i >> 2, w = i & 3;
-    if (w < 2) h2_glds16(PA[w][pl], s + pl * PLANE + (w * 256 + wave * 64) * 16);
-    else h2_glds16(PB[w - 2][pl], s + (2 + pl) * PLANE + ((w - 2) * 256 + wave * 64) * 16);
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * SLAB));
+    if (w < 2) dma16(rA, VA[w], pl * apl_b, base + (unsigned)(pl * PLANE + w * 4096));
+    else dma16(rB, VB[w - 2], pl * xpl_b, base + (unsigned)((2 + pl) * PLANE + (w - 2) * 4096));
   };
   auto issue = [&](const int buf) {
 #pragma unroll
@@ -903,7 +920,8 @@ extern "C" int catseg_conv2d_bwd_weight_f16x2(const catseg_conv_desc* d, const v
                                               const void* dy_scale, float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
   CS_REQUIRE(d && !d->stem4 && d->groups <= 1 && d->Cin % 8 == 0, "conv bwd_weight f16x2: dense, Cin % 8 == 0");
   CS_REQUIRE(cs_aligned16(x_planes) && cs_aligned16(dy_planes) && cs_aligned16(dw) && x_scale && dy_scale, "conv bwd_weight f16x2: alignment");
-  CS_REQUIRE((long long)d->B * d->H * d->W * d->Cin < (1ll << 31), "conv bwd_weight f16x2: 32-bit offsets");
+  CS_REQUIRE((long long)d->B * d->H * d->W * d->Cin * 4 < (1ll << 32) - 64 && (long long)d->B * d->Ho * d->Wo * ((d->Cout + 7) & ~7) * 4 < (1ll << 32) - 64,
+             "conv bwd_weight f16x2: an operand's two planes must stay below 4 GB");
   const size_t need = catseg_conv2d_bwd_weight_f16x2_workspace(d);
   if (workspace_bytes < need || (need && !workspace)) {
     catseg_set_error("conv bwd_weight f16x2: workspace %zu < %zu", workspace_bytes, need);
