@@ -441,8 +441,9 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
         ws = workspace(lib.catseg_conv2d_bwd_weight_bf16x3_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
         dgrad_blk = (stride == 1 and "dgrad" in B3_OPS and _b3_eligible(rows_of(x), Cin, kh * kw, (Cout + 7) // 8 * 8)
                      and _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16, rows_of(dy), Cin, kh * kw))
-        if _h2():
-            # two fp16 planes per operand (csrc/igemm_f16x2.hip); dy's blocked planes for this layer's backward-data from the same pass
+        if _h2() and 4 * rows_of(x) * Cin < B3_PLANE_LIMIT and 4 * rows_of(dy) * ((Cout + 7) // 8 * 8) < B3_PLANE_LIMIT:
+            # two fp16 planes per operand (csrc/igemm_f16x2.hip; each operand's planes behind one 32-bit-offset buffer resource); dy's
+            # blocked planes for this layer's backward-data from the same pass
             wsb = workspace(lib.catseg_conv2d_bwd_weight_f16x2_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
             with _Timed("split3", 0.0):
                 xp, xsc = _split3_cached(x, "h2p")

@@ -10,7 +10,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAI
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O/p2" -- python3 "$R/tools/bench_one.py" $KIND 4 $SHAPE $TILE > "$O/p2.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d "$O/p3" -- python3 "$R/tools/bench_one.py" $KIND 4 $SHAPE $TILE > "$O/p3.log" 2>&1
 NAME=igemm_b3
-case $KIND in fwd|dgrad|wgrad) NAME=igemm_f32;; esac
+case $KIND in fwd|dgrad|wgrad) NAME=igemm_f32;; h2fwd|h2dgrad) NAME=igemm_h2w;; h2wgrad) NAME=igemm_h2t;; esac
 python3 "$R/tools/pmc_summary.py" $NAME "$O/p1" "$O/p2" "$O/p3" > "$O/summary.json"
 cat "$O/summary.json"
 rm -rf "$O"/p?/*/*kernel_trace.csv 2>/dev/null
