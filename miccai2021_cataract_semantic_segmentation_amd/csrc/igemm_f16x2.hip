@@ -442,15 +442,27 @@ __global__ __launch_bounds__(256, 1) void igemm_h2w_kernel(const H2Args p) {
     for (int u = 0; u < TN; ++u) {
       const int col = n0 + wn * 128 + u * 32 + l31;
       const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+      // what is added to the tile (previous contents when accumulating, the residual branch) is read for all 16 rows FIRST: loads
+      // interleaved with the stores cannot be hoisted over them (they may alias) and each waited for its own round trip -- a second
+      // head's backward-data accumulating into the shared 720-channel gradient cost 5.9 instead of 4.4 ms
+      float add[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 128 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float a = 0.f;
+        if (row < p.M && col < p.N) {
+          if (p.accumulate) a = p.C[(long long)row * p.ldc + col];
+          if (p.residual != nullptr) a += p.residual[(long long)row * p.ldr + col];
+        }
+        add[r] = a;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 128 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < p.M) {
           float* dst = p.C + (long long)row * p.ldc + col;
           if (col < p.N) {
-            float v = acc[t][u][r] + bv;
-            if (p.accumulate) v += *dst;
-            if (p.residual != nullptr) v += p.residual[(long long)row * p.ldr + col];
+            float v = (acc[t][u][r] + bv) + add[r];
             if (p.relu) v = fmaxf(v, 0.f);
             *dst = v;
           } else if (col < p.zero_to) {
