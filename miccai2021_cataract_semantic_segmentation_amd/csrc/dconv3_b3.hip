@@ -73,6 +73,14 @@ struct DcCfg {
   static_assert(IPT + 2 <= NSTEP, "the prefetch of the next halo tile is spread over the K-steps: item i is loaded in step i, split in step i + 2");
 };
 
+// (timing-only build -DDC_AB2: two planes and three products instead of three and six -- WRONG results; what the f16x2 arithmetic of
+//  csrc/igemm_f16x2.hip would buy these kernels: the l plane is neither stored, streamed nor read, the products mm / hl / lh are dropped)
+#ifdef DC_AB2
+#define DC_NPL 2
+#else
+#define DC_NPL 3
+#endif
+
 struct DcArgs {
   const float* x;
   int ldx;
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
     }
     // pin the arithmetic to this K-step (LLVM would otherwise sink it to the stash, in front of the block-wide barrier)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < DC_NPL; ++p) {
       typedef int v4i __attribute__((ext_vector_type(4)));
       v4i t = __builtin_bit_cast(v4i, pl[i][p]);
 #pragma unroll
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
       if (item_live(i)) {
         *(bf16x8*)(smem + dst) = pl[i][0];
         *(bf16x8*)(smem + dst + G::XPS) = pl[i][1];
-        *(bf16x8*)(smem + dst + 2 * G::XPS) = pl[i][2];
+        if (DC_NPL == 3) *(bf16x8*)(smem + dst + 2 * G::XPS) = pl[i][2];
       }
     }
   };
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
 #pragma unroll
     for (int i = 0; i < (G::WITEMS + G::NW - 1) / G::NW; ++i) {
       const int it = wave + i * G::NW;
-      if (it < G::WITEMS) dc_glds16(src + it * 1024, dst + it * 1024);
+      if (it < G::WITEMS * DC_NPL / 3) dc_glds16(src + it * 1024, dst + it * 1024);
     }
   };
 
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
     if (s < 9) o = xb[pt] + offa + 2 * ua.win * G::KGS;
     else o = xb[pt] + (2 * ua.win - (kg & 2)) * G::KGS + (kg >> 1 ? offb : offa);   // group kg -> window 2, group kg & 1
 #pragma unroll
-    for (int p = 0; p < 3; ++p) xf[set][pt][p] = *(const bf16x8*)(smem + p * G::XPS + o);
+    for (int p = 0; p < DC_NPL; ++p) xf[set][pt][p] = *(const bf16x8*)(smem + p * G::XPS + o);
   };
   auto xread = [&](const int s, const int set) {
 #pragma unroll
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
   auto wread1 = [&](const int slot, const int ct) {
     const unsigned char* wbuf = smem + G::XBYTES + slot * G::WSTEP;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) wf[ct][p] = *(const bf16x8*)(wbuf + p * G::WPS + wb + ct * 256);
+    for (int p = 0; p < DC_NPL; ++p) wf[ct][p] = *(const bf16x8*)(wbuf + p * G::WPS + wb + ct * 256);
   };
 
   f32x4 acc[G::CB][G::PB];
@@ -401,9 +409,11 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
 #pragma unroll
           for (int pt = 0; pt < G::PB; ++pt) {
             f32x4 c = acc[ct][pt];
+#if DC_NPL == 3
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][1], xf[set][pt][1], c, 0, 0, 0);   // m m
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[set][pt][2], c, 0, 0, 0);   // h l
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][2], xf[set][pt][0], c, 0, 0, 0);   // l h
+#endif
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[set][pt][1], c, 0, 0, 0);   // h m
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][1], xf[set][pt][0], c, 0, 0, 0);   // m h
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[set][pt][0], c, 0, 0, 0);   // h h
@@ -624,7 +634,7 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
         pl[i][2][j] = (__bf16)(r1 - (float)mm);
       }
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {       // pin the arithmetic to this K-step
+      for (int p = 0; p < DC_NPL; ++p) {       // pin the arithmetic to this K-step
         typedef int v4i __attribute__((ext_vector_type(4)));
         v4i t = __builtin_bit_cast(v4i, pl[i][p]);
 #pragma unroll
@@ -644,7 +654,7 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
         if (item_live(i)) {
           *(bf16x8*)(smem + dst) = pl[i][0];
           *(bf16x8*)(smem + dst + G::XPS) = pl[i][1];
-          *(bf16x8*)(smem + dst + 2 * G::XPS) = pl[i][2];
+          if (DC_NPL == 3) *(bf16x8*)(smem + dst + 2 * G::XPS) = pl[i][2];
         }
       }
     };
@@ -655,7 +665,7 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
 #pragma unroll
       for (int i = 0; i < (G::WITEMS + G::NW - 1) / G::NW; ++i) {
         const int it = hw + i * G::NW;
-        if (it < G::WITEMS) dc_glds16(src + it * 1024, dst + it * 1024);
+        if (it < G::WITEMS * DC_NPL / 3) dc_glds16(src + it * 1024, dst + it * 1024);
       }
     };
     target(t_begin, 0);
@@ -721,12 +731,12 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
     if (s < 9) o = xb[pt] + offa + 2 * ua.win * G::KGS;
     else o = xb[pt] + (2 * ua.win - (kg & 2)) * G::KGS + (kg >> 1 ? offb : offa);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) xf[pt][p] = *(const bf16x8*)(smem + p * G::XPS + o);
+    for (int p = 0; p < DC_NPL; ++p) xf[pt][p] = *(const bf16x8*)(smem + p * G::XPS + o);
   };
   auto wread1 = [&](const int slot, const int ct) {
     const unsigned char* wbuf = smem + G::XBYTES + slot * G::WSTEP;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) wf[ct][p] = *(const bf16x8*)(wbuf + p * G::WPS + wb + ct * 256);
+    for (int p = 0; p < DC_NPL; ++p) wf[ct][p] = *(const bf16x8*)(wbuf + p * G::WPS + wb + ct * 256);
   };
   f32x4 acc[G::CB][G::PB];
   int gs = 0;
@@ -758,9 +768,11 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
 #pragma unroll
           for (int pt = 0; pt < G::PB; ++pt) {
             f32x4 c = acc[ct][pt];
+#if DC_NPL == 3
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][1], xf[pt][1], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[pt][2], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][2], xf[pt][0], c, 0, 0, 0);
+#endif
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[pt][1], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][1], xf[pt][0], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[pt][0], c, 0, 0, 0);

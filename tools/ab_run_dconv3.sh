@@ -18,7 +18,7 @@ def timeit(fn, n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 out = "%-28s" % os.path.basename(sys.argv[1])
-for (B, H, W, C) in [(8, 136, 240, 48), (8, 68, 120, 96)]:
+for (B, H, W, C) in [(8, 136, 240, 48), (8, 68, 120, 96), (8, 34, 60, 192), (8, 17, 30, 384)]:
     if not lib.catseg_dconv3_supported(C):
         continue
     x = torch.randn(B, H, W, C, device=dev)
