@@ -136,7 +136,9 @@ def DTYPE_STRING():
         return "f32"
     heads = ("forward / backward-data of those with > 192 output columns: operands scaled by a per-tensor power of two and split into 2 fp16 "
              "planes (22 significant bits), 3 fp16 MFMA products; " if ops.HEADS == "f16x2" else "")
-    return ("f32 (convolutions with K >= 2048 and >= 192 output columns, and the 3x3 trunk convolutions of the HRNet widths: " + heads +
+    trunk = ("forward / backward-data of the trunk convolutions likewise (prescale from the producer's amax record, split in the kernel); "
+             if ops.TRUNK == "f16x2" else "")
+    return ("f32 (convolutions with K >= 2048 and >= 192 output columns, and the 3x3 trunk convolutions of the HRNet widths: " + heads + trunk +
             "otherwise fp32 operands split exactly into 3 bf16 planes, 6 bf16 MFMA products; fp32 accumulate everywhere)")
 
 
@@ -371,12 +373,15 @@ def main():
         PEAK_F32, PEAK_B3, PEAK_H2 = 157.3, 2500.0 / 6.0, 2500.0 / 3.0
 
         def peak_of(kind):
-            return PEAK_H2 if kind.endswith("_h2") or kind == "h2w" else (PEAK_B3 if kind.endswith(("_b3", "_d3")) or kind in ("b3w", "d3") else PEAK_F32)
+            if kind.endswith(("_h2", "_d3h")) or kind in ("h2w", "d3h"):
+                return PEAK_H2
+            return PEAK_B3 if kind.endswith(("_b3", "_d3")) or kind in ("b3w", "d3") else PEAK_F32
         mm = {k: v for k, v in agg.items() if not k.startswith("hbm:") and k != "split3" and v[1] > 0}
         # the dominant KERNEL (as rocprofv3 --stats names it): forward and backward-data of the bf16x3 layers are launches of one
         # kernel (igemm_b3w_kernel); the fp32 operations are the NT / NN / TN layouts of igemm_f32_kernel
         KERNEL_OF = {"fwd_b3": "b3w", "dgrad_b3": "b3w", "wgrad_b3": "wgrad_b3", "fwd": "fwd", "dgrad": "dgrad", "wgrad": "wgrad",
-                     "fwd_d3": "d3", "dgrad_d3": "d3", "wgrad_d3": "wgrad_d3", "fwd_h2": "h2w", "dgrad_h2": "h2w", "wgrad_h2": "wgrad_h2"}
+                     "fwd_d3": "d3", "dgrad_d3": "d3", "wgrad_d3": "wgrad_d3", "fwd_h2": "h2w", "dgrad_h2": "h2w", "wgrad_h2": "wgrad_h2",
+                     "fwd_d3h": "d3h", "dgrad_d3h": "d3h"}
         groups = {}
         for k, v in mm.items():
             g = groups.setdefault(KERNEL_OF.get(k, k), [0.0, 0.0, 0])
@@ -384,8 +389,8 @@ def main():
         dom = max(groups, key=lambda k: groups[k][1])
         # (an fp32 layout is a union of 4-6 tile instantiations that rocprofv3 lists as separate kernels, the largest of them
         #  < 40 % of the layout's time: a single-symbol bf16x3 kernel with at least half of that time is the larger KERNEL)
-        for k in ("h2w", "wgrad_h2", "b3w", "wgrad_b3", "d3", "wgrad_d3"):
-            if k in groups and dom not in ("h2w", "wgrad_h2", "b3w", "wgrad_b3", "d3", "wgrad_d3") and groups[k][1] >= 0.5 * groups[dom][1]:
+        for k in ("h2w", "wgrad_h2", "b3w", "wgrad_b3", "d3h", "d3", "wgrad_d3"):
+            if k in groups and dom not in ("h2w", "wgrad_h2", "b3w", "wgrad_b3", "d3h", "d3", "wgrad_d3") and groups[k][1] >= 0.5 * groups[dom][1]:
                 dom = k
                 break
         fl, sec, n = groups[dom]
@@ -405,6 +410,8 @@ def main():
                  "wgrad_b3": "igemm_b3t_kernel (conv2d backward-weight, bf16x3 split precision, incl. slab reduction)",
                  "wgrad_h2": "igemm_h2t_kernel (conv2d backward-weight of the large layers, f16x2 split precision, incl. slab reduction)",
                  "wgrad_d3": "dwgrad3_b3_kernel (direct 3x3 conv2d backward-weight of the HRNet trunk, bf16x3 split precision, incl. slab reduction)",
+                 "d3h": "dconv3_h2_kernel (direct 3x3 conv2d forward and backward-data of the HRNet trunk, f16x2 split precision: the fp32 halo "
+                        "tile scaled by its producer's amax record and split into two fp16 planes in registers, three MFMA products)",
                  "d3": "dconv3_b3_kernel (direct 3x3 conv2d forward and backward-data of the HRNet trunk, bf16x3 split precision, "
                        "in-kernel split of the fp32 halo tile)"}.get(dom, dom)
         tot_fl = sum(v[0] for v in mm.values())
@@ -431,9 +438,9 @@ def main():
         lb_ms = (sum(v[0] / (peak_of(k) * 1e12) for k, v in mm.items())
                  + sum(v[0] for k, v in agg.items() if k.startswith("hbm:")) / 8e12) / 2 * 1e3
         roof["whole_step"] = {"lower_bound_ms": lb_ms, "measured_ms": dt / args.steps * 1e3, "frac": lb_ms / (dt / args.steps * 1e3),
-                              "f16x2_tflop_per_step": sum(v[0] for k, v in mm.items() if k.endswith("_h2")) / 2 / 1e12,
+                              "f16x2_tflop_per_step": sum(v[0] for k, v in mm.items() if k.endswith(("_h2", "_d3h"))) / 2 / 1e12,
                               "bf16x3_tflop_per_step": sum(v[0] for k, v in mm.items() if k.endswith(("_b3", "_d3"))) / 2 / 1e12,
-                              "fp32_tflop_per_step": sum(v[0] for k, v in mm.items() if not k.endswith(("_b3", "_d3", "_h2"))) / 2 / 1e12}
+                              "fp32_tflop_per_step": sum(v[0] for k, v in mm.items() if not k.endswith(("_b3", "_d3", "_h2", "_d3h"))) / 2 / 1e12}
     comm = None
     if world > 1:
         comm = model._grad_sync.stats()          # every rank (it synchronises its device); rank 0 prints

@@ -185,6 +185,23 @@ int catseg_dconv3(int B, int H, int W, int C, const float* x, int ldx, const voi
 int catseg_dconv3_bnbwd(int B, int H, int W, int C, const float* dy, int lddy, const void* wimg_bwd, float* g, int ldg, const float* q,
                         int ldq, const float* stats, const float* gamma, const float* beta, float* part, size_t part_floats,
                         catseg_stream_t stream);
+/* The same direct kernels on TWO fp16 planes and THREE products (csrc/dconv3_f16x2.hip = dconv3_b3.hip compiled with DC_H2; the
+ * arithmetic of catseg_conv2d_fwd_f16x2_blocked).  The activation is split inside the kernel, so its power-of-two prescale comes from a
+ * DEVICE amax record of CATSEG_AMAX_RECORD_BYTES = 2048 bytes (16 uint32 slots 128 bytes apart; max over the slots = bits of max|x|
+ * over the whole tensor) that the PRODUCER of x accumulated (catseg_bn_apply_amax, catseg_add_n_act_amax, catseg_bn_backward_amax /
+ * _pre_amax: one fire-and-forget atomicMax per block into slot blockIdx % 16; the caller zeroes the record before the producer
+ * runs).  A record value above the true maximum is safe, one below it overflows fp16.
+ *   catseg_dconv3_f16x2_prep_batch: as catseg_dconv3_prep_batch (same entry records) + `records`, n x 8 bytes: per weight image
+ *                                   {bits of max|w|, exponent}, computed on the device (memset + amax launch + image launch). */
+#define CATSEG_AMAX_RECORD_BYTES 2048
+size_t catseg_dconv3_f16x2_wimg_bytes(int C);
+int catseg_dconv3_f16x2_prep_batch(const float* flat, int n, const void* entries, void* wimg_base, void* records, catseg_stream_t stream);
+int catseg_dconv3_f16x2(int B, int H, int W, int C, const float* x, int ldx, const void* x_record, const void* wimg, const void* w_record,
+                        const float* bias, float* y, int ldy, int accumulate, float* bn_part, size_t bn_part_floats, int* bn_counts,
+                        catseg_stream_t stream);
+int catseg_dconv3_bnbwd_f16x2(int B, int H, int W, int C, const float* dy, int lddy, const void* dy_record, const void* wimg_bwd,
+                              const void* w_record, float* g, int ldg, const float* q, int ldq, const float* stats, const float* gamma,
+                              const float* beta, float* part, size_t part_floats, catseg_stream_t stream);
 /* backward-weight of the same layers (csrc/dwgrad3_b3.hip): dw[o,ky,kx,c] = sum_p dy[p, o] * x[pix(p,ky,kx), c], C in {48, 96, 192, 384};
  * x and dy are read as fp32 and split inside the kernel, fragments by transposed LDS reads, per-block partial sums in
  * `workspace` (catseg_dwgrad3_workspace bytes) added in a fixed order */
@@ -230,6 +247,20 @@ int catseg_bn_backward(const float* dz, int lddz, const float* z, int ldz, const
                        float* dy, int lddy, float* dgamma, float* dbeta, float* dres, int lddres,
                        int dres_accumulate, void* workspace, size_t workspace_bytes,
                        catseg_stream_t stream);
+/* catseg_bn_apply / catseg_bn_backward / catseg_bn_backward_pre / catseg_add_n_act with the output's max |value| folded into
+ * amax_record (CATSEG_AMAX_RECORD_BYTES of device memory, zeroed by the caller; NULL = the plain call): the prescale source of
+ * catseg_dconv3_f16x2 */
+int catseg_bn_apply_amax(const float* y, int ldy, const float* mean, const float* scale, const float* beta, const float* residual, int ldr,
+                         float* z, int ldz, long long rows, int C, int relu, void* amax_record, catseg_stream_t stream);
+int catseg_bn_backward_amax(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* stats,
+                            const float* gamma, const float* beta, long long rows, int C, int relu, float* dy, int lddy, float* dgamma,
+                            float* dbeta, float* dres, int lddres, int dres_accumulate, void* workspace, size_t workspace_bytes,
+                            void* amax_record, catseg_stream_t stream);
+int catseg_bn_backward_pre_amax(const float* g, int ldg, const float* q, int ldq, const float* stats, const float* gamma,
+                                const float* partials, int n_blocks, long long rows, int C, float* dq, int lddq, float* dgamma,
+                                float* dbeta, void* workspace, size_t workspace_bytes, void* amax_record, catseg_stream_t stream);
+int catseg_add_n_act_amax(const float* const* in, const int* ld, int n, float* out, int ldo, long long rows, int C, int relu,
+                          void* amax_record, catseg_stream_t stream);
 /* the rest of catseg_bn_backward when g (already masked) and the per-block sums [n_blocks][2][C] of g and g * xhat come from
  * catseg_dconv3_bnbwd: merges the sums (dgamma, dbeta) and writes dq = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)).
  * workspace >= 2 * C floats (rounded up to 256 bytes). */

@@ -47,6 +47,14 @@ _SIGS = {
     "catseg_dconv3_prep_batch": (I, [P, I, P, P, P]),
     "catseg_dconv3": (I, [I, I, I, I, P, I, P, P, P, I, I, P, SZ, P, P]),
     "catseg_dconv3_bnbwd": (I, [I, I, I, I, P, I, P, P, I, P, I, P, P, P, P, SZ, P]),
+    "catseg_dconv3_f16x2_wimg_bytes": (SZ, [I]),
+    "catseg_dconv3_f16x2_prep_batch": (I, [P, I, P, P, P, P]),
+    "catseg_dconv3_f16x2": (I, [I, I, I, I, P, I, P, P, P, P, P, I, I, P, SZ, P, P]),
+    "catseg_dconv3_bnbwd_f16x2": (I, [I, I, I, I, P, I, P, P, P, P, I, P, I, P, P, P, P, SZ, P]),
+    "catseg_bn_apply_amax": (I, [P, I, P, P, P, P, I, P, I, L, I, I, P, P]),
+    "catseg_bn_backward_amax": (I, [P, I, P, I, P, I, P, P, P, L, I, I, P, I, P, P, P, I, I, P, SZ, P, P]),
+    "catseg_bn_backward_pre_amax": (I, [P, I, P, I, P, P, P, I, L, I, P, I, P, P, P, SZ, P, P]),
+    "catseg_add_n_act_amax": (I, [P, P, I, P, I, L, I, I, P, P]),
     "catseg_conv2d_fwd_fused": (I, [P, P, P, P, P, I, I, P, P]),
     "catseg_fold_bn": (I, [P, P, P, P, P, P, F, I, I, P, P, P]),
     "catseg_conv2d_bwd_data": (I, [P, P, P, P, I, P]),

@@ -29,6 +29,44 @@ void catseg_set_error(const char* fmt, ...);
     }                                                                            \
   } while (0)
 
+#ifdef __HIPCC__
+// per-tensor amax record of an ACTIVATION: CS_AMAX_SLOTS words 128 bytes apart (2 KB); a producing kernel folds the bits of its
+// blocks' max |value| into slot blockIdx.x % CS_AMAX_SLOTS -- block reduction, then ONE fire-and-forget atomicMax per block, spread
+// over 16 cache lines (a single word made every wave of a 8192-block launch queue on one L2 line: +18 ms per training step); the
+// consumer takes the max over the slots.  Max is order-independent: deterministic.  Zeroed once per step by the host.
+#define CS_AMAX_SLOTS 16
+#define CS_AMAX_STRIDE 32        // words between slots
+#define CS_AMAX_WORDS (CS_AMAX_SLOTS * CS_AMAX_STRIDE)
+__device__ __forceinline__ void cs_amax_commit(unsigned m, unsigned* rec) {   // called by every thread of the block
+  __shared__ unsigned cs_amax_sm[16];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) cs_amax_sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 1; w < nw; ++w) m = max(m, cs_amax_sm[w]);
+    if (m) atomicMax(rec + (blockIdx.x % CS_AMAX_SLOTS) * CS_AMAX_STRIDE, m);
+  }
+}
+// the same into ONE word (small launches: the per-layer weight records)
+__device__ __forceinline__ void cs_amax_commit1(unsigned m, unsigned* word) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(word, m);
+}
+// consumer side: max over the slots (every lane of the wave gets it)
+__device__ __forceinline__ unsigned cs_amax_read(const unsigned* rec) {
+  unsigned m = rec[(threadIdx.x & (CS_AMAX_SLOTS - 1)) * CS_AMAX_STRIDE];
+#pragma unroll
+  for (int o = CS_AMAX_SLOTS / 2; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  return m;
+}
+__device__ __forceinline__ unsigned cs_abs_bits4(const float __attribute__((ext_vector_type(4))) v) {
+  return max(max(__float_as_uint(v[0]) & 0x7FFFFFFFu, __float_as_uint(v[1]) & 0x7FFFFFFFu),
+             max(__float_as_uint(v[2]) & 0x7FFFFFFFu, __float_as_uint(v[3]) & 0x7FFFFFFFu));
+}
+#endif
 static inline bool cs_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline size_t cs_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -17,12 +17,47 @@
 // LDS images (conflict-free ds_read_b128 by construction): 8-channel groups are the OUTER index, [k-group][halo pixel][16 B],
 // the k-group stride a multiple of 256 B: the 16 lanes that ds_read_b128 serves per cycle hold 16 different pixels (or output
 // channels) of at most two k-groups and therefore 16 different 16-byte slots of the 256-byte bank row.
+//
+// This file compiles twice.  As it is: three bf16 planes, six products (the text above).  Through dconv3_f16x2.hip (-DDC_H2): TWO fp16
+// planes and THREE products, the arithmetic of igemm_f16x2.hip -- the activation is scaled by 2^e (e from the 8-byte amax record its
+// PRODUCER filled: catseg_bn_apply_amax / catseg_add_n_act_amax / catseg_bn_backward_amax) while it is split in registers, the weight
+// image carries its own exponent, the epilogue scales the accumulators back; entry points catseg_dconv3_f16x2*.
 #include "common.h"
+
+#ifdef DC_H2
+#define DC_NPL 2
+#define DC_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define dconv3_b3_kernel dconv3_h2_kernel
+#define dconv3_b3_spec_kernel dconv3_h2_spec_kernel
+#define dconv3_prep_kernel dconv3_h2_prep_kernel
+#define dconv3_prep_batch_kernel dconv3_h2_prep_batch_kernel
+#elif defined(DC_AB2)
+// (timing-only build -DDC_AB2: two planes and three products of the bf16 arithmetic -- WRONG results; what the f16x2 build was worth
+//  before it existed: the l plane is neither stored, streamed nor read, the products mm / hl / lh are dropped)
+#define DC_NPL 2
+#define DC_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#else
+#define DC_NPL 3
+#define DC_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifdef DC_H2
+typedef _Float16 dc_t;
+#else
+typedef __bf16 dc_t;
+#endif
+typedef dc_t bf16x8 __attribute__((ext_vector_type(8)));     // eight 16-bit plane elements (fp16 in the DC_H2 build)
 typedef unsigned short u16;
+
+// prescale exponent from the bits of a tensor's max |x| (igemm_f16x2.hip: h2_exponent): amax * 2^e in [2^14, 2^15)
+__host__ __device__ inline int dc_exponent(unsigned amax_bits) {
+  const int ex = (int)((amax_bits >> 23) & 0xFF);
+  if (ex == 0 || ex == 255) return 0;
+  const int e = 14 - (ex - 127);
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -55,9 +90,9 @@ struct DcCfg {
   static constexpr int NKG = KC / 8;
   static constexpr int KGS = HP * 16;                      // bytes between 8-channel groups (multiple of 256)
   static constexpr int XPS = NKG * KGS;                    // bytes between planes
-  static constexpr int XBYTES = 3 * XPS;
+  static constexpr int XBYTES = DC_NPL * XPS;
   static constexpr int WPS = 64 * NT;                      // bytes per plane of one K-step of weights: [4 k-groups][NT][16 B]
-  static constexpr int WSTEP = 3 * WPS;
+  static constexpr int WSTEP = DC_NPL * WPS;
   static constexpr int NCHUNK = C / KC, NSTEP = steps_of(KC);
   // staging: one wave instruction = a unit of 16 consecutive halo pixels x 4 channel groups (lane = pixel + 16 * group): the
   // 8-lane groups of a ds_write_b128 then hit 8 consecutive 16-byte slots (conflict-free; a lane order with the channel groups
@@ -72,14 +107,6 @@ struct DcCfg {
   static_assert(SCR <= XBYTES, "epilogue scratch");
   static_assert(IPT + 2 <= NSTEP, "the prefetch of the next halo tile is spread over the K-steps: item i is loaded in step i, split in step i + 2");
 };
-
-// (timing-only build -DDC_AB2: two planes and three products instead of three and six -- WRONG results; what the f16x2 arithmetic of
-//  csrc/igemm_f16x2.hip would buy these kernels: the l plane is neither stored, streamed nor read, the products mm / hl / lh are dropped)
-#ifdef DC_AB2
-#define DC_NPL 2
-#else
-#define DC_NPL 3
-#endif
 
 struct DcArgs {
   const float* x;
@@ -102,6 +129,9 @@ struct DcArgs {
   const float* bq_gamma;
   const float* bq_beta;
   float* bq_part;         // [tile][2][C] or nullptr
+  // DC_H2: the activation's amax record (word 0 = bits of max|x|, filled by its producer) and the weight image's record (word 1 = exponent)
+  const unsigned* x_rec;
+  const int* w_rec;
 };
 
 __device__ __forceinline__ void dc_glds16(const void* src, void* lds_wave_base) {
@@ -207,6 +237,10 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
 
   // ---- this block's run of tiles; the blocks that share an XCD (equal blockIdx.x % 8) get neighbouring runs ---------------------
   const int ntile = a.B * a.tiles_y * a.tiles_x;
+#ifdef DC_H2
+  const int ex_x = __builtin_amdgcn_readfirstlane(dc_exponent(cs_amax_read(a.x_rec)));   // prescale of the activation (its producer's amax record)
+  const int ex_w = __builtin_amdgcn_readfirstlane(a.w_rec[1]);              // prescale of the weight image
+#endif
   int t_begin, t_end;
   {
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -235,7 +269,7 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
     it_off[i] = (((px / G::HW - 1) * a.W + it_hx[i]) * a.ldx + (item_live(i) ? item_g8(i) * 8 : 0)) * 4;
   }
   f32x4 pre[G::IPT][2];      // (whole-vector bit casts only: __builtin_bit_cast of ONE vector element reads element 0, hipcc 7.2)
-  bf16x8 pl[G::IPT][3];
+  bf16x8 pl[G::IPT][DC_NPL];
   const int img_bytes = ((a.H * a.W - 1) * a.ldx + G::KC) * 4;
   __amdgpu_buffer_rsrc_t f_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, img_bytes, 0x00020000);
   int f_x0 = 0, f_org = 0;           // fetch target: first column of the tile, byte offset of its origin pixel in the image
@@ -262,12 +296,21 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float v = pre[i][j >> 2][j & 3];
+#ifdef DC_H2
+      const float xs = __builtin_ldexpf(v, ex_x);
+      const _Float16 hh = (_Float16)xs;
+      pl[i][0][j] = hh;
+      pl[i][1][j] = (_Float16)(xs - (float)hh);
+#else
       const __bf16 hh = (__bf16)v;
       const float r1 = v - (float)hh;
       const __bf16 mm = (__bf16)r1;
       pl[i][0][j] = hh;
       pl[i][1][j] = mm;
+#if DC_NPL == 3
       pl[i][2][j] = (__bf16)(r1 - (float)mm);
+#endif
+#endif
     }
     // pin the arithmetic to this K-step (LLVM would otherwise sink it to the stash, in front of the block-wide barrier)
 #pragma unroll
@@ -310,7 +353,7 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
 #pragma unroll
     for (int i = 0; i < (G::WITEMS + G::NW - 1) / G::NW; ++i) {
       const int it = wave + i * G::NW;
-      if (it < G::WITEMS * DC_NPL / 3) dc_glds16(src + it * 1024, dst + it * 1024);
+      if (it < G::WITEMS) dc_glds16(src + it * 1024, dst + it * 1024);
     }
   };
 
@@ -322,7 +365,7 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
   for (int pt = 0; pt < G::PB; ++pt) xb[pt] = kg * G::KGS + (prow(pt) * G::RW + pcol(pt)) * 16;
   const int wb = kg * (G::NT * 16) + (wc * G::CB * 16 + i16) * 16;
   constexpr int XD = G::XPF ? 2 : 1;
-  bf16x8 xf[XD][G::PB][3], wf[G::CB][3];
+  bf16x8 xf[XD][G::PB][DC_NPL], wf[G::CB][DC_NPL];
   auto xread1 = [&](const int s, const int set, const int pt) {   // pixel fragments of K-step s (current chunk image), pixel tile pt
     const Unit ua = unit_of(G::KC, s, 0), ub = unit_of(G::KC, s, 1);
     const int offa = ((ua.tap / 3) * G::RW + ua.tap % 3) * 16, offb = ((ub.tap / 3) * G::RW + ub.tap % 3) * 16;
@@ -410,13 +453,13 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
           for (int pt = 0; pt < G::PB; ++pt) {
             f32x4 c = acc[ct][pt];
 #if DC_NPL == 3
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][1], xf[set][pt][1], c, 0, 0, 0);   // m m
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[set][pt][2], c, 0, 0, 0);   // h l
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][2], xf[set][pt][0], c, 0, 0, 0);   // l h
+            c = DC_MFMA(wf[ct][1], xf[set][pt][1], c, 0, 0, 0);   // m m
+            c = DC_MFMA(wf[ct][0], xf[set][pt][2], c, 0, 0, 0);   // h l
+            c = DC_MFMA(wf[ct][2], xf[set][pt][0], c, 0, 0, 0);   // l h
 #endif
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[set][pt][1], c, 0, 0, 0);   // h m
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][1], xf[set][pt][0], c, 0, 0, 0);   // m h
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[set][pt][0], c, 0, 0, 0);   // h h
+            c = DC_MFMA(wf[ct][0], xf[set][pt][1], c, 0, 0, 0);   // h m
+            c = DC_MFMA(wf[ct][1], xf[set][pt][0], c, 0, 0, 0);   // m h
+            c = DC_MFMA(wf[ct][0], xf[set][pt][0], c, 0, 0, 0);   // h h
             acc[ct][pt] = c;
 #ifndef DC_NO_XREAD
             if (!G::XPF && ct == G::CB - 1 && s + 1 < G::NSTEP) {   // single fragment set: refilled behind its last use
@@ -466,6 +509,15 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
     }
 
     // ---- epilogue: bias, store, BatchNorm partials ----------------------------------------------------------------------------
+#ifdef DC_H2
+    // back to the operands' scale, 2^-(e_x + e_w), in two exact steps
+#pragma unroll
+    for (int ct = 0; ct < G::CB; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < G::PB; ++pt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ct][pt][r] = __builtin_ldexpf(__builtin_ldexpf(acc[ct][pt][r], -ex_x), -ex_w);
+#endif
     bool p_ok[G::PB];
 #pragma unroll
     for (int pt = 0; pt < G::PB; ++pt) p_ok[pt] = y0 + prow(pt) < a.H && x0 + pcol(pt) < a.W;
@@ -580,6 +632,10 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
   const int i16 = lane & 15, kg = lane >> 4;
   const int cob = blockIdx.y;
   const int ntile = a.B * a.tiles_y * a.tiles_x;
+#ifdef DC_H2
+  const int ex_x = __builtin_amdgcn_readfirstlane(dc_exponent(cs_amax_read(a.x_rec)));   // prescale of the activation (its producer's amax record)
+  const int ex_w = __builtin_amdgcn_readfirstlane(a.w_rec[1]);              // prescale of the weight image
+#endif
   int t_begin, t_end;
   {
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -606,7 +662,7 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
       it_off[i] = (((px / G::HW - 1) * a.W + it_hx[i]) * a.ldx + (item_live(i) ? item_g8(i) * 8 : 0)) * 4;
     }
     f32x4 pre[G::IPT][2];
-    bf16x8 pl[G::IPT][3];
+    bf16x8 pl[G::IPT][DC_NPL];
     const int img_bytes = ((a.H * a.W - 1) * a.ldx + G::KC) * 4;
     __amdgpu_buffer_rsrc_t f_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, img_bytes, 0x00020000);
     int f_x0 = 0, f_org = 0;
@@ -626,12 +682,21 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float v = pre[i][j >> 2][j & 3];
+#ifdef DC_H2
+        const float xs = __builtin_ldexpf(v, ex_x);
+        const _Float16 hh = (_Float16)xs;
+        pl[i][0][j] = hh;
+        pl[i][1][j] = (_Float16)(xs - (float)hh);
+#else
         const __bf16 hh = (__bf16)v;
         const float r1 = v - (float)hh;
         const __bf16 mm = (__bf16)r1;
         pl[i][0][j] = hh;
         pl[i][1][j] = mm;
+#if DC_NPL == 3
         pl[i][2][j] = (__bf16)(r1 - (float)mm);
+#endif
+#endif
       }
 #pragma unroll
       for (int p = 0; p < DC_NPL; ++p) {       // pin the arithmetic to this K-step
@@ -665,7 +730,7 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
 #pragma unroll
       for (int i = 0; i < (G::WITEMS + G::NW - 1) / G::NW; ++i) {
         const int it = hw + i * G::NW;
-        if (it < G::WITEMS * DC_NPL / 3) dc_glds16(src + it * 1024, dst + it * 1024);
+        if (it < G::WITEMS) dc_glds16(src + it * 1024, dst + it * 1024);
       }
     };
     target(t_begin, 0);
@@ -723,7 +788,7 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
 #pragma unroll
   for (int pt = 0; pt < G::PB; ++pt) xb[pt] = kg * G::KGS + (prow(pt) * G::RW + pcol(pt)) * 16;
   const int wb = kg * (G::NT * 16) + (wc * G::CB * 16 + i16) * 16;
-  bf16x8 xf[G::PB][3], wf[G::CB][3];
+  bf16x8 xf[G::PB][DC_NPL], wf[G::CB][DC_NPL];
   auto xread1 = [&](const int s, const int pt) {
     const Unit ua = unit_of(G::KC, s, 0), ub = unit_of(G::KC, s, 1);
     const int offa = ((ua.tap / 3) * G::RW + ua.tap % 3) * 16, offb = ((ub.tap / 3) * G::RW + ub.tap % 3) * 16;
@@ -769,13 +834,13 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
           for (int pt = 0; pt < G::PB; ++pt) {
             f32x4 c = acc[ct][pt];
 #if DC_NPL == 3
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][1], xf[pt][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[pt][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][2], xf[pt][0], c, 0, 0, 0);
+            c = DC_MFMA(wf[ct][1], xf[pt][1], c, 0, 0, 0);
+            c = DC_MFMA(wf[ct][0], xf[pt][2], c, 0, 0, 0);
+            c = DC_MFMA(wf[ct][2], xf[pt][0], c, 0, 0, 0);
 #endif
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[pt][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][1], xf[pt][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][0], xf[pt][0], c, 0, 0, 0);
+            c = DC_MFMA(wf[ct][0], xf[pt][1], c, 0, 0, 0);
+            c = DC_MFMA(wf[ct][1], xf[pt][0], c, 0, 0, 0);
+            c = DC_MFMA(wf[ct][0], xf[pt][0], c, 0, 0, 0);
             acc[ct][pt] = c;
             if (ct == G::CB - 1 && s + 1 < G::NSTEP) {     // pixel fragments of the next step behind their last use
               __builtin_amdgcn_sched_barrier(0);
@@ -791,6 +856,15 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
       }
     }
     // ---- epilogue ---------------------------------------------------------------------------------------------------------------
+#ifdef DC_H2
+    // back to the operands' scale, 2^-(e_x + e_w), in two exact steps
+#pragma unroll
+    for (int ct = 0; ct < G::CB; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < G::PB; ++pt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ct][pt][r] = __builtin_ldexpf(__builtin_ldexpf(acc[ct][pt][r], -ex_x), -ex_w);
+#endif
     bool p_ok[G::PB];
 #pragma unroll
     for (int pt = 0; pt < G::PB; ++pt) p_ok[pt] = y0 + prow(pt) < a.H && x0 + pcol(pt) < a.W;
@@ -892,7 +966,7 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
 //   forward:       A[co][k = (tap, c)]  = w[co][tap][c]
 //   backward-data: A[ci][k = (tap, o)]  = w[o][8 - tap][ci]      (dx = conv of dy with the transposed, tap-mirrored bank)
 __device__ __forceinline__ void dconv3_prep_body(const float* __restrict__ w, int C, int KC, int NT, int dgrad, u16* __restrict__ img,
-                                                 long long first, long long stride) {
+                                                 long long first, long long stride, int e) {
   const int nstep = steps_of(KC), nchunk = C / KC;
   const long long total = (long long)(C / NT) * nchunk * nstep * NT * 32;
   for (long long i = first; i < total; i += stride) {
@@ -908,6 +982,14 @@ __device__ __forceinline__ void dconv3_prep_body(const float* __restrict__ w, in
     const int o = cob * NT + co;
     float v = 0.f;
     if (u.live) v = dgrad ? w[((long long)c * 9 + (8 - u.tap)) * C + o] : w[((long long)o * 9 + u.tap) * C + c];
+#ifdef DC_H2
+    const long long base = (((long long)(cob * nchunk + chunk) * nstep + step) * 2) * (32LL * NT) + ((long long)g * NT + co) * 8 + j;
+    const float xs = __builtin_ldexpf(v, e);
+    const _Float16 hh = (_Float16)xs;
+    img[base] = __builtin_bit_cast(u16, hh);
+    img[base + 32LL * NT] = __builtin_bit_cast(u16, (_Float16)(xs - (float)hh));
+#else
+    (void)e;
     const __bf16 hh = (__bf16)v;
     const float r1 = v - (float)hh;
     const __bf16 mm = (__bf16)r1;
@@ -916,22 +998,44 @@ __device__ __forceinline__ void dconv3_prep_body(const float* __restrict__ w, in
     img[base] = __builtin_bit_cast(u16, hh);
     img[base + 32LL * NT] = __builtin_bit_cast(u16, mm);
     img[base + 64LL * NT] = __builtin_bit_cast(u16, ll);
+#endif
   }
 }
 
-__global__ __launch_bounds__(256) void dconv3_prep_kernel(const float* __restrict__ w, int C, int KC, int NT, int dgrad, u16* __restrict__ img) {
-  dconv3_prep_body(w, C, KC, NT, dgrad, img, blockIdx.x * (long long)blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
-}
-
 // all layers of a network in one launch: entry e = {weight offset (floats) in the flat parameter buffer, C, direction, image offset
-// (bytes)}, blockIdx.y = entry
+// (bytes)}, blockIdx.y = entry.  DC_H2: recs[2 * entry] = bits of the layer's max |w| (dconv3_h2_amax_batch_kernel), the exponent
+// derived from it goes to recs[2 * entry + 1] (read by the convolution's epilogue)
 struct DcPrepEntry { long long w_off; long long img_off; int C, KC, NT, dgrad; };
+#ifdef DC_H2
+__global__ __launch_bounds__(256) void dconv3_h2_amax_batch_kernel(const float* __restrict__ flat, const DcPrepEntry* __restrict__ ent,
+                                                                   unsigned* __restrict__ recs) {
+  const DcPrepEntry e = ent[blockIdx.y];
+  const float* w = flat + e.w_off;
+  const long long n = (long long)e.C * 9 * e.C;
+  unsigned m = 0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    m = max(m, __float_as_uint(w[i]) & 0x7FFFFFFFu);
+  cs_amax_commit1(m, recs + 2 * blockIdx.y);
+}
+__global__ __launch_bounds__(256) void dconv3_prep_batch_kernel(const float* __restrict__ flat, const DcPrepEntry* __restrict__ ent,
+                                                                unsigned char* __restrict__ img_base, unsigned* __restrict__ recs) {
+  const DcPrepEntry e = ent[blockIdx.y];
+  const int ex = dc_exponent(recs[2 * blockIdx.y]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) ((int*)recs)[2 * blockIdx.y + 1] = ex;
+  dconv3_prep_body(flat + e.w_off, e.C, e.KC, e.NT, e.dgrad, (u16*)(img_base + e.img_off), blockIdx.x * (long long)blockDim.x + threadIdx.x,
+                   (long long)gridDim.x * blockDim.x, ex);
+}
+#else
+__global__ __launch_bounds__(256) void dconv3_prep_kernel(const float* __restrict__ w, int C, int KC, int NT, int dgrad, u16* __restrict__ img) {
+  dconv3_prep_body(w, C, KC, NT, dgrad, img, blockIdx.x * (long long)blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x, 0);
+}
 __global__ __launch_bounds__(256) void dconv3_prep_batch_kernel(const float* __restrict__ flat, const DcPrepEntry* __restrict__ ent,
                                                                 unsigned char* __restrict__ img_base) {
   const DcPrepEntry e = ent[blockIdx.y];
   dconv3_prep_body(flat + e.w_off, e.C, e.KC, e.NT, e.dgrad, (u16*)(img_base + e.img_off), blockIdx.x * (long long)blockDim.x + threadIdx.x,
-                   (long long)gridDim.x * blockDim.x);
+                   (long long)gridDim.x * blockDim.x, 0);
 }
+#endif
 
 //                     C  KC  NT WC WP PB TPH TPW PH PW  XPF
 using Cfg48 = DcCfg<48, 48, 48, 1, 4, 2, 8, 1, 1, 16, true>;    // tile  8 x 16, wave = 48 co x 32 px
@@ -980,6 +1084,14 @@ int dc_launch(const DcArgs& a, int C, hipStream_t st) {
 
 }  // namespace
 
+namespace {
+int dc_run(int B, int H, int W, int C, const float* x, int ldx, const void* wimg, const float* bias, float* y, int ldy, int accumulate,
+           float* bn_part, size_t bn_part_floats, int* bn_counts, const float* bq_y, int bq_ldy, const float* bq_stats,
+           const float* bq_gamma, const float* bq_beta, float* bq_part, size_t bq_part_floats, const void* x_rec, const void* w_rec,
+           catseg_stream_t stream);
+}
+
+#ifndef DC_H2
 extern "C" int catseg_debug_set_dconv3_blocks(int blocks) {
   g_dc_blocks = blocks > 0 ? blocks : 512;
   return CATSEG_OK;
@@ -1040,16 +1152,11 @@ extern "C" int catseg_dconv3_layout(int C, int* kc, int* nt) {
   return 1;
 }
 
-namespace {
-int dc_run(int B, int H, int W, int C, const float* x, int ldx, const void* wimg, const float* bias, float* y, int ldy, int accumulate,
-           float* bn_part, size_t bn_part_floats, int* bn_counts, const float* bq_y, int bq_ldy, const float* bq_stats,
-           const float* bq_gamma, const float* bq_beta, float* bq_part, size_t bq_part_floats, catseg_stream_t stream);
-}
 
 extern "C" int catseg_dconv3(int B, int H, int W, int C, const float* x, int ldx, const void* wimg, const float* bias, float* y, int ldy,
                              int accumulate, float* bn_part, size_t bn_part_floats, int* bn_counts, catseg_stream_t stream) {
   return dc_run(B, H, W, C, x, ldx, wimg, bias, y, ldy, accumulate, bn_part, bn_part_floats, bn_counts, nullptr, 0, nullptr, nullptr, nullptr,
-                nullptr, 0, stream);
+                nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int catseg_dconv3_bnbwd(int B, int H, int W, int C, const float* dy, int lddy, const void* wimg_bwd, float* g, int ldg,
@@ -1059,13 +1166,58 @@ extern "C" int catseg_dconv3_bnbwd(int B, int H, int W, int C, const float* dy, 
   CS_REQUIRE(ldq >= C && ldq % 4 == 0 && cs_aligned16(q) && cs_aligned16(stats) && cs_aligned16(gamma) && cs_aligned16(beta) &&
                  cs_aligned16(part), "dconv3 bnbwd: alignment / row strides");
   CS_REQUIRE((long long)H * W * (long long)ldq < (1LL << 31), "dconv3 bnbwd: image too large for 32-bit offsets");
-  return dc_run(B, H, W, C, dy, lddy, wimg_bwd, nullptr, g, ldg, 0, nullptr, 0, nullptr, q, ldq, stats, gamma, beta, part, part_floats, stream);
+  return dc_run(B, H, W, C, dy, lddy, wimg_bwd, nullptr, g, ldg, 0, nullptr, 0, nullptr, q, ldq, stats, gamma, beta, part, part_floats, nullptr, nullptr, stream);
 }
+
+#else   // ---------------------------------------------------------------- DC_H2: the two-plane fp16 build (dconv3_f16x2.hip)
+extern "C" size_t catseg_dconv3_f16x2_wimg_bytes(int C) {
+  const DcPlan p = dc_plan(C);
+  if (!p.kind) return 0;
+  return (size_t)(C / p.NT) * (C / p.KC) * steps_of(p.KC) * 128 * p.NT;
+}
+
+// as catseg_dconv3_prep_batch; records = n x {uint32 bits of max|w|, int32 exponent} (DEVICE, 8 bytes per entry): zeroed, filled by
+// the amax launch, completed by the image launch.  Three stream operations for all layers of a network.
+extern "C" int catseg_dconv3_f16x2_prep_batch(const float* flat, int n, const void* entries, void* wimg_base, void* records,
+                                              catseg_stream_t stream) {
+  CS_REQUIRE(flat && entries && wimg_base && records && n > 0, "dconv3 f16x2 prep batch: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(records, 0, (size_t)n * 8, st) != hipSuccess) { catseg_set_error("dconv3 f16x2 prep: memset failed"); return CATSEG_EHIP; }
+  hipLaunchKernelGGL(dconv3_h2_amax_batch_kernel, dim3(16, n), dim3(256), 0, st, flat, (const DcPrepEntry*)entries, (unsigned*)records);
+  hipLaunchKernelGGL(dconv3_prep_batch_kernel, dim3(48, n), dim3(256), 0, st, flat, (const DcPrepEntry*)entries, (unsigned char*)wimg_base,
+                     (unsigned*)records);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// catseg_dconv3 on two fp16 planes: x_record = the activation's amax record (16 words 128 bytes apart, their max = bits of max|x| over
+// the WHOLE tensor, as its producer left it: catseg_bn_apply_amax, catseg_add_n_act_amax, catseg_bn_backward(_pre)_amax; a larger value is safe, a
+// smaller one overflows fp16), w_record = the weight image's record from catseg_dconv3_f16x2_prep_batch
+extern "C" int catseg_dconv3_f16x2(int B, int H, int W, int C, const float* x, int ldx, const void* x_record, const void* wimg,
+                                   const void* w_record, const float* bias, float* y, int ldy, int accumulate, float* bn_part,
+                                   size_t bn_part_floats, int* bn_counts, catseg_stream_t stream) {
+  CS_REQUIRE(x_record && w_record, "dconv3 f16x2: amax records missing");
+  return dc_run(B, H, W, C, x, ldx, wimg, bias, y, ldy, accumulate, bn_part, bn_part_floats, bn_counts, nullptr, 0, nullptr, nullptr, nullptr,
+                nullptr, 0, x_record, w_record, stream);
+}
+
+extern "C" int catseg_dconv3_bnbwd_f16x2(int B, int H, int W, int C, const float* dy, int lddy, const void* dy_record, const void* wimg_bwd,
+                                         const void* w_record, float* g, int ldg, const float* q, int ldq, const float* stats,
+                                         const float* gamma, const float* beta, float* part, size_t part_floats, catseg_stream_t stream) {
+  CS_REQUIRE(q && stats && gamma && beta && part && dy_record && w_record, "dconv3 bnbwd f16x2: bad args");
+  CS_REQUIRE(ldq >= C && ldq % 4 == 0 && cs_aligned16(q) && cs_aligned16(stats) && cs_aligned16(gamma) && cs_aligned16(beta) &&
+                 cs_aligned16(part), "dconv3 bnbwd f16x2: alignment / row strides");
+  CS_REQUIRE((long long)H * W * (long long)ldq < (1LL << 31), "dconv3 bnbwd f16x2: image too large for 32-bit offsets");
+  return dc_run(B, H, W, C, dy, lddy, wimg_bwd, nullptr, g, ldg, 0, nullptr, 0, nullptr, q, ldq, stats, gamma, beta, part, part_floats, dy_record,
+                w_record, stream);
+}
+#endif
 
 namespace {
 int dc_run(int B, int H, int W, int C, const float* x, int ldx, const void* wimg, const float* bias, float* y, int ldy, int accumulate,
            float* bn_part, size_t bn_part_floats, int* bn_counts, const float* bq_y, int bq_ldy, const float* bq_stats,
-           const float* bq_gamma, const float* bq_beta, float* bq_part, size_t bq_part_floats, catseg_stream_t stream) {
+           const float* bq_gamma, const float* bq_beta, float* bq_part, size_t bq_part_floats, const void* x_rec, const void* w_rec,
+           catseg_stream_t stream) {
   const DcPlan p = dc_plan(C);
   CS_REQUIRE(p.kind, "dconv3: unsupported channel count %d", C);
   CS_REQUIRE(B > 0 && H > 0 && W > 0 && x && wimg && y, "dconv3: bad args");
@@ -1081,6 +1233,7 @@ int dc_run(int B, int H, int W, int C, const float* x, int ldx, const void* wimg
   a.bn_part = bn_part;
   a.bn_cnt = bn_counts;
   a.bq_y = bq_y; a.bq_ldy = bq_ldy; a.bq_stats = bq_stats; a.bq_gamma = bq_gamma; a.bq_beta = bq_beta; a.bq_part = bq_part;
+  a.x_rec = (const unsigned*)x_rec; a.w_rec = (const int*)w_rec;
   const long long ntile = (long long)B * a.tiles_y * a.tiles_x;
   if (bn_part) CS_REQUIRE(bn_counts && bn_part_floats >= (size_t)ntile * 3 * C, "dconv3: BatchNorm partial buffer too small");
   if (bq_part) CS_REQUIRE(bq_part_floats >= (size_t)ntile * 2 * C, "dconv3 bnbwd: partial buffer too small");

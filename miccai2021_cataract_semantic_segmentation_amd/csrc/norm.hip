@@ -170,9 +170,10 @@ __device__ __forceinline__ f32x4 bn_affine(f32x4 y, f32x4 mean, f32x4 scale, f32
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ mean,
                                                        const float* __restrict__ scale, const float* __restrict__ beta,
                                                        const float* __restrict__ res, int ldr, float* __restrict__ z,
-                                                       int ldz, long long rows, int C, int relu) {
+                                                       int ldz, long long rows, int C, int relu, unsigned* __restrict__ amax) {
   const int cpt = C >> 2;
   const long long total = rows * cpt;
+  unsigned m = 0;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / cpt;
     const int c = (int)(i - r * cpt) * 4;
@@ -182,7 +183,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
     }
     *(f32x4*)(z + r * ldz + c) = v;
+    m = max(m, cs_abs_bits4(v));
   }
+  if (amax) cs_amax_commit(m, amax);       // (uniform per launch: the shuffles run with every lane)
 }
 
 // backward partials: sg = sum g, sgx = sum g * xhat
@@ -285,9 +288,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ coef, long long rows, int C,
                                                            int relu, float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres,
-                                                           int dres_acc) {
+                                                           int dres_acc, unsigned* __restrict__ amax) {
   const int cpt = C >> 2;
   const long long total = rows * cpt;
+  unsigned m = 0;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / cpt;
     const int c = (int)(i - r * cpt) * 4;
@@ -302,11 +306,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const f32x4 xh = (yy - mean) * inv;
     const f32x4 o = ld4(gamma + c) * inv * (g - ld4(coef + c) - xh * ld4(coef + C + c));
     *(f32x4*)(dy + r * lddy + c) = o;
+    m = max(m, cs_abs_bits4(o));
     if (dres) {
       f32x4* d = (f32x4*)(dres + r * lddres + c);
       *d = dres_acc ? (*d + g) : g;
     }
   }
+  if (amax) cs_amax_commit(m, amax);
 }
 
 int grid_for(long long total) {
@@ -399,24 +405,43 @@ extern "C" int catseg_bn_eval_scale(int C, const float* gamma, const float* runn
   return CATSEG_OK;
 }
 
+extern "C" int catseg_bn_apply_amax(const float* y, int ldy, const float* mean, const float* scale, const float* beta, const float* residual,
+                                    int ldr, float* z, int ldz, long long rows, int C, int relu, void* amax_record, catseg_stream_t stream);
 extern "C" int catseg_bn_apply(const float* y, int ldy, const float* mean, const float* scale, const float* beta,
                                const float* residual, int ldr, float* z, int ldz, long long rows, int C, int relu,
                                catseg_stream_t stream) {
+  return catseg_bn_apply_amax(y, ldy, mean, scale, beta, residual, ldr, z, ldz, rows, C, relu, nullptr, stream);
+}
+// the same, and max|z| folded into amax_record[0] (the 8-byte per-tensor record of catseg_dconv3_f16x2; zeroed by the caller; may be null)
+extern "C" int catseg_bn_apply_amax(const float* y, int ldy, const float* mean, const float* scale, const float* beta, const float* residual,
+                                    int ldr, float* z, int ldz, long long rows, int C, int relu, void* amax_record, catseg_stream_t stream) {
   CS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && ldy % 4 == 0 && ldz % 4 == 0 && (residual == nullptr || ldr % 4 == 0),
              "bn apply: C and ld must be multiples of 4");
   CS_REQUIRE(cs_aligned16(y) && cs_aligned16(z) && cs_aligned16(mean) && cs_aligned16(scale) && cs_aligned16(beta) &&
                  cs_aligned16(residual), "bn apply: alignment");
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, mean, scale,
-                     beta, residual, ldr, z, ldz, rows, C, relu);
+                     beta, residual, ldr, z, ldz, rows, C, relu, (unsigned*)amax_record);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
 
+extern "C" int catseg_bn_backward_amax(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* stats,
+                                       const float* gamma, const float* beta, long long rows, int C, int relu, float* dy, int lddy,
+                                       float* dgamma, float* dbeta, float* dres, int lddres, int dres_accumulate, void* workspace,
+                                       size_t workspace_bytes, void* amax_record, catseg_stream_t stream);
 extern "C" int catseg_bn_backward(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                                   const float* stats, const float* gamma, const float* beta, long long rows, int C, int relu,
                                   float* dy, int lddy, float* dgamma, float* dbeta, float* dres, int lddres,
                                   int dres_accumulate, void* workspace, size_t workspace_bytes,
                                   catseg_stream_t stream) {
+  return catseg_bn_backward_amax(dz, lddz, z, ldz, y, ldy, stats, gamma, beta, rows, C, relu, dy, lddy, dgamma, dbeta, dres, lddres, dres_accumulate,
+                                 workspace, workspace_bytes, nullptr, stream);
+}
+// the same, and max|dy| folded into amax_record[0] (may be null)
+extern "C" int catseg_bn_backward_amax(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* stats,
+                                       const float* gamma, const float* beta, long long rows, int C, int relu, float* dy, int lddy,
+                                       float* dgamma, float* dbeta, float* dres, int lddres, int dres_accumulate, void* workspace,
+                                       size_t workspace_bytes, void* amax_record, catseg_stream_t stream) {
   CS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0, "bn bwd: C and ld must be multiples of 4");
   CS_REQUIRE(!relu || (z != nullptr && ldz % 4 == 0) || (z == nullptr && beta != nullptr && dres == nullptr),
              "bn bwd: relu needs z, or (no residual branch) beta to recompute the mask from y");
@@ -437,7 +462,7 @@ extern "C" int catseg_bn_backward(const float* dz, int lddz, const float* z, int
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
 #endif
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma,
-                     beta, (const float*)coef, rows, C, relu, dy, lddy, dres, lddres, dres_accumulate);
+                     beta, (const float*)coef, rows, C, relu, dy, lddy, dres, lddres, dres_accumulate, (unsigned*)amax_record);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
@@ -445,9 +470,18 @@ extern "C" int catseg_bn_backward(const float* dz, int lddz, const float* z, int
 // backward of z = relu(bn(q)) when the producer of dz has already masked it (g = dz where z > 0) and left the per-block sums
 // [n_blocks][2][C] of g and g * xhat (catseg_dconv3_bnbwd): the merge of the sums and the apply pass, i.e. catseg_bn_backward
 // without its first pass over (dz, q)
+extern "C" int catseg_bn_backward_pre_amax(const float* g, int ldg, const float* q, int ldq, const float* stats, const float* gamma,
+                                           const float* partials, int n_blocks, long long rows, int C, float* dq, int lddq, float* dgamma,
+                                           float* dbeta, void* workspace, size_t workspace_bytes, void* amax_record, catseg_stream_t stream);
 extern "C" int catseg_bn_backward_pre(const float* g, int ldg, const float* q, int ldq, const float* stats, const float* gamma,
                                       const float* partials, int n_blocks, long long rows, int C, float* dq, int lddq, float* dgamma,
                                       float* dbeta, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+  return catseg_bn_backward_pre_amax(g, ldg, q, ldq, stats, gamma, partials, n_blocks, rows, C, dq, lddq, dgamma, dbeta, workspace, workspace_bytes,
+                                     nullptr, stream);
+}
+extern "C" int catseg_bn_backward_pre_amax(const float* g, int ldg, const float* q, int ldq, const float* stats, const float* gamma,
+                                           const float* partials, int n_blocks, long long rows, int C, float* dq, int lddq, float* dgamma,
+                                           float* dbeta, void* workspace, size_t workspace_bytes, void* amax_record, catseg_stream_t stream) {
   CS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && ldg % 4 == 0 && ldq % 4 == 0 && lddq % 4 == 0 && n_blocks > 0 && partials,
              "bn bwd (pre): C and ld must be multiples of 4");
   CS_REQUIRE(cs_aligned16(g) && cs_aligned16(q) && cs_aligned16(dq) && cs_aligned16(stats) && cs_aligned16(gamma), "bn bwd (pre): alignment");
@@ -460,7 +494,7 @@ extern "C" int catseg_bn_backward_pre(const float* g, int ldg, const float* q, i
   float* coef = (float*)workspace;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partials, n_blocks, rows, C, dgamma, dbeta, coef);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, st, g, ldg, (const float*)nullptr, 0, q, ldq, stats,
-                     gamma, (const float*)nullptr, (const float*)coef, rows, C, 0, dq, lddq, (float*)nullptr, 0, 0);
+                     gamma, (const float*)nullptr, (const float*)coef, rows, C, 0, dq, lddq, (float*)nullptr, 0, 0, (unsigned*)amax_record);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

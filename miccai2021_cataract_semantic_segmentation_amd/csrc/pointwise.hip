@@ -65,9 +65,10 @@ struct AddArgs {
   int ld[4];
   int n;
 };
-__global__ void add_n_act_kernel(AddArgs a, float* __restrict__ out, int ldo, long long rows, int C, int relu) {
+__global__ void add_n_act_kernel(AddArgs a, float* __restrict__ out, int ldo, long long rows, int C, int relu, unsigned* __restrict__ amax) {
   const int cpt = C >> 2;
   const long long total = rows * cpt;
+  unsigned m = 0;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / cpt;
     const int c = (int)(i - r * cpt) * 4;
@@ -75,7 +76,9 @@ __global__ void add_n_act_kernel(AddArgs a, float* __restrict__ out, int ldo, lo
     for (int k = 1; k < a.n; ++k) v += *(const f32x4*)(a.in[k] + r * a.ld[k] + c);
     if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
     *(f32x4*)(out + r * ldo + c) = v;
+    m = max(m, cs_abs_bits4(v));
   }
+  if (amax) cs_amax_commit(m, amax);
 }
 // g = dz * (z > 0)
 __global__ void relu_bwd_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz, float* __restrict__ g, int ldg,
@@ -547,8 +550,15 @@ extern "C" int catseg_axpy2d(const float* src, int lds, float* dst, int ldd, lon
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
+extern "C" int catseg_add_n_act_amax(const float* const* in, const int* ld, int n, float* out, int ldo, long long rows, int C, int relu,
+                                     void* amax_record, catseg_stream_t stream);
 extern "C" int catseg_add_n_act(const float* const* in, const int* ld, int n, float* out, int ldo, long long rows, int C, int relu,
                                 catseg_stream_t stream) {
+  return catseg_add_n_act_amax(in, ld, n, out, ldo, rows, C, relu, nullptr, stream);
+}
+// the same, and max|out| folded into amax_record[0] (may be null)
+extern "C" int catseg_add_n_act_amax(const float* const* in, const int* ld, int n, float* out, int ldo, long long rows, int C, int relu,
+                                     void* amax_record, catseg_stream_t stream) {
   CS_REQUIRE(n >= 1 && n <= 4 && rows > 0 && C > 0 && C % 4 == 0 && ldo % 4 == 0 && cs_aligned16(out), "add_n: bad args");
   AddArgs a;
   a.n = n;
@@ -557,7 +567,8 @@ extern "C" int catseg_add_n_act(const float* const* in, const int* ld, int n, fl
     a.ld[i] = i < n ? ld[i] : 0;
     if (i < n) CS_REQUIRE(cs_aligned16(in[i]) && ld[i] % 4 == 0, "add_n: input %d misaligned", i);
   }
-  hipLaunchKernelGGL(add_n_act_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, out, ldo, rows, C, relu);
+  hipLaunchKernelGGL(add_n_act_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, out, ldo, rows, C, relu,
+                     (unsigned*)amax_record);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

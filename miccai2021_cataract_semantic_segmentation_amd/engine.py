@@ -628,14 +628,15 @@ class EngineNet(nn.Module):
         """weight images of the direct 3x3 kernels (ops.Dconv3Bank): every eligible layer of the network, one launch per step"""
         fp = self.flat()
         bank = getattr(self, "_d3bank", None)
-        if bank is None or (bank is not False and bank.flat is not fp.flat):
+        h2 = ops._trunk_h2()
+        if bank is None or (bank is not False and (bank.flat is not fp.flat or bank.h2 != h2)):
             ws = []
             for m in self.modules():
                 if (isinstance(m, Conv2d) and not m.stem and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
                         and m.dilation == (1, 1) and m.groups == 1 and m.in_channels == m.out_channels
                         and ops.lib.catseg_dconv3_supported(m.in_channels) and id(m.weight) in fp.offsets):
                     ws.append((m.weight.data, fp.offsets[id(m.weight)]))
-            bank = ops.Dconv3Bank(fp.flat, ws) if ws else False
+            bank = ops.Dconv3Bank(fp.flat, ws, h2=h2) if ws else False
             self._d3bank = bank
         return bank
 
@@ -645,6 +646,8 @@ class EngineNet(nn.Module):
             bank = self._d3_bank()
             if bank:
                 bank.refresh()
+            if ops._trunk_h2():
+                ops.reset_amax_pool(x.device)      # the per-tensor amax records of this step (ops.new_amax)
         cx = Ctx(self.training, record, None)
         outs = self._body(cx, x)
         if not record:

@@ -225,12 +225,56 @@ def _d3_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
             and Cin == Cout and rows >= DCONV3_MIN_ROWS and lib.catseg_dconv3_supported(Cin))
 
 
-def dconv3_weight_image(w, backward_data=False):
-    """pre-split weight image of the direct kernel (cached until release_b3_cache(): one per layer and direction per step)"""
-    key = (w.data_ptr(), bool(backward_data))
+# Arithmetic of the direct trunk kernels' forward / backward-data: "f16x2" = two fp16 planes, three products (csrc/dconv3_f16x2.hip) for
+# every launch whose input carries an amax record (left by its producer: bn_apply, add_n_act, bn_backward), "bf16x3" = three bf16 planes,
+# six products.  CATSEG_TRUNK selects; inputs without a record always take the bf16x3 kernel.
+TRUNK = _os.environ.get("CATSEG_TRUNK", "f16x2")
+
+
+def _trunk_h2():
+    return TRUNK == "f16x2" and PRECISION == "bf16x3"
+
+
+_amax_pool = {}
+AMAX_POOL_RECORDS = 2048
+AMAX_WORDS = 512        # int32 words per record (include/catseg.h: CATSEG_AMAX_RECORD_BYTES): 16 slots 128 bytes apart
+
+
+def reset_amax_pool(device=None):
+    """zero the per-tensor amax records -- once per step, before its forward"""
+    for key, ent in _amax_pool.items():
+        if device is None or key == (device.type, device.index):
+            ent[0].zero_()
+            ent[1] = 0
+
+
+def new_amax(device):
+    """a zeroed amax record (int32[AMAX_WORDS] view into a per-device pool; the pool is replaced by a fresh one when it runs out)"""
+    key = (device.type, device.index)
+    ent = _amax_pool.get(key)
+    if ent is None or ent[1] >= AMAX_POOL_RECORDS:
+        ent = [torch.zeros(AMAX_WORDS * AMAX_POOL_RECORDS, dtype=torch.int32, device=device), 0]
+        _amax_pool[key] = ent
+    i = ent[1]
+    ent[1] = i + 1
+    return ent[0][AMAX_WORDS * i:AMAX_WORDS * (i + 1)]
+
+
+def amax_of(t):
+    """the record a producing kernel attached to t, or None"""
+    return getattr(t, "_amax", None)
+
+
+def dconv3_weight_image(w, backward_data=False, h2=False):
+    """pre-split weight image of the direct kernel (cached until release_b3_cache(): one per layer and direction per step);
+    h2: the two-plane fp16 image and its scale record, (image, record)"""
+    key = (w.data_ptr(), bool(backward_data), bool(h2))
     img = _d3_wimg.get(key)
     if img is None:
         C = w.shape[0]
+        if h2:       # (layers outside a Dconv3Bank: a one-layer bank over the weight tensor itself)
+            Dconv3Bank(w, [(w, 0)], h2=True).refresh()
+            return _d3_wimg[key]
         img = torch.empty(lib.catseg_dconv3_wimg_bytes(C), dtype=torch.uint8, device=w.device)
         check(lib.catseg_dconv3_prep(ptr(w), C, 1 if backward_data else 0, ptr(img), stream()))
         _d3_wimg[key] = img
@@ -239,12 +283,14 @@ def dconv3_weight_image(w, backward_data=False):
 
 class Dconv3Bank:
     """the weight images of every direct-kernel layer of one network, written by ONE launch per step
-    (catseg_dconv3_prep_batch over the flat parameter buffer) instead of two small launches per layer"""
+    (catseg_dconv3_prep_batch over the flat parameter buffer) instead of two small launches per layer.
+    h2: the two-plane fp16 images of csrc/dconv3_f16x2.hip with their per-layer scale records (amax + image launch)"""
 
-    def __init__(self, flat, weights):
+    def __init__(self, flat, weights, h2=False):
         """weights: [(parameter tensor (a view into flat), offset in floats)] of the eligible 3x3 layers"""
         import numpy as np
         self.flat = flat
+        self.h2 = h2
         rec = np.zeros(2 * len(weights), dtype=[("w", "<i8"), ("img", "<i8"), ("C", "<i4"), ("KC", "<i4"), ("NT", "<i4"), ("dg", "<i4")])
         off = 0
         self.slices = []
@@ -252,24 +298,31 @@ class Dconv3Bank:
         for i, (w, woff) in enumerate(weights):
             C = w.shape[0]
             lib.catseg_dconv3_layout(C, ctypes.byref(kc), ctypes.byref(nt))
-            nbytes = lib.catseg_dconv3_wimg_bytes(C)
+            nbytes = lib.catseg_dconv3_f16x2_wimg_bytes(C) if h2 else lib.catseg_dconv3_wimg_bytes(C)
             for dg in (0, 1):
                 rec[2 * i + dg] = (woff, off, C, kc.value, nt.value, dg)
-                self.slices.append((w, dg, off, nbytes))
+                self.slices.append((w, dg, off, nbytes, 2 * i + dg))
                 off += (nbytes + 255) // 256 * 256
         self.entries = torch.from_numpy(rec.view(np.uint8).copy()).to(flat.device)
         self.n = len(rec)
         self.images = torch.empty(max(off, 256), dtype=torch.uint8, device=flat.device)
+        self.records = torch.zeros(2 * self.n, dtype=torch.int32, device=flat.device) if h2 else None
 
     def refresh(self):
         """(re)write every image from the current parameters and publish them to dconv3_weight_image's cache"""
+        if self.h2:
+            check(lib.catseg_dconv3_f16x2_prep_batch(ptr(self.flat), self.n, ptr(self.entries), ptr(self.images), ptr(self.records), stream()))
+            for w, dg, off, nbytes, k in self.slices:
+                _d3_wimg[(w.data_ptr(), bool(dg), True)] = (self.images[off:off + nbytes], self.records[2 * k:2 * k + 2])
+            return
         check(lib.catseg_dconv3_prep_batch(ptr(self.flat), self.n, ptr(self.entries), ptr(self.images), stream()))
-        for w, dg, off, nbytes in self.slices:
-            _d3_wimg[(w.data_ptr(), bool(dg))] = self.images[off:off + nbytes]
+        for w, dg, off, nbytes, k in self.slices:
+            _d3_wimg[(w.data_ptr(), bool(dg), False)] = self.images[off:off + nbytes]
 
 
-def dconv3(x, wimg, bias=None, out=None, accumulate=False, bn_stats=False):
-    """y (+)= conv3x3(x) from a weight image; bn_stats: also returns (partials, n_tiles, 0, counts) for bn_finalize"""
+def dconv3(x, wimg, bias=None, out=None, accumulate=False, bn_stats=False, x_amax=None):
+    """y (+)= conv3x3(x) from a weight image; bn_stats: also returns (partials, n_tiles, 0, counts) for bn_finalize.
+    x_amax: the input's amax record -> the two-plane fp16 kernel; wimg is then (image, record) of dconv3_weight_image(..., h2=True)"""
     B, H, W, C = x.shape
     if out is None:
         out = new_act(B, H, W, C, x.device)
@@ -280,8 +333,12 @@ def dconv3(x, wimg, bias=None, out=None, accumulate=False, bn_stats=False):
         nt = lib.catseg_dconv3_tiles(C, B, H, W, None, None)
         part = _bn_part_buffer(3 * nt * C + nt, x.device)
         cnt = part[3 * nt * C:3 * nt * C + nt].view(torch.int32)
-    check(lib.catseg_dconv3(B, H, W, C, ptr(x), ld_of(x), ptr(wimg), ptr(bias), ptr(out), ld_of(out), 1 if accumulate else 0,
-                            ptr(part), 3 * nt * C, ptr(cnt), stream()))
+    if x_amax is not None:
+        check(lib.catseg_dconv3_f16x2(B, H, W, C, ptr(x), ld_of(x), ptr(x_amax), ptr(wimg[0]), ptr(wimg[1]), ptr(bias), ptr(out), ld_of(out),
+                                      1 if accumulate else 0, ptr(part), 3 * nt * C, ptr(cnt), stream()))
+    else:
+        check(lib.catseg_dconv3(B, H, W, C, ptr(x), ld_of(x), ptr(wimg), ptr(bias), ptr(out), ld_of(out), 1 if accumulate else 0,
+                                ptr(part), 3 * nt * C, ptr(cnt), stream()))
     if bn_stats:
         return out, (part, nt, 0, cnt)
     return out
@@ -317,9 +374,10 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
         part = _bn_part_buffer(3 * ((rows + 63) // 64) * Cout, x.device)
         tr, nt = ctypes.c_int(0), ctypes.c_int(0)
     if not stem4 and zero_to == 0 and w_ptr_tensor.dim() == 4 and _d3_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
-        wimg = dconv3_weight_image(w_ptr_tensor)
-        with _Timed("fwd_d3", flops):
-            res = dconv3(x, wimg, bias, out=out, bn_stats=bn_stats)
+        rec = amax_of(x) if _trunk_h2() else None
+        wimg = dconv3_weight_image(w_ptr_tensor, h2=rec is not None)
+        with _Timed("fwd_d3h" if rec is not None else "fwd_d3", flops):
+            res = dconv3(x, wimg, bias, out=out, bn_stats=bn_stats, x_amax=rec)
         return res
     if "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(rows, Cout, kh * kw, Cin):
         d = make_desc(x.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
@@ -389,17 +447,23 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
         accumulate = False
     flops = 2.0 * rows_of(dy) * Cout * (Cin // groups) * kh * kw
     if w.dim() == 4 and _d3_ok(B * H * W, Cin, Cout, kh, kw, stride, pad, dil, groups):
-        wimg = dconv3_weight_image(w, backward_data=True)
+        rec = amax_of(dy) if _trunk_h2() else None
+        wimg = dconv3_weight_image(w, backward_data=True, h2=rec is not None)
+        kind = "dgrad_d3h" if rec is not None else "dgrad_d3"
         if bn_src is not None and BN_BWD_FUSE and not accumulate:
             q, stats, gamma, beta = bn_src
             nt = lib.catseg_dconv3_tiles(Cin, B, H, W, None, None)
             part = torch.empty(2 * nt * Cin, dtype=torch.float32, device=dy.device)
-            with _Timed("dgrad_d3", flops):
-                check(lib.catseg_dconv3_bnbwd(B, H, W, Cin, ptr(dy), ld_of(dy), ptr(wimg), ptr(out), ld_of(out), ptr(q), ld_of(q),
-                                              ptr(stats), ptr(gamma), ptr(beta), ptr(part), part.numel(), stream()))
+            with _Timed(kind, flops):
+                if rec is not None:
+                    check(lib.catseg_dconv3_bnbwd_f16x2(B, H, W, Cin, ptr(dy), ld_of(dy), ptr(rec), ptr(wimg[0]), ptr(wimg[1]), ptr(out), ld_of(out),
+                                                        ptr(q), ld_of(q), ptr(stats), ptr(gamma), ptr(beta), ptr(part), part.numel(), stream()))
+                else:
+                    check(lib.catseg_dconv3_bnbwd(B, H, W, Cin, ptr(dy), ld_of(dy), ptr(wimg), ptr(out), ld_of(out), ptr(q), ld_of(q),
+                                                  ptr(stats), ptr(gamma), ptr(beta), ptr(part), part.numel(), stream()))
             return out, (part, nt)
-        with _Timed("dgrad_d3", flops):
-            dconv3(dy, wimg, None, out=out, accumulate=accumulate)
+        with _Timed(kind, flops):
+            dconv3(dy, wimg, None, out=out, accumulate=accumulate, x_amax=rec)
         return out
     if groups == 1 and "dgrad" in B3_OPS and _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1):
         d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
@@ -509,6 +573,7 @@ def bn_eval_scale(gamma, running_var, eps):
 
 
 def bn_apply(y, mean, scale, beta, residual, relu, out=None):
+    """the output carries an amax record (out._amax: max|out| accumulated by the kernel) when the trunk runs the f16x2 kernels"""
     if out is None:
         out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
     with _Timed("hbm:bn_apply", 4.0 * y.numel() * (3 if residual is not None else 2)):
@@ -517,9 +582,12 @@ def bn_apply(y, mean, scale, beta, residual, relu, out=None):
 
 
 def _bn_apply(y, mean, scale, beta, residual, relu, out):
-    check(lib.catseg_bn_apply(ptr(y), ld_of(y), ptr(mean), ptr(scale), ptr(beta), ptr(residual),
-                              ld_of(residual) if residual is not None else 0, ptr(out), ld_of(out), rows_of(y),
-                              y.shape[-1], 1 if relu else 0, stream()))
+    rec = new_amax(y.device) if _trunk_h2() else None
+    check(lib.catseg_bn_apply_amax(ptr(y), ld_of(y), ptr(mean), ptr(scale), ptr(beta), ptr(residual),
+                                   ld_of(residual) if residual is not None else 0, ptr(out), ld_of(out), rows_of(y),
+                                   y.shape[-1], 1 if relu else 0, ptr(rec), stream()))
+    if rec is not None:
+        out._amax = rec
     return out
 
 
@@ -546,16 +614,22 @@ def bn_backward_pre(g, q, stats, gamma, partials, dgamma, dbeta, dq_out=None):
         dq_out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
     ws = workspace(lib.catseg_bn_workspace(rows, C), q.device)
     with _Timed("hbm:bn_backward", 4.0 * q.numel() * 3):      # one pass: g and q read, dq written
-        check(lib.catseg_bn_backward_pre(ptr(g), ld_of(g), ptr(q), ld_of(q), ptr(stats), ptr(gamma), ptr(part), nt, rows, C, ptr(dq_out),
-                                         ld_of(dq_out), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), stream()))
+        rec = new_amax(q.device) if _trunk_h2() else None
+        check(lib.catseg_bn_backward_pre_amax(ptr(g), ld_of(g), ptr(q), ld_of(q), ptr(stats), ptr(gamma), ptr(part), nt, rows, C, ptr(dq_out),
+                                              ld_of(dq_out), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), ptr(rec), stream()))
+    if rec is not None:
+        dq_out._amax = rec
     return dq_out
 
 
 def _bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres, dres_accumulate, dy_out, beta, rows, C, ws):
-    check(lib.catseg_bn_backward(ptr(dz), ld_of(dz), ptr(z), ld_of(z) if z is not None else 0, ptr(y), ld_of(y), ptr(stats),
-                                 ptr(gamma), ptr(beta), rows, C, 1 if relu else 0, ptr(dy_out), ld_of(dy_out), ptr(dgamma), ptr(dbeta),
-                                 ptr(dres), ld_of(dres) if dres is not None else 0, 1 if dres_accumulate else 0, ptr(ws),
-                                 ws.numel(), stream()))
+    rec = new_amax(y.device) if _trunk_h2() else None
+    check(lib.catseg_bn_backward_amax(ptr(dz), ld_of(dz), ptr(z), ld_of(z) if z is not None else 0, ptr(y), ld_of(y), ptr(stats),
+                                      ptr(gamma), ptr(beta), rows, C, 1 if relu else 0, ptr(dy_out), ld_of(dy_out), ptr(dgamma), ptr(dbeta),
+                                      ptr(dres), ld_of(dres) if dres is not None else 0, 1 if dres_accumulate else 0, ptr(ws),
+                                      ws.numel(), ptr(rec), stream()))
+    if rec is not None:
+        dy_out._amax = rec
     return dy_out
 
 
@@ -778,7 +852,10 @@ def add_n_act(terms, relu, out=None):
     n = len(terms)
     ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in terms])
     lds = (ctypes.c_int * n)(*[ld_of(t) for t in terms])
-    check(lib.catseg_add_n_act(ptrs, lds, n, ptr(out), ld_of(out), rows_of(t0), t0.shape[-1], 1 if relu else 0, stream()))
+    rec = new_amax(t0.device) if _trunk_h2() else None
+    check(lib.catseg_add_n_act_amax(ptrs, lds, n, ptr(out), ld_of(out), rows_of(t0), t0.shape[-1], 1 if relu else 0, ptr(rec), stream()))
+    if rec is not None:
+        out._amax = rec
     return out
 
 

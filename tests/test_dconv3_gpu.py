@@ -86,8 +86,9 @@ BQ_CASES = [(2, 16, 32, 48), (1, 19, 37, 48), (2, 5, 7, 48), (2, 8, 64, 96), (1,
             (1, 17, 30, 384), (2, 16, 32, 64), (1, 19, 37, 64)]
 
 
+@pytest.mark.parametrize("h2", [False, True], ids=["bf16x3", "f16x2"])
 @pytest.mark.parametrize("case", BQ_CASES)
-def test_backward_data_with_fused_bn_backward_pass(ops, case, spec):
+def test_backward_data_with_fused_bn_backward_pass(ops, case, spec, h2):
     """out = relu(bn1(q)); y = conv2(out) (models/HRNetv2.py:36-47): the backward-data launch of conv2 masks its result with
     relu(bn1(q)) > 0 and leaves the per-tile sums of the first pass of bn1's backward (catseg_dconv3_bnbwd), catseg_bn_backward_pre
     finishes.  dq, dgamma, dbeta against fp64 autograd through relu(batch_norm(q)) -> conv2d, and against the two-pass route
@@ -105,12 +106,15 @@ def test_backward_data_with_fused_bn_backward_pass(ops, case, spec):
     out = F.relu(F.batch_norm(q64, None, None, g64, b64, True, 0.1, 1e-5))
     F.conv2d(out, w.double(), None, 1, 1, 1).backward(gy.double())
     qd, gyd = nhwc(q), nhwc(gy)
+    if h2:      # the incoming gradient carries its producer's amax record: the two-plane fp16 build of the kernel takes the launch
+        gyd._amax = _record_of(ops, gyd)
     gd, bd = gamma.cuda(), beta.cuda()
     wd = w.cuda().contiguous(memory_format=torch.channels_last)
     stats, _ = ops.bn_train_stats(qd, gd, 1e-5, 0.1, torch.zeros(C).cuda(), torch.ones(C).cuda())
     saved = (ops.PRECISION, ops.DCONV3_MIN_ROWS)
     ops.PRECISION, ops.DCONV3_MIN_ROWS = "bf16x3", 1
     try:
+        ops.PROFILE = []
         # fused: one backward-data launch + merge + apply
         gbuf = torch.full((B, H, W, C), float("nan")).cuda()
         r = ops.conv_bwd_data(gyd, wd, (B, H, W, C), 3, 3, 1, 1, 1, out=gbuf, bn_src=(qd, stats, gd, bd))
@@ -121,7 +125,10 @@ def test_backward_data_with_fused_bn_backward_pass(ops, case, spec):
         dz = ops.conv_bwd_data(gyd, wd, (B, H, W, C), 3, 3, 1, 1, 1)
         dgam2, dbet2 = torch.empty(C).cuda(), torch.empty(C).cuda()
         dq2 = ops.bn_backward(dz, None, qd, stats, gd, True, dgam2, dbet2, beta=bd)
+        kinds = {k for k, *_ in ops.PROFILE}
+        assert kinds >= ({"dgrad_d3h"} if h2 and ops.TRUNK == "f16x2" else {"dgrad_d3"}), kinds
     finally:
+        ops.PROFILE = None
         ops.PRECISION, ops.DCONV3_MIN_ROWS = saved
         ops.release_b3_cache()
     zpos = nhwc(out.detach().float()) > 0
@@ -136,6 +143,61 @@ def test_backward_data_with_fused_bn_backward_pass(ops, case, spec):
     close(dq, dq2, 1e-5)
     close(dgam, dgam2, 1e-5)
     close(dbet, dbet2, 1e-5)
+
+
+def _record_of(ops, t, slack=1.0):
+    """an amax record as a producing kernel leaves it (max over its slots = bits of max|t|; slack > 1: a conservative bound)"""
+    rec = ops.new_amax(t.device)
+    rec[32 * 5:32 * 5 + 1] = (t.abs().max() * slack).reshape(1).view(torch.int32)       # (any one of the 16 slots)
+    return rec
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("mag", [1.0, 2e-6, 3e4])
+def test_dconv3_f16x2_forward_backward_data_vs_fp64(ops, case, spec, mag):
+    """the two-plane fp16 build of the direct kernels (csrc/dconv3_f16x2.hip): prescale from the input's amax record, weight image with
+    its own exponent; forward (+bias, BatchNorm partials) and backward-data (write / accumulate) against fp64 at activation magnitudes
+    fp16 could not hold unscaled; a conservative record (8x the true maximum) changes nothing measurable"""
+    from miccai2021_cataract_semantic_segmentation_amd._lib import lib
+    B, H, W, C = case
+    if not lib.catseg_dconv3_supported(C) or (mag != 1.0 and (B * H * W < 100 or C == 64)):
+        pytest.skip("width not built / covered at mag 1")
+    g = torch.Generator().manual_seed(sum(case) + 7)
+    x = torch.randn(B, C, H, W, generator=g) * torch.exp(1.5 * torch.randn(1, C, 1, 1, generator=g)) * mag
+    w = torch.randn(C, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5
+    b = torch.randn(C, generator=g) * mag
+    xr = x.double().requires_grad_()
+    y64 = F.conv2d(xr, w.double(), b.double(), 1, 1, 1)
+    gy = torch.randn(y64.shape, generator=g) * 1e-5
+    y64.backward(gy.double())
+    xd, wd = nhwc(x), w.cuda().contiguous(memory_format=torch.channels_last)
+    wimg = ops.dconv3_weight_image(wd, h2=True)
+    y, part = ops.dconv3(xd, wimg, b.cuda(), bn_stats=True, x_amax=_record_of(ops, xd))
+    e = close2(nchw(y), y64.detach(), 2e-5)
+    y8, _ = ops.dconv3(xd, wimg, b.cuda(), bn_stats=True, x_amax=_record_of(ops, xd, 8.0))
+    close2(nchw(y8), y64.detach(), 2e-5)
+    gamma, rm, rv = torch.ones(C).cuda(), torch.zeros(C).cuda(), torch.ones(C).cuda()
+    stats, _ = ops.bn_finalize(part, B * H * W, C, gamma, 0.0, 0.1, rm, rv)
+    y2 = y64.detach().permute(1, 0, 2, 3).reshape(C, -1)
+    assert float((stats[:C].cpu().double() - y2.mean(1)).abs().max()) <= 2e-5 * float(y2.abs().max())
+    if B * H * W > 1:
+        assert float((stats[C:].cpu().double() * y2.var(1, unbiased=False).sqrt() - 1).abs().max()) <= 1e-4
+    wimg_t = ops.dconv3_weight_image(wd, backward_data=True, h2=True)
+    gyd = nhwc(gy)
+    dx = ops.dconv3(gyd, wimg_t, x_amax=_record_of(ops, gyd))
+    e2 = close2(nchw(dx), xr.grad, 2e-5)
+    dx2 = ops.dconv3(gyd, wimg_t, out=dx.clone(), accumulate=True, x_amax=_record_of(ops, gyd))
+    close2(nchw(dx2), 2 * xr.grad, 2e-5)
+    ops.release_b3_cache()
+    print("dconv3 f16x2 %s x %g: forward %.2g, backward-data %.2g of the output scale" % (case, mag, e, e2))
+
+
+def close2(a, b, rtol):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    scale = b.abs().max().item() + 1e-300
+    assert err <= rtol * scale, "max abs err %g (ref scale %g)" % (err, scale)
+    return err / scale
 
 
 def test_dconv3_inside_concat_buffers(ops):
@@ -200,7 +262,18 @@ def test_batched_weight_images_equal_single_prep(ops):
     ops.release_b3_cache()
     for w in ws:
         for dg in (False, True):
-            assert torch.equal(got[(w.data_ptr(), dg)], ops.dconv3_weight_image(w, backward_data=dg))
+            assert torch.equal(got[(w.data_ptr(), dg, False)], ops.dconv3_weight_image(w, backward_data=dg))
+    ops.release_b3_cache()
+    # the two-plane fp16 bank: every image = fp16 split of w * 2^e with the layer's own exponent e = 14 - floor(log2 max|w|)
+    bank = ops.Dconv3Bank(flat, list(zip(ws, offs)), h2=True)
+    bank.refresh()
+    for w, c in zip(ws, widths):
+        img, rec = ops._d3_wimg[(w.data_ptr(), False, True)]
+        amax = float(w.abs().max())
+        e = int(rec.cpu()[1])
+        assert 2.0 ** 14 <= amax * 2.0 ** e < 2.0 ** 15 and img.numel() == lib.catseg_dconv3_f16x2_wimg_bytes(c)
+        v = img.view(torch.float16).float()
+        assert float(v.abs().max()) <= 2.0 ** 15 and bool(torch.isfinite(v).all())
     ops.release_b3_cache()
 
 
