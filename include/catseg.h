@@ -202,6 +202,10 @@ int catseg_dconv3_f16x2(int B, int H, int W, int C, const float* x, int ldx, con
 int catseg_dconv3_bnbwd_f16x2(int B, int H, int W, int C, const float* dy, int lddy, const void* dy_record, const void* wimg_bwd,
                               const void* w_record, float* g, int ldg, const float* q, int ldq, const float* stats, const float* gamma,
                               const float* beta, float* part, size_t part_floats, catseg_stream_t stream);
+/* backward-weight on two fp16 planes (csrc/dwgrad3_f16x2.hip = dwgrad3_b3.hip compiled with DW_H2): both operands' amax records;
+ * workspace = catseg_dwgrad3_workspace */
+int catseg_dwgrad3_f16x2(int B, int H, int W, int C, const float* x, int ldx, const void* x_record, const float* dy, int ldy,
+                         const void* dy_record, float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
 /* backward-weight of the same layers (csrc/dwgrad3_b3.hip): dw[o,ky,kx,c] = sum_p dy[p, o] * x[pix(p,ky,kx), c], C in {48, 96, 192, 384};
  * x and dy are read as fp32 and split inside the kernel, fragments by transposed LDS reads, per-block partial sums in
  * `workspace` (catseg_dwgrad3_workspace bytes) added in a fixed order */

@@ -47,6 +47,7 @@ _SIGS = {
     "catseg_dconv3_prep_batch": (I, [P, I, P, P, P]),
     "catseg_dconv3": (I, [I, I, I, I, P, I, P, P, P, I, I, P, SZ, P, P]),
     "catseg_dconv3_bnbwd": (I, [I, I, I, I, P, I, P, P, I, P, I, P, P, P, P, SZ, P]),
+    "catseg_dwgrad3_f16x2": (I, [I, I, I, I, P, I, P, P, I, P, P, P, SZ, P]),
     "catseg_dconv3_f16x2_wimg_bytes": (SZ, [I]),
     "catseg_dconv3_f16x2_prep_batch": (I, [P, I, P, P, P, P]),
     "catseg_dconv3_f16x2": (I, [I, I, I, I, P, I, P, P, P, P, P, I, I, P, SZ, P, P]),

@@ -15,9 +15,33 @@
 // 8 consecutive rows then fall into 8 different 32-byte bank groups.
 #include "common.h"
 
+// This file compiles twice (as dconv3_b3.hip does): as it is -- three bf16 planes, six products -- and through dwgrad3_f16x2.hip (-DDW_H2):
+// TWO fp16 planes, THREE products; both operands are scaled by 2^e from their producers' amax records while they are split in registers
+// and the partial sums are scaled back when the slabs are written; entry point catseg_dwgrad3_f16x2.
+#ifdef DW_H2
+#define DW_NPL 2
+#define DW_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define dwgrad3_b3_kernel dwgrad3_h2_kernel
+#define dwgrad3_reduce_kernel dwgrad3_h2_reduce_kernel
+#else
+#define DW_NPL 3
+#define DW_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
+
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifdef DW_H2
+typedef _Float16 dw_t;
+__device__ __forceinline__ int dw_exponent(unsigned amax_bits) {      // igemm_f16x2.hip: amax * 2^e in [2^14, 2^15)
+  const int ex = (int)((amax_bits >> 23) & 0xFF);
+  if (ex == 0 || ex == 255) return 0;
+  const int e = 14 - (ex - 127);
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+#else
+typedef __bf16 dw_t;
+#endif
+typedef dw_t bf16x8 __attribute__((ext_vector_type(8)));     // eight 16-bit plane elements (fp16 in the DW_H2 build)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -36,8 +60,8 @@ struct WgCfg {
   static constexpr int NPX_X = XH * XW, NPX_D = TH * TW;
   static constexpr int ROWB_X = wg_rowbytes(NCI), ROWB_D = wg_rowbytes(COT);
   static constexpr int XPS = (NPX_X * ROWB_X + 255) / 256 * 256, DPS = (NPX_D * ROWB_D + 255) / 256 * 256;
-  static constexpr int D0 = 3 * XPS;
-  static constexpr int LDS = 3 * XPS + 3 * DPS;
+  static constexpr int D0 = DW_NPL * XPS;
+  static constexpr int LDS = DW_NPL * (XPS + DPS);
   static constexpr int NKS = TH * TW / 32;
   static constexpr int NGB_X = (NCI / 8 + 3) / 4, NGB_D = (COT / 8 + 3) / 4;
   static constexpr int NU_X = ((NPX_X + 15) / 16) * NGB_X, NU_D = (NPX_D / 16) * NGB_D;
@@ -54,6 +78,8 @@ struct WgArgs {
   int tiles_y, tiles_x;
   float* slabs;          // [splits][C][9][C]
   long long slab_stride;
+  const unsigned* x_rec;   // DW_H2: the operands' amax records (common.h: cs_amax_read)
+  const unsigned* dy_rec;
 };
 
 template <class G>
@@ -73,6 +99,10 @@ __global__ __launch_bounds__(G::NTHR, 2) void dwgrad3_b3_kernel(const WgArgs a) 
 
   const int ntile = a.B * a.tiles_y * a.tiles_x;
   const int t_begin = (int)((long long)blockIdx.x * ntile / gridDim.x), t_end = (int)((long long)(blockIdx.x + 1) * ntile / gridDim.x);
+#ifdef DW_H2
+  const int ex_x = __builtin_amdgcn_readfirstlane(dw_exponent(cs_amax_read(a.x_rec)));
+  const int ex_d = __builtin_amdgcn_readfirstlane(dw_exponent(cs_amax_read(a.dy_rec)));
+#endif
 
   // ---- staging items: unit u = wave + i NW; units [0, NU_X) = input rows, the rest = dy; lane = pixel + 16 (channel group) ----
   f32x4 pre[G::IPT][2];
@@ -109,7 +139,18 @@ __global__ __launch_bounds__(G::NTHR, 2) void dwgrad3_b3_kernel(const WgArgs a) 
 #pragma unroll
     for (int i = 0; i < G::IPT; ++i) {
       const int u = wave + i * G::NW;
-      bf16x8 h, m, l;
+      bf16x8 h, m;
+#ifdef DW_H2
+      const int ex = u < G::NU_X ? ex_x : ex_d;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xs = __builtin_ldexpf(pre[i][j >> 2][j & 3], ex);
+        const _Float16 hh = (_Float16)xs;
+        h[j] = hh;
+        m[j] = (_Float16)(xs - (float)hh);
+      }
+#else
+      bf16x8 l;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float vv = pre[i][j >> 2][j & 3];
@@ -120,6 +161,7 @@ __global__ __launch_bounds__(G::NTHR, 2) void dwgrad3_b3_kernel(const WgArgs a) 
         m[j] = mm;
         l[j] = (__bf16)(r1 - (float)mm);
       }
+#endif
       int dst, ps;
       bool live;
       if (u < G::NU_X) {
@@ -137,7 +179,9 @@ __global__ __launch_bounds__(G::NTHR, 2) void dwgrad3_b3_kernel(const WgArgs a) 
       if (live) {
         *(bf16x8*)(smem + dst) = h;
         *(bf16x8*)(smem + dst + ps) = m;
+#ifndef DW_H2
         *(bf16x8*)(smem + dst + 2 * ps) = l;
+#endif
       }
     }
   };
@@ -178,26 +222,28 @@ __global__ __launch_bounds__(G::NTHR, 2) void dwgrad3_b3_kernel(const WgArgs a) 
     if (tile + 1 < t_end) fetch(tile + 1);   // in flight under this tile's MFMAs
 #pragma unroll
     for (int ks = 0; ks < G::NKS; ++ks) {
-      bf16x8 af[G::MT][3];
+      bf16x8 af[G::MT][DW_NPL];
 #pragma unroll
       for (int mt = 0; mt < G::MT; ++mt)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[mt][p] = frag(a_base + ks * 32 * G::ROWB_D + mt * 32 + p * G::DPS, 16 * G::ROWB_D);
+        for (int p = 0; p < DW_NPL; ++p) af[mt][p] = frag(a_base + ks * 32 * G::ROWB_D + mt * 32 + p * G::DPS, 16 * G::ROWB_D);
 #pragma unroll
       for (int j = 0; j < G::NTW; ++j) {
         if (wn + j * G::WN < G::NTL) {
-          bf16x8 bf[3];
+          bf16x8 bf[DW_NPL];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bf[p] = frag(b_base + ks * 2 * G::XW * G::ROWB_X + noff[j] + p * G::XPS, G::XW * G::ROWB_X);
+          for (int p = 0; p < DW_NPL; ++p) bf[p] = frag(b_base + ks * 2 * G::XW * G::ROWB_X + noff[j] + p * G::XPS, G::XW * G::ROWB_X);
 #pragma unroll
           for (int mt = 0; mt < G::MT; ++mt) {
             f32x4 c = acc[mt][j];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][1], bf[1], c, 0, 0, 0);   // m m
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][0], bf[2], c, 0, 0, 0);   // h l
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][2], bf[0], c, 0, 0, 0);   // l h
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][0], bf[1], c, 0, 0, 0);   // h m
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][1], bf[0], c, 0, 0, 0);   // m h
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][0], bf[0], c, 0, 0, 0);   // h h
+#if DW_NPL == 3
+            c = DW_MFMA(af[mt][1], bf[1], c, 0, 0, 0);   // m m
+            c = DW_MFMA(af[mt][0], bf[2], c, 0, 0, 0);   // h l
+            c = DW_MFMA(af[mt][2], bf[0], c, 0, 0, 0);   // l h
+#endif
+            c = DW_MFMA(af[mt][0], bf[1], c, 0, 0, 0);   // h m   (DW_H2: plane 1 = l)
+            c = DW_MFMA(af[mt][1], bf[0], c, 0, 0, 0);   // m h
+            c = DW_MFMA(af[mt][0], bf[0], c, 0, 0, 0);   // h h
             acc[mt][j] = c;
           }
         }
@@ -218,7 +264,11 @@ __global__ __launch_bounds__(G::NTHR, 2) void dwgrad3_b3_kernel(const WgArgs a) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int o = cot0 + (wm * G::MT + mt) * 16 + 4 * kg + r;
+#ifdef DW_H2
+          out[((long long)(o * 3 + ky) * 3 + kx) * a.C + ci0 + ct * 16 + i16] = __builtin_ldexpf(__builtin_ldexpf(acc[mt][j][r], -ex_x), -ex_d);
+#else
           out[((long long)(o * 3 + ky) * 3 + kx) * a.C + ci0 + ct * 16 + i16] = acc[mt][j][r];
+#endif
         }
       }
     }
@@ -272,6 +322,20 @@ WgPlan wg_plan(int C, int B, int H, int W) {
 
 }  // namespace
 
+namespace {
+int wg_run(int B, int H, int W, int C, const float* x, int ldx, const float* dy, int ldy, float* dw, void* workspace, size_t workspace_bytes,
+           const void* x_rec, const void* dy_rec, catseg_stream_t stream);
+}
+
+#ifdef DW_H2
+// catseg_dwgrad3 on two fp16 planes: x_record / dy_record = the operands' amax records (include/catseg.h: catseg_dconv3_f16x2);
+// workspace as catseg_dwgrad3_workspace
+extern "C" int catseg_dwgrad3_f16x2(int B, int H, int W, int C, const float* x, int ldx, const void* x_record, const float* dy, int ldy,
+                                    const void* dy_record, float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(x_record && dy_record, "dwgrad3 f16x2: amax records missing");
+  return wg_run(B, H, W, C, x, ldx, dy, ldy, dw, workspace, workspace_bytes, x_record, dy_record, stream);
+}
+#else
 extern "C" int catseg_debug_set_dwgrad3_blocks(int blocks) {
   g_wg_blocks = blocks > 0 ? blocks : 512;
   return CATSEG_OK;
@@ -286,6 +350,13 @@ extern "C" size_t catseg_dwgrad3_workspace(int B, int H, int W, int C) {
 
 extern "C" int catseg_dwgrad3(int B, int H, int W, int C, const float* x, int ldx, const float* dy, int ldy, float* dw, void* workspace,
                               size_t workspace_bytes, catseg_stream_t stream) {
+  return wg_run(B, H, W, C, x, ldx, dy, ldy, dw, workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+#endif
+
+namespace {
+int wg_run(int B, int H, int W, int C, const float* x, int ldx, const float* dy, int ldy, float* dw, void* workspace, size_t workspace_bytes,
+           const void* x_rec, const void* dy_rec, catseg_stream_t stream) {
   const WgPlan p = wg_plan(C, B, H, W);
   CS_REQUIRE(p.kind, "dwgrad3: unsupported channel count %d", C);
   CS_REQUIRE(B > 0 && H > 0 && W > 0 && x && dy && dw && workspace, "dwgrad3: bad args");
@@ -304,6 +375,7 @@ extern "C" int catseg_dwgrad3(int B, int H, int W, int C, const float* x, int ld
   a.tiles_x = (W + 15) / 16;
   a.slabs = (float*)workspace;
   a.slab_stride = wel;
+  a.x_rec = (const unsigned*)x_rec; a.dy_rec = (const unsigned*)dy_rec;
   hipStream_t st = (hipStream_t)stream;
   if (p.kind == 1) hipLaunchKernelGGL((dwgrad3_b3_kernel<Wg48>), dim3(p.splits, p.variants), dim3(Wg48::NTHR), 0, st, a);
   else if (p.kind == 3) hipLaunchKernelGGL((dwgrad3_b3_kernel<Wg64>), dim3(p.splits, p.variants), dim3(Wg64::NTHR), 0, st, a);
@@ -313,3 +385,4 @@ extern "C" int catseg_dwgrad3(int B, int H, int W, int C, const float* x, int ld
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
+}  // namespace

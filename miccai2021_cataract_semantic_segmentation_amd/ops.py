@@ -539,8 +539,13 @@ def dwgrad3(x, dy, dw, dbias=None, flops=0.0):
     B, H, W, C = x.shape
     need = lib.catseg_dwgrad3_workspace(B, H, W, C)
     ws = workspace(need + 256 * C * 4, x.device)
-    with _Timed("wgrad_d3", flops or 2.0 * B * H * W * C * C * 9):
-        check(lib.catseg_dwgrad3(B, H, W, C, ptr(x), ld_of(x), ptr(dy), ld_of(dy), ptr(dw), ptr(ws), need, stream()))
+    rx, rd = (amax_of(x), amax_of(dy)) if _trunk_h2() else (None, None)
+    if rx is not None and rd is not None:      # both operands carry their producers' amax records: two fp16 planes, three products
+        with _Timed("wgrad_d3h", flops or 2.0 * B * H * W * C * C * 9):
+            check(lib.catseg_dwgrad3_f16x2(B, H, W, C, ptr(x), ld_of(x), ptr(rx), ptr(dy), ld_of(dy), ptr(rd), ptr(dw), ptr(ws), need, stream()))
+    else:
+        with _Timed("wgrad_d3", flops or 2.0 * B * H * W * C * C * 9):
+            check(lib.catseg_dwgrad3(B, H, W, C, ptr(x), ld_of(x), ptr(dy), ld_of(dy), ptr(dw), ptr(ws), need, stream()))
     if dbias is not None:
         check(lib.catseg_bias_grad(ptr(dy), ld_of(dy), rows_of(dy), C, ptr(dbias), ptr(ws), ws.numel(), stream()))
     return dw

@@ -282,6 +282,34 @@ WG_CASES = [(2, 8, 32, 48), (1, 19, 37, 48), (3, 5, 7, 48), (1, 1, 50, 48), (2, 
 
 
 @pytest.mark.parametrize("case", WG_CASES)
+@pytest.mark.parametrize("mags", [(1.0, 1.0), (3e3, 2e-6)])
+def test_dwgrad3_f16x2_vs_fp64(ops, case, mags):
+    """the two-plane fp16 build of the direct backward-weight kernel: both operands prescaled from their amax records"""
+    from miccai2021_cataract_semantic_segmentation_amd._lib import lib
+    B, H, W, C = case
+    if not lib.catseg_dwgrad3_supported(C):
+        pytest.skip("width not built")
+    g = torch.Generator().manual_seed(sum(case) + 3)
+    x = torch.randn(B, C, H, W, generator=g) * torch.exp(1.5 * torch.randn(1, C, 1, 1, generator=g)) * mags[0]
+    dy = torch.randn(B, C, H, W, generator=g) * torch.exp(1.5 * torch.randn(1, C, 1, 1, generator=g)) * mags[1]
+    w = torch.zeros(C, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, 1, 1, 1).backward(dy.double())
+    xd, dyd = nhwc(x), nhwc(dy)
+    xd._amax, dyd._amax = _record_of(ops, xd), _record_of(ops, dyd, 3.0)
+    dw = torch.full((C, C, 3, 3), float("nan")).cuda().contiguous(memory_format=torch.channels_last)
+    saved = ops.TRUNK, ops.PRECISION
+    ops.TRUNK, ops.PRECISION = "f16x2", "bf16x3"
+    try:
+        ops.PROFILE = []
+        ops.dwgrad3(xd, dyd, dw)
+        assert [k for k, *_ in ops.PROFILE] == ["wgrad_d3h"]
+    finally:
+        ops.PROFILE = None
+        ops.TRUNK, ops.PRECISION = saved
+    close2(dw, w.grad, 2e-5)
+
+
+@pytest.mark.parametrize("case", WG_CASES)
 def test_dwgrad3_vs_fp64(ops, case):
     """direct split-precision backward-weight (csrc/dwgrad3_b3.hip) against the fp64 autograd of F.conv2d, inputs with a wide dynamic
     range, tensors inside wider buffers, every block count from one tile per block to one block"""

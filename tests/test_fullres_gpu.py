@@ -87,8 +87,8 @@ def test_ocrnet_hrnet48_fullres_train_step_vs_oracle():
     ops.PROFILE = None
     # the production kernels really ran: blocked bf16x3 heads, direct trunk kernels in all three directions, fp32 elsewhere
     heads = {"fwd_h2", "dgrad_h2", "wgrad_h2"} if ops.HEADS == "f16x2" else {"fwd_b3", "dgrad_b3", "wgrad_b3"}
-    trunk = {"fwd_d3h", "dgrad_d3h"} if ops.TRUNK == "f16x2" else {"fwd_d3", "dgrad_d3"}
-    assert heads | trunk | {"wgrad_d3", "fwd", "dgrad", "wgrad"} <= kinds, kinds
+    trunk = {"fwd_d3h", "dgrad_d3h", "wgrad_d3h"} if ops.TRUNK == "f16x2" else {"fwd_d3", "dgrad_d3", "wgrad_d3"}
+    assert heads | trunk | {"fwd", "dgrad", "wgrad"} <= kinds, kinds
     final_h, interm_h = final.detach().cpu(), interm.detach().cpu()
     params = [k for k, v in S.items() if v.dtype.is_floating_point and "running" not in k]
     for k in params:

@@ -18,6 +18,8 @@ def group(name):
     m = re.search(r"igemm_f32_kernel<(\d)", name)
     if m:
         return LAY[m.group(1)]
+    if "dwgrad3_h2_" in name:
+        return "wgrad_d3h"
     if "dconv3_h2_kernel" in name or "dconv3_h2_spec_kernel" in name:
         return "d3h"            # f16x2 direct kernels, forward AND backward-data
     if "dconv3_h2_" in name:
