@@ -15,10 +15,18 @@ for (B, H, W, C) in [(8, 136, 240, 48), (8, 68, 120, 96), (8, 34, 60, 192), (8, 
     w2 = (torch.randn(96, 96, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
     wimg2, y2 = ops.dconv3_weight_image(w2), torch.empty_like(x2)
     wimg, wimg_t = ops.dconv3_weight_image(w), ops.dconv3_weight_image(w, backward_data=True)
+    # the f16x2 builds of the same kernels (operands carrying amax records)
+    x._amax = ops.new_amax(dev); x._amax[32:33] = x.abs().max().reshape(1).view(torch.int32)
+    himg, himg_t = ops.dconv3_weight_image(w, h2=True), ops.dconv3_weight_image(w, backward_data=True, h2=True)
+    href = ops.dconv3(x, himg, None, x_amax=x._amax).clone()
+    hrefd = ops.dconv3(x, himg_t, x_amax=x._amax).clone()
+    hdw0 = torch.empty_like(w)
     ref, (part, nt, _, cnt) = ops.dconv3(x, wimg, None, bn_stats=True)
     ref = ref.clone(); refp = part[:3 * nt * C].clone()
     refd = ops.dconv3(x, wimg_t).clone()
     dw0 = torch.empty_like(w); ops.dwgrad3(x, ref, dw0)
+    ref._amax = ops.new_amax(dev); ref._amax[64:65] = ref.abs().max().reshape(1).view(torch.int32)
+    ops.dwgrad3(x, ref, hdw0)            # (both operands carry records: the f16x2 kernel)
     for it in range(150):
         with torch.cuda.stream(side):
             if it % 3 == 1:
@@ -29,7 +37,16 @@ for (B, H, W, C) in [(8, 136, 240, 48), (8, 68, 120, 96), (8, 34, 60, 192), (8, 
         y = torch.full_like(x, float("nan"))
         out, (part, nt, _, cnt) = ops.dconv3(x, wimg, None, out=y, bn_stats=True)
         d = ops.dconv3(x, wimg_t, out=torch.full_like(x, float("nan")))
+        hy = ops.dconv3(x, himg, None, out=torch.full_like(x, float("nan")), x_amax=x._amax)
+        hd = ops.dconv3(x, himg_t, out=torch.full_like(x, float("nan")), x_amax=x._amax)
+        hdw = torch.full_like(w, float("nan")); ops.dwgrad3(x, ref, hdw)
+        if not (torch.equal(hy, href) and torch.equal(hd, hrefd) and torch.equal(hdw, hdw0)):
+            bad += 1
+            print("MISMATCH f16x2", (B, H, W, C), it, float((hy - href).abs().max()), float((hd - hrefd).abs().max()), float((hdw - hdw0).abs().max()), flush=True)
+        rk, ref._amax = ref._amax, None
+        x_rec, x._amax = x._amax, None
         dw = torch.full_like(w, float("nan")); ops.dwgrad3(x, ref, dw)
+        ref._amax, x._amax = rk, x_rec
         if not torch.equal(out, ref) or not torch.equal(part[:3 * nt * C], refp) or not torch.equal(d, refd) or not torch.equal(dw, dw0):
             bad += 1
             print("MISMATCH", (B, H, W, C), it, float((out - ref).abs().max()), float((d - refd).abs().max()), float((dw - dw0).abs().max()), flush=True)
