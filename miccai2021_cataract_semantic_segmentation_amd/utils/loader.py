@@ -25,7 +25,7 @@ from .ingest import GpuIngest, sample_flips
 
 class PinnedFrameLoader:
     def __init__(self, dataset, batch_size, experiment, sampler=None, shuffle=True, drop_last=True, flip_probability=(0.0, 0.5),
-                 pad=(2, 2), normalise=False, nhwc4=False, device="cuda", prefetch=3, workers=4, seed=0, rank=0, world=1,
+                 pad=(2, 2), normalise=False, nhwc4=False, device="cuda", prefetch=3, workers=1, seed=0, rank=0, world=1,
                  blur=False, colorjitter=False):
         """blur / colorjitter: the 'blur' / 'colorjitter' entries of the reference's `transforms` config list (utils/utils.py:412-417):
         BlurPIL(probability=.05, kernel_limits=(3, 7)) and ColorJitter((2/3, 1.5) x 3, hue (-.05, .05)) on the padded uint8 frames,
@@ -130,8 +130,16 @@ class PinnedFrameLoader:
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
+        in_copy = []       # (event, slot): staging slots whose host -> device copy may still be reading them
         try:
             while True:
+                # a staging slot goes back to the producer once its copy has left it.  The host never WAITS for that (unless every slot
+                # is still in a copy): HIP maps streams onto a few hardware queues, the copy may sit behind a whole step of kernels the
+                # host has already enqueued, and a blocking wait here stalled the launch loop of the next step by 15 ... 45 ms
+                while in_copy and (in_copy[0][0].query() or len(in_copy) >= len(self._slots)):
+                    ev, sl = in_copy.pop(0)
+                    ev.synchronize()
+                    free.put(sl)
                 item = ready.get()
                 if item is None:
                     break
@@ -146,8 +154,7 @@ class PinnedFrameLoader:
                 img_d.record_stream(torch.cuda.current_stream(self.device))
                 lbl_d.record_stream(torch.cuda.current_stream(self.device))
                 x, labels = self.ingest(img_d, lbl_d, fl, nhwc4=self.nhwc4, blur_radii=br, jitter=jt)
-                done.synchronize()                                         # the staging slot may be refilled once the copy has left it
-                free.put(slot)
+                in_copy.append((done, slot))
                 yield x, labels
         finally:
             # the consumer is done or has abandoned the iterator (break / exception): stop the producer and wait for it, so that it
@@ -159,3 +166,5 @@ class PinnedFrameLoader:
                 except queue.Empty:
                     break
             th.join()
+            for ev, _ in in_copy:          # (the next iteration refills the slots: their copies must have left them)
+                ev.synchronize()
