@@ -128,6 +128,11 @@ class PinnedFrameLoader:
             finally:
                 put(ready, None)
 
+        # the consumer's thread is the one that launches the training step's ~3000 kernels: a fill thread holding the interpreter lock for a
+        # whole default switch interval (5 ms) at a time starves the GPU; hand the lock over at 0.5 ms
+        import sys
+        if sys.getswitchinterval() > 5e-4:
+            sys.setswitchinterval(5e-4)
         th = threading.Thread(target=producer, daemon=True)
         th.start()
         in_copy = []       # (event, slot): staging slots whose host -> device copy may still be reading them
