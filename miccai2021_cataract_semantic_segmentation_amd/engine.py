@@ -646,9 +646,10 @@ class EngineNet(nn.Module):
             bank = self._d3_bank()
             if bank:
                 bank.refresh()
-            if ops._trunk_h2():
-                ops.reset_amax_pool(x.device)      # the per-tensor amax records of this step (ops.new_amax)
         cx = Ctx(self.training, record, None)
+        if ops._trunk_h2() and self.training:
+            cx.amax_scope = ops.AmaxScope(x.device)     # the per-tensor amax records of this forward pass and of its backward
+            ops.set_amax_scope(cx.amax_scope)
         outs = self._body(cx, x)
         if not record:
             ops.release_b3_cache()      # a recorded forward keeps its split planes for the backward-weight pass (_end_backward frees them)
@@ -668,6 +669,8 @@ class EngineNet(nn.Module):
                                "between backward passes")
         fp = self.flat()
         fp.bind_grads()
+        if getattr(cx, "amax_scope", None) is not None:
+            ops.set_amax_scope(cx.amax_scope)           # (another forward pass may have run since this one)
         if self._grad_sync is not None:
             cx.on_param_grad = self._grad_sync.param_ready
             self._grad_sync.begin(fp)

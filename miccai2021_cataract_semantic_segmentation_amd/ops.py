@@ -235,29 +235,39 @@ def _trunk_h2():
     return TRUNK == "f16x2" and PRECISION == "bf16x3"
 
 
-_amax_pool = {}
-AMAX_POOL_RECORDS = 2048
+AMAX_SCOPE_RECORDS = 1024
 AMAX_WORDS = 512        # int32 words per record (include/catseg.h: CATSEG_AMAX_RECORD_BYTES): 16 slots 128 bytes apart
+_amax_scope = None
 
 
-def reset_amax_pool(device=None):
-    """zero the per-tensor amax records -- once per step, before its forward"""
-    for key, ent in _amax_pool.items():
-        if device is None or key == (device.type, device.index):
-            ent[0].zero_()
-            ent[1] = 0
+class AmaxScope:
+    """the amax records of ONE forward pass and its backward: zeroed chunks of AMAX_SCOPE_RECORDS records, handed out in order.  A
+    record lives as long as a tensor (or this scope) refers to its chunk -- a second forward pass (another network, a second
+    micro-batch before the first backward) gets its own scope and cannot clear records that are still waiting for their backward."""
+
+    def __init__(self, device):
+        self.device, self.chunk, self.i = device, None, AMAX_SCOPE_RECORDS
+
+    def new(self):
+        if self.i >= AMAX_SCOPE_RECORDS:
+            self.chunk, self.i = torch.zeros(AMAX_WORDS * AMAX_SCOPE_RECORDS, dtype=torch.int32, device=self.device), 0
+        i = self.i
+        self.i = i + 1
+        return self.chunk[AMAX_WORDS * i:AMAX_WORDS * (i + 1)]
+
+
+def set_amax_scope(scope):
+    """the scope new_amax() draws from (the engine sets it at the start of a recorded forward and of its backward)"""
+    global _amax_scope
+    _amax_scope = scope
 
 
 def new_amax(device):
-    """a zeroed amax record (int32[AMAX_WORDS] view into a per-device pool; the pool is replaced by a fresh one when it runs out)"""
-    key = (device.type, device.index)
-    ent = _amax_pool.get(key)
-    if ent is None or ent[1] >= AMAX_POOL_RECORDS:
-        ent = [torch.zeros(AMAX_WORDS * AMAX_POOL_RECORDS, dtype=torch.int32, device=device), 0]
-        _amax_pool[key] = ent
-    i = ent[1]
-    ent[1] = i + 1
-    return ent[0][AMAX_WORDS * i:AMAX_WORDS * (i + 1)]
+    """a zeroed amax record (int32[AMAX_WORDS]) from the current scope (a private scope per device outside the engine)"""
+    global _amax_scope
+    if _amax_scope is None or _amax_scope.device != device:
+        _amax_scope = AmaxScope(device)
+    return _amax_scope.new()
 
 
 def amax_of(t):
