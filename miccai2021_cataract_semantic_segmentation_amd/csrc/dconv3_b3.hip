@@ -1038,8 +1038,11 @@ __global__ __launch_bounds__(256) void dconv3_prep_batch_kernel(const float* __r
 #endif
 
 //                     C  KC  NT WC WP PB TPH TPW PH PW  XPF
-using Cfg48 = DcCfg<48, 48, 48, 1, 4, 2, 8, 1, 1, 16, true>;    // tile  8 x 16, wave = 48 co x 32 px
-using Cfg64 = DcCfg<64, 32, 64, 1, 4, 2, 8, 1, 1, 16, true>;    // tile  8 x 16, wave = 64 co x 32 px (the stage-1 bottlenecks' 3x3)
+#ifndef DC_SPEC48      // (A/B hook: wave specialisation for 48 / 64 channels.  bf16x3 build: 65 -> 70 us; f16x2 build: 53 / 52 -> 54 / 50 us at 48
+#define DC_SPEC48 false  //  channels, 72 -> 84 us at 64: not adopted in either)
+#endif
+using Cfg48 = DcCfg<48, 48, 48, 1, 4, 2, 8, 1, 1, 16, true, DC_SPEC48>;    // tile  8 x 16, wave = 48 co x 32 px
+using Cfg64 = DcCfg<64, 32, 64, 1, 4, 2, 8, 1, 1, 16, true, DC_SPEC48>;    // tile  8 x 16, wave = 64 co x 32 px (the stage-1 bottlenecks' 3x3)
 using Cfg96 = DcCfg<96, 32, 96, 2, 2, 4, 4, 2, 1, 16, false>;    // tile  4 x 32, wave = 48 co x 64 px (A/B alternative)
 
 using Cfg96s = DcCfg<96, 32, 96, 2, 2, 2, 4, 1, 1, 16, true, true>;   // tile 4 x 16, wave = 48 co x 32 px, specialised waves (the default for 96)
