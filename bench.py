@@ -501,26 +501,26 @@ def main():
                     return 64
                 def __getitem__(self, i):
                     return self.img[i], self.lbl[i]
-            loader = PinnedFrameLoader(_Frames(), batch_size=B, experiment=3, flip_probability=(0.0, 0.5), pad=(2, 2), normalise=False,
-                                       device=dev, blur=True, colorjitter=True, seed=rank)
+            def make_loader():
+                return PinnedFrameLoader(_Frames(), batch_size=B, experiment=3, flip_probability=(0.0, 0.5), pad=(2, 2), normalise=False,
+                                         device=dev, blur=True, colorjitter=True, seed=rank)
 
-            def forever():
+            def forever(loader):
                 while True:
                     for b_ in loader:
                         yield b_
-            gen = forever()
-            # the loader's frames carry other labels than the synthetic batch (random 30 x 30 blocks of raw class ids): the Lovasz work of a
-            # step depends on them.  What the PIPELINE costs is the difference to the same batches already resident in HBM.
-            resident = [tuple(t.clone() for t in next(gen)) for _ in range(8)]
-
-            def cycle():
-                while True:
-                    for b_ in resident:
-                        yield b_
+            # The loader's frames carry other labels than the synthetic batch (random 30 x 30 blocks of raw class ids) and every batch its own
+            # flips / blur / jitter: the Lovasz work of a step depends on them.  What the PIPELINE costs is the difference between the SAME ten
+            # batches (two warm-up + eight timed, in the same order) already resident in HBM and delivered by a second, identically seeded loader.
+            gen = forever(make_loader())
+            resident = [tuple(t.clone() for t in next(gen)) for _ in range(10)]
+            gen.close()
             side_state()
-            dtr = timed_steps(8, cycle(), warm=2)
+            dtr = timed_steps(8, iter(resident), warm=2)
             side_state()
+            gen = forever(make_loader())
             dtl = timed_steps(8, gen, warm=2)
+            gen.close()
             side["through_loader"] = {"frames_per_s": world * B / dtl, "ms_per_step": dtl * 1e3, "steps": 8,
                                       "same_batches_resident_ms_per_step": dtr * 1e3,
                                       "pipeline": "PinnedFrameLoader (64 host uint8 frames 540x960, one fill thread) -> pinned staging -> "
