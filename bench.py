@@ -523,7 +523,7 @@ def main():
             gen.close()
             side["through_loader"] = {"frames_per_s": world * B / dtl, "ms_per_step": dtl * 1e3, "steps": 8,
                                       "same_batches_resident_ms_per_step": dtr * 1e3,
-                                      "pipeline": "PinnedFrameLoader (64 host uint8 frames 540x960, one fill thread) -> pinned staging -> "
+                                      "pipeline": "PinnedFrameLoader (64 host uint8 frames 540x960, stacked by the consumer thread between steps) -> pinned staging -> "
                                                   "copy on a side stream -> GpuIngest(label remap, flip, pad to 544, BlurPIL, ColorJitter, ToTensor) -> train step",
                                       "sustains_step_rate": bool(dtl <= 1.05 * dtr)}      # (within 5 %: the ingest kernels themselves are on the step's stream)
     cpu = None

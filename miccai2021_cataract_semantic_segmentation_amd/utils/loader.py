@@ -25,7 +25,7 @@ from .ingest import GpuIngest, sample_flips
 
 class PinnedFrameLoader:
     def __init__(self, dataset, batch_size, experiment, sampler=None, shuffle=True, drop_last=True, flip_probability=(0.0, 0.5),
-                 pad=(2, 2), normalise=False, nhwc4=False, device="cuda", prefetch=3, workers=1, seed=0, rank=0, world=1,
+                 pad=(2, 2), normalise=False, nhwc4=False, device="cuda", prefetch=3, workers=0, seed=0, rank=0, world=1,
                  blur=False, colorjitter=False):
         """blur / colorjitter: the 'blur' / 'colorjitter' entries of the reference's `transforms` config list (utils/utils.py:412-417):
         BlurPIL(probability=.05, kernel_limits=(3, 7)) and ColorJitter((2/3, 1.5) x 3, hue (-.05, .05)) on the padded uint8 frames,
@@ -35,7 +35,12 @@ class PinnedFrameLoader:
         self.ingest = GpuIngest(experiment, pad=pad, normalise=normalise, device=device)
         self.flip_p, self.nhwc4 = flip_probability, nhwc4
         self.blur, self.colorjitter = bool(blur), bool(colorjitter)
-        self.prefetch, self.workers = max(int(prefetch), 1), max(int(workers), 1)
+        # workers = 0: no fill thread -- each batch is stacked into its staging slot by the CONSUMER's thread inside next(), i.e. after the
+        # previous step's kernels have been enqueued and while the GPU runs them (a fill thread shares the interpreter lock with the
+        # launch loop of ~3000 kernels per step: on a busy host that stretched an HRNet-W48 step by 10 - 30 ms; the inline fill costs the
+        # host ~9 ms per batch of eight 540 x 960 frames that it has to spare).  workers >= 1: a producer thread (datasets whose
+        # __getitem__ releases the interpreter lock for long: decoding).
+        self.prefetch, self.workers = max(int(prefetch), 1), max(int(workers), 0)
         self.seed, self.epoch, self.rank, self.world = seed, 0, rank, world
         self.sampler, self.shuffle = sampler, shuffle
         if world > 1 and sampler is not None:
@@ -131,10 +136,13 @@ class PinnedFrameLoader:
         # the consumer's thread is the one that launches the training step's ~3000 kernels: a fill thread holding the interpreter lock for a
         # whole default switch interval (5 ms) at a time starves the GPU; hand the lock over at 0.5 ms
         import sys
-        if sys.getswitchinterval() > 5e-4:
+        if self.workers > 0 and sys.getswitchinterval() > 5e-4:
             sys.setswitchinterval(5e-4)
+        inline = self.workers == 0
         th = threading.Thread(target=producer, daemon=True)
-        th.start()
+        if not inline:
+            th.start()
+        nxt = 0            # (inline fill: index of the next batch)
         in_copy = []       # (event, slot): staging slots whose host -> device copy may still be reading them
         try:
             while True:
@@ -145,7 +153,19 @@ class PinnedFrameLoader:
                     ev, sl = in_copy.pop(0)
                     ev.synchronize()
                     free.put(sl)
-                item = ready.get()
+                if inline:
+                    if nxt >= len(batches):
+                        break
+                    if free.empty():           # every slot still in a copy: wait for the oldest
+                        ev, sl = in_copy.pop(0)
+                        ev.synchronize()
+                        free.put(sl)
+                    sl = free.get()
+                    fill(sl, batches[nxt])
+                    item = (sl, len(batches[nxt]), flips[nxt], blurs[nxt], jitters[nxt])
+                    nxt += 1
+                else:
+                    item = ready.get()
                 if item is None:
                     break
                 slot, n, fl, br, jt = item
@@ -170,6 +190,7 @@ class PinnedFrameLoader:
                     ready.get_nowait()
                 except queue.Empty:
                     break
-            th.join()
+            if not inline:
+                th.join()
             for ev, _ in in_copy:          # (the next iteration refills the slots: their copies must have left them)
                 ev.synchronize()
