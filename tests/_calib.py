@@ -20,6 +20,9 @@ import numpy as np
 import torch
 
 
+_CPU_CACHE = {}
+
+
 def _cpu_grads(spec, seed, forward, loss_of, x, lbl, dt, threads=None, mkldnn=True):
     from oracle.state import fill_state
     old = torch.get_num_threads()
@@ -44,17 +47,24 @@ def calibrated_grad_check(model, spec, seed, forward, loss_of, x, lbl, med=2.0, 
     split = ops.PRECISION == "bf16x3"
     p95 = p95 if p95 is not None else 16.0
     mx = mx if mx is not None else 64.0
-    g64 = _cpu_grads(spec, seed, forward, loss_of, x, lbl, torch.float64)
-    variants = [_cpu_grads(spec, seed, forward, loss_of, x, lbl, torch.float32),
-                _cpu_grads(spec, seed, forward, loss_of, x, lbl, torch.float32, threads=2),
-                _cpu_grads(spec, seed, forward, loss_of, x, lbl, torch.float32, mkldnn=False)]
+    # the four CPU evaluations do not depend on the GPU arithmetic under test: the second precision parameter of a test (same label,
+    # same inputs) reuses them (they are most of the whole-network tests' time)
+    key = (label, seed, tuple(x.shape), float(x.double().sum()), int(lbl.sum()))
+    if key not in _CPU_CACHE:
+        g64 = _cpu_grads(spec, seed, forward, loss_of, x, lbl, torch.float64)
+        variants = [_cpu_grads(spec, seed, forward, loss_of, x, lbl, torch.float32),
+                    _cpu_grads(spec, seed, forward, loss_of, x, lbl, torch.float32, threads=2),
+                    _cpu_grads(spec, seed, forward, loss_of, x, lbl, torch.float32, mkldnn=False)]
+        _CPU_CACHE.clear()          # (one entry: the fp64 gradients of a 65 M-parameter network are 0.5 GB)
+        _CPU_CACHE[key] = (g64, {k: [float((v[k] - g).norm()) for v in variants] for k, g in g64.items()})
+    g64, errs = _CPU_CACHE[key]
     P = dict(model.named_parameters())
     ratios, worst, spread = [], 0.0, []
     for k, g in g64.items():
         n64 = float(g.norm())
         if n64 < 1e-7 or P[k].grad is None:
             continue
-        es = [float((v[k] - g).norm()) for v in variants]
+        es = errs[k]
         eh = float((P[k].grad.detach().cpu().double() - g).norm())
         ratios.append(eh / (max(es) + 1e-4 * n64))
         spread.append(max(es) / (min(es) + 1e-30))
