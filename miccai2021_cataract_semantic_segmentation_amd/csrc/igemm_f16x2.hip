@@ -480,8 +480,6 @@ __global__ __launch_bounds__(256, 1) void igemm_h2w_kernel(const H2Args p) {
 // the hardware transpose ds_read_b64_tr_b16.  48 MFMAs per K-step in the order lh | hh | hl, iteration = hh(k), hl(k), lh(k+1) with
 // every fragment set re-read for step k+1 behind its last use (all from the slot of step k+1); NSLOT slots, LDS-DMA NSLOT - 1 K-steps
 // ahead (step k+NSLOT into the slot of step k, behind the barrier that ends its reads).
-__device__ __attribute__((aligned(256))) float g_zero_page_h2[64];
-
 struct H2TArgs {
   const u16* dy;  long long dy_plane; int ldo;     // [P][ldo] planes, ldo = roundup(Cout, 8)
   const u16* x;   long long x_plane;  int ldx;     // [B*H*W][ldx] planes
@@ -492,13 +490,7 @@ struct H2TArgs {
   int H, W, Ho, Wo, kw, stride, pad, dil;
   int step_b, step_qy, step_rx;                    // 16 pixels = step_b images + step_qy rows + step_rx pixels
   int tilesM, tilesN;
-  const float* zero;
 };
-
-__device__ __forceinline__ void h2_glds16(const void* src, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
   constexpr int TM = 4, TN = 4;
@@ -649,7 +641,7 @@ __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
 
   if (nks > 0) {
 #pragma unroll
-    for (int sl = 0; sl < NSLOT; ++sl) {    // (past the end of the slab every source is the zero page)
+    for (int sl = 0; sl < NSLOT; ++sl) {    // (past the end of the slab every offset is out of range = zeros)
       prep();
       issue(sl);
     }
@@ -746,17 +738,6 @@ __global__ void h2_reduce_slabs_kernel(const float* __restrict__ slabs, float* _
     for (int k = 1; k < splits; ++k) a += s[i + k * stride4];
     o[i] = a;
   }
-}
-
-const float* zero_page_h2() {
-  static const float* z[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!z[dev]) {
-    void* q = nullptr;
-    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_page_h2)) == hipSuccess) z[dev] = (const float*)q;
-  }
-  return z[dev];
 }
 
 int h2t_splits(int tiles, long long P) {
@@ -955,7 +936,6 @@ extern "C" int catseg_conv2d_bwd_weight_f16x2(const catseg_conv_desc* d, const v
   const int sp = (a.P + a.rows_per_split - 1) / a.rows_per_split;
   a.ldc = a.N; a.c_split_stride = (long long)a.M * a.N;
   a.C = sp > 1 ? (float*)workspace : dw;
-  a.zero = zero_page_h2();
   hipLaunchKernelGGL(igemm_h2t_kernel, dim3(a.tilesM * a.tilesN * sp), dim3(256), 0, st, a);
   CS_LAUNCH_CHECK();
   if (sp > 1) {

@@ -139,7 +139,10 @@ def test_bf16x3_layer_selection():
     assert not ops._b3_eligible(8 * 17 * 30, 384, 9, 384)              # 384-channel branch: too few tiles
     assert ops._b3_eligible(rows, 512, 1, 1024)                        # the wide 1x1 of the OCR head at stride 4 ...
     assert ops._b3_eligible(rows, 1024, 1, 512)                        # ... and its backward-data (N = 1024, K = 512)
-    assert not ops._b3_eligible(8 * 68 * 120, 512, 1, 1024)            # the same layer at stride 8 (OCRNet-R50): fp32
+    assert ops._b3_eligible(8 * 68 * 120, 512, 1, 1024)                # the same layer at stride 8 (OCRNet-R50; 65 280 pixels): since round 3
+    assert ops._b3_eligible(8 * 68 * 120, 2048, 1, 512)                # ResNet50 layer 4, 1x1 512 -> 2048 on the stride-8 map
+    assert not ops._b3_eligible(4 * 68 * 120, 512, 1, 1024)            # half the batch: fp32
+    assert not ops._b3_eligible(8 * 68 * 120, 256, 1, 1024)            # an extent of 256 (ResNet50 layer 3): fp32
     assert not ops._b3_eligible(rows, 256, 1, 512)                     # smaller 1x1 layers: fp32
     assert ops._b3_eligible(8 * 68 * 120, 512, 9, 2048)                # OCRNet-R50 conv_high_map
     assert not ops._b3_eligible(8 * 68 * 120, 512, 9, 2044)            # Cin % 8
