@@ -1,4 +1,5 @@
-"""Run the direct 3x3 kernel alone (for rocprofv3 passes).  usage: run_dconv3.py [fwd|dgrad] [n] [B,H,W,C] [blocks]"""
+"""Run the direct 3x3 kernel alone (for rocprofv3 passes).  usage: run_dconv3.py [fwd|dgrad|h2fwd|h2dgrad] [n] [B,H,W,C] [blocks]
+(h2*: the two-plane fp16 build; eight inputs in turn, so that they are not cache resident)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,9 +15,19 @@ dev = torch.device("cuda")
 x = torch.randn(B, H, W, C, device=dev)
 w = (torch.randn(C, C, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
 y = torch.empty_like(x)
-wimg = ops.dconv3_weight_image(w, backward_data=(kind == "dgrad"))
-torch.cuda.synchronize()
-for _ in range(n):
-    ops.dconv3(x, wimg, None, out=y, bn_stats=(kind == "fwd"))
+if kind.startswith("h2"):
+    xs = [torch.randn(B, H, W, C, device=dev) for _ in range(8)]
+    for t in xs:
+        t._amax = ops.new_amax(dev)
+        t._amax[0:1] = t.abs().max().reshape(1).view(torch.int32)
+    wimg = ops.dconv3_weight_image(w, backward_data=(kind == "h2dgrad"), h2=True)
+    torch.cuda.synchronize()
+    for i in range(n):
+        ops.dconv3(xs[i % 8], wimg, None, out=y, bn_stats=(kind == "h2fwd"), x_amax=xs[i % 8]._amax)
+else:
+    wimg = ops.dconv3_weight_image(w, backward_data=(kind == "dgrad"))
+    torch.cuda.synchronize()
+    for _ in range(n):
+        ops.dconv3(x, wimg, None, out=y, bn_stats=(kind == "fwd"))
 torch.cuda.synchronize()
 print("done", kind, 2.0 * B * H * W * C * C * 9 / 1e9, "GF per launch")
