@@ -240,6 +240,7 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
 #ifdef DC_H2
   const int ex_x = __builtin_amdgcn_readfirstlane(dc_exponent(cs_amax_read(a.x_rec)));   // prescale of the activation (its producer's amax record)
   const int ex_w = __builtin_amdgcn_readfirstlane(a.w_rec[1]);              // prescale of the weight image
+  const float sc_x = __builtin_ldexpf(1.f, ex_x);                            // 2^e_x (|e| <= 100: a normal float; x * 2^e is exact)
 #endif
   int t_begin, t_end;
   {
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
     for (int j = 0; j < 8; ++j) {
       const float v = pre[i][j >> 2][j & 3];
 #ifdef DC_H2
-      const float xs = __builtin_ldexpf(v, ex_x);
+      const float xs = v * sc_x;
       const _Float16 hh = (_Float16)xs;
       pl[i][0][j] = hh;
       pl[i][1][j] = (_Float16)(xs - (float)hh);
@@ -510,13 +511,21 @@ __global__ __launch_bounds__(G::NTHR, 2) void dconv3_b3_kernel(const DcArgs a) {
 
     // ---- epilogue: bias, store, BatchNorm partials ----------------------------------------------------------------------------
 #ifdef DC_H2
-    // back to the operands' scale, 2^-(e_x + e_w), in two exact steps
+    // back to the operands' scale, 2^-(e_x + e_w): one exact multiplication while that power of two is a normal float, else two steps
+    if (ex_x + ex_w >= -120 && ex_x + ex_w <= 120) {
+      const float sc = __builtin_ldexpf(1.f, -(ex_x + ex_w));
 #pragma unroll
-    for (int ct = 0; ct < G::CB; ++ct)
+      for (int ct = 0; ct < G::CB; ++ct)
 #pragma unroll
-      for (int pt = 0; pt < G::PB; ++pt)
+        for (int pt = 0; pt < G::PB; ++pt) acc[ct][pt] *= sc;
+    } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[ct][pt][r] = __builtin_ldexpf(__builtin_ldexpf(acc[ct][pt][r], -ex_x), -ex_w);
+      for (int ct = 0; ct < G::CB; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < G::PB; ++pt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[ct][pt][r] = __builtin_ldexpf(__builtin_ldexpf(acc[ct][pt][r], -ex_x), -ex_w);
+    }
 #endif
     bool p_ok[G::PB];
 #pragma unroll
@@ -635,6 +644,7 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
 #ifdef DC_H2
   const int ex_x = __builtin_amdgcn_readfirstlane(dc_exponent(cs_amax_read(a.x_rec)));   // prescale of the activation (its producer's amax record)
   const int ex_w = __builtin_amdgcn_readfirstlane(a.w_rec[1]);              // prescale of the weight image
+  const float sc_x = __builtin_ldexpf(1.f, ex_x);                            // 2^e_x (|e| <= 100: a normal float; x * 2^e is exact)
 #endif
   int t_begin, t_end;
   {
@@ -683,7 +693,7 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
       for (int j = 0; j < 8; ++j) {
         const float v = pre[i][j >> 2][j & 3];
 #ifdef DC_H2
-        const float xs = __builtin_ldexpf(v, ex_x);
+        const float xs = v * sc_x;
         const _Float16 hh = (_Float16)xs;
         pl[i][0][j] = hh;
         pl[i][1][j] = (_Float16)(xs - (float)hh);
@@ -857,13 +867,21 @@ __global__ __launch_bounds__(2 * G::NTHR, 4) void dconv3_b3_spec_kernel(const Dc
     }
     // ---- epilogue ---------------------------------------------------------------------------------------------------------------
 #ifdef DC_H2
-    // back to the operands' scale, 2^-(e_x + e_w), in two exact steps
+    // back to the operands' scale, 2^-(e_x + e_w): one exact multiplication while that power of two is a normal float, else two steps
+    if (ex_x + ex_w >= -120 && ex_x + ex_w <= 120) {
+      const float sc = __builtin_ldexpf(1.f, -(ex_x + ex_w));
 #pragma unroll
-    for (int ct = 0; ct < G::CB; ++ct)
+      for (int ct = 0; ct < G::CB; ++ct)
 #pragma unroll
-      for (int pt = 0; pt < G::PB; ++pt)
+        for (int pt = 0; pt < G::PB; ++pt) acc[ct][pt] *= sc;
+    } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[ct][pt][r] = __builtin_ldexpf(__builtin_ldexpf(acc[ct][pt][r], -ex_x), -ex_w);
+      for (int ct = 0; ct < G::CB; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < G::PB; ++pt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[ct][pt][r] = __builtin_ldexpf(__builtin_ldexpf(acc[ct][pt][r], -ex_x), -ex_w);
+    }
 #endif
     bool p_ok[G::PB];
 #pragma unroll

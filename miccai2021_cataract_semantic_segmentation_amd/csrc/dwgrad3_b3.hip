@@ -102,6 +102,9 @@ __global__ __launch_bounds__(G::NTHR, 2) void dwgrad3_b3_kernel(const WgArgs a) 
 #ifdef DW_H2
   const int ex_x = __builtin_amdgcn_readfirstlane(dw_exponent(cs_amax_read(a.x_rec)));
   const int ex_d = __builtin_amdgcn_readfirstlane(dw_exponent(cs_amax_read(a.dy_rec)));
+  const float sc_x = __builtin_ldexpf(1.f, ex_x), sc_d = __builtin_ldexpf(1.f, ex_d);     // (|e| <= 100: normal floats; x * 2^e is exact)
+  const bool one_step = ex_x + ex_d >= -120 && ex_x + ex_d <= 120;
+  const float sc_out = __builtin_ldexpf(1.f, one_step ? -(ex_x + ex_d) : 0);
 #endif
 
   // ---- staging items: unit u = wave + i NW; units [0, NU_X) = input rows, the rest = dy; lane = pixel + 16 (channel group) ----
@@ -141,10 +144,10 @@ __global__ __launch_bounds__(G::NTHR, 2) void dwgrad3_b3_kernel(const WgArgs a) 
       const int u = wave + i * G::NW;
       bf16x8 h, m;
 #ifdef DW_H2
-      const int ex = u < G::NU_X ? ex_x : ex_d;
+      const float sc = u < G::NU_X ? sc_x : sc_d;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float xs = __builtin_ldexpf(pre[i][j >> 2][j & 3], ex);
+        const float xs = pre[i][j >> 2][j & 3] * sc;
         const _Float16 hh = (_Float16)xs;
         h[j] = hh;
         m[j] = (_Float16)(xs - (float)hh);
@@ -265,7 +268,8 @@ __global__ __launch_bounds__(G::NTHR, 2) void dwgrad3_b3_kernel(const WgArgs a) 
         for (int r = 0; r < 4; ++r) {
           const int o = cot0 + (wm * G::MT + mt) * 16 + 4 * kg + r;
 #ifdef DW_H2
-          out[((long long)(o * 3 + ky) * 3 + kx) * a.C + ci0 + ct * 16 + i16] = __builtin_ldexpf(__builtin_ldexpf(acc[mt][j][r], -ex_x), -ex_d);
+          out[((long long)(o * 3 + ky) * 3 + kx) * a.C + ci0 + ct * 16 + i16] =
+              one_step ? acc[mt][j][r] * sc_out : __builtin_ldexpf(__builtin_ldexpf(acc[mt][j][r], -ex_x), -ex_d);
 #else
           out[((long long)(o * 3 + ky) * 3 + kx) * a.C + ci0 + ct * 16 + i16] = acc[mt][j][r];
 #endif
