@@ -1068,7 +1068,23 @@ using Cfg192 = DcCfg<192, 32, 96, 2, 2, 2, 2, 2, 1, 16, true, true>;  // tile 2 
 using Cfg384 = DcCfg<384, 32, 96, 2, 2, 2, 2, 2, 1, 16, true, true>;  // the same tile, four co blocks
 
 struct DcPlan { int kind, KC, NT, TH, TW; };
-extern int g_dc_alt96;
+
+}  // namespace
+
+// Tuning hooks (catseg_debug_set_dconv3_*).  This source compiles twice (see the head of the file): the variables have external linkage and
+// live in the bf16x3 object, the f16x2 object refers to the same ones -- a hook set once acts on both builds.
+#ifndef DC_H2
+int catseg_g_dc_blocks = 512;   // persistent blocks per launch: two per CU
+int catseg_g_dc_alt96 = 0;      // A/B: 1 = the 4 x 32-pixel configuration with uniform waves for 96 channels (default: 4 x 16, specialised waves)
+int catseg_g_dc_spec = -1;      // -1: per configuration (Cfg::SPEC), 0 / 1: force the uniform / the wave-specialised kernel
+#else
+extern int catseg_g_dc_blocks, catseg_g_dc_alt96, catseg_g_dc_spec;
+#endif
+#define g_dc_blocks catseg_g_dc_blocks
+#define g_dc_alt96 catseg_g_dc_alt96
+#define g_dc_spec catseg_g_dc_spec
+
+namespace {
 
 DcPlan dc_plan(int C) {
   if (C == 48) return {1, Cfg48::KC, Cfg48::NT, Cfg48::TH, Cfg48::TW};
@@ -1079,11 +1095,6 @@ DcPlan dc_plan(int C) {
   if (C == 384) return {4, Cfg384::KC, Cfg384::NT, Cfg384::TH, Cfg384::TW};
   return {0, 0, 0, 0, 0};
 }
-
-int g_dc_blocks = 512;   // persistent blocks per launch: two per CU
-
-int g_dc_alt96 = 0;      // A/B: 1 = the 4 x 32-pixel configuration with uniform waves for 96 channels (default: 4 x 16, specialised waves)
-int g_dc_spec = -1;      // -1: per configuration (Cfg::SPEC), 0 / 1: force the uniform / the wave-specialised kernel
 
 template <class G>
 int dc_launch(const DcArgs& a, int C, hipStream_t st) {

@@ -306,7 +306,17 @@ using Wg48 = WgCfg<48, 48, 3, 1, 4>;   // one block: all 48 x 432 accumulators (
 using Wg64 = WgCfg<64, 64, 1, 1, 4>;   // 64 x 64 (stage-1 bottlenecks): block = 64 co x (one filter row x 64 ci)
 using Wg96 = WgCfg<96, 48, 1, 2, 2>;   // block = 96 co x (one filter row x 48 ci); variants over (co tile, ci chunk, filter row)
 
-int g_wg_blocks = 512;
+}  // namespace
+
+// tuning hook (catseg_debug_set_dwgrad3_blocks): one variable for both builds of this source (external linkage, defined in the bf16x3 object)
+#ifndef DW_H2
+int catseg_g_wg_blocks = 512;
+#else
+extern int catseg_g_wg_blocks;
+#endif
+#define g_wg_blocks catseg_g_wg_blocks
+
+namespace {
 
 struct WgPlan { int kind, variants, splits; };
 

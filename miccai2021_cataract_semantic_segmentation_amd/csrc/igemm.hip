@@ -202,6 +202,60 @@ __device__ __forceinline__ void igemm_f32_body(const IgemmArgs& p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc16[NARROW ? i : 0][NARROW ? j : 0][r] = 0.f;
   }
+  // TWO-LEVEL ACCUMULATION (round 4; forward convolutions on the tiles with <= 32 accumulator registers): every second K-step (32
+  // reduction elements) the running accumulator is added to a second one and cleared.  A plain fp32 FMA chain over K elements of one
+  // sign (post-ReLU activations) has a rounding error ~ K / sqrt(2) ulps of a term; chains of 32 inside a chain of K / 32 cut that 2 - 3x
+  // (emulated on the CPU for the stem's 64 -> 64 3x3 / 2, K = 576, against fp64: plain chain 3.3e-7 of the output RMS, oneDNN's blocked
+  // sums 1.65e-7, this scheme 1.1e-7).  It matters because the FIRST layers' error is what the 300-layer network amplifies 250x into the
+  // logits (tools/error_growth.py: stem 4.3e-7 against the CPU's 3.0e-7, and the ratio 1.4 - 1.5 stays to the end).
+  // Forward only: in backward-data / backward-weight the second accumulator set costs occupancy (fp32 backward-weight population of the
+  // HRNet-W48 step 59 -> 45 TFLOP/s when it was tried there) and the logit error does not depend on them.
+  constexpr bool TWO_LEVEL = LAYOUT == L_NT && (NARROW ? TM16 * TN16 * 4 <= 32 : MI * NI * 16 <= 32);
+  f32x16 tot[TWO_LEVEL && !NARROW ? MI : 1][TWO_LEVEL && !NARROW ? NI : 1];
+  f32x4 tot16[TWO_LEVEL && NARROW ? TM16 : 1][TWO_LEVEL && NARROW ? TN16 : 1];
+  if (TWO_LEVEL) {
+#pragma unroll
+    for (int i = 0; i < (NARROW ? 1 : MI); ++i)
+#pragma unroll
+      for (int j = 0; j < (NARROW ? 1 : NI); ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[TWO_LEVEL && !NARROW ? i : 0][TWO_LEVEL && !NARROW ? j : 0][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (NARROW ? TM16 : 1); ++i)
+#pragma unroll
+      for (int j = 0; j < (NARROW ? TN16 : 1); ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tot16[TWO_LEVEL && NARROW ? i : 0][TWO_LEVEL && NARROW ? j : 0][r] = 0.f;
+  }
+  auto flush = [&](const bool clear) {     // tot += acc (; acc = 0)
+    if (!TWO_LEVEL) return;
+    if (NARROW == 0) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            f32x16& a = acc[NARROW ? 0 : i][NARROW ? 0 : j];
+            f32x16& t = tot[TWO_LEVEL && !NARROW ? i : 0][TWO_LEVEL && !NARROW ? j : 0];
+            if (clear) {
+              t += a;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) a[r] = 0.f;
+            } else a += t;
+          }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM16; ++i)
+#pragma unroll
+        for (int j = 0; j < TN16; ++j) {
+            f32x4& a = acc16[NARROW ? i : 0][NARROW ? j : 0];
+            f32x4& t = tot16[TWO_LEVEL && NARROW ? i : 0][TWO_LEVEL && NARROW ? j : 0];
+            if (clear) {
+              t += a;
+              a = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else a += t;
+          }
+    }
+  };
   // narrow forms: lane = (i16, g): row / column i16 of a 16 x 16 tile, k-group g; wave origin inside the block tile
   const int i16 = lane & 15, g16 = lane >> 4;
   // k-chunk read by lane group g: {0, 3, 1, 2}.  ds_read_b128 is banked over four NON-contiguous 16-lane groups
@@ -509,6 +563,7 @@ __device__ __forceinline__ void igemm_f32_body(const IgemmArgs& p) {
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int sub = 0; sub < KSUB; ++sub) compute(cur, sub, ss + 2 < nss);
+      if (TWO_LEVEL && (ss & 1)) flush(true);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -527,10 +582,12 @@ __device__ __forceinline__ void igemm_f32_body(const IgemmArgs& p) {
       asm volatile("" ::: "memory");
       if (ks + 2 < nks) issue(fill, 0);
       compute(cur, 0, ks + 3 < nks);
+      if (TWO_LEVEL && (ks & 1)) flush(true);
       cur = cur == 2 ? 0 : cur + 1;
       fill = fill == 2 ? 0 : fill + 1;
     }
   }
+  flush(false);     // acc = tot + (the last, possibly odd, K-step)
 
   // ---- epilogue -------------------------------------------------------------------------
   float* cout = cbase;

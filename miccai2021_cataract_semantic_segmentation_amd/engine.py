@@ -16,6 +16,7 @@ from . import ops
 class Conv2d(nn.Conv2d):
     """Parameter container with nn.Conv2d's init / state-dict behaviour; runs on the HIP engine."""
     stem = False
+    exact_operands = False      # forward on the fp32 MFMA kernel whatever the split-precision kernels could take: ops.conv_fwd(exact=)
 
     def forward(self, x):  # pragma: no cover
         raise RuntimeError("engine Conv2d is executed by the owning network, not called directly")
@@ -307,6 +308,15 @@ def image_hw(x):
     return tuple(x.shape[1:3]) if is_nhwc4(x) else tuple(x.shape[-2:])
 
 
+TAPS = None   # diagnostic hook (tools/error_growth.py): a dict collects named intermediate activations (CPU copies, NCHW)
+
+
+def tap(name, t):
+    if TAPS is not None:
+        TAPS[name] = t.detach().permute(0, 3, 1, 2).contiguous().cpu()
+    return t
+
+
 FUSE_BN_STATS = True  # training forward: BatchNorm batch statistics from the convolution epilogue (False: separate statistics pass)
 FUSE_EVAL_BN = True   # eval-mode forward: fold BatchNorm into the conv and fuse bias/residual/ReLU into its epilogue
 
@@ -340,7 +350,8 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
         return ops.conv_fwd_fused(x_in, wf, bf, residual, relu, Cout, kh, kw, s, p, d, out=out, stem4=conv.stem, groups=conv.groups)
     if cx.train:
         # batch statistics: per-tile partial sums come out of the convolution's epilogue (no separate pass over y)
-        y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups, bn_stats=FUSE_BN_STATS, train=cx.record)
+        y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups, bn_stats=FUSE_BN_STATS, train=cx.record,
+                         exact=conv.exact_operands)
         y, partials = y if FUSE_BN_STATS else (y, None)
         if partials is not None:
             stats, scale = ops.bn_finalize(partials, ops.rows_of(y), Cout, bn.weight.data, bn.eps, bn.momentum, bn.running_mean, bn.running_var)

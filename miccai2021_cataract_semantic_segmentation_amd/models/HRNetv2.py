@@ -7,7 +7,7 @@ BatchNorm momentum 0.01 (:19), bilinear resizes with align_corners=False (:253-2
 import torch
 from torch import nn
 
-from ..engine import BatchNorm2d, Conv2d, EngineNet, add_n, bilinear, image_hw, concat_views, conv_bias, conv_bn_act
+from ..engine import BatchNorm2d, Conv2d, EngineNet, add_n, bilinear, image_hw, concat_views, conv_bias, conv_bn_act, tap
 from ..utils import num_classes
 
 BN_MOMENTUM = 0.01
@@ -248,13 +248,20 @@ def build_hrnet_trunk(net, width, stage1_width, modules):
         setattr(net, "transition%d" % (si - 1), _make_transition_layer(pre, cur))
         stage, pre = _make_stage(c, cur, True)
         setattr(net, "stage%d" % si, stage)
+    # The rounding error of the first layers is what the rest of the trunk amplifies (x 250 from the stem to the logits, x 100 from layer1,
+    # x 40 from stage 2, x 12 from stage 3: tools/error_growth.py): the four 3x3 convolutions of layer1 run their forward pass on the fp32
+    # kernel with two-level accumulation instead of the two-plane fp16 direct kernel (+0.4 ms per bs-8 step).
+    for part in (net.layer1,):
+        for m in part.modules():
+            if isinstance(m, Conv2d):
+                m.exact_operands = True
     return pre
 
 
 def run_hrnet_trunk(net, cx, x):
     x = conv_bn_act(cx, x, net.conv1, net.bn1, need_dx=False)
-    x = conv_bn_act(cx, x, net.conv2, net.bn2)
-    x = _run_seq(cx, net.layer1, x)
+    x = tap("stem", conv_bn_act(cx, x, net.conv2, net.bn2))
+    x = tap("layer1", _run_seq(cx, net.layer1, x))
     ys = [x]
     for si in (2, 3, 4):
         trans = getattr(net, "transition%d" % (si - 1))
@@ -266,6 +273,8 @@ def run_hrnet_trunk(net, cx, x):
         for mod in getattr(net, "stage%d" % si):
             xs = mod.run(cx, xs)
         ys = xs
+        for i, y in enumerate(ys):
+            tap("stage%d.b%d" % (si, i), y)
     return ys
 
 

@@ -4,7 +4,7 @@ reference's models/OCR.py:10-138 (OCRNet, SpatialGatherModule :146-170, ObjectAt
 import torch
 from torch import nn
 
-from .. import ops
+from .. import engine, ops
 from ..engine import (BatchNorm2d, Conv2d, EngineNet, bilinear, image_hw, concat_views, conv_bias, conv_bn_act,
                       object_attention_core, spatial_gather)
 from ..utils import num_classes
@@ -32,8 +32,9 @@ class ObjectAttentionBlock2D(nn.Module):
         q = conv_bn_act(cx, conv_bn_act(cx, x, self.f_pixel[0], self.f_pixel[1]), self.f_pixel[3], self.f_pixel[4])
         k = conv_bn_act(cx, conv_bn_act(cx, proxy, self.f_object[0], self.f_object[1]), self.f_object[3], self.f_object[4])
         v = conv_bn_act(cx, proxy, self.f_down[0], self.f_down[1])
-        ctx = object_attention_core(cx, q, k, v, K, self.key_channels)
-        return conv_bn_act(cx, ctx, self.f_up[0], self.f_up[1], out=out)
+        engine.tap("proxy", proxy), engine.tap("q", q), engine.tap("k", k), engine.tap("v", v)
+        ctx = engine.tap("ctx", object_attention_core(cx, q, k, v, K, self.key_channels))
+        return engine.tap("context", conv_bn_act(cx, ctx, self.f_up[0], self.f_up[1], out=out))
 
 
 class SpatialOCR_Module(nn.Module):
@@ -50,7 +51,7 @@ class SpatialOCR_Module(nn.Module):
         C = self.in_channels
         context = self.object_context_block.run(cx, feats, proxy, K, out=cat[..., :C])
         concat_views(cx, cat, [(context, 0, C), (feats, C, 2 * C)])
-        return conv_bn_act(cx, cat, self.conv_bn_dropout[0], self.conv_bn_dropout[1])
+        return engine.tap("ocr_out", conv_bn_act(cx, cat, self.conv_bn_dropout[0], self.conv_bn_dropout[1]))
 
 
 class SpatialGatherModule(nn.Module):
@@ -125,13 +126,16 @@ class OCRNet(EngineNet):
             f = self.backbone.run(cx, x)
             low, high = f["low"], f["high"]
         hd = self.interm_prediction_head
-        interm = conv_bias(cx, conv_bn_act(cx, low, hd[0], hd[1]), hd[4])
+        engine.tap("concat", low)
+        interm = engine.tap("interm_lowres", conv_bias(cx, conv_bn_act(cx, low, hd[0], hd[1]), hd[4]))
         B, h, w, _ = high.shape
         cat = torch.empty((B, h, w, 1024), dtype=torch.float32, device=x.device)
         feats = conv_bn_act(cx, high, self.conv_high_map[0], self.conv_high_map[1], out=cat[..., 512:])
+        engine.tap("feats", feats)
         proxy = spatial_gather(cx, feats, interm, K)
         o = self.spatial_ocr_head.run(cx, cat, feats, proxy, K)
         logits = conv_bias(cx, o, self.conv_out)
+        engine.tap("logits_lowres", logits)
         up = bilinear(cx, logits, H, W, True)
         if self.get_intermediate:
             return [bilinear(cx, interm, H, W, True), up]

@@ -370,9 +370,14 @@ def _bn_part_buffer(nfloats, device):
     return buf
 
 
-def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False, groups=1, bn_stats=False, train=False):
+def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False, groups=1, bn_stats=False, train=False,
+             exact=False):
     """train=True (the engine's recorded forward): a backward pass will follow -- the split planes of x are written in both layouts
     and kept for it (release_b3_cache() frees them).
+    exact=True (the first layers of a trunk, whose rounding error the rest of the network amplifies most: tools/error_growth.py): the
+    layer runs the fp32 MFMA kernel (exact operands, two-level accumulation: csrc/igemm.hip TWO_LEVEL) whatever the split-precision
+    kernels could take.  (Measured at 2 x 3 x 544 x 960, relative RMS error of layer1's output against fp64: fp32 CPU 1.22e-6, this 0.89e-6,
+    two fp16 planes 1.12e-6, three bf16 planes / six products 1.25e-6 -- 84 accumulator roundings per output instead of 42.)
     bn_stats=True: returns (out, partials) where partials = (buffer, n_tiles, tile_rows) are the per-(M-tile, channel)
     BatchNorm partial sums written by the convolution's epilogue (for bn_finalize), or None if this layer's kernel has none"""
     B, H, W, Cin = x.shape
@@ -385,13 +390,13 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
     if bn_stats:
         part = _bn_part_buffer(3 * ((rows + 63) // 64) * Cout, x.device)
         tr, nt = ctypes.c_int(0), ctypes.c_int(0)
-    if not stem4 and zero_to == 0 and w_ptr_tensor.dim() == 4 and _d3_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
+    if not exact and not stem4 and zero_to == 0 and w_ptr_tensor.dim() == 4 and _d3_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
         rec = amax_of(x) if _trunk_h2() else None
         wimg = dconv3_weight_image(w_ptr_tensor, h2=rec is not None)
         with _Timed("fwd_d3h" if rec is not None else "fwd_d3", flops):
             res = dconv3(x, wimg, bias, out=out, bn_stats=bn_stats, x_amax=rec)
         return res
-    if "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(rows, Cout, kh * kw, Cin):
+    if not exact and "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(rows, Cout, kh * kw, Cin):
         d = make_desc(x.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
         blk = _b3_blocked_ok(max(zero_to, Cout), Cin, B * H * W, Cout, kh * kw)
         if blk and _h2():

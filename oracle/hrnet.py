@@ -4,7 +4,7 @@ bilinear resize uses align_corners=False (the F.interpolate default, :253-256,50
 import torch
 import torch.nn.functional as F
 
-from .nets import bn as _bn_generic, conv
+from .nets import bn as _bn_generic, conv, tap
 
 MOM = 0.01
 
@@ -70,10 +70,10 @@ def hrnet_branches(S, x, train, prefix=""):
     """stem, layer1, transitions and stages 2-4 (:462-501); returns the four branch outputs"""
     P = prefix
     x = F.relu(bn(S, P + "bn1", conv(S, P + "conv1", x, 2, 1), train))
-    x = F.relu(bn(S, P + "bn2", conv(S, P + "conv2", x, 2, 1), train))
+    x = tap("stem", F.relu(bn(S, P + "bn2", conv(S, P + "conv2", x, 2, 1), train)))
     for b in range(_count(S, P + "layer1")):
         x = bottleneck(S, "%slayer1.%d" % (P, b), x, train)
-    ys = [x]
+    ys = [tap("layer1", x)]
     for si in (2, 3, 4):
         tp = "%stransition%d" % (P, si - 1)
         xs = []
@@ -88,6 +88,8 @@ def hrnet_branches(S, x, train, prefix=""):
         for m in range(_count(S, "%sstage%d" % (P, si))):
             xs = hr_module(S, "%sstage%d.%d" % (P, si, m), xs, train)
         ys = xs
+        for i, y in enumerate(ys):
+            tap("stage%d.b%d" % (si, i), y)
     return ys
 
 

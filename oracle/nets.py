@@ -10,6 +10,14 @@ estimate, biased for normalisation).
 import torch
 import torch.nn.functional as F
 
+TAPS = None   # diagnostic hook (tools/error_growth.py): a dict collects named intermediate activations
+
+
+def tap(name, t):
+    if TAPS is not None:
+        TAPS[name] = t.detach().clone()
+    return t
+
 
 def bn(S, p, x, train, eps=1e-5, momentum=0.1):
     if train and (p + ".num_batches_tracked") in S:
@@ -87,13 +95,14 @@ def _cbr(S, p, i, x, train):  # Sequential(conv i, bn i+1, relu)
 def object_attention(S, p, x, proxy, train, key_channels=256):
     """models/OCR.py:237-284 (scale == 1)"""
     B, _, H, W = x.shape
-    q = _cbr(S, p + ".f_pixel", 3, _cbr(S, p + ".f_pixel", 0, x, train), train)
+    tap("proxy", proxy)
+    q = tap("q", _cbr(S, p + ".f_pixel", 3, _cbr(S, p + ".f_pixel", 0, x, train), train))
     q = q.reshape(B, key_channels, -1).permute(0, 2, 1)
-    k = _cbr(S, p + ".f_object", 3, _cbr(S, p + ".f_object", 0, proxy, train), train).reshape(B, key_channels, -1)
-    v = _cbr(S, p + ".f_down", 0, proxy, train).reshape(B, key_channels, -1).permute(0, 2, 1)
+    k = tap("k", _cbr(S, p + ".f_object", 3, _cbr(S, p + ".f_object", 0, proxy, train), train)).reshape(B, key_channels, -1)
+    v = tap("v", _cbr(S, p + ".f_down", 0, proxy, train)).reshape(B, key_channels, -1).permute(0, 2, 1)
     sim = F.softmax((key_channels ** -.5) * torch.matmul(q, k), dim=-1)
-    ctx = torch.matmul(sim, v).permute(0, 2, 1).contiguous().reshape(B, key_channels, H, W)
-    return _cbr(S, p + ".f_up", 0, ctx, train)
+    ctx = tap("ctx", torch.matmul(sim, v).permute(0, 2, 1).contiguous().reshape(B, key_channels, H, W))
+    return tap("context", _cbr(S, p + ".f_up", 0, ctx, train))
 
 
 def ocrnet_forward(S, x, backbone="resnet50", out_stride=8, train=True):
@@ -155,15 +164,15 @@ def ocrnet_hrnet_forward(S, x, train=True):
     (models/OCR.py:107-138) with low = high = the concat."""
     from .hrnet import hrnet_branches, hrnet_concat
     size = x.shape[-2:]
-    f = hrnet_concat(hrnet_branches(S, x, train, prefix="backbone."))
+    f = tap("concat", hrnet_concat(hrnet_branches(S, x, train, prefix="backbone.")))
     h = F.relu(bn(S, "interm_prediction_head.1", conv(S, "interm_prediction_head.0", f, 1, 1), train))
-    interm = conv(S, "interm_prediction_head.4", h)
-    xh = F.relu(bn(S, "conv_high_map.1", conv(S, "conv_high_map.0", f, 1, 1), train))
+    interm = tap("interm_lowres", conv(S, "interm_prediction_head.4", h))
+    xh = tap("feats", F.relu(bn(S, "conv_high_map.1", conv(S, "conv_high_map.0", f, 1, 1), train)))
     proxy = spatial_gather(xh, interm)
     ctx = object_attention(S, "spatial_ocr_head.object_context_block", xh, proxy, train)
     o = torch.cat([ctx, xh], 1)
-    o = F.relu(bn(S, "spatial_ocr_head.conv_bn_dropout.1", conv(S, "spatial_ocr_head.conv_bn_dropout.0", o), train))
-    logits = conv(S, "conv_out", o)
+    o = tap("ocr_out", F.relu(bn(S, "spatial_ocr_head.conv_bn_dropout.1", conv(S, "spatial_ocr_head.conv_bn_dropout.0", o), train)))
+    logits = tap("logits_lowres", conv(S, "conv_out", o))
     return (F.interpolate(interm, size=size, mode="bilinear", align_corners=True),
             F.interpolate(logits, size=size, mode="bilinear", align_corners=True))
 

@@ -1,12 +1,21 @@
 """Full-resolution parity under the PRODUCTION plan: the networks at the bench sizes (3 x 544 x 960, config 5 at 3 x 1088 x 1920), the
-default arithmetic selection (ops.PRECISION as shipped: bf16x3 on the large layers and on the HRNet trunk's direct kernels, exact
-fp32 elsewhere), NO threshold forcing -- the tile forms, blocked planes, split counts and persistent-block schedules of the timed
-benchmark -- against the CPU oracle evaluated at the same size (one oracle evaluation per network, shared by the assertions).
+default arithmetic selection (ops.PRECISION / TRUNK / HEADS as shipped: two fp16 planes on the HRNet trunk's direct kernels and on the
+head layers, exact fp32 elsewhere), NO threshold forcing -- the tile forms, blocked planes, split counts and persistent-block schedules
+of the timed benchmark -- against the CPU oracle evaluated at the same size (one oracle evaluation per network, shared by the assertions
+and by every arithmetic plan of tests/_fullres.py: production, fp32, trunk_bf16x3, heads_bf16x3, all_bf16x3).
 
-The oracle is test infrastructure (oracle/__init__.py); every HIP call goes through the C ABI.  Tolerances: logits 1e-3 ABSOLUTE
-(north star) with the relative figure printed, loss 1e-4, BatchNorm running statistics 1e-4 relative, per-tensor gradient norms and
-directions against the fp32 CPU oracle on a fixed subset, and the UNMASKED count of argmax disagreements printed next to the count
-the fp32 CPU evaluation itself has against an fp64 evaluation."""
+The oracle is test infrastructure (oracle/__init__.py); every HIP call goes through the C ABI.  THE BAR (asserted by `_logit_bar`, every
+figure also written to the JSON record gpurun_out/parity_fullres.json so that a passing run leaves evidence; a copy is kept as
+profiles/r04_parity_fullres.json):
+  (a) max |logit_hip - logit_fp64| <= 1e-3 ABSOLUTE against the fp64 evaluation of the oracle (the north star's 1e-3);
+  (b) the same distance <= 1.2 x the fp32 CPU oracle's own distance to fp64 (+1e-5): the HIP path is not noisier than the reference
+      arithmetic it replaces (production plan; the other plans: <= 2 x);
+  (c) max |logit_hip - logit_cpu32| <= 1e-3 of the logit scale (two fp32 evaluations that are each ~0.7e-3 absolute from fp64 can be
+      1.4e-3 apart: an absolute 1e-3 between THEM is not a property either has; the absolute figure is recorded);
+  (d) label maps: no disagreement with the fp64 map where the fp64 top-2 margin exceeds 2.2 x the logit error made, and the UNMASKED
+      count of disagreements with fp64 <= 1.25 x the fp32 CPU run's own count (+8) in the production plan.
+Loss 1e-4, BatchNorm running statistics 1e-4 relative, per-tensor gradient norms and directions against the fp32 CPU oracle on a fixed
+subset."""
 import numpy as np
 import pytest
 import torch
@@ -19,26 +28,32 @@ def _need_gpu():
         pytest.skip("needs a GPU")
 
 
-def _labels(B, H, W, K, seed):
-    g = torch.Generator().manual_seed(seed)
-    lbl = torch.randint(0, K + 1, (B, H // 32, W // 32), generator=g)
-    return lbl.repeat_interleave(32, 1).repeat_interleave(32, 2).contiguous()
+from _fullres import block_labels as _labels  # noqa: E402
+import _fullres as FR  # noqa: E402
 
 
-def _argmax_report(name, hip, cpu32, cpu64):
-    """unmasked label-map disagreements; the assertion: wherever HIP and the fp64 oracle disagree, the fp64 top-2 margin is within the
-    logit error made (a tie broken the other way), and there are not more such pixels than a few times the fp32 CPU run's own"""
-    a_h, a_c, a_64 = hip.argmax(1), cpu32.argmax(1), cpu64.argmax(1)
-    n = a_64.numel()
-    d_hc, d_h64, d_c64 = int((a_h != a_c).sum()), int((a_h != a_64).sum()), int((a_c != a_64).sum())
-    top2 = cpu64.topk(2, dim=1).values
-    margin = (top2[:, 0] - top2[:, 1])
-    err = float((hip.double() - cpu64).abs().max())
-    bad = (a_h != a_64) & (margin > 2.2 * err)
-    print("%s argmax disagreements (unmasked, of %d pixels): hip vs cpu32 %d, hip vs fp64 %d, cpu32 vs fp64 %d; max |logit - fp64| hip %.3g cpu32 %.3g"
-          % (name, n, d_hc, d_h64, d_c64, err, float((cpu32.double() - cpu64).abs().max())))
-    assert int(bad.sum()) == 0, "label differs from the fp64 oracle at %d pixels whose margin exceeds the logit error" % int(bad.sum())
-    assert d_h64 <= 4 * d_c64 + 64, (d_h64, d_c64)
+def _logit_bar(section, plan, hip, cpu32, f64, production=True, extra=None, noise_factor=None):
+    """bars (a) - (d) of the module docstring; records the figures.  (a) is absolute for logits of the trained-like scale (<= 10); a
+    random-weight network whose logits explode (eval-mode ResNeXt101-UPerNet: 4e5) is held to 1e-4 of its scale instead"""
+    scale = float(cpu32.abs().max())
+    fig = {"logit_scale": scale, "e_abs_vs_cpu32": float((hip - cpu32).abs().max()), "e_abs_vs_fp64": float((hip.double() - f64).abs().max()),
+           "cpu32_e_abs_vs_fp64": float((cpu32.double() - f64).abs().max()),
+           "e_rms_vs_fp64": float((hip.double() - f64).pow(2).mean().sqrt()), "cpu32_e_rms_vs_fp64": float((cpu32.double() - f64).pow(2).mean().sqrt()),
+           "argmax": FR.argmax_figures(hip, cpu32, f64)}
+    fig.update(extra or {})
+    FR.record(section, plan, fig)
+    print(section, plan, fig)
+    am = fig["argmax"]
+    assert fig["e_abs_vs_fp64"] <= 1e-3 * max(1.0, scale / 10), ("(a) absolute distance to the fp64 oracle", fig)
+    nf = noise_factor or (1.2 if production else 2.0)
+    assert fig["e_abs_vs_fp64"] <= nf * fig["cpu32_e_abs_vs_fp64"] + 1e-5, ("(b) noisier than the fp32 CPU path", fig)
+    assert fig["e_abs_vs_cpu32"] <= 1e-3 * max(1.0, scale), ("(c) distance to the fp32 CPU oracle", fig)
+    assert am["outside_error_band"] == 0, ("(d) label differs from the fp64 oracle where the margin exceeds the logit error", fig)
+    if production:
+        assert am["hip_vs_fp64"] <= 1.25 * am["cpu32_vs_fp64"] + 8, ("(d) unmasked label-map disagreements", fig)
+    else:
+        assert am["hip_vs_fp64"] <= 2 * am["cpu32_vs_fp64"] + 32, ("(d) unmasked label-map disagreements", fig)
+    return fig
 
 
 def _grad_subset_check(name, model, S, keys):
@@ -57,66 +72,42 @@ def _grad_subset_check(name, model, S, keys):
         assert abs(r - 1) < 2e-2 and c > 0.999, (k, r, c)
 
 
-def test_ocrnet_hrnet48_fullres_train_step_vs_oracle():
-    """the BENCH model at the BENCH resolution (batch 2 of 8: the CPU oracle's fp64 forward has to fit the test budget): logits, loss,
-    BatchNorm statistics, gradients, label maps"""
+@pytest.mark.parametrize("plan", list(FR.PLANS))
+def test_ocrnet_hrnet48_fullres_train_step_vs_oracle(plan):
+    """the BENCH model at the BENCH resolution (batch 2 of 8: the CPU oracle's fp64 forward has to fit the test budget) under every
+    arithmetic plan (ONE oracle evaluation for all of them): logits and label maps for each; loss, BatchNorm statistics, gradients and
+    the kernel populations for the production plan"""
     _need_gpu()
-    import bench
-    from oracle import nets as ON, losses as OL
-    from oracle.state import fill_state, spec_of
     from miccai2021_cataract_semantic_segmentation_amd import ops
-    from miccai2021_cataract_semantic_segmentation_amd.models import OCRNet
-    from miccai2021_cataract_semantic_segmentation_amd.losses import TwoScaleLoss
-    assert ops.PRECISION == "bf16x3" and ops.B3_MIN_K == 2048 and ops.DCONV3_MIN_ROWS == 2048, "production plan expected"
-    B, H, W, K = 2, 544, 960, 25
-    model = OCRNet(dict(bench.MODELS["ocrnet_hrnet48"][0]), 3)
-    spec = spec_of(model.state_dict())
-    S = fill_state(spec, 41)
-    model.load_state_dict(S)
-    model.cuda().train()
-    g = torch.Generator().manual_seed(9)
-    x = torch.rand(B, 3, H, W, generator=g)
-    lbl = _labels(B, H, W, K, 10)
-    crit = TwoScaleLoss({"experiment": 3, "interm": {"name": "LovaszSoftmax", "args": [], "weight": 0.4},
-                         "final": {"name": "LovaszSoftmax", "args": [], "weight": 1.0}})
-    ops.PROFILE = []
-    interm, final = model(x.cuda())
-    loss = crit(interm, final, lbl.cuda())
-    loss.backward()
-    kinds = {k for k, *_ in ops.PROFILE}
-    ops.PROFILE = None
-    # the production kernels really ran: blocked bf16x3 heads, direct trunk kernels in all three directions, fp32 elsewhere
-    heads = {"fwd_h2", "dgrad_h2", "wgrad_h2"} if ops.HEADS == "f16x2" else {"fwd_b3", "dgrad_b3", "wgrad_b3"}
-    trunk = {"fwd_d3h", "dgrad_d3h", "wgrad_d3h"} if ops.TRUNK == "f16x2" else {"fwd_d3", "dgrad_d3", "wgrad_d3"}
-    assert heads | trunk | {"fwd", "dgrad", "wgrad"} <= kinds, kinds
-    final_h, interm_h = final.detach().cpu(), interm.detach().cpu()
-    params = [k for k, v in S.items() if v.dtype.is_floating_point and "running" not in k]
-    for k in params:
-        S[k].requires_grad_()
-    oi, of = ON.ocrnet_hrnet_forward(S, x, train=True)
-    ol = OL.two_scale_lovasz(oi, of, lbl, 0.4, 1.0)
-    ol.backward()
-    S64 = {k: (v.detach().double() if v.dtype.is_floating_point else v.clone()) for k, v in fill_state(spec, 41).items()}
-    with torch.no_grad():
-        f64 = ON.ocrnet_hrnet_forward(S64, x.double(), train=True)[1]
-    of_d, oi_d = of.detach(), oi.detach()
-    e_abs = float((final_h - of_d).abs().max())
-    e_int = float((interm_h - oi_d).abs().max())
-    scale = float(of_d.abs().max())
-    e_h64, e_c64 = float((final_h.double() - f64).abs().max()), float((of_d.double() - f64).abs().max())
-    print("OCRNet-HRNet-W48 %dx%dx%d: max |logit - cpu32| final %.3g absolute = %.3g of the logit scale %.3g, intermediate %.3g; against the fp64 oracle: "
-          "hip %.3g, cpu32 %.3g; loss hip %.7f cpu %.7f" % (B, H, W, e_abs, e_abs / scale, scale, e_int, e_h64, e_c64, float(loss), float(ol)))
-    # 1e-3 of the logit scale (the scale of this random-weight network is ~10: the fp32 CPU evaluation itself sits ~1e-3 absolute away
-    # from the fp64 one), and never further from the fp64 oracle than 3x the fp32 CPU run is
-    assert e_abs <= 1e-3 * max(1.0, scale) and e_int <= 1e-3 * max(1.0, float(oi_d.abs().max()))
-    assert e_h64 <= 3 * e_c64 + 1e-5, (e_h64, e_c64)
-    assert abs(float(loss) - float(ol)) < 1e-4
+    assert ops.PRECISION == "bf16x3" and ops.TRUNK == "f16x2" and ops.HEADS == "f16x2", "shipped defaults expected"
+    assert ops.B3_MIN_K == 2048 and ops.DCONV3_MIN_ROWS == 2048, "production plan expected"
+    orc = FR.hrnet48_oracle()
+    model, interm_h, final_h, loss_h, kinds = FR.hrnet48_hip(orc, plan)
+    S = orc["S"]
+    production = plan == "production"
+    fig = _logit_bar("ocrnet_hrnet48_2x544x960", plan, final_h, orc["final32"], orc["final64"], production,
+                     {"e_abs_interm_vs_cpu32": float((interm_h - orc["interm32"]).abs().max()),
+                      "e_abs_interm_vs_fp64": float((interm_h.double() - orc["interm64"]).abs().max()),
+                      "cpu32_e_abs_interm_vs_fp64": float((orc["interm32"].double() - orc["interm64"]).abs().max()),
+                      "loss_hip": loss_h, "loss_cpu32": orc["loss32"], "loss_fp64": orc["loss64"],
+                      "kernel_populations": sorted(k for k in kinds if not k.startswith("hbm:"))})
+    assert fig["e_abs_interm_vs_cpu32"] <= 1e-3 * max(1.0, float(orc["interm32"].abs().max()))
+    assert abs(loss_h - orc["loss32"]) < 1e-4
+    # the kernels of the plan really ran
+    P, T, Hd = FR.PLANS[plan]
+    if P == "fp32":
+        assert {"fwd", "dgrad", "wgrad"} <= kinds and not any("_d3" in k or "_h2" in k or "_b3" in k for k in kinds), kinds
+    else:
+        heads = {"fwd_h2", "dgrad_h2", "wgrad_h2"} if Hd == "f16x2" else {"fwd_b3", "dgrad_b3", "wgrad_b3"}
+        trunk = {"fwd_d3h", "dgrad_d3h", "wgrad_d3h"} if T == "f16x2" else {"fwd_d3", "dgrad_d3", "wgrad_d3"}
+        assert heads | trunk | {"fwd", "dgrad", "wgrad"} <= kinds, kinds
+    if not production:
+        return
     sd = model.state_dict()
     for k in ("backbone.bn1.running_mean", "backbone.stage2.0.branches.0.1.bn1.running_var", "backbone.stage4.2.branches.3.3.bn2.running_var",
               "backbone.stage3.1.branches.1.2.bn2.running_mean", "conv_high_map.1.running_var"):
         a, b = sd[k].detach().cpu().double(), S[k].detach().double()
         assert float((a - b).abs().max()) <= 1e-5 + 1e-4 * float(b.abs().max()), k
-    _argmax_report("OCRNet-HRNet-W48 full resolution", final_h, of_d, f64)
     keys = ["backbone.conv1.weight", "backbone.layer1.0.conv2.weight", "backbone.stage2.0.branches.0.0.conv1.weight",
             "backbone.stage2.0.branches.1.3.conv2.weight", "backbone.stage3.2.branches.2.1.conv1.weight",
             "backbone.stage4.1.branches.3.2.conv2.weight", "backbone.stage4.2.branches.0.3.conv1.weight",
@@ -158,12 +149,8 @@ def test_deeplabv3plus_r50_fullres_train_step_vs_oracle():
     with torch.no_grad():
         f64 = ON.deeplabv3plus_forward(S64, x.double(), train=True)
     out_h, ref_d = out.detach().cpu(), ref.detach()
-    e_abs, scale = float((out_h - ref_d).abs().max()), float(ref_d.abs().max())
-    print("DeepLabv3+-R50 %dx%dx%d: max |logit - cpu32| %.3g (relative %.3g of scale %.3g); loss hip %.7f cpu %.7f"
-          % (B, H, W, e_abs, e_abs / scale, scale, float(loss), float(ol)))
-    assert e_abs <= 1e-3 * max(1.0, scale)
+    _logit_bar("deeplabv3plus_r50_2x544x960", "production", out_h, ref_d, f64, True, {"loss_hip": float(loss), "loss_cpu32": float(ol)})
     assert abs(float(loss) - float(ol)) < 1e-4
-    _argmax_report("DeepLabv3+-R50 full resolution", out_h, ref_d, f64)
     have = dict(model.named_parameters())
     keys = [k for k in ("backbone.conv1.weight", "backbone.layer2.1.conv2.weight", "backbone.layer4.2.conv2.weight", "aspp.convs.1.0.weight",
                         "aspp.convs.3.0.weight", "aspp.project.0.weight", "decoder.conv_low.0.weight", "decoder.conv_out.0.weight",
@@ -200,7 +187,6 @@ def test_resnext101_upernet_fullres_inference_vs_oracle():
         f64 = upernet_forward(S64, _resnext_oracle(S64, x.double()), False)
         f64 = f64[0] if isinstance(f64, (tuple, list)) else f64
     out_h = out.detach().cpu()
-    e_abs, scale = float((out_h - ref).abs().max()), float(ref.abs().max())
-    print("ResNeXt101-UPerNet 1x1088x1920: max |logit - cpu32| %.3g (relative %.3g of scale %.3g)" % (e_abs, e_abs / scale, scale))
-    assert e_abs <= 1e-3 * max(1.0, scale)
-    _argmax_report("ResNeXt101-UPerNet full resolution", out_h, ref, f64)
+    # (b) with factor 4: the fused inference path folds BatchNorm into the weights (one more rounding of every weight) and runs the wide
+    # layers on three bf16 planes; measured 3.5e-6 of the logit scale against the fp32 CPU oracle's 1.1e-6, label maps identical
+    _logit_bar("resnext101_upernet_1x1088x1920_inference", "production", out_h, ref, f64, True, noise_factor=4.0)
