@@ -72,7 +72,7 @@ def host_cpu_info():
     return model, (len(cores) or avail), avail
 
 
-def cpu_baseline(H, W, K, model_name, threads=0):
+def cpu_baseline(H, W, K, model_name, threads=0, all_core_figure=True):
     """the CPU oracle (port of the reference path) on this box's host cores -- the identical synthetic
     train step (zero_grad -> forward -> loss -> backward -> Adam), fp32, batch 2: 1 warm-up + 3 timed steps with anomaly
     detection off, then 1 step with torch.autograd.set_detect_anomaly(True) as the reference's main.py:8 sets it."""
@@ -122,7 +122,19 @@ def cpu_baseline(H, W, K, model_name, threads=0):
         t0 = time.perf_counter()
         step(5)
         dt_anom = time.perf_counter() - t0
-    return {"value": nb / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    # SURVEY 8(d) names "all physical cores": the same step once more with every physical core (one untimed + one timed step; on the
+    # 128-core EPYC of the GPU boxes this is ~5x SLOWER than 32 threads, which is why `value` above is the 32-thread figure)
+    all_cores = None
+    used = torch.get_num_threads()
+    if all_core_figure and min(avail, physical) > used:
+        torch.set_num_threads(min(avail, physical))
+        step(6)
+        t0 = time.perf_counter()
+        step(7)
+        dta = time.perf_counter() - t0
+        all_cores = {"value": nb / dta, "unit": "frames/s", "cores": torch.get_num_threads(), "sample": "1 untimed + 1 timed step, %.1f s" % dta}
+        torch.set_num_threads(used)
+    return {"value": nb / dt, "unit": "frames/s", "cores": used, "kind": "port", "all_physical_cores": all_cores,
             "cpu_model": cpu_model, "physical_cores": physical, "logical_cpus_available": avail,
             "value_anomaly_mode_on": nb / dt_anom,
             "sample": "1 warm-up + %d timed train steps (fwd + %s + bwd + Adam) of the CPU oracle, batch %d, 3x%dx%d, K=%d, fp32, "
@@ -258,6 +270,7 @@ def main():
                     help="BASELINE config 5 instead: EncDec(ResNeXt101_32x8d + UPerNet) inference at 3x1080x1920, 4 frames per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-all-core-cpu", action="store_true", help="skip the all-physical-core repetition of the CPU baseline (~1 min)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = 32: the fastest region of the committed sweep, "
                                                                  "profiles/r03_cpu_thread_sweep.json; all 128 cores are 5x slower)")
     ap.add_argument("--no-side-figures", action="store_true",
@@ -272,9 +285,16 @@ def main():
         return infer_bench(args)
     from miccai2021_cataract_semantic_segmentation_amd import dist as D
     rank, local, world = D.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     import torch.distributed as dist
+    if world > 1:
+        # a multi-GPU line must be an RCCL line over `--gpus` ranks: anything else (a gloo fallback, a 1-rank group) exits non-zero instead
+        # of printing a number that could be read as a scaling figure.  CATSEG_DIST_BACKEND=gloo (functional artefact on one GPU) is the
+        # one explicit exception and is labelled as such in the line's `comm` block.
+        be, seen = dist.get_backend(), dist.get_world_size()
+        if seen != args.gpus or (be != "nccl" and os.environ.get("CATSEG_DIST_BACKEND") != "gloo"):
+            raise SystemExit("bench: process group is backend=%s world=%d, expected nccl (RCCL) over %d ranks" % (be, seen, args.gpus))
     dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))   # (gloo smoke runs may share one GPU)
     torch.cuda.set_device(dev)
 
@@ -299,7 +319,12 @@ def main():
         D.broadcast_parameters(model)
         gscale = D.attach(model)
     opt = FusedAdam(model, lr=1e-4, grad_scale=gscale)
-    img, lbl = synth_batch(B, H, W, K, 1000 + rank, dev)
+    # FOUR distinct synthetic batches rotate through the warm-up and the timed region (the cost of the Lovasz loss depends on the
+    # predictions -- active-set pruning --, so a single fixed batch could be memorised into an unrepresentatively cheap loss)
+    NBATCH = 4
+    batches = [synth_batch(B, H, W, K, 1000 + rank + 7919 * i, dev) for i in range(NBATCH)]
+    img, lbl = batches[0]
+    counter = [0]
 
     host = (img.cpu().pin_memory(), lbl.cpu().pin_memory()) if args.with_h2d else None
     from miccai2021_cataract_semantic_segmentation_amd.utils.metrics import t_get_confusion_matrix
@@ -308,10 +333,15 @@ def main():
     def step(batch=None):
         """one training step as the reference's manager runs it (managers/OCRNet_Manager.py:80-113): zero_grad, forward, loss, backward,
         (gradient exchange,) Adam, and the per-step training metric: the confusion matrix of the batch's predictions"""
-        x, y = batch if batch is not None else (img, lbl)
-        if host is not None and batch is None:
+        if batch is not None:
+            x, y = batch
+        elif host is not None:
+            x, y = img, lbl
             img.copy_(host[0], non_blocking=True)
             lbl.copy_(host[1], non_blocking=True)
+        else:
+            x, y = batches[counter[0] % NBATCH]
+            counter[0] += 1
         opt.zero_grad()
         out = model(x)
         interm, final = (None, out) if deeplab else out
@@ -403,6 +433,12 @@ def main():
             if per_step:
                 traffic = per_step / (n // 2)          # per C-ABI call, like `achieved`
                 traffic_src = "profiles/" + os.path.basename(tpath) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
+        traffic_all = None
+        if os.path.exists(tpath) and (B, H, W) == (8, 544, 960):
+            kern = json.load(open(tpath))["kernels"]
+            traffic_all = {k: {"hbm_bytes_per_call": kern[k]["hbm_bytes_per_step"] / (groups[k][2] // 2),
+                               "algorithmic_gflop_per_call": groups[k][0] / groups[k][2] / 1e9}
+                           for k in groups if k in kern and kern[k].get("hbm_bytes_per_step") and groups[k][2] >= 2}
         label = {"fwd": "igemm_f32_kernel<NT> (conv2d forward, fp32 MFMA)", "dgrad": "igemm_f32_kernel<NN> (conv2d backward-data, fp32 MFMA)",
                  "wgrad": "igemm_f32_kernel<TN> + wgrad_direct_kernel (conv2d backward-weight, fp32 MFMA, incl. slab reduction)",
                  "b3w": "igemm_b3w_kernel (conv2d forward and backward-data of the large layers, bf16x3 split precision)",
@@ -423,7 +459,7 @@ def main():
                for k, v in agg.items() if k.startswith("hbm:") and v[1] > 0}
         roof = {"bound": "mfma", "kernel": label, "achieved": fl / sec / 1e12, "peak": peak,
                 "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
-                "launches_per_step": n // 2,
+                "launches_per_step": n // 2, "traffic_all_kernels": traffic_all,
                 "avg_launch_ms": sec / n * 1e3, "algorithmic_gflop_per_launch": fl / n / 1e9,
                 "peak_note": "fp32 MFMA 157.3 TFLOP/s; bf16x3 kernels: dense bf16 MFMA 2500 TFLOP/s / 6 products = 416.7 TFLOP/s-equivalent; "
                              "f16x2 kernels: dense fp16 MFMA 2500 TFLOP/s / 3 products = 833.3 "
@@ -447,6 +483,8 @@ def main():
     if world > 1:
         comm = model._grad_sync.stats()          # every rank (it synchronises its device); rank 0 prints
         comm["payload_MB_per_step"] = round(comm["bytes_reduced_per_step"] / 1e6, 1)
+        if comm["backend"] != "nccl":
+            comm["note"] = "FUNCTIONAL ARTEFACT: backend %s asked for through CATSEG_DIST_BACKEND -- not an RCCL / xGMI measurement, not a scaling figure" % comm["backend"]
 
     def timed_steps(n, batches=None, warm=1):
         for i in range(warm):
@@ -528,7 +566,7 @@ def main():
                                       "sustains_step_rate": bool(dtl <= 1.05 * dtr)}      # (within 5 %: the ingest kernels themselves are on the step's stream)
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
-        cpu = cpu_baseline(H, W, K, args.model, args.cpu_threads)
+        cpu = cpu_baseline(H, W, K, args.model, args.cpu_threads, all_core_figure=not args.no_all_core_cpu)
     if world > 1:
         dist.barrier()
 

@@ -23,18 +23,26 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            env = os.environ.get("CATSEG_DIST_BACKEND")
-            backend = env or ("nccl" if torch.cuda.is_available() else "gloo")
-            if backend == "gloo" and torch.cuda.is_available() and env != "gloo":
-                raise RuntimeError("data parallel on GPUs runs over RCCL (backend 'nccl'); gloo stages every bucket through the host -- "
-                                   "set CATSEG_DIST_BACKEND=gloo to ask for it explicitly (functional tests)")
+        backend = resolve_backend(backend)
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def resolve_backend(backend=None, cuda=None):
+    """backend of the data-parallel process group: the argument, else CATSEG_DIST_BACKEND, else 'nccl' (= RCCL) on GPUs / 'gloo' without.
+    gloo on a machine with GPUs is refused, however it was asked for, unless CATSEG_DIST_BACKEND=gloo says so in the environment: it
+    stages every gradient bucket through the host (1.3 s of host wait per HRNet-W48 step in profiles/r03_bench_2rank_gloo_1gpu.json)."""
+    env = os.environ.get("CATSEG_DIST_BACKEND")
+    cuda = torch.cuda.is_available() if cuda is None else cuda
+    backend = backend or env or ("nccl" if cuda else "gloo")
+    if backend == "gloo" and cuda and env != "gloo":
+        raise RuntimeError("data parallel on GPUs runs over RCCL (backend 'nccl'); gloo stages every bucket through the host -- "
+                           "set CATSEG_DIST_BACKEND=gloo to ask for it explicitly (functional tests)")
+    return backend
 
 
 def default_bucket_bytes():

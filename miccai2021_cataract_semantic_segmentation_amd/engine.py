@@ -221,7 +221,7 @@ class Ctx:
             own = torch.empty(src.shape, dtype=torch.float32, device=src.device)
             ops.axpy(src, own, 1.0, False)
             self.grads[k] = own
-        return self.grads[k]
+        return ops.drop_amax(self.grads[k])     # (the caller accumulates into it: a producer's amax record no longer bounds it)
 
     def give(self, t, g, shared=False):
         assert id(t) not in self.bn_pre, "conv_bn_act(private_in=True): the input has a second consumer"
@@ -375,6 +375,7 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
         def bwd():
             dz = cx.take(z)
             pre = cx.bn_pre.pop(id(z), None)
+            cx.bn_src.pop(id(z), None)          # (its private_in consumer, if any, has run: y is not kept alive beyond this layer's backward)
             if dz is None:
                 return
             dres, acc = (None, False)
@@ -659,7 +660,10 @@ class EngineNet(nn.Module):
                 bank.refresh()
         cx = Ctx(self.training, record, None)
         if ops._trunk_h2() and self.training:
-            cx.amax_scope = ops.AmaxScope(x.device)     # the per-tensor amax records of this forward pass and of its backward
+            # the per-tensor amax records of this forward pass and of its backward: ONE chunk, zeroed here on the main stream, sized from
+            # the previous pass of this network (+25 %: a rollover inside a parallel region would have to be ordered against its siblings)
+            cx.amax_scope = ops.AmaxScope(x.device, max(ops.AMAX_SCOPE_RECORDS, int(1.25 * getattr(self, "_amax_records", 0)) + 64))
+            self._amax_scope_live = cx.amax_scope
             ops.set_amax_scope(cx.amax_scope)
         outs = self._body(cx, x)
         if not record:
@@ -674,11 +678,17 @@ class EngineNet(nn.Module):
         self._grads_pending = False
 
     def _begin_backward(self, cx):
-        if self._grads_pending:
-            raise RuntimeError("second backward() before zero_grad(): the HIP engine's tape overwrites parameter gradients "
-                               "(no accumulation over several backward passes); call optimiser.zero_grad() / model.zero_grad() "
-                               "between backward passes")
         fp = self.flat()
+        if self._grads_pending:
+            if all(p.grad is None for p in fp.params):
+                # optimiser.zero_grad(set_to_none=True) of a stock torch optimiser (torch.optim.Adam(model.parameters()) in the reference's
+                # loop, managers/OCRNet_Manager.py:80-90) detached every .grad: that IS the zero_grad between two backward passes
+                fp.grad.zero_()
+                self._grads_pending = False
+            else:
+                raise RuntimeError("second backward() before zero_grad(): the HIP engine's tape overwrites parameter gradients "
+                                   "(no accumulation over several backward passes); call optimiser.zero_grad() / model.zero_grad() "
+                                   "between backward passes")
         fp.bind_grads()
         if getattr(cx, "amax_scope", None) is not None:
             ops.set_amax_scope(cx.amax_scope)           # (another forward pass may have run since this one)
@@ -687,6 +697,8 @@ class EngineNet(nn.Module):
             self._grad_sync.begin(fp)
 
     def _end_backward(self, cx):
+        if getattr(cx, "amax_scope", None) is not None:
+            self._amax_records = max(getattr(self, "_amax_records", 0), cx.amax_scope.used)
         ops.release_b3_cache()
         self._grads_pending = True
         if self._grad_sync is not None:

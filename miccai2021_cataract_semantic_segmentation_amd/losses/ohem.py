@@ -7,7 +7,7 @@ from torch import nn
 
 from .. import ops
 from ..utils import IGNORE_LABEL
-from ._common import as_pixel_rows, scale_by
+from ._common import as_pixel_rows, scale_by, upsample_to_labels
 
 
 class _OhemFn(torch.autograd.Function):
@@ -41,8 +41,5 @@ class OhemCrossEntropy(nn.Module):
             self.ignore_label = -100
 
     def forward(self, score, target, **kwargs):
-        if score.shape[2:] != target.shape[1:]:
-            # the reference resizes with F.upsample(mode='bilinear') (align_corners=False) here; every network of this
-            # package already returns logits at label resolution
-            raise NotImplementedError("OhemCrossEntropy: logits must already be at label resolution")
+        score = upsample_to_labels(score, target)      # losses/OhemCrossEntropy.py:23-26 (F.upsample, align_corners=False)
         return _OhemFn.apply(score, target, self.ignore_label, float(self.thresh), int(self.min_kept))

@@ -3,6 +3,7 @@ import torch
 from torch import nn
 
 from ..utils import IGNORE_LABEL
+from ._common import upsample_to_labels
 from .cross_entropy import CrossEntropyLoss
 from .lovasz import LovaszSoftmax
 from .ohem import OhemCrossEntropy
@@ -43,8 +44,8 @@ class TwoScaleLoss(nn.Module):
             raise NotImplementedError("different losses for interm {} and final {}".format(config["interm"], config["final"]))
 
     def forward(self, logits_interm, logits_final, target):
-        if logits_interm.shape[2:] != target.shape[1:]:
-            raise NotImplementedError("intermediate logits must already be at label resolution (OCRNet upsamples them)")
+        # "upsample intermediate if not already upsampled" (losses/TwoScaleLoss.py:45-48; F.upsample's default align_corners=False)
+        logits_interm = upsample_to_labels(logits_interm, target)
         if CONCURRENT and logits_final.is_cuda:
             # the two losses are independent: the intermediate one runs on a side stream (its sort / scan passes interleave with
             # the final loss's; every kernel of a loss call is ordered on the stream it was issued to, workspaces are per stream)

@@ -243,18 +243,34 @@ _amax_scope = None
 
 
 class AmaxScope:
-    """the amax records of ONE forward pass and its backward: zeroed chunks of AMAX_SCOPE_RECORDS records, handed out in order.  A
-    record lives as long as a tensor (or this scope) refers to its chunk -- a second forward pass (another network, a second
-    micro-batch before the first backward) gets its own scope and cannot clear records that are still waiting for their backward."""
+    """the amax records of ONE forward pass and its backward: zeroed chunks of records, handed out in order.  A record lives as long as a
+    tensor (or this scope) refers to its chunk -- a second forward pass (another network, a second micro-batch before the first backward)
+    gets its own scope and cannot clear records that are still waiting for their backward.
+    A chunk is zero-filled on the stream that is current when it is created (the first one at the stem, on the main stream; `records` sizes
+    it for the whole pass when the owner knows the count of its previous pass).  Records are handed out on other streams too (HRNet's
+    branch regions): the first request from a stream that may not be ordered behind the fill waits for the fill's event, so that a late
+    memset can never erase an amax a sibling stream has already accumulated."""
 
-    def __init__(self, device):
-        self.device, self.chunk, self.i = device, None, AMAX_SCOPE_RECORDS
+    def __init__(self, device, records=AMAX_SCOPE_RECORDS):
+        self.device, self.chunk, self.n, self.i = device, None, max(int(records), 16), 0
+        self.used = 0
+        self.i = self.n        # (first new() allocates)
+        self.event, self.ordered = None, set()
 
     def new(self):
-        if self.i >= AMAX_SCOPE_RECORDS:
-            self.chunk, self.i = torch.zeros(AMAX_WORDS * AMAX_SCOPE_RECORDS, dtype=torch.int32, device=self.device), 0
+        cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        if self.i >= self.n:
+            self.chunk, self.i = torch.zeros(AMAX_WORDS * self.n, dtype=torch.int32, device=self.device), 0
+            if cur is not None:
+                self.event = torch.cuda.Event()
+                self.event.record(cur)
+                self.ordered = {cur.cuda_stream}
+        elif cur is not None and cur.cuda_stream not in self.ordered:
+            cur.wait_event(self.event)
+            self.ordered.add(cur.cuda_stream)
         i = self.i
         self.i = i + 1
+        self.used += 1
         return self.chunk[AMAX_WORDS * i:AMAX_WORDS * (i + 1)]
 
 
@@ -275,6 +291,15 @@ def new_amax(device):
 def amax_of(t):
     """the record a producing kernel attached to t, or None"""
     return getattr(t, "_amax", None)
+
+
+def drop_amax(t):
+    """a tensor that is about to be modified IN PLACE (an accumulating launch) loses the amax record its producer attached: the record
+    would underestimate the new contents, and an underestimate overflows the fp16 planes of the trunk kernels (their prescale leaves one
+    bit of headroom).  Without a record the consumer takes the three-plane bf16 kernel, which needs none."""
+    if t is not None and getattr(t, "_amax", None) is not None:
+        t._amax = None
+    return t
 
 
 def dconv3_weight_image(w, backward_data=False, h2=False):
@@ -339,6 +364,7 @@ def dconv3(x, wimg, bias=None, out=None, accumulate=False, bn_stats=False, x_ama
     if out is None:
         out = new_act(B, H, W, C, x.device)
         accumulate = False
+    drop_amax(out)
     part = cnt = None
     nt = 0
     if bn_stats:
@@ -462,6 +488,7 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
     if out is None:
         out = new_act(B, H, W, Cin, dy.device)
         accumulate = False
+    drop_amax(out)
     flops = 2.0 * rows_of(dy) * Cout * (Cin // groups) * kh * kw
     if w.dim() == 4 and _d3_ok(B * H * W, Cin, Cout, kh, kw, stride, pad, dil, groups):
         rec = amax_of(dy) if _trunk_h2() else None
@@ -675,6 +702,7 @@ def stem_unpack_grad(pk, dw, O):
 
 
 def axpy(src, dst, alpha=1.0, accumulate=True):
+    drop_amax(dst)
     check(lib.catseg_axpy2d(ptr(src), ld_of(src), ptr(dst), ld_of(dst), rows_of(src), src.shape[-1], alpha,
                             1 if accumulate else 0, stream()))
     return dst

@@ -64,9 +64,17 @@ def lovasz_softmax_np(logits, target):
     return tot / max(n, 1)
 
 
+def resize_to_labels(logits, target):
+    """the resize branch of the reference's losses (losses/TwoScaleLoss.py:45-48, losses/OhemCrossEntropy.py:23-26):
+    F.upsample(input, size=(h, w), mode='bilinear') = F.interpolate(..., align_corners=False)"""
+    if tuple(logits.shape[2:]) != tuple(target.shape[1:]):
+        logits = F.interpolate(logits, size=tuple(target.shape[1:]), mode="bilinear", align_corners=False)
+    return logits
+
+
 def two_scale_lovasz(interm, final, target, w_interm=0.4, w_final=1.0):
-    """losses/TwoScaleLoss.py:43-52 (sizes already equal for OCRNet)"""
-    return lovasz_softmax(final, target) * w_final + lovasz_softmax(interm, target) * w_interm
+    """losses/TwoScaleLoss.py:43-52"""
+    return lovasz_softmax(final, target) * w_final + lovasz_softmax(resize_to_labels(interm, target), target) * w_interm
 
 
 def cross_entropy(logits, target, experiment):
@@ -75,8 +83,9 @@ def cross_entropy(logits, target, experiment):
 
 
 def ohem_cross_entropy(score, target, experiment=None, thresh=0.7, min_kept=100000):
-    """losses/OhemCrossEntropy.py:22-39 (score already at label resolution)"""
+    """losses/OhemCrossEntropy.py:22-39"""
     ignore = IGNORE_LABEL[experiment] if experiment in (2, 3) else -100
+    score = resize_to_labels(score, target)
     pred = F.softmax(score, dim=1)
     pixel_losses = F.cross_entropy(score, target, ignore_index=ignore, reduction="none").reshape(-1)
     mask = target.reshape(-1) != ignore

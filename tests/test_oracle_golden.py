@@ -144,3 +144,28 @@ def test_ingest_oracle_matches_reference(golden):
             assert np.array_equal(lbl, g["e%d_lbl" % exp][b])
             want = g["e%d_img" % exp][b].transpose(2, 0, 1).astype(np.float32) / np.float32(255)
             assert np.array_equal(x, want)
+
+
+def test_loss_resize_branch_vs_reference(golden):
+    """the oracle's restatement of the resize-on-mismatch branch (losses/TwoScaleLoss.py:45-48, losses/OhemCrossEntropy.py:23-26) against
+    fixtures from the REAL reference (tests/golden/make_golden_resize.py): loss and both gradients"""
+    import torch
+    from oracle import losses as OL
+    g = golden("losses_resize")
+    cases = {"ts_lovasz": lambda i, f, t: OL.two_scale_lovasz(i, f, t),
+             "ts_ce": lambda i, f, t: OL.cross_entropy(f, t, 2) + 0.4 * OL.cross_entropy(OL.resize_to_labels(i, t), t, 2),
+             "ts_ohem": lambda i, f, t: OL.ohem_cross_entropy(f, t, 3, 0.6, 150) + 0.4 * OL.ohem_cross_entropy(i, t, 3, 0.6, 150)}
+    for name, fn in cases.items():
+        i = torch.from_numpy(g[name + "_interm"]).requires_grad_()
+        f = torch.from_numpy(g[name + "_final"]).requires_grad_()
+        t = torch.from_numpy(g[name + "_target"])
+        loss = fn(i, f, t)
+        loss.backward()
+        assert abs(float(loss) - float(g[name + "_loss"])) < 2e-6, name
+        assert float((i.grad - torch.from_numpy(g[name + "_ginterm"])).abs().max()) < 1e-7, name
+        assert float((f.grad - torch.from_numpy(g[name + "_gfinal"])).abs().max()) < 1e-7, name
+    s = torch.from_numpy(g["ohem_score"]).requires_grad_()
+    loss = OL.ohem_cross_entropy(s, torch.from_numpy(g["ohem_target"]), 2, 0.5, 500)
+    loss.backward()
+    assert abs(float(loss) - float(g["ohem_loss"])) < 2e-6
+    assert float((s.grad - torch.from_numpy(g["ohem_grad"])).abs().max()) < 1e-7
