@@ -214,6 +214,27 @@ size_t catseg_dwgrad3_workspace(int B, int H, int W, int C);
 int catseg_dwgrad3(int B, int H, int W, int C, const float* x, int ldx, const float* dy, int ldy, float* dw, void* workspace,
                    size_t workspace_bytes, catseg_stream_t stream);
 
+/* ---- fp16 x 2 OPERAND PLANES written by the producer of a tensor, and the direct 3x3 kernels that stream them (round 4;
+ * csrc/planes.h, csrc/dconv3_pl.hip).  Replaces, for the same reference layers as catseg_dconv3_f16x2 (conv3x3(planes, planes) of
+ * models/HRNetv2.py:22-65), the in-kernel fp32 -> 2 x fp16 split: planes = [plane h / l][C / 8 channel groups][pixel][8] fp16,
+ * catseg_planes_bytes(rows, C) bytes, written with the exponent e that the tensor's amax record holds in word 1 (xs = x * 2^e).
+ *   catseg_planes_from_f32:  standalone producer (tests; tensors whose producing kernel writes no planes).  compute_amax != 0: the record
+ *                            is zeroed and max|x| taken here; else its 16 amax slots are taken as they are (a larger value is safe).
+ *   catseg_dconv3_pl:        catseg_dconv3_f16x2 on planes.  BatchNorm partials PER WAVE: catseg_dconv3_pl_rows(C, B, H, W) rows of
+ *                            [3][C] floats + one int32 count per row, for catseg_bn_finalize_counts.  out_record (may be NULL): max|y| is
+ *                            folded into its amax slots (the BatchNorm that follows derives the exponent of ITS output planes from it).
+ *   catseg_dconv3_pl_bnbwd:  catseg_dconv3_bnbwd_f16x2 on planes of dy; part = [rows][2][C]; max|g| to out_record. */
+int catseg_dconv3_pl_supported(int C);
+int catseg_dconv3_pl_rows(int C, int B, int H, int W);
+size_t catseg_planes_bytes(long long rows, int C);
+int catseg_planes_from_f32(const float* x, int ld, long long rows, int C, void* record, void* planes, int compute_amax, catseg_stream_t stream);
+int catseg_dconv3_pl(int B, int H, int W, int C, const void* planes, const void* planes_record, const void* wimg, const void* w_record,
+                     const float* bias, float* y, int ldy, int accumulate, float* bn_part, size_t bn_part_floats, int* bn_counts,
+                     void* out_record, catseg_stream_t stream);
+int catseg_dconv3_pl_bnbwd(int B, int H, int W, int C, const void* dy_planes, const void* dy_record, const void* wimg_bwd, const void* w_record,
+                           float* g, int ldg, const float* q, int ldq, const float* stats, const float* gamma, const float* beta, float* part,
+                           size_t part_floats, void* out_record, catseg_stream_t stream);
+
 /* (tuning / measurement hooks live in catseg_debug.h: they are process-global and not part of the product surface) */
 
 /* ---- BatchNorm (+ReLU, +residual) — nn.BatchNorm2d/ReLU at e.g. models/OCR.py:74-75,

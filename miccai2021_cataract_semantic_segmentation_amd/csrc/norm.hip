@@ -106,6 +106,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
       const bool last = b == nrb - 1;
       double nb = last ? n_last : n_full, inv = last ? inv_last : inv_full;
       if (counts) {                         // per-block row counts (2-D pixel tiles with ragged edges: csrc/dconv3_b3.hip)
+        if (counts[b] == 0) return;         // (a wave of csrc/dconv3_pl.hip whose pixel rows all lie below the image)
         nb = (double)counts[b];
         inv = 1.0 / nb;
       }

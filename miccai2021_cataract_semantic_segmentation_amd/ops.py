@@ -382,6 +382,51 @@ def dconv3(x, wimg, bias=None, out=None, accumulate=False, bn_stats=False, x_ama
     return out
 
 
+class Planes:
+    """the fp16 x 2 operand planes of an NHWC activation (csrc/planes.h) + its record (amax slots, word 1 = the planes' exponent)"""
+    __slots__ = ("buf", "rec", "shape")
+
+    def __init__(self, buf, rec, shape):
+        self.buf, self.rec, self.shape = buf, rec, tuple(shape)
+
+
+def planes_of(t):
+    """the planes a producing kernel attached to t, or None"""
+    return getattr(t, "_planes", None)
+
+
+def planes_from_f32(x, rec=None):
+    """standalone producer: planes of x with the exponent from max|x| (rec given: its amax slots are taken as they are)"""
+    B, H, W, C = x.shape
+    buf = torch.empty(lib.catseg_planes_bytes(B * H * W, C), dtype=torch.uint8, device=x.device)
+    own = rec is None
+    if own:
+        rec = new_amax(x.device)
+    check(lib.catseg_planes_from_f32(ptr(x), ld_of(x), B * H * W, C, ptr(rec), ptr(buf), 1 if own else 0, stream()))
+    return Planes(buf, rec, x.shape)
+
+
+def dconv3_pl(xp, wimg, bias=None, out=None, accumulate=False, bn_stats=False, out_rec=None):
+    """y (+)= conv3x3(x) from the planes of x (Planes) and an f16x2 weight image (image, record); bn_stats: also returns
+    (partials, n_rows, 0, counts) for bn_finalize -- per-WAVE rows"""
+    B, H, W, C = xp.shape
+    if out is None:
+        out = new_act(B, H, W, C, xp.buf.device)
+        accumulate = False
+    drop_amax(out)
+    part = cnt = None
+    nr = 0
+    if bn_stats:
+        nr = lib.catseg_dconv3_pl_rows(C, B, H, W)
+        part = _bn_part_buffer(3 * nr * C + nr, xp.buf.device)
+        cnt = part[3 * nr * C:3 * nr * C + nr].view(torch.int32)
+    check(lib.catseg_dconv3_pl(B, H, W, C, ptr(xp.buf), ptr(xp.rec), ptr(wimg[0]), ptr(wimg[1]), ptr(bias), ptr(out), ld_of(out),
+                               1 if accumulate else 0, ptr(part), 3 * nr * C, ptr(cnt), ptr(out_rec), stream()))
+    if bn_stats:
+        return out, (part, nr, 0, cnt)
+    return out
+
+
 _bn_part = {}
 
 

@@ -1,0 +1,37 @@
+"""the direct trunk kernels: in-kernel split (catseg_dconv3_f16x2) against producer-written planes (catseg_dconv3_pl), forward + BatchNorm
+partials, on eight tensors in turn (not cache resident).  Usage: python tools/time_pl.py [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from miccai2021_cataract_semantic_segmentation_amd import ops
+dev = torch.device("cuda")
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+for (B, H, W, C) in [(8, 136, 240, 48), (8, 68, 120, 96), (8, 34, 60, 192), (8, 17, 30, 384), (8, 136, 240, 64)]:
+    xs = [torch.randn(B, H, W, C, device=dev) for _ in range(8)]
+    for x in xs:
+        x._amax = ops.new_amax(dev)
+        x._amax[0:1] = x.abs().max().reshape(1).view(torch.int32)
+    w = (torch.randn(C, C, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    wimg = ops.dconv3_weight_image(w, h2=True)
+    xps = [ops.planes_from_f32(x, x._amax) for x in xs]
+    y = torch.empty_like(xs[0])
+
+    def t(fn):
+        for i in range(8):
+            fn(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            for i in range(8):
+                fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (8 * reps) * 1e3
+    old = t(lambda i: ops.dconv3(xs[i], wimg, None, out=y, bn_stats=True, x_amax=xs[i]._amax))
+    new = t(lambda i: ops.dconv3_pl(xps[i], wimg, None, out=y, bn_stats=True))
+    newp = t(lambda i: ops.dconv3_pl(xps[i], wimg, None, out=y))
+    gf = 2.0 * B * H * W * C * C * 9 / 1e9
+    print("C=%3d  %dx%dx%d: in-kernel split %.1f us, planes %.1f us (%.0f TFLOP/s-eq, %.2f of 833), planes without BN partials %.1f us"
+          % (C, B, H, W, old, new, gf / new / 1e3, gf / new / 1e3 / 833.3, newp), flush=True)
+    ops.release_b3_cache()
