@@ -541,7 +541,7 @@ def main():
                     return self.img[i], self.lbl[i]
             def make_loader():
                 return PinnedFrameLoader(_Frames(), batch_size=B, experiment=3, flip_probability=(0.0, 0.5), pad=(2, 2), normalise=False,
-                                         device=dev, blur=True, colorjitter=True, seed=rank)
+                                         device=dev, blur=True, colorjitter=True, seed=rank, worker_processes=4)
 
             def forever(loader):
                 while True:
@@ -550,18 +550,22 @@ def main():
             # The loader's frames carry other labels than the synthetic batch (random 30 x 30 blocks of raw class ids) and every batch its own
             # flips / blur / jitter: the Lovasz work of a step depends on them.  What the PIPELINE costs is the difference between the SAME ten
             # batches (two warm-up + eight timed, in the same order) already resident in HBM and delivered by a second, identically seeded loader.
-            gen = forever(make_loader())
+            ld = make_loader()
+            gen = forever(ld)
             resident = [tuple(t.clone() for t in next(gen)) for _ in range(10)]
             gen.close()
+            ld.close()
             side_state()
             dtr = timed_steps(8, iter(resident), warm=2)
             side_state()
-            gen = forever(make_loader())
+            ld = make_loader()
+            gen = forever(ld)
             dtl = timed_steps(8, gen, warm=2)
             gen.close()
+            ld.close()
             side["through_loader"] = {"frames_per_s": world * B / dtl, "ms_per_step": dtl * 1e3, "steps": 8,
                                       "same_batches_resident_ms_per_step": dtr * 1e3,
-                                      "pipeline": "PinnedFrameLoader (64 host uint8 frames 540x960, stacked by the consumer thread between steps) -> pinned staging -> "
+                                      "pipeline": "PinnedFrameLoader (64 host uint8 frames 540x960, stacked by 4 forked worker processes into shared pinned staging slots) -> "
                                                   "copy on a side stream -> GpuIngest(label remap, flip, pad to 544, BlurPIL, ColorJitter, ToTensor) -> train step",
                                       "sustains_step_rate": bool(dtl <= 1.05 * dtr)}      # (within 5 %: the ingest kernels themselves are on the step's stream)
     cpu = None

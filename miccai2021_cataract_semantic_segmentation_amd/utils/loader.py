@@ -13,6 +13,9 @@ computes, and remap / flip / reflect-pad / ToTensor / Normalize happen in one ke
 second element is ignored) -- e.g. ``cv2.imread`` + BGR->RGB as datasets/Dataset_from_df.py:36-44 does.  With WORLD_SIZE > 1
 the index stream is sharded by rank (dist.ShardedSampler).  blur= / colorjitter= apply BlurPIL / ColorJitter on the GPU (utils/augment.py).
 """
+import multiprocessing
+import multiprocessing.connection
+import os
 import queue
 import threading
 
@@ -23,10 +26,80 @@ from .augment import sample_blur, sample_color_jitter
 from .ingest import GpuIngest, sample_flips
 
 
+def _worker_main(conn, dataset, slots, widx, nworkers):
+    """a loader worker PROCESS (forked, never exec'ed; it never touches the GPU): for every task (slot, ids, token) it reads frames
+    widx, widx + nworkers, ... of the batch from the dataset and writes them into the SHARED staging slot, then answers with the token"""
+    try:
+        torch.set_num_threads(1)
+        while True:
+            task = conn.recv()
+            if task is None:
+                break
+            slot, ids, token = task
+            img_buf, lbl_buf = slots[slot]
+            for j in range(widx, len(ids), nworkers):
+                item = dataset[ids[j]]
+                img_buf[j].copy_(torch.as_tensor(np.ascontiguousarray(item[0])))
+                lbl_buf[j].copy_(torch.as_tensor(np.ascontiguousarray(item[1])))
+            conn.send(token)
+    except (EOFError, KeyboardInterrupt, BrokenPipeError):
+        pass
+    finally:
+        os._exit(0)            # (no interpreter shutdown in a forked copy of a process that has initialised the GPU)
+
+
+class _WorkerPool:
+    """worker processes filling shared, pinned staging slots (the reference's DataLoader(num_workers=...),
+    managers/BaseManager.py:298-305).  The processes are FORKED from the loader's process (as torch's DataLoader forks its workers): no
+    exec of a GPU-initialised process, the dataset needs no pickling; they only read the dataset and write host memory."""
+
+    def __init__(self, dataset, slots, n):
+        ctx = multiprocessing.get_context("fork")
+        self.conns, self.procs = [], []
+        for w in range(n):
+            a, b = ctx.Pipe(duplex=True)
+            p = ctx.Process(target=_worker_main, args=(b, dataset, slots, w, n), daemon=True)
+            p.start()
+            b.close()
+            self.conns.append(a)
+            self.procs.append(p)
+        self.pending = {}        # token -> answers still missing
+
+    def submit(self, slot, ids, token):
+        self.pending[token] = len(self.conns)
+        for c in self.conns:
+            c.send((slot, list(ids), token))
+
+    def wait(self, token):
+        """blocks (interpreter lock released while polling the pipes) until every worker has answered `token`"""
+        while self.pending.get(token, 0) > 0:
+            for c in self.conns:
+                while c.poll(0):
+                    self.pending[c.recv()] -= 1
+            if self.pending[token] > 0:
+                multiprocessing.connection.wait(self.conns, timeout=0.05)
+        self.pending.pop(token, None)
+
+    def close(self):
+        for c in self.conns:
+            try:
+                c.send(None)
+            except (BrokenPipeError, OSError):
+                pass
+        for p in self.procs:
+            p.join(timeout=2.0)
+            if p.is_alive():
+                p.terminate()       # (this exact child)
+                p.join(timeout=1.0)
+        for c in self.conns:
+            c.close()
+        self.conns, self.procs = [], []
+
+
 class PinnedFrameLoader:
     def __init__(self, dataset, batch_size, experiment, sampler=None, shuffle=True, drop_last=True, flip_probability=(0.0, 0.5),
                  pad=(2, 2), normalise=False, nhwc4=False, device="cuda", prefetch=3, workers=0, seed=0, rank=0, world=1,
-                 blur=False, colorjitter=False):
+                 blur=False, colorjitter=False, worker_processes=0):
         """blur / colorjitter: the 'blur' / 'colorjitter' entries of the reference's `transforms` config list (utils/utils.py:412-417):
         BlurPIL(probability=.05, kernel_limits=(3, 7)) and ColorJitter((2/3, 1.5) x 3, hue (-.05, .05)) on the padded uint8 frames,
         as GPU kernels (utils/augment.py)"""
@@ -46,8 +119,23 @@ class PinnedFrameLoader:
         if world > 1 and sampler is not None:
             from ..dist import check_unsharded
             check_unsharded(sampler)        # (this loader takes the rank's slice itself)
+        # worker_processes = N: N forked processes read the dataset and stack the frames into SHARED pinned staging slots; the consumer's
+        # thread only enqueues the host -> device copy and the ingest kernels (immune to the interpreter lock and to a slow __getitem__)
+        self.nproc = max(int(worker_processes), 0)
+        self._pool = None
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self._slots = None
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.close()
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001
+            pass
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
@@ -68,8 +156,72 @@ class PinnedFrameLoader:
         return n // self.batch if self.drop_last else (n + self.batch - 1) // self.batch
 
     def _alloc(self, h, w):
+        if self.nproc:
+            # shared memory first (the workers inherit the mapping at the fork), then page-locked in THIS process for the asynchronous copies
+            self.close()
+            self._slots = [(torch.empty((self.batch, h, w, 3), dtype=torch.uint8).share_memory_(),
+                            torch.empty((self.batch, h, w), dtype=torch.uint8).share_memory_()) for _ in range(self.prefetch + 1)]
+            self._pool = _WorkerPool(self.dataset, self._slots, self.nproc)
+            rt = torch.cuda.cudart()
+            for pair in self._slots:
+                for t in pair:
+                    err = rt.cudaHostRegister(t.data_ptr(), t.numel(), 0)
+                    if int(err) != 0:
+                        raise RuntimeError("hipHostRegister of a shared staging slot failed: %s" % (err,))
+            return
         self._slots = [(torch.empty((self.batch, h, w, 3), dtype=torch.uint8).pin_memory(),
                         torch.empty((self.batch, h, w), dtype=torch.uint8).pin_memory()) for _ in range(self.prefetch + 1)]
+
+    def _emit(self, slot, n, fl, br, jt):
+        """host -> device copy of a filled staging slot on the side stream + the ingest kernels; returns (x, labels, copy event)"""
+        img_buf, lbl_buf = self._slots[slot]
+        with torch.cuda.stream(self.copy_stream):          # pinned: truly asynchronous
+            img_d = img_buf[:n].to(self.device, non_blocking=True)
+            lbl_d = lbl_buf[:n].to(self.device, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.copy_stream)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(done)                               # the ingest kernel waits for the copy, the host does not
+        img_d.record_stream(cur)
+        lbl_d.record_stream(cur)
+        x, labels = self.ingest(img_d, lbl_d, fl, nhwc4=self.nhwc4, blur_radii=br, jitter=jt)
+        return x, labels, done
+
+    def _iter_processes(self, batches, flips, blurs, jitters):
+        """the worker processes run `prefetch` batches ahead; a staging slot returns to them when its copy has left it"""
+        pool = self._pool
+        free = list(range(len(self._slots)))
+        in_copy, submitted, slot_of = [], 0, {}
+        self._tok = getattr(self, "_tok", 0)
+        base = self._tok
+        self._tok += len(batches)
+        try:
+            bi = 0
+            while bi < len(batches):
+                while in_copy and in_copy[0][0].query():   # copies that have left their slot (never a blocking wait here)
+                    free.append(in_copy.pop(0)[1])
+                while submitted < min(len(batches), bi + self.prefetch) and free:
+                    sl = free.pop(0)
+                    slot_of[submitted] = sl
+                    pool.submit(sl, batches[submitted], base + submitted)
+                    submitted += 1
+                if submitted <= bi:                        # every slot is still in a copy: wait for the oldest
+                    ev, sl = in_copy.pop(0)
+                    ev.synchronize()
+                    free.append(sl)
+                    continue
+                pool.wait(base + bi)
+                sl = slot_of.pop(bi)
+                x, labels, done = self._emit(sl, len(batches[bi]), flips[bi], blurs[bi], jitters[bi])
+                in_copy.append((done, sl))
+                bi += 1
+                yield x, labels
+        finally:
+            for t in range(base, base + submitted):       # (abandoned iteration: the workers finish what they were given)
+                if t in pool.pending:
+                    pool.wait(t)
+            for ev, _ in in_copy:
+                ev.synchronize()
 
     def __iter__(self):
         idx = self._indices()
@@ -85,8 +237,12 @@ class PinnedFrameLoader:
         ready = queue.Queue(maxsize=self.prefetch)
         free = queue.Queue()
         first = self.dataset[batches[0][0]] if batches else None
-        if first is not None and (self._slots is None or tuple(self._slots[0][0].shape[1:3]) != tuple(np.asarray(first[0]).shape[:2])):
+        if first is not None and (self._slots is None or tuple(self._slots[0][0].shape[1:3]) != tuple(np.asarray(first[0]).shape[:2])
+                                  or (self.nproc and self._pool is None)):
             self._alloc(*np.asarray(first[0]).shape[:2])
+        if self.nproc and batches:
+            yield from self._iter_processes(batches, flips, blurs, jitters)
+            return
         for s in range(len(self._slots or [])):
             free.put(s)
         stop = threading.Event()

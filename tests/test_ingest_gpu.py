@@ -134,3 +134,47 @@ def test_pinned_frame_loader_with_blur_and_colour_jitter():
         assert torch.equal(labels, plain[bi][1])
         changed = changed or not torch.equal(x, plain[bi][0])
     assert changed                                                      # the colour jitter did something
+
+
+class _ModeFrames:
+    """deterministic uint8 frames (module level: the forked worker processes inherit it)"""
+
+    def __init__(self, n=26, h=36, w=48):
+        self.n, self.h, self.w = n, h, w
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        rng = np.random.RandomState(1000 + i)
+        return rng.randint(0, 256, (self.h, self.w, 3)).astype(np.uint8), rng.randint(0, 36, (self.h, self.w)).astype(np.uint8)
+
+
+@pytest.mark.parametrize("mode", [dict(workers=0), dict(workers=1), dict(worker_processes=2), dict(worker_processes=3, prefetch=1)])
+def test_pinned_frame_loader_modes_agree_and_survive_an_abandoned_epoch(mode):
+    """the three ways the staging slots get filled -- inline on the consumer's thread (workers=0, the default), a fill thread, FORKED worker
+    PROCESSES writing shared pinned slots -- deliver identical batches; an iteration abandoned after two batches (break) is followed by a
+    clean second epoch; more batches than staging slots (all slots in a copy at some point)"""
+    _need_gpu()
+    from miccai2021_cataract_semantic_segmentation_amd.utils import GpuIngest, PinnedFrameLoader
+    from miccai2021_cataract_semantic_segmentation_amd.utils.ingest import sample_flips
+    ds = _ModeFrames()
+    loader = PinnedFrameLoader(ds, batch_size=4, experiment=3, seed=5, **mode)
+    try:
+        it = iter(loader)
+        first = [next(it) for _ in range(2)]
+        it.close()                                   # abandoned after two batches
+        assert all(x.shape == (4, 3, 40, 48) for x, _ in first)
+        idx = loader._indices()                      # the second epoch's order (epoch counter already advanced once)
+        out = [(x.clone(), l.clone()) for x, l in loader]
+        assert len(out) == 6
+        rng = np.random.RandomState(5 * 1000003 + 2)
+        for bi, (x, labels) in enumerate(out):
+            ids = idx[bi * 4:(bi + 1) * 4]
+            flips = sample_flips(4, (0.0, 0.5), rng)
+            img = torch.from_numpy(np.stack([ds[i][0] for i in ids]))
+            lbl = torch.from_numpy(np.stack([ds[i][1] for i in ids]))
+            xr, lr = GpuIngest(3)(img, lbl, flips)
+            assert torch.equal(x, xr) and torch.equal(labels, lr), (mode, bi)
+    finally:
+        loader.close()
