@@ -490,22 +490,20 @@ __global__ __launch_bounds__(512, 4) void dconv3_pl_kernel(const PlArgs a) {
         }
       }
       if (a.bn_part) {
-        // (wave mean, sum(v - mean), sum((v - mean)^2)) per channel over this wave's valid pixels: the 16 lanes of a k-group hold 16 pixels
-        // of the same four channels
+        // (K, sum(v - K), sum((v - K)^2)) per channel over this wave's valid pixels, ONE pass: the shift K is the value of the wave's first
+        // pixel (lane 0 of each 16-lane row holds it for that row's four channels: DPP row_share; it is a valid pixel whenever the wave
+        // has any: rows run top to bottom, columns left to right) -- any sample of the data is as good a shift as the mean, and
+        // catseg_bn_finalize_counts merges (K, s1, s2) rows with arbitrary K.  The 16 lanes of a k-group hold 16 pixels of the same channels.
         float* part = a.bn_part + (long long)prw * 3 * G::C + cob * G::NT;
-        const float inv = nvalid > 0 ? 1.f / (float)nvalid : 0.f;
 #pragma unroll
         for (int ct = 0; ct < G::CB; ++ct)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float v = 0.f;
-#pragma unroll
-            for (int pt = 0; pt < G::PB; ++pt) v += p_ok[pt] ? acc[ct][pt][r] : 0.f;
-            const float mean = pl_row16_sum(v) * inv;
+            const float K = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[ct][0][r]), 0x150, 0xF, 0xF, true));
             float d1 = 0.f, d2 = 0.f;
 #pragma unroll
             for (int pt = 0; pt < G::PB; ++pt) {
-              const float d = p_ok[pt] ? acc[ct][pt][r] - mean : 0.f;
+              const float d = p_ok[pt] ? acc[ct][pt][r] - K : 0.f;
               d1 += d;
               d2 += d * d;
             }
@@ -513,7 +511,7 @@ __global__ __launch_bounds__(512, 4) void dconv3_pl_kernel(const PlArgs a) {
             d2 = pl_row16_sum(d2);
             if (i16 == 0) {
               const int c = cl + ct * 16 + r;
-              part[c] = mean;
+              part[c] = nvalid > 0 ? K : 0.f;
               part[G::C + c] = d1;
               part[2 * G::C + c] = d2;
             }
