@@ -235,6 +235,14 @@ int catseg_dconv3_pl_bnbwd(int B, int H, int W, int C, const void* dy_planes, co
                            float* g, int ldg, const float* q, int ldq, const float* stats, const float* gamma, const float* beta, float* part,
                            size_t part_floats, void* out_record, catseg_stream_t stream);
 
+/* catseg_dwgrad3_f16x2 on producer-written planes of BOTH operands (csrc/dwgrad3_pl.hip): dw[o][ky][kx][c] = sum_px dy[px][o] x[px + tap][c]
+ * for the trunk widths 48 / 96 / 192 / 384 (autograd of F.conv2d, models/HRNetv2.py:22-65); workspace = catseg_dwgrad3_pl_workspace bytes
+ * (slabs of partial sums, added in a fixed order: deterministic) */
+int catseg_dwgrad3_pl_supported(int C);
+size_t catseg_dwgrad3_pl_workspace(int B, int H, int W, int C);
+int catseg_dwgrad3_pl(int B, int H, int W, int C, const void* x_planes, const void* x_record, const void* dy_planes, const void* dy_record,
+                      float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
+
 /* (tuning / measurement hooks live in catseg_debug.h: they are process-global and not part of the product surface) */
 
 /* ---- BatchNorm (+ReLU, +residual) — nn.BatchNorm2d/ReLU at e.g. models/OCR.py:74-75,

@@ -58,6 +58,9 @@ _SIGS = {
     "catseg_planes_from_f32": (I, [P, I, L, I, P, P, I, P]),
     "catseg_dconv3_pl": (I, [I, I, I, I, P, P, P, P, P, P, I, I, P, SZ, P, P, P]),
     "catseg_dconv3_pl_bnbwd": (I, [I, I, I, I, P, P, P, P, P, I, P, I, P, P, P, P, SZ, P, P]),
+    "catseg_dwgrad3_pl_supported": (I, [I]),
+    "catseg_dwgrad3_pl_workspace": (SZ, [I, I, I, I]),
+    "catseg_dwgrad3_pl": (I, [I, I, I, I, P, P, P, P, P, P, SZ, P]),
     "catseg_bn_apply_amax": (I, [P, I, P, P, P, P, I, P, I, L, I, I, P, P]),
     "catseg_bn_backward_amax": (I, [P, I, P, I, P, I, P, P, P, L, I, I, P, I, P, P, P, I, I, P, SZ, P, P]),
     "catseg_bn_backward_pre_amax": (I, [P, I, P, I, P, P, P, I, L, I, P, I, P, P, P, SZ, P, P]),

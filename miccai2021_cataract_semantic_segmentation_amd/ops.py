@@ -427,6 +427,16 @@ def dconv3_pl(xp, wimg, bias=None, out=None, accumulate=False, bn_stats=False, o
     return out
 
 
+def dwgrad3_pl(xp, dyp, dw):
+    """backward-weight of a 3x3 / stride 1 / pad 1 trunk convolution from the planes of x and dy (Planes)"""
+    B, H, W, C = xp.shape
+    need = lib.catseg_dwgrad3_pl_workspace(B, H, W, C)
+    ws = workspace(need + 256, xp.buf.device)
+    with _Timed("wgrad_d3p", 2.0 * B * H * W * C * C * 9):
+        check(lib.catseg_dwgrad3_pl(B, H, W, C, ptr(xp.buf), ptr(xp.rec), ptr(dyp.buf), ptr(dyp.rec), ptr(dw), ptr(ws), need, stream()))
+    return dw
+
+
 _bn_part = {}
 
 

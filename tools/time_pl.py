@@ -33,5 +33,18 @@ for (B, H, W, C) in [(8, 136, 240, 48), (8, 68, 120, 96), (8, 34, 60, 192), (8, 
     newp = t(lambda i: ops.dconv3_pl(xps[i], wimg, None, out=y))
     gf = 2.0 * B * H * W * C * C * 9 / 1e9
     print("C=%3d  %dx%dx%d: in-kernel split %.1f us, planes %.1f us (%.0f TFLOP/s-eq, %.2f of 833), planes without BN partials %.1f us"
-          % (C, B, H, W, old, new, gf / new / 1e3, gf / new / 1e3 / 833.3, newp), flush=True)
+          % (C, B, H, W, old, new, gf / new * 1e3 / 1e3, gf / new / 833.3, newp), flush=True)
+    if ops.lib.catseg_dwgrad3_pl_supported(C):
+        dys = [torch.randn(B, H, W, C, device=dev) * 1e-3 for _ in range(8)]
+        for d in dys:
+            d._amax = ops.new_amax(dev)
+            d._amax[0:1] = d.abs().max().reshape(1).view(torch.int32)
+        dps = [ops.planes_from_f32(d, d._amax) for d in dys]
+        dw = torch.empty_like(w)
+        saved, ops.TRUNK = ops.TRUNK, "f16x2"
+        wold = t(lambda i: ops.dwgrad3(xs[i], dys[i], dw))
+        ops.TRUNK = saved
+        wnew = t(lambda i: ops.dwgrad3_pl(xps[i], dps[i], dw))
+        print("       backward-weight (incl. slab reduction): in-kernel split %.1f us, planes %.1f us (%.0f TFLOP/s-eq, %.2f of 833)"
+              % (wold, wnew, gf / wnew, gf / wnew / 833.3), flush=True)
     ops.release_b3_cache()
