@@ -42,7 +42,7 @@ MODELS = {
     "deeplabv3plus_r50": ({"backbone": "resnet50", "out_stride": 8, "pretrained": False}, "DeepLabv3+-ResNet50-OS8"),
 }
 IS_DEEPLAB = lambda name: name.startswith("deeplab")   # noqa: E731
-PROFILE_ROUND = "r03"   # profiles/<round>_pmc_traffic_<model>.json feeds roofline.traffic
+PROFILE_ROUND = "r04"   # profiles/<round>_pmc_traffic_<model>.json feeds roofline.traffic
 
 
 def host_cpu_info():

@@ -15,7 +15,14 @@ dev = torch.device("cuda")
 x = torch.randn(B, H, W, C, device=dev)
 w = (torch.randn(C, C, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
 y = torch.empty_like(x)
-if kind.startswith("h2"):
+if kind.startswith("pl"):       # the planes kernel (csrc/dconv3_pl.hip): producer-written planes of eight inputs in turn
+    xs = [torch.randn(B, H, W, C, device=dev) for _ in range(8)]
+    xps = [ops.planes_from_f32(t) for t in xs]
+    wimg = ops.dconv3_weight_image(w, backward_data=(kind == "pldgrad"), h2=True)
+    torch.cuda.synchronize()
+    for i in range(n):
+        ops.dconv3_pl(xps[i % 8], wimg, None, out=y, bn_stats=(kind == "plfwd"))
+elif kind.startswith("h2"):
     xs = [torch.randn(B, H, W, C, device=dev) for _ in range(8)]
     for t in xs:
         t._amax = ops.new_amax(dev)
