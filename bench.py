@@ -404,7 +404,7 @@ def main():
         PEAK_F32, PEAK_B3, PEAK_H2 = 157.3, 2500.0 / 6.0, 2500.0 / 3.0
 
         def peak_of(kind):
-            if kind.endswith(("_h2", "_d3h")) or kind in ("h2w", "d3h", "wgrad_d3h"):
+            if kind.endswith(("_h2", "_d3h", "_d3p")) or kind in ("h2w", "d3h", "wgrad_d3h", "d3p"):
                 return PEAK_H2
             return PEAK_B3 if kind.endswith(("_b3", "_d3")) or kind in ("b3w", "d3") else PEAK_F32
         mm = {k: v for k, v in agg.items() if not k.startswith("hbm:") and k != "split3" and v[1] > 0}
@@ -412,7 +412,7 @@ def main():
         # kernel (igemm_b3w_kernel); the fp32 operations are the NT / NN / TN layouts of igemm_f32_kernel
         KERNEL_OF = {"fwd_b3": "b3w", "dgrad_b3": "b3w", "wgrad_b3": "wgrad_b3", "fwd": "fwd", "dgrad": "dgrad", "wgrad": "wgrad",
                      "fwd_d3": "d3", "dgrad_d3": "d3", "wgrad_d3": "wgrad_d3", "fwd_h2": "h2w", "dgrad_h2": "h2w", "wgrad_h2": "wgrad_h2",
-                     "fwd_d3h": "d3h", "dgrad_d3h": "d3h", "wgrad_d3h": "wgrad_d3h"}
+                     "fwd_d3h": "d3h", "dgrad_d3h": "d3h", "wgrad_d3h": "wgrad_d3h", "fwd_d3p": "d3p", "dgrad_d3p": "d3p", "wgrad_d3p": "wgrad_d3p"}
         groups = {}
         for k, v in mm.items():
             g = groups.setdefault(KERNEL_OF.get(k, k), [0.0, 0.0, 0])
@@ -420,8 +420,9 @@ def main():
         dom = max(groups, key=lambda k: groups[k][1])
         # (an fp32 layout is a union of 4-6 tile instantiations that rocprofv3 lists as separate kernels, the largest of them
         #  < 40 % of the layout's time: a single-symbol bf16x3 kernel with at least half of that time is the larger KERNEL)
-        for k in ("h2w", "wgrad_h2", "b3w", "wgrad_b3", "d3h", "d3", "wgrad_d3h", "wgrad_d3"):
-            if k in groups and dom not in ("h2w", "wgrad_h2", "b3w", "wgrad_b3", "d3h", "d3", "wgrad_d3h", "wgrad_d3") and groups[k][1] >= 0.5 * groups[dom][1]:
+        SPLIT = ("h2w", "wgrad_h2", "b3w", "wgrad_b3", "d3p", "d3h", "d3", "wgrad_d3p", "wgrad_d3h", "wgrad_d3")
+        for k in SPLIT:
+            if k in groups and dom not in SPLIT and groups[k][1] >= 0.5 * groups[dom][1]:
                 dom = k
                 break
         fl, sec, n = groups[dom]
@@ -448,6 +449,9 @@ def main():
                  "wgrad_h2": "igemm_h2t_kernel (conv2d backward-weight of the large layers, f16x2 split precision, incl. slab reduction)",
                  "wgrad_d3h": "dwgrad3_h2_kernel (direct 3x3 conv2d backward-weight of the HRNet trunk, f16x2 split precision, incl. slab reduction)",
                  "wgrad_d3": "dwgrad3_b3_kernel (direct 3x3 conv2d backward-weight of the HRNet trunk, bf16x3 split precision, incl. slab reduction)",
+                 "d3p": "dconv3_pl_kernel (direct 3x3 conv2d forward and backward-data of the HRNet trunk on PRODUCER-WRITTEN fp16 x 2 planes: halo tiles "
+                        "and weights stream into LDS by LDS-DMA from helper waves, three MFMA products)",
+                 "wgrad_d3p": "dwgrad3_pl_kernel (direct 3x3 conv2d backward-weight of the HRNet trunk on producer-written planes of x and dy, incl. slab reduction)",
                  "d3h": "dconv3_h2_kernel (direct 3x3 conv2d forward and backward-data of the HRNet trunk, f16x2 split precision: the fp32 halo "
                         "tile scaled by its producer's amax record and split into two fp16 planes in registers, three MFMA products)",
                  "d3": "dconv3_b3_kernel (direct 3x3 conv2d forward and backward-data of the HRNet trunk, bf16x3 split precision, "
@@ -476,9 +480,9 @@ def main():
         lb_ms = (sum(v[0] / (peak_of(k) * 1e12) for k, v in mm.items())
                  + sum(v[0] for k, v in agg.items() if k.startswith("hbm:")) / 8e12) / 2 * 1e3
         roof["whole_step"] = {"lower_bound_ms": lb_ms, "measured_ms": dt / args.steps * 1e3, "frac": lb_ms / (dt / args.steps * 1e3),
-                              "f16x2_tflop_per_step": sum(v[0] for k, v in mm.items() if k.endswith(("_h2", "_d3h"))) / 2 / 1e12,
+                              "f16x2_tflop_per_step": sum(v[0] for k, v in mm.items() if k.endswith(("_h2", "_d3h", "_d3p"))) / 2 / 1e12,
                               "bf16x3_tflop_per_step": sum(v[0] for k, v in mm.items() if k.endswith(("_b3", "_d3"))) / 2 / 1e12,
-                              "fp32_tflop_per_step": sum(v[0] for k, v in mm.items() if not k.endswith(("_b3", "_d3", "_h2", "_d3h"))) / 2 / 1e12}
+                              "fp32_tflop_per_step": sum(v[0] for k, v in mm.items() if not k.endswith(("_b3", "_d3", "_h2", "_d3h", "_d3p"))) / 2 / 1e12}
     comm = None
     if world > 1:
         comm = model._grad_sync.stats()          # every rank (it synchronises its device); rank 0 prints

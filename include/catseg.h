@@ -235,6 +235,31 @@ int catseg_dconv3_pl_bnbwd(int B, int H, int W, int C, const void* dy_planes, co
                            float* g, int ldg, const float* q, int ldq, const float* stats, const float* gamma, const float* beta, float* part,
                            size_t part_floats, void* out_record, catseg_stream_t stream);
 
+/* PRODUCERS of planes: the kernels that write a trunk activation / gradient write its planes in the same pass (csrc/norm.hip,
+ * csrc/pointwise.hip).  The exponent is fixed BEFORE the pass from a bound of max| |:
+ *   catseg_bn_finalize_counts_bound: catseg_bn_finalize_counts, and z_record[2] = max_c |scale_c| (max|y| + |mean_c|) + |beta_c| (max|y| from
+ *                                    y_record, the record catseg_dconv3_pl's epilogue filled)                  [nn.BatchNorm2d training forward]
+ *   catseg_bn_apply_planes:          catseg_bn_apply writing planes (+ z itself when z != NULL); exponent from z_record's bound + max|residual|
+ *   catseg_add_n_act_planes:         catseg_add_n_act writing out and its planes; exponent from the sum of the terms' max| |  [HRNet fuse sum]
+ *   catseg_bn_backward_planes / _pre_planes: catseg_bn_backward / catseg_bn_backward_pre with dy as planes ONLY; bound
+ *                                    |gamma invstd| (max|g| + |mean g| + max|xhat| |mean g xhat|) per channel       [autograd of BatchNorm2d] */
+int catseg_bn_finalize_counts_bound(const float* partials, int n_blocks, const int* counts, long long rows, int C, const float* gamma,
+                                    const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* stats_out,
+                                    float* scale, const void* y_record, void* z_record, catseg_stream_t stream);
+int catseg_bn_apply_planes(const float* y, int ldy, const float* mean, const float* scale, const float* beta, const float* residual, int ldr,
+                           const void* residual_record, float* z, int ldz, void* z_planes, long long rows, int C, int relu, void* z_record,
+                           catseg_stream_t stream);
+int catseg_add_n_act_planes(const float* const* in, const int* ld, const void* const* term_records, int n, float* out, int ldo, void* out_planes,
+                            long long rows, int C, int relu, void* out_record, catseg_stream_t stream);
+int catseg_bn_backward_planes(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* stats, const float* gamma,
+                              const float* beta, long long rows, int C, int relu, void* dy_planes, void* dy_record, void* g_record,
+                              const void* y_record, float* dgamma, float* dbeta, float* dres, int lddres, int dres_accumulate, void* workspace,
+                              size_t workspace_bytes, catseg_stream_t stream);
+int catseg_bn_backward_pre_planes(const float* g, int ldg, const float* q, int ldq, const float* stats, const float* gamma, const float* partials,
+                                  int n_blocks, long long rows, int C, void* dq_planes, void* dq_record, const void* g_record,
+                                  const void* y_record, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                  catseg_stream_t stream);
+
 /* catseg_dwgrad3_f16x2 on producer-written planes of BOTH operands (csrc/dwgrad3_pl.hip): dw[o][ky][kx][c] = sum_px dy[px][o] x[px + tap][c]
  * for the trunk widths 48 / 96 / 192 / 384 (autograd of F.conv2d, models/HRNetv2.py:22-65); workspace = catseg_dwgrad3_pl_workspace bytes
  * (slabs of partial sums, added in a fixed order: deterministic) */

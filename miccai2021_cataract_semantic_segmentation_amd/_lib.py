@@ -61,6 +61,11 @@ _SIGS = {
     "catseg_dwgrad3_pl_supported": (I, [I]),
     "catseg_dwgrad3_pl_workspace": (SZ, [I, I, I, I]),
     "catseg_dwgrad3_pl": (I, [I, I, I, I, P, P, P, P, P, P, SZ, P]),
+    "catseg_bn_finalize_counts_bound": (I, [P, I, P, L, I, P, P, F, F, P, P, P, P, P, P, P]),
+    "catseg_bn_apply_planes": (I, [P, I, P, P, P, P, I, P, P, I, P, L, I, I, P, P]),
+    "catseg_add_n_act_planes": (I, [P, P, P, I, P, I, P, L, I, I, P, P]),
+    "catseg_bn_backward_planes": (I, [P, I, P, I, P, I, P, P, P, L, I, I, P, P, P, P, P, P, P, I, I, P, SZ, P]),
+    "catseg_bn_backward_pre_planes": (I, [P, I, P, I, P, P, P, I, L, I, P, P, P, P, P, P, P, SZ, P]),
     "catseg_bn_apply_amax": (I, [P, I, P, P, P, P, I, P, I, L, I, I, P, P]),
     "catseg_bn_backward_amax": (I, [P, I, P, I, P, I, P, P, P, L, I, I, P, I, P, P, P, I, I, P, SZ, P, P]),
     "catseg_bn_backward_pre_amax": (I, [P, I, P, I, P, P, P, I, L, I, P, I, P, P, P, SZ, P, P]),

@@ -536,19 +536,17 @@ __global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __res
   const int e = cs_plane_exponent(bound);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     ((int*)rec)[CS_REC_EXP] = e;
-    rec[CS_REC_BOUND] = bound;
+    rec[CS_REC_FINAL] = bound;
   }
   const float sc = __builtin_ldexpf(1.f, e);
   const int NG = C >> 3, gblocks = (NG + 7) >> 3;
-  const long long rblocks = (rows + 63) >> 6;
-  const int g = threadIdx.x & 7, rl = threadIdx.x >> 3;          // 8 channel groups x 32 rows per pass
+  const long long rblocks = (rows + CsPlaneTile::ROWS - 1) / CsPlaneTile::ROWS;          // 8 channel groups x 32 rows per pass
   for (long long t = blockIdx.x; t < rblocks * gblocks; t += gridDim.x) {
-    const long long row0 = (t / gblocks) << 6;
-    const int g0 = (int)(t % gblocks) << 3;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int row = rl + 32 * half;
-      if (row0 + row < rows && g0 + g < NG) {
+    const long long row0 = (t / gblocks) * CsPlaneTile::ROWS;
+    const int g0 = (int)(t % gblocks) << 3, ng = NG - g0 < 8 ? NG - g0 : 8;
+    for (int i = threadIdx.x; i < CsPlaneTile::ROWS * ng; i += 256) {
+      const int row = i / ng, g = i - row * ng;
+      if (row0 + row < rows) {
         const float* src = x + (row0 + row) * ld + (g0 + g) * 8;
         const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
         const float xs[8] = {v0[0] * sc, v0[1] * sc, v0[2] * sc, v0[3] * sc, v1[0] * sc, v1[1] * sc, v1[2] * sc, v1[3] * sc};
@@ -557,7 +555,7 @@ __global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __res
     }
     __syncthreads();
     const long long left = rows - row0;
-    CsPlaneTile::flush(sm, planes, rows, NG, row0, left < 64 ? (int)left : 64, g0, NG - g0 < 8 ? NG - g0 : 8);
+    CsPlaneTile::flush(sm, planes, rows, NG, row0, left < CsPlaneTile::ROWS ? (int)left : CsPlaneTile::ROWS, g0, ng);
     __syncthreads();
   }
 }
@@ -662,7 +660,7 @@ extern "C" int catseg_planes_from_f32(const float* x, int ld, long long rows, in
     long long blocks = (rows * (C / 4) + 255) / 256;
     hipLaunchKernelGGL(amax_f32_kernel, dim3((int)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, x, ld, rows, C, (unsigned*)record);
   }
-  const long long tiles = ((rows + 63) / 64) * ((C / 8 + 7) / 8);
+  const long long tiles = ((rows + 127) / 128) * ((C / 8 + 7) / 8);
   hipLaunchKernelGGL(planes_from_f32_kernel, dim3((int)(tiles > 4096 ? 4096 : tiles)), dim3(256), 0, st, x, ld, rows, C, (unsigned*)record,
                      (unsigned char*)planes);
   CS_LAUNCH_CHECK();

@@ -2,7 +2,7 @@
 // forward and backward, on NHWC fp32 activations.  HBM-bound: every pass streams the
 // activation once with 16-byte accesses; per-channel reductions are two-level
 // (per-block shifted sums -> fp64 Chan merge), deterministic (no atomics).
-#include "common.h"
+#include "planes.h"
 
 namespace {
 
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nrb, long long rpb, long long rows, int C,
                                                            const float* __restrict__ gamma, float eps, float momentum, float* running_mean,
                                                            float* running_var, float* __restrict__ stats, float* __restrict__ scale,
-                                                           const int* __restrict__ counts) {
+                                                           const int* __restrict__ counts, const unsigned* __restrict__ y_rec = nullptr,
+                                                           unsigned* __restrict__ z_rec = nullptr, const float* __restrict__ beta = nullptr) {
   const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
   const int c = blockIdx.x * 4 + cl;
   const bool live = c < C;
@@ -146,6 +147,15 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   stats[c] = (float)mean;
   stats[C + c] = invstd;
   scale[c] = gamma[c] * invstd;
+  if (z_rec) {
+    // bound of the normalised output of this channel, BEFORE the pass that computes it: |fma(y - mean, scale, beta)| <= |scale| (max|y| +
+    // |mean|) + |beta|, with max|y| from the convolution's epilogue (csrc/dconv3_pl.hip).  The maximum over the channels (positive floats
+    // order like their bit patterns) is what catseg_bn_apply_planes derives the planes' exponent from (csrc/planes.h).
+    unsigned ym = 0;
+    for (int i = 0; i < CS_AMAX_SLOTS; ++i) ym = max(ym, y_rec[i * CS_AMAX_STRIDE]);
+    const float bound = (fabsf(gamma[c] * invstd) * (__uint_as_float(ym) + fabsf((float)mean)) + fabsf(beta[c])) * 1.001f;
+    atomicMax(z_rec + CS_REC_BOUND, __float_as_uint(bound));
+  }
   if (running_mean) {
     const float unb = (float)(m2 / (n > 1 ? n - 1 : 1));
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
@@ -189,12 +199,68 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   if (amax) cs_amax_commit(m, amax);       // (uniform per launch: the shuffles run with every lane)
 }
 
+// The same pass writing the fp16 x 2 operand planes of z (csrc/planes.h) -- and z itself only if someone reads it as fp32 (zf != nullptr:
+// the residual branch of the next block, the HRNet fuse layers; the first convolution's output inside a BasicBlock has one consumer, the
+// direct 3x3 kernel, and exists as planes only).  Tiles of 64 rows x 64 channels per block iteration; the exponent comes from the bound
+// bn_finalize_kernel left in the record (+ max|residual| from the residual's own record).
+__global__ __launch_bounds__(256) void bn_apply_planes_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ mean,
+                                                              const float* __restrict__ scale, const float* __restrict__ beta,
+                                                              const float* __restrict__ res, int ldr, const unsigned* __restrict__ res_rec,
+                                                              float* __restrict__ zf, int ldz, unsigned char* __restrict__ planes,
+                                                              long long rows, int C, int relu, unsigned* __restrict__ rec) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[CsPlaneTile::BYTES];
+  float bound = __uint_as_float(rec[CS_REC_BOUND]);
+  if (res) bound += __uint_as_float(cs_amax_read(res_rec));
+  const int e = cs_plane_exponent(__float_as_uint(bound));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ((int*)rec)[CS_REC_EXP] = e;
+    rec[CS_REC_FINAL] = __float_as_uint(bound);
+  }
+  const float sc = __builtin_ldexpf(1.f, e);
+  const int NG = C >> 3, gblocks = (NG + 7) >> 3;
+  const long long rblocks = (rows + CsPlaneTile::ROWS - 1) / CsPlaneTile::ROWS;
+  unsigned m = 0;
+  for (long long t = blockIdx.x; t < rblocks * gblocks; t += gridDim.x) {
+    const long long row0 = (t / gblocks) * CsPlaneTile::ROWS;
+    const int g0 = (int)(t % gblocks) << 3, ng = NG - g0 < 8 ? NG - g0 : 8;
+    for (int i = threadIdx.x; i < CsPlaneTile::ROWS * ng; i += 256) {
+      const int row = i / ng, g = i - row * ng;
+      if (row0 + row < rows) {
+        const long long r = row0 + row;
+        const int c = (g0 + g) * 8;
+        f32x4 v0 = bn_affine(ld4(y + r * ldy + c), ld4(mean + c), ld4(scale + c), ld4(beta + c));
+        f32x4 v1 = bn_affine(ld4(y + r * ldy + c + 4), ld4(mean + c + 4), ld4(scale + c + 4), ld4(beta + c + 4));
+        if (res) {
+          v0 += ld4(res + r * ldr + c);
+          v1 += ld4(res + r * ldr + c + 4);
+        }
+        if (relu) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
+        }
+        if (zf) {
+          *(f32x4*)(zf + r * ldz + c) = v0;
+          *(f32x4*)(zf + r * ldz + c + 4) = v1;
+        }
+        m = max(m, max(cs_abs_bits4(v0), cs_abs_bits4(v1)));
+        const float xs[8] = {v0[0] * sc, v0[1] * sc, v0[2] * sc, v0[3] * sc, v1[0] * sc, v1[1] * sc, v1[2] * sc, v1[3] * sc};
+        CsPlaneTile::stage(sm, row, g, xs);
+      }
+    }
+    __syncthreads();
+    const long long left = rows - row0;
+    CsPlaneTile::flush(sm, planes, rows, NG, row0, left < CsPlaneTile::ROWS ? (int)left : CsPlaneTile::ROWS, g0, ng);
+    __syncthreads();
+  }
+  cs_amax_commit(m, rec);      // max|z| as it turned out (the next layer's bound adds it when z is its residual)
+}
+
 // backward partials: sg = sum g, sgx = sum g * xhat
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z,
                                                              int ldz, const float* __restrict__ y, int ldy,
                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, long long rows, int C, int relu,
-                                                             RowSplit s, float* __restrict__ part) {
+                                                             RowSplit s, float* __restrict__ part, unsigned* __restrict__ gmax_rec = nullptr) {
   const int t = threadIdx.x;
   const int cg = blockIdx.y * s.tpr + t % s.tpr;
   const int rl = t / s.tpr;
@@ -203,6 +269,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   const long long r1 = min(r0 + s.rpb, rows);
   const bool act = (c < C) && (rl < s.rpp);
   f32x4 sg = {0, 0, 0, 0}, sgx = {0, 0, 0, 0};
+  unsigned gm = 0;
   if (act) {
     const f32x4 mean = ld4(stats + c), inv = ld4(stats + C + c);
     f32x4 sc = {0, 0, 0, 0}, be = {0, 0, 0, 0};
@@ -229,6 +296,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         const f32x4 xh = (yy[u] - mean) * inv;
         sg += g[u];
         sgx += g[u] * xh;
+        gm = max(gm, cs_abs_bits4(g[u]));
       }
     }
     for (; r < r1; r += st) {
@@ -242,6 +310,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
       const f32x4 xh = (yy - mean) * inv;
       sg += g;
       sgx += g * xh;
+      gm = max(gm, cs_abs_bits4(g));
     }
   }
   __shared__ f32x4 sh1[256], sh2[256];
@@ -257,12 +326,16 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     *(f32x4*)(o + c) = sg;
     *(f32x4*)(o + C + c) = sgx;
   }
+  if (gmax_rec) cs_amax_commit(gm, gmax_rec);     // max |masked gradient|: the bound of the output's planes needs it (bn_bwd_finalize_kernel)
 }
 
 // 16 channels x 64 row lanes per block: up to 2040 partial rows (one per pixel tile of the direct kernels) are ~8 loads deep per
 // thread (with 64 channels x 16 row lanes they were 32 deep: a latency chain of ~10 us on 1 - 6 blocks); fixed summation order
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nrb, long long rows, int C,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
+                                                               const unsigned* __restrict__ gmax_rec = nullptr,
+                                                               const unsigned* __restrict__ y_rec = nullptr, const float* __restrict__ stats = nullptr,
+                                                               const float* __restrict__ gamma = nullptr, unsigned* __restrict__ dy_rec = nullptr) {
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   double sg = 0, sgx = 0;
@@ -282,6 +355,73 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   if (dgamma) dgamma[c] = (float)sgx;
   coef[c] = (float)(sg / (double)rows);
   coef[C + c] = (float)(sgx / (double)rows);
+  if (dy_rec) {
+    // bound of dy = gamma invstd (g - mean(g) - xhat mean(g xhat)) for this channel, before the pass that computes it:
+    //   |dy| <= |gamma invstd| (max|g| + |mean(g)| + max|xhat| |mean(g xhat)|),   max|xhat| <= (max|y| + |mean|) invstd
+    unsigned gm = 0, ym = 0;
+    for (int i = 0; i < CS_AMAX_SLOTS; ++i) {
+      gm = max(gm, gmax_rec[i * CS_AMAX_STRIDE]);
+      ym = max(ym, y_rec[i * CS_AMAX_STRIDE]);
+    }
+    const float inv = stats[C + c], xh = (__uint_as_float(ym) + fabsf(stats[c])) * inv;
+    const float bound = fabsf(gamma[c] * inv) * (__uint_as_float(gm) + fabsf(coef[c]) + xh * fabsf(coef[C + c])) * 1.001f;
+    atomicMax(dy_rec + CS_REC_BOUND, __float_as_uint(bound));
+  }
+}
+
+// bn_bwd_apply_kernel writing dy as fp16 x 2 planes ONLY (csrc/planes.h): its two consumers -- backward-data and backward-weight of the
+// convolution in front of this BatchNorm, csrc/dconv3_pl.hip / dwgrad3_pl.hip -- stream planes.  The residual gradient stays fp32.
+__global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz,
+                                                                  const float* __restrict__ y, int ldy, const float* __restrict__ stats,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const float* __restrict__ coef, long long rows, int C, int relu,
+                                                                  unsigned char* __restrict__ planes, unsigned* __restrict__ rec,
+                                                                  float* __restrict__ dres, int lddres, int dres_acc) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[CsPlaneTile::BYTES];
+  const int e = cs_plane_exponent(rec[CS_REC_BOUND]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ((int*)rec)[CS_REC_EXP] = e;
+    rec[CS_REC_FINAL] = rec[CS_REC_BOUND];
+  }
+  const float sc = __builtin_ldexpf(1.f, e);
+  const int NG = C >> 3, gblocks = (NG + 7) >> 3;
+  const long long rblocks = (rows + CsPlaneTile::ROWS - 1) / CsPlaneTile::ROWS;
+  for (long long t = blockIdx.x; t < rblocks * gblocks; t += gridDim.x) {
+    const long long row0 = (t / gblocks) * CsPlaneTile::ROWS;
+    const int g0 = (int)(t % gblocks) << 3, ng = NG - g0 < 8 ? NG - g0 : 8;
+    for (int i = threadIdx.x; i < CsPlaneTile::ROWS * ng; i += 256) {
+      const int row = i / ng, g8 = i - row * ng;
+      if (row0 + row < rows) {
+        const long long r = row0 + row;
+        float xs[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int c = (g0 + g8) * 8 + 4 * q;
+          f32x4 g = ld4(dz + r * lddz + c);
+          const f32x4 inv = ld4(stats + C + c), mean = ld4(stats + c);
+          const f32x4 yy = ld4(y + r * ldy + c);
+          if (relu) {
+            const f32x4 zz = z ? ld4(z + r * ldz + c) : bn_affine(yy, mean, ld4(gamma + c) * inv, ld4(beta + c));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
+          }
+          const f32x4 xh = (yy - mean) * inv;
+          const f32x4 o = ld4(gamma + c) * inv * (g - ld4(coef + c) - xh * ld4(coef + C + c));     // = bn_bwd_apply_kernel's expression
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xs[4 * q + k] = o[k] * sc;
+          if (dres) {
+            f32x4* d = (f32x4*)(dres + r * lddres + c);
+            *d = dres_acc ? (*d + g) : g;
+          }
+        }
+        CsPlaneTile::stage(sm, row, g8, xs);
+      }
+    }
+    __syncthreads();
+    const long long left = rows - row0;
+    CsPlaneTile::flush(sm, planes, rows, NG, row0, left < CsPlaneTile::ROWS ? (int)left : CsPlaneTile::ROWS, g0, ng);
+    __syncthreads();
+  }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z,
@@ -496,6 +636,92 @@ extern "C" int catseg_bn_backward_pre_amax(const float* g, int ldg, const float*
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partials, n_blocks, rows, C, dgamma, dbeta, coef);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, st, g, ldg, (const float*)nullptr, 0, q, ldq, stats,
                      gamma, (const float*)nullptr, (const float*)coef, rows, C, 0, dq, lddq, (float*)nullptr, 0, 0, (unsigned*)amax_record);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+
+// ---- producers of fp16 x 2 operand planes (csrc/planes.h; round 4) ---------------------------------------------------------------------------
+// catseg_bn_finalize_counts + the bound of the normalised output: z_record[CS_REC_BOUND] = max over the channels of
+// |scale| (max|y| + |mean|) + |beta|, with max|y| from y_record (the amax slots catseg_dconv3_pl's epilogue filled)
+extern "C" int catseg_bn_finalize_counts_bound(const float* partials, int n_blocks, const int* counts, long long rows, int C, const float* gamma,
+                                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                               float* stats_out, float* scale, const void* y_record, void* z_record, catseg_stream_t stream) {
+  CS_REQUIRE(partials && counts && n_blocks > 0 && rows > 0 && C > 0 && beta && y_record && z_record, "bn finalize (bound): bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, (hipStream_t)stream, partials, n_blocks, (long long)1, rows, C,
+                     gamma, eps, momentum, running_mean, running_var, stats_out, scale, counts, (const unsigned*)y_record, (unsigned*)z_record, beta);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// catseg_bn_apply that writes the planes of z (z_planes, catseg_planes_bytes(rows, C)) with the exponent derived from z_record's bound
+// (+ max|residual| from residual_record), z itself only when z != NULL, and folds max|z| into z_record's amax slots
+extern "C" int catseg_bn_apply_planes(const float* y, int ldy, const float* mean, const float* scale, const float* beta, const float* residual,
+                                      int ldr, const void* residual_record, float* z, int ldz, void* z_planes, long long rows, int C, int relu,
+                                      void* z_record, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && ldy % 4 == 0 && (z == nullptr || ldz % 4 == 0) && (residual == nullptr || (ldr % 4 == 0 && residual_record)),
+             "bn apply (planes): C must be a multiple of 8, ld of 4; a residual needs its amax record");
+  CS_REQUIRE(cs_aligned16(y) && cs_aligned16(z) && cs_aligned16(mean) && cs_aligned16(scale) && cs_aligned16(beta) && cs_aligned16(residual) &&
+                 cs_aligned16(z_planes) && z_planes && z_record, "bn apply (planes): alignment");
+  const long long tiles = ((rows + 127) / 128) * ((C / 8 + 7) / 8);
+  hipLaunchKernelGGL(bn_apply_planes_kernel, dim3((int)(tiles > 8192 ? 8192 : tiles)), dim3(256), 0, (hipStream_t)stream, y, ldy, mean, scale, beta,
+                     residual, ldr, (const unsigned*)residual_record, z, ldz, (unsigned char*)z_planes, rows, C, relu, (unsigned*)z_record);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// catseg_bn_backward with dy written as planes ONLY.  g_record: a zeroed amax record, receives max|masked gradient| (first pass);
+// y_record: max|y| of the forward pass; dy_record: zeroed, receives the bound, the exponent and nothing else
+extern "C" int catseg_bn_backward_planes(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* stats,
+                                         const float* gamma, const float* beta, long long rows, int C, int relu, void* dy_planes, void* dy_record,
+                                         void* g_record, const void* y_record, float* dgamma, float* dbeta, float* dres, int lddres,
+                                         int dres_accumulate, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && dy_planes && dy_record && g_record && y_record,
+             "bn bwd (planes): C must be a multiple of 8, ld of 4; records required");
+  CS_REQUIRE(!relu || (z != nullptr && ldz % 4 == 0) || (z == nullptr && beta != nullptr && dres == nullptr),
+             "bn bwd (planes): relu needs z, or (no residual branch) beta to recompute the mask from y");
+  CS_REQUIRE(cs_aligned16(dz) && cs_aligned16(y) && cs_aligned16(dy_planes) && cs_aligned16(stats) && cs_aligned16(gamma) && cs_aligned16(z) &&
+                 cs_aligned16(dres), "bn bwd (planes): alignment");
+  if (workspace_bytes < catseg_bn_workspace(rows, C) || !workspace) {
+    catseg_set_error("bn bwd (planes): workspace too small");
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const RowSplit s = plan_rows(rows, C);
+  float* part = (float*)workspace;
+  float* coef = part + (size_t)kMaxRowBlocks * 3 * ((C + 3) & ~3);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma, beta, rows, C, relu, s, part,
+                     (unsigned*)g_record);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef,
+                     (const unsigned*)g_record, (const unsigned*)y_record, stats, gamma, (unsigned*)dy_record);
+  const long long tiles = ((rows + 127) / 128) * ((C / 8 + 7) / 8);
+  hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3((int)(tiles > 8192 ? 8192 : tiles)), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma,
+                     beta, (const float*)coef, rows, C, relu, (unsigned char*)dy_planes, (unsigned*)dy_record, dres, lddres, dres_accumulate);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// catseg_bn_backward_pre with dq written as planes only.  g_record: the amax record catseg_dconv3_pl_bnbwd filled with max|g|
+extern "C" int catseg_bn_backward_pre_planes(const float* g, int ldg, const float* q, int ldq, const float* stats, const float* gamma,
+                                             const float* partials, int n_blocks, long long rows, int C, void* dq_planes, void* dq_record,
+                                             const void* g_record, const void* y_record, float* dgamma, float* dbeta, void* workspace,
+                                             size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && ldg % 4 == 0 && ldq % 4 == 0 && n_blocks > 0 && partials && dq_planes && dq_record && g_record && y_record,
+             "bn bwd (pre, planes): bad args");
+  CS_REQUIRE(cs_aligned16(g) && cs_aligned16(q) && cs_aligned16(dq_planes) && cs_aligned16(stats) && cs_aligned16(gamma), "bn bwd (pre, planes): alignment");
+  const size_t need = cs_align_up((size_t)2 * ((C + 3) & ~3) * 4, 256);
+  if (workspace_bytes < need || !workspace) {
+    catseg_set_error("bn bwd (pre, planes): workspace too small");
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* coef = (float*)workspace;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partials, n_blocks, rows, C, dgamma, dbeta, coef,
+                     (const unsigned*)g_record, (const unsigned*)y_record, stats, gamma, (unsigned*)dq_record);
+  const long long tiles = ((rows + 127) / 128) * ((C / 8 + 7) / 8);
+  hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3((int)(tiles > 8192 ? 8192 : tiles)), dim3(256), 0, st, g, ldg, (const float*)nullptr, 0, q, ldq,
+                     stats, gamma, (const float*)nullptr, (const float*)coef, rows, C, 0, (unsigned char*)dq_planes, (unsigned*)dq_record,
+                     (float*)nullptr, 0, 0);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

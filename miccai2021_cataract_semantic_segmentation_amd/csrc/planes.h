@@ -14,12 +14,14 @@
 // overflow fp16 -- every bound used is a proven upper bound.
 //
 // Per-tensor record (uint32[CS_AMAX_WORDS], 2 KB, zeroed by the host): words 32 s (s = 0 .. 15) = bits of max|x| as the producer saw
-// it (cs_amax_commit), word 1 = e (int32) the planes were written with, word 2 = bits of the bound e was derived from.
+// it (cs_amax_commit), word 1 = e (int32) the planes were written with, word 2 = bits of the bound a finalize kernel left, word 3 = bits of
+// the bound e was finally derived from.
 #pragma once
 #include "common.h"
 
 #define CS_REC_EXP 1
-#define CS_REC_BOUND 2
+#define CS_REC_BOUND 2      /* what a finalize kernel leaves (atomicMax over the channels) BEFORE the producing pass reads it */
+#define CS_REC_FINAL 3      /* the bound the exponent was finally derived from (CS_REC_BOUND + max|residual| ...): written by the producing pass */
 
 // prescale exponent for a tensor whose max|x| is at most `bound` (bits of a non-negative float): bound * 2^e in [2^14, 2^15)
 __host__ __device__ inline int cs_plane_exponent(unsigned bound_bits) {
@@ -32,11 +34,14 @@ __host__ __device__ inline int cs_plane_exponent(unsigned bound_bits) {
 #ifdef __HIPCC__
 typedef _Float16 cs_h8 __attribute__((ext_vector_type(8)));
 
-// Block-level writer: a 256-thread block holds a tile of 64 rows x 64 channels (8 groups).  stage(): every thread hands in 8 consecutive
-// channels of one row (already scaled by 2^e); flush(): after a block barrier the tile leaves as 1 KB runs (64 rows x 16 B per wave
-// instruction).  LDS image [plane][group][65 rows][16 B] (the odd row count spreads the eight groups a quarter-wave writes over the banks).
+// Block-level writer: a 256-thread block holds a tile of 128 rows x up to 8 channel groups (64 channels).  The (row, group) items of a tile
+// are numbered row-major (item = row * ngroups + group): item i of a pass belongs to thread i % 256, so that the threads of a wave read
+// whole 32-byte groups of consecutive channels of consecutive rows (coalesced) and NO lane idles when the tensor has 6 groups (48
+// channels: 768 items = 3 full passes).  stage(): a thread hands in 8 consecutive channels of one row (already scaled by 2^e); flush(): after
+// a block barrier the tile leaves as 1 KB runs (64 rows x 16 B per wave instruction).  LDS image [plane][group][129 rows][16 B] (the odd
+// row count spreads the groups a quarter-wave writes over the banks).
 struct CsPlaneTile {
-  static constexpr int ROWS = 64, GROUPS = 8, GS = (ROWS + 1) * 16, PS = GROUPS * GS;
+  static constexpr int ROWS = 128, GROUPS = 8, GS = (ROWS + 1) * 16, PS = GROUPS * GS;
   static constexpr int BYTES = 2 * PS;
   __device__ static __forceinline__ void stage(unsigned char* sm, int row, int group, const float (&xs)[8]) {
     cs_h8 h, l;
@@ -53,10 +58,12 @@ struct CsPlaneTile {
   __device__ static __forceinline__ void flush(const unsigned char* sm, unsigned char* planes, long long P, int NG, long long row0, int nrows,
                                                int g0, int ngroups) {
     for (int i = threadIdx.x; i < 2 * GROUPS * ROWS; i += blockDim.x) {
-      const int row = i & (ROWS - 1), g = (i >> 6) & (GROUPS - 1), p = i >> 9;
+      const int row = i & (ROWS - 1), g = (i >> 7) & (GROUPS - 1), p = i >> 10;
       if (row < nrows && g < ngroups)
         *(cs_h8*)(planes + (((long long)p * NG + g0 + g) * P + row0 + row) * 16) = *(const cs_h8*)(sm + p * PS + g * GS + row * 16);
     }
   }
 };
+// tiles of a [rows][C] tensor and the (row, group) of item i of tile t: CS_PLANE_TILES / cs_plane_item
+__device__ __forceinline__ long long cs_plane_tiles(long long rows, int NG) { return ((rows + CsPlaneTile::ROWS - 1) / CsPlaneTile::ROWS) * ((NG + 7) >> 3); }
 #endif

@@ -1,7 +1,7 @@
 // HBM-bound companions of the convolutions: layout transforms, max-pool, bilinear resize,
 // global average pool and the two softmaxes of the OCR head.  All NHWC fp32, all
 // deterministic (backward passes are written as gathers, never atomics).
-#include "common.h"
+#include "planes.h"
 
 namespace {
 
@@ -79,6 +79,53 @@ __global__ void add_n_act_kernel(AddArgs a, float* __restrict__ out, int ldo, lo
     m = max(m, cs_abs_bits4(v));
   }
   if (amax) cs_amax_commit(m, amax);
+}
+// the same sum writing out AND its fp16 x 2 planes (csrc/planes.h): |sum| <= sum of the terms' max| | (their amax records), known before the pass
+struct AddRecs { const unsigned* rec[4]; };
+__global__ __launch_bounds__(256) void add_n_act_planes_kernel(AddArgs a, AddRecs rr, float* __restrict__ out, int ldo, unsigned char* __restrict__ planes,
+                                                               long long rows, int C, int relu, unsigned* __restrict__ rec) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[CsPlaneTile::BYTES];
+  float bound = 0.f;
+  for (int k = 0; k < a.n; ++k) bound += __uint_as_float(cs_amax_read(rr.rec[k]));
+  const int e = cs_plane_exponent(__float_as_uint(bound * 1.001f));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ((int*)rec)[CS_REC_EXP] = e;
+    rec[CS_REC_FINAL] = __float_as_uint(bound * 1.001f);
+  }
+  const float sc = __builtin_ldexpf(1.f, e);
+  const int NG = C >> 3, gblocks = (NG + 7) >> 3;
+  const long long rblocks = (rows + CsPlaneTile::ROWS - 1) / CsPlaneTile::ROWS;
+  unsigned m = 0;
+  for (long long t = blockIdx.x; t < rblocks * gblocks; t += gridDim.x) {
+    const long long row0 = (t / gblocks) * CsPlaneTile::ROWS;
+    const int g0 = (int)(t % gblocks) << 3, ng = NG - g0 < 8 ? NG - g0 : 8;
+    for (int i = threadIdx.x; i < CsPlaneTile::ROWS * ng; i += 256) {
+      const int row = i / ng, g = i - row * ng;
+      if (row0 + row < rows) {
+        const long long r = row0 + row;
+        const int c = (g0 + g) * 8;
+        f32x4 v0 = *(const f32x4*)(a.in[0] + r * a.ld[0] + c), v1 = *(const f32x4*)(a.in[0] + r * a.ld[0] + c + 4);
+        for (int k = 1; k < a.n; ++k) {
+          v0 += *(const f32x4*)(a.in[k] + r * a.ld[k] + c);
+          v1 += *(const f32x4*)(a.in[k] + r * a.ld[k] + c + 4);
+        }
+        if (relu) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
+        }
+        *(f32x4*)(out + r * ldo + c) = v0;
+        *(f32x4*)(out + r * ldo + c + 4) = v1;
+        m = max(m, max(cs_abs_bits4(v0), cs_abs_bits4(v1)));
+        const float xs[8] = {v0[0] * sc, v0[1] * sc, v0[2] * sc, v0[3] * sc, v1[0] * sc, v1[1] * sc, v1[2] * sc, v1[3] * sc};
+        CsPlaneTile::stage(sm, row, g, xs);
+      }
+    }
+    __syncthreads();
+    const long long left = rows - row0;
+    CsPlaneTile::flush(sm, planes, rows, NG, row0, left < CsPlaneTile::ROWS ? (int)left : CsPlaneTile::ROWS, g0, ng);
+    __syncthreads();
+  }
+  cs_amax_commit(m, rec);
 }
 // g = dz * (z > 0)
 __global__ void relu_bwd_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz, float* __restrict__ g, int ldg,
@@ -569,6 +616,27 @@ extern "C" int catseg_add_n_act_amax(const float* const* in, const int* ld, int 
   }
   hipLaunchKernelGGL(add_n_act_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, out, ldo, rows, C, relu,
                      (unsigned*)amax_record);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+// catseg_add_n_act_amax that also writes the planes of out (exponent from the SUM of the terms' amax records: term_records[i] = the amax
+// record of in[i], each the max over its 16 slots)
+extern "C" int catseg_add_n_act_planes(const float* const* in, const int* ld, const void* const* term_records, int n, float* out, int ldo,
+                                       void* out_planes, long long rows, int C, int relu, void* out_record, catseg_stream_t stream) {
+  CS_REQUIRE(n >= 1 && n <= 4 && rows > 0 && C > 0 && C % 8 == 0 && ldo % 4 == 0 && cs_aligned16(out) && cs_aligned16(out_planes) && out_planes &&
+                 out_record && term_records, "add_n (planes): bad args");
+  AddArgs a;
+  AddRecs rr;
+  a.n = n;
+  for (int i = 0; i < 4; ++i) {
+    a.in[i] = i < n ? in[i] : nullptr;
+    a.ld[i] = i < n ? ld[i] : 0;
+    rr.rec[i] = i < n ? (const unsigned*)term_records[i] : nullptr;
+    if (i < n) CS_REQUIRE(cs_aligned16(in[i]) && ld[i] % 4 == 0 && term_records[i], "add_n (planes): input %d misaligned / without a record", i);
+  }
+  const long long tiles = ((rows + 127) / 128) * ((C / 8 + 7) / 8);
+  hipLaunchKernelGGL(add_n_act_planes_kernel, dim3((int)(tiles > 8192 ? 8192 : tiles)), dim3(256), 0, (hipStream_t)stream, a, rr, out, ldo,
+                     (unsigned char*)out_planes, rows, C, relu, (unsigned*)out_record);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

@@ -313,7 +313,14 @@ TAPS = None   # diagnostic hook (tools/error_growth.py): a dict collects named i
 
 def tap(name, t):
     if TAPS is not None:
-        TAPS[name] = t.detach().permute(0, 3, 1, 2).contiguous().cpu()
+        if getattr(t, "_planes_only", False):       # (exists as fp16 x 2 planes only: h + l, rescaled)
+            pl = t._planes
+            B, H, W, C = pl.shape
+            hl = pl.buf.view(torch.float16).view(2, C // 8, B * H * W, 8).float()
+            v = (hl[0] + hl[1]).permute(1, 0, 2).reshape(B, H, W, C) * 2.0 ** (-int(pl.rec[1]))
+            TAPS[name] = v.permute(0, 3, 1, 2).contiguous().cpu()
+        else:
+            TAPS[name] = t.detach().permute(0, 3, 1, 2).contiguous().cpu()
     return t
 
 
@@ -321,12 +328,14 @@ FUSE_BN_STATS = True  # training forward: BatchNorm batch statistics from the co
 FUSE_EVAL_BN = True   # eval-mode forward: fold BatchNorm into the conv and fuse bias/residual/ReLU into its epilogue
 
 
-def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=True, private_in=False):
+def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=True, private_in=False, sole_conv_out=False):
     """conv -> BatchNorm (batch stats in training) -> (+residual) -> (ReLU).  x NHWC (or the raw
     NCHW image for the stem).  Returns z (NHWC).
     private_in: the caller states that x is the output of the preceding conv_bn_act (ReLU, no residual) and has NO other consumer
     (the first half of a BasicBlock).  The backward-data kernel of this layer may then run the first pass of that BatchNorm's
-    backward in its epilogue (ops.conv_bwd_data(bn_src=...))."""
+    backward in its epilogue (ops.conv_bwd_data(bn_src=...)).
+    sole_conv_out: the caller states that the OUTPUT of this layer feeds nothing but one conv_bn_act(private_in=True) (the same first half
+    of a BasicBlock, seen from the producer): on the planes route (ops.planes_ok) it then exists as fp16 x 2 planes only."""
     w = conv.weight
     Cout = w.shape[0]
     kh, kw = conv.kernel_size
@@ -342,6 +351,7 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
         x_in, wk = x, w.data
     bias = conv.bias.data if conv.bias is not None else None
     cx.claim(w, conv.bias, bn.weight, bn.bias)
+    zrec = yrec = None
     if not cx.train and not cx.record and FUSE_EVAL_BN:
         # inference fast path: eval-mode BatchNorm folded into the weights, bias + residual + ReLU applied in
         # the convolution epilogue — one kernel per layer, no separate normalisation pass over HBM
@@ -353,7 +363,15 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
         y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups, bn_stats=FUSE_BN_STATS, train=cx.record,
                          exact=conv.exact_operands)
         y, partials = y if FUSE_BN_STATS else (y, None)
-        if partials is not None:
+        # planes route: the convolution streamed planes and left max|y|; then the BatchNorm's output gets planes too (exponent from a bound)
+        yrec = getattr(y, "_yrec", None)
+        if (yrec is not None and partials is not None and out is None and ops.planes_ok(Cout, ops.rows_of(y))
+                and (residual is None or ops.amax_of(residual) is not None)):
+            zrec = ops.new_amax(y.device)
+        if zrec is not None:
+            stats, scale = ops.bn_finalize(partials, ops.rows_of(y), Cout, bn.weight.data, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                                           bound=(bn.bias.data, yrec, zrec))
+        elif partials is not None:
             stats, scale = ops.bn_finalize(partials, ops.rows_of(y), Cout, bn.weight.data, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
         else:
             stats, scale = ops.bn_train_stats(y, bn.weight.data, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
@@ -364,7 +382,8 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
         stats = None
         mean = bn.running_mean
         scale = ops.bn_eval_scale(bn.weight.data, bn.running_var, bn.eps)
-    z = ops.bn_apply(y, mean, scale, bn.bias.data, residual, relu, out=out)
+    z = ops.bn_apply(y, mean, scale, bn.bias.data, residual, relu, out=out, planes_rec=zrec,
+                     planes_only=zrec is not None and sole_conv_out and relu and residual is None)
     if cx.record:
         if not cx.train:
             raise NotImplementedError("backward through eval-mode BatchNorm is not on the training path")
@@ -381,6 +400,24 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
             dres, acc = (None, False)
             if residual is not None:
                 dres, acc = cx.dest(residual)
+            if yrec is not None and (pre is None or len(pre) == 3) and ops.planes_of(x_in) is not None and conv.bias is None:
+                # planes route: the gradient of the convolution's output exists as planes only; backward-weight and backward-data stream them
+                if pre is not None:
+                    dyp = ops.bn_backward_pre_planes(dz, y, stats, bn.weight.data, pre, yrec, cx.pgrad(bn.weight), cx.pgrad(bn.bias))
+                else:
+                    z_mask = z if (residual is not None or not relu) else None
+                    dyp = ops.bn_backward_planes(dz, z_mask, y, stats, bn.weight.data, relu, cx.pgrad(bn.weight), cx.pgrad(bn.bias), dres, acc,
+                                                 bn.bias.data, yrec)
+                del dz
+                ops.dwgrad3_pl(ops.planes_of(x_in), dyp, cx.pgrad(w))
+                if need_dx:
+                    dx, accx = cx.dest(x)
+                    src = cx.bn_src.get(id(x)) if (private_in and not accx) else None
+                    r = ops.conv_bwd_data_pl(dyp, w.data, dx, accumulate=accx, bn_src=src)
+                    if isinstance(r, tuple):
+                        cx.bn_pre[id(x)] = r[1]
+                cx.done(bn.weight, bn.bias, w, conv.bias)
+                return
             if pre is not None:
                 # dz is already masked and its per-tile sums exist (the consumer's backward-data epilogue): merge + apply only
                 dy = ops.bn_backward_pre(dz, y, stats, bn.weight.data, pre, cx.pgrad(bn.weight), cx.pgrad(bn.bias))

@@ -35,7 +35,7 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def run(self, cx, x):
-        o = conv_bn_act(cx, x, self.conv1, self.bn1)
+        o = conv_bn_act(cx, x, self.conv1, self.bn1, sole_conv_out=True)      # (o feeds conv2 and nothing else: private_in below)
         idt = x if self.downsample is None else conv_bn_act(cx, x, self.downsample[0], self.downsample[1], relu=False)
         return conv_bn_act(cx, o, self.conv2, self.bn2, relu=True, residual=idt, private_in=True)
 

@@ -237,6 +237,30 @@ def _trunk_h2():
     return TRUNK == "f16x2" and PRECISION == "bf16x3"
 
 
+# The trunk on PRODUCER-WRITTEN planes (round 4; csrc/planes.h, dconv3_pl.hip, dwgrad3_pl.hip): BatchNorm apply / the HRNet fuse sum / BatchNorm
+# backward write the fp16 x 2 operand planes of what they produce, the direct kernels stream them by LDS-DMA.  CATSEG_TRUNK_PLANES=0: the
+# round-3 route (fp32 tensors + amax records, split inside the convolution kernels).
+PLANES = _os.environ.get("CATSEG_TRUNK_PLANES", "1") != "0"
+
+
+def _trunk_planes():
+    return PLANES and _trunk_h2() and DCONV3
+
+
+# Widths that take the planes route.  Measured within one run on the HRNet-W48 step (tools/ab_planes.py, min / median of 4 rounds, ms): fp32
+# tensors + in-kernel split 118.9 / 128.9, planes for all four widths 118.4 / 118.6, planes for 96 / 192 / 384 only 117.1 / 117.5, planes for 48
+# only 120.8 / 121.0.  The 48-channel layers stay on the round-3 kernel: standalone the planes kernel is 5 us faster there too (47.8 against
+# 52.7 us), but it owns its CUs (eight waves of 128 registers per block, two blocks: every register of the SIMDs), whereas the uniform
+# four-wave kernel leaves room for the BatchNorm / reduction kernels of the other branch streams to run beside it.
+PLANES_WIDTHS = tuple(int(v) for v in _os.environ.get("CATSEG_PLANES_WIDTHS", "96,192,384").split(",") if v)
+
+
+def planes_ok(C, rows):
+    """a trunk tensor of C channels and `rows` pixels takes the planes route: both plane kernels support the width"""
+    return bool(_trunk_planes() and C in PLANES_WIDTHS and rows >= DCONV3_MIN_ROWS and lib.catseg_dconv3_pl_supported(C)
+                and lib.catseg_dwgrad3_pl_supported(C))
+
+
 AMAX_SCOPE_RECORDS = 1024
 AMAX_WORDS = 512        # int32 words per record (include/catseg.h: CATSEG_AMAX_RECORD_BYTES): 16 slots 128 bytes apart
 _amax_scope = None
@@ -299,6 +323,8 @@ def drop_amax(t):
     bit of headroom).  Without a record the consumer takes the three-plane bf16 kernel, which needs none."""
     if t is not None and getattr(t, "_amax", None) is not None:
         t._amax = None
+    if t is not None and getattr(t, "_planes", None) is not None:
+        t._planes = None           # (planes describe the old contents)
     return t
 
 
@@ -472,6 +498,18 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
         part = _bn_part_buffer(3 * ((rows + 63) // 64) * Cout, x.device)
         tr, nt = ctypes.c_int(0), ctypes.c_int(0)
     if not exact and not stem4 and zero_to == 0 and w_ptr_tensor.dim() == 4 and _d3_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
+        if bias is None and planes_ok(Cin, rows) and (planes_of(x) is not None or amax_of(x) is not None):
+            xp = planes_of(x)
+            if xp is None:      # a tensor whose producer wrote no planes (the first block behind a transition): one split pass, kept for backward
+                xp = planes_from_f32(x, rec=amax_of(x))
+                x._planes = xp
+            yrec = new_amax(x.device)
+            with _Timed("fwd_d3p", flops):
+                res = dconv3_pl(xp, dconv3_weight_image(w_ptr_tensor, h2=True), None, out=out, bn_stats=bn_stats, out_rec=yrec)
+            (res[0] if bn_stats else res)._yrec = yrec
+            return res
+        if getattr(x, "_planes_only", False):
+            raise RuntimeError("a planes-only activation reached a convolution that does not stream planes")
         rec = amax_of(x) if _trunk_h2() else None
         wimg = dconv3_weight_image(w_ptr_tensor, h2=rec is not None)
         with _Timed("fwd_d3h" if rec is not None else "fwd_d3", flops):
@@ -517,11 +555,17 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
     return out
 
 
-def bn_finalize(partials, rows, C, gamma, eps, momentum, running_mean, running_var):
-    """batch statistics from the convolution epilogue's per-tile partials: (stats [mean(C), invstd(C)], scale)"""
+def bn_finalize(partials, rows, C, gamma, eps, momentum, running_mean, running_var, bound=None):
+    """batch statistics from the convolution epilogue's per-tile partials: (stats [mean(C), invstd(C)], scale).
+    bound = (beta, y_record, z_record): also leaves the bound of the normalised output in z_record (csrc/norm.hip: the exponent of z's planes)"""
     part, n_tiles, tile_rows = partials[:3]
     stats = torch.empty(2 * C, dtype=torch.float32, device=part.device)
     scale = torch.empty(C, dtype=torch.float32, device=part.device)
+    if bound is not None:
+        beta, yrec, zrec = bound
+        check(lib.catseg_bn_finalize_counts_bound(ptr(part), n_tiles, ptr(partials[3]), rows, C, ptr(gamma), ptr(beta), eps, momentum,
+                                                  ptr(running_mean), ptr(running_var), ptr(stats), ptr(scale), ptr(yrec), ptr(zrec), stream()))
+        return stats, scale
     if len(partials) > 3:       # tiles with individual pixel counts (the direct 3x3 kernel's 2-D tiles)
         check(lib.catseg_bn_finalize_counts(ptr(part), n_tiles, ptr(partials[3]), rows, C, ptr(gamma), eps, momentum, ptr(running_mean),
                                             ptr(running_var), ptr(stats), ptr(scale), stream()))
@@ -676,12 +720,77 @@ def bn_eval_scale(gamma, running_var, eps):
     return scale
 
 
-def bn_apply(y, mean, scale, beta, residual, relu, out=None):
-    """the output carries an amax record (out._amax: max|out| accumulated by the kernel) when the trunk runs the f16x2 kernels"""
+def bn_apply(y, mean, scale, beta, residual, relu, out=None, planes_rec=None, planes_only=False):
+    """the output carries an amax record (out._amax: max|out| accumulated by the kernel) when the trunk runs the f16x2 kernels.
+    planes_rec (the record bn_finalize(bound=...) left the bound in): the kernel also writes the fp16 x 2 planes of the output (out._planes);
+    planes_only: and NOT the fp32 output -- `out` is then an unwritten placeholder that only plane-streaming kernels may consume"""
     if out is None:
         out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    if planes_rec is not None:
+        buf = torch.empty(lib.catseg_planes_bytes(rows_of(y), y.shape[-1]), dtype=torch.uint8, device=y.device)
+        # algorithmic bytes: y (+ residual) read, planes written (4 B / element, like fp32), z written unless planes only
+        with _Timed("hbm:bn_apply", 4.0 * y.numel() * ((3 if residual is not None else 2) + (0 if planes_only else 1))):
+            check(lib.catseg_bn_apply_planes(ptr(y), ld_of(y), ptr(mean), ptr(scale), ptr(beta), ptr(residual),
+                                             ld_of(residual) if residual is not None else 0, ptr(amax_of(residual)) if residual is not None else None,
+                                             None if planes_only else ptr(out), ld_of(out), ptr(buf), rows_of(y), y.shape[-1], 1 if relu else 0,
+                                             ptr(planes_rec), stream()))
+        out._amax = planes_rec
+        out._planes = Planes(buf, planes_rec, y.shape)
+        out._planes_only = bool(planes_only)
+        return out
     with _Timed("hbm:bn_apply", 4.0 * y.numel() * (3 if residual is not None else 2)):
         _bn_apply(y, mean, scale, beta, residual, relu, out)
+    return out
+
+
+def bn_backward_planes(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres, dres_accumulate, beta, y_rec):
+    """bn_backward whose result exists as planes only (returned: Planes); y_rec: the forward convolution's max|y| record"""
+    C = y.shape[-1]
+    rows = rows_of(y)
+    ws = workspace(lib.catseg_bn_workspace(rows, C), y.device)
+    buf = torch.empty(lib.catseg_planes_bytes(rows, C), dtype=torch.uint8, device=y.device)
+    rec, grec = new_amax(y.device), new_amax(y.device)
+    with _Timed("hbm:bn_backward", 4.0 * y.numel() * (5 + (1 if dres is not None else 0))):
+        check(lib.catseg_bn_backward_planes(ptr(dz), ld_of(dz), ptr(z), ld_of(z) if z is not None else 0, ptr(y), ld_of(y), ptr(stats), ptr(gamma),
+                                            ptr(beta), rows, C, 1 if relu else 0, ptr(buf), ptr(rec), ptr(grec), ptr(y_rec), ptr(dgamma), ptr(dbeta),
+                                            ptr(dres), ld_of(dres) if dres is not None else 0, 1 if dres_accumulate else 0, ptr(ws), ws.numel(),
+                                            stream()))
+    return Planes(buf, rec, y.shape)
+
+
+def bn_backward_pre_planes(g, q, stats, gamma, pre, y_rec, dgamma, dbeta):
+    """bn_backward_pre (g already masked, its per-wave sums and max|g| from catseg_dconv3_pl_bnbwd: pre = (partials, rows, g_record)) whose
+    result exists as planes only"""
+    C = q.shape[-1]
+    rows = rows_of(q)
+    part, nr, grec = pre
+    ws = workspace(lib.catseg_bn_workspace(rows, C), q.device)
+    buf = torch.empty(lib.catseg_planes_bytes(rows, C), dtype=torch.uint8, device=q.device)
+    rec = new_amax(q.device)
+    with _Timed("hbm:bn_backward", 4.0 * q.numel() * 3):
+        check(lib.catseg_bn_backward_pre_planes(ptr(g), ld_of(g), ptr(q), ld_of(q), ptr(stats), ptr(gamma), ptr(part), nr, rows, C, ptr(buf), ptr(rec),
+                                                ptr(grec), ptr(y_rec), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), stream()))
+    return Planes(buf, rec, q.shape)
+
+
+def conv_bwd_data_pl(dyp, w, out, accumulate=False, bn_src=None):
+    """backward-data of a trunk 3x3 convolution from the planes of dy; bn_src as in conv_bwd_data: then returns
+    (g, (partials, rows, g_record)) for bn_backward_pre(_planes)"""
+    B, H, W, C = dyp.shape
+    wimg = dconv3_weight_image(w, backward_data=True, h2=True)
+    flops = 2.0 * B * H * W * C * C * 9
+    drop_amax(out)
+    if bn_src is not None and BN_BWD_FUSE and not accumulate:
+        q, stats, gamma, beta = bn_src
+        nr = lib.catseg_dconv3_pl_rows(C, B, H, W)
+        part = torch.empty(2 * nr * C, dtype=torch.float32, device=out.device)
+        grec = new_amax(out.device)
+        with _Timed("dgrad_d3p", flops):
+            check(lib.catseg_dconv3_pl_bnbwd(B, H, W, C, ptr(dyp.buf), ptr(dyp.rec), ptr(wimg[0]), ptr(wimg[1]), ptr(out), ld_of(out), ptr(q), ld_of(q),
+                                             ptr(stats), ptr(gamma), ptr(beta), ptr(part), part.numel(), ptr(grec), stream()))
+        return out, (part, nr, grec)
+    with _Timed("dgrad_d3p", flops):
+        dconv3_pl(dyp, wimg, None, out=out, accumulate=accumulate)
     return out
 
 
@@ -713,7 +822,7 @@ def bn_backward_pre(g, q, stats, gamma, partials, dgamma, dbeta, dq_out=None):
     returned: merge + apply pass only"""
     C = q.shape[-1]
     rows = rows_of(q)
-    part, nt = partials
+    part, nt = partials[:2]
     if dq_out is None:
         dq_out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
     ws = workspace(lib.catseg_bn_workspace(rows, C), q.device)
@@ -793,6 +902,10 @@ def bilinear_fwd(x, Ho, Wo, align_corners, out=None, accumulate=False):
     with _Timed("hbm:bilinear_fwd", 4.0 * (x.numel() + out.numel() * (2 if accumulate else 1))):
         check(lib.catseg_bilinear_fwd(ptr(x), ld_of(x), ptr(out), ld_of(out), B, H, W, C, Ho, Wo, 1 if align_corners else 0,
                                       1 if accumulate else 0, stream()))
+    if accumulate:
+        drop_amax(out)
+    elif amax_of(x) is not None:
+        out._amax = amax_of(x)       # an interpolation with weights in [0, 1] that sum to 1: max|out| <= max|x| (the fuse sum's bound adds it)
     return out
 
 
@@ -957,6 +1070,15 @@ def add_n_act(terms, relu, out=None):
     n = len(terms)
     ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in terms])
     lds = (ctypes.c_int * n)(*[ld_of(t) for t in terms])
+    if planes_ok(t0.shape[-1], rows_of(t0)) and all(amax_of(t) is not None for t in terms):
+        rec = new_amax(t0.device)
+        recs = (ctypes.c_void_p * n)(*[amax_of(t).data_ptr() for t in terms])
+        buf = torch.empty(lib.catseg_planes_bytes(rows_of(t0), t0.shape[-1]), dtype=torch.uint8, device=t0.device)
+        check(lib.catseg_add_n_act_planes(ptrs, lds, recs, n, ptr(out), ld_of(out), ptr(buf), rows_of(t0), t0.shape[-1], 1 if relu else 0, ptr(rec),
+                                          stream()))
+        out._amax = rec
+        out._planes = Planes(buf, rec, t0.shape)
+        return out
     rec = new_amax(t0.device) if _trunk_h2() else None
     check(lib.catseg_add_n_act_amax(ptrs, lds, n, ptr(out), ld_of(out), rows_of(t0), t0.shape[-1], 1 if relu else 0, ptr(rec), stream()))
     if rec is not None:

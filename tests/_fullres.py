@@ -11,13 +11,14 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RECORD = os.environ.get("CATSEG_PARITY_RECORD", os.path.join(ROOT, "gpurun_out", "parity_fullres.json"))
 
-# arithmetic plans: name -> (ops.PRECISION, ops.TRUNK, ops.HEADS)
+# arithmetic plans: name -> (ops.PRECISION, ops.TRUNK, ops.HEADS, ops.PLANES)
 PLANS = {
-    "production": ("bf16x3", "f16x2", "f16x2"),
-    "fp32": ("fp32", "f16x2", "f16x2"),
-    "trunk_bf16x3": ("bf16x3", "bf16x3", "f16x2"),
-    "heads_bf16x3": ("bf16x3", "f16x2", "bf16x3"),
-    "all_bf16x3": ("bf16x3", "bf16x3", "bf16x3"),
+    "production": ("bf16x3", "f16x2", "f16x2", True),            # trunk on producer-written fp16 x 2 planes
+    "trunk_in_kernel_split": ("bf16x3", "f16x2", "f16x2", False),  # the round-3 route: fp32 tensors, split inside the convolution kernels
+    "fp32": ("fp32", "f16x2", "f16x2", True),
+    "trunk_bf16x3": ("bf16x3", "bf16x3", "f16x2", True),
+    "heads_bf16x3": ("bf16x3", "f16x2", "bf16x3", True),
+    "all_bf16x3": ("bf16x3", "bf16x3", "bf16x3", True),
 }
 
 
@@ -50,14 +51,14 @@ class set_plan:
 
     def __enter__(self):
         from miccai2021_cataract_semantic_segmentation_amd import ops
-        self.saved = (ops.PRECISION, ops.TRUNK, ops.HEADS)
+        self.saved = (ops.PRECISION, ops.TRUNK, ops.HEADS, ops.PLANES)
         ops.release_b3_cache()
-        ops.PRECISION, ops.TRUNK, ops.HEADS = PLANS[self.name]
+        ops.PRECISION, ops.TRUNK, ops.HEADS, ops.PLANES = PLANS[self.name]
         return self
 
     def __exit__(self, *exc):
         from miccai2021_cataract_semantic_segmentation_amd import ops
-        ops.PRECISION, ops.TRUNK, ops.HEADS = self.saved
+        ops.PRECISION, ops.TRUNK, ops.HEADS, ops.PLANES = self.saved
         ops.release_b3_cache()
         return False
 

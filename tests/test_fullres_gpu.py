@@ -79,7 +79,7 @@ def test_ocrnet_hrnet48_fullres_train_step_vs_oracle(plan):
     the kernel populations for the production plan"""
     _need_gpu()
     from miccai2021_cataract_semantic_segmentation_amd import ops
-    assert ops.PRECISION == "bf16x3" and ops.TRUNK == "f16x2" and ops.HEADS == "f16x2", "shipped defaults expected"
+    assert ops.PRECISION == "bf16x3" and ops.TRUNK == "f16x2" and ops.HEADS == "f16x2" and ops.PLANES, "shipped defaults expected"
     assert ops.B3_MIN_K == 2048 and ops.DCONV3_MIN_ROWS == 2048, "production plan expected"
     orc = FR.hrnet48_oracle()
     model, interm_h, final_h, loss_h, kinds = FR.hrnet48_hip(orc, plan)
@@ -94,13 +94,15 @@ def test_ocrnet_hrnet48_fullres_train_step_vs_oracle(plan):
     assert fig["e_abs_interm_vs_cpu32"] <= 1e-3 * max(1.0, float(orc["interm32"].abs().max()))
     assert abs(loss_h - orc["loss32"]) < 1e-4
     # the kernels of the plan really ran
-    P, T, Hd = FR.PLANS[plan]
+    P, T, Hd, PL = FR.PLANS[plan]
     if P == "fp32":
         assert {"fwd", "dgrad", "wgrad"} <= kinds and not any("_d3" in k or "_h2" in k or "_b3" in k for k in kinds), kinds
     else:
         heads = {"fwd_h2", "dgrad_h2", "wgrad_h2"} if Hd == "f16x2" else {"fwd_b3", "dgrad_b3", "wgrad_b3"}
-        trunk = {"fwd_d3h", "dgrad_d3h", "wgrad_d3h"} if T == "f16x2" else {"fwd_d3", "dgrad_d3", "wgrad_d3"}
+        trunk = ({"fwd_d3p", "dgrad_d3p", "wgrad_d3p"} if PL else {"fwd_d3h", "dgrad_d3h", "wgrad_d3h"}) if T == "f16x2" else {"fwd_d3", "dgrad_d3", "wgrad_d3"}
         assert heads | trunk | {"fwd", "dgrad", "wgrad"} <= kinds, kinds
+        if PL and T == "f16x2":     # the planes route took every trunk layer but the first convolution behind each transition (its input has no record)
+            assert not any(k.endswith("_d3") for k in kinds), kinds
     if not production:
         return
     sd = model.state_dict()
