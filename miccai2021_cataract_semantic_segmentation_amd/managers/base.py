@@ -70,6 +70,12 @@ class BaseManager:
         self.log_dir = pathlib.Path(self.config["log_path"]) / self.run_id
         if self.rank == 0:
             self.log_dir.mkdir(parents=True, exist_ok=True)
+        # `manager_class(config)` as main.py:61 constructs it: the reference's load_data() (cv2 / pandas decoding, out of this path's scope)
+        # is replaced by a callable the configuration names -- config['data']['dataset_factory'](config) -> (train_set, valid_set, sampler)
+        factory = self.config["data"].get("dataset_factory")
+        if train_set is None and valid_set is None and callable(factory):
+            made = tuple(factory(self.config))
+            train_set, valid_set, train_sampler = (made + (None, None, None))[:3]
         self.train_set, self.valid_set, self.train_sampler = train_set, valid_set, train_sampler
         self.load_model()
         self.loss = self.optimiser = self.scheduler = None

@@ -33,6 +33,10 @@ def test_ocrnet_manager_train_validate_infer(tmp_path):
     inf = OCRNetManager(cfg2, None, va)
     miou = inf.infer()[0]
     assert abs(round(miou, 4) - metrics["best_miou"]) < 2e-3
+    # `manager_class(config)` exactly as main.py:61 calls it: the datasets come from the factory the configuration names
+    cfg3 = dict(cfg, mode="inference", load_checkpoint=m.run_id)
+    cfg3["data"] = dict(cfg["data"], dataset_factory=lambda c: (None, SyntheticCataractDataset(3, 64, 96, 17, seed=2)))
+    assert abs(OCRNetManager(cfg3).infer()[0] - miou) < 1e-9
 
 
 def _shipped(name):
