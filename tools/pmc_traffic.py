@@ -18,6 +18,12 @@ def group(name):
     m = re.search(r"igemm_f32_kernel<(\d)", name)
     if m:
         return LAY[m.group(1)]
+    if "dwgrad3_pl" in name:
+        return "wgrad_d3p"      # backward-weight on producer-written planes + its slab reduction (round 4)
+    if "dconv3_pl_kernel" in name:
+        return "d3p"            # forward AND backward-data on producer-written planes (round 4)
+    if "planes_from_f32" in name:
+        return "d3_prep"
     if "dwgrad3_h2_" in name:
         return "wgrad_d3h"
     if "dconv3_h2_kernel" in name or "dconv3_h2_spec_kernel" in name:
