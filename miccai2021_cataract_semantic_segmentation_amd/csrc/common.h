@@ -67,6 +67,25 @@ __device__ __forceinline__ unsigned cs_abs_bits4(const float __attribute__((ext_
              max(__float_as_uint(v[2]) & 0x7FFFFFFFu, __float_as_uint(v[3]) & 0x7FFFFFFFu));
 }
 #endif
+#ifdef __HIPCC__
+// Row-major walk over the float4 quads of a [rows][C] tensor WITHOUT a division in the loop (round 4).  The grid-stride form
+// `r = i / cpt` with a 64-bit i cost ~80 VALU instructions per 16 bytes moved: the elementwise kernels were instruction-bound at ~0.5 of
+// the HBM rate.  Here thread g of the launch visits quads g, g + S, g + 2 S, ... with S = (threads of the launch rounded down to a
+// multiple of cpt): its channel quad never changes and its row advances by S / cpt -- one division per THREAD.  Consecutive threads still
+// touch consecutive quads (coalesced).  Returns false for the (< cpt) threads past S; they must still take part in block-wide epilogues.
+__device__ __forceinline__ bool cs_quad_walk(int cpt, long long& r, int& c, long long& rstep) {
+  const long long T = (long long)gridDim.x * blockDim.x;
+  rstep = T / cpt;
+  const long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  r = g / cpt;
+  c = (int)(g - r * cpt) * 4;
+  return rstep > 0 && g < rstep * cpt;
+}
+#define CS_QUAD_LOOP(rows, cpt, r, c)                                                             \
+  long long r, r##_step; int c;                                                                  \
+  if (cs_quad_walk(cpt, r, c, r##_step))                                                         \
+    for (; r < (rows); r += r##_step)
+#endif
 static inline bool cs_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline size_t cs_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -562,11 +562,8 @@ __global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void amax_f32_kernel(const float* __restrict__ x, int ld, long long rows, int C, unsigned* __restrict__ rec) {
   const int cpt = C >> 2;
-  const long long total = rows * cpt;
   unsigned m = 0;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / cpt;
-    const int c = (int)(i - r * cpt) * 4;
+  CS_QUAD_LOOP(rows, cpt, r, c) {
     m = max(m, cs_abs_bits4(*(const f32x4*)(x + r * ld + c)));
   }
   cs_amax_commit(m, rec);

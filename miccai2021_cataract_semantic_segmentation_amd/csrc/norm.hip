@@ -183,11 +183,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ res, int ldr, float* __restrict__ z,
                                                        int ldz, long long rows, int C, int relu, unsigned* __restrict__ amax) {
   const int cpt = C >> 2;
-  const long long total = rows * cpt;
   unsigned m = 0;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / cpt;
-    const int c = (int)(i - r * cpt) * 4;
+  CS_QUAD_LOOP(rows, cpt, r, c) {
     f32x4 v = bn_affine(ld4(y + r * ldy + c), ld4(mean + c), ld4(scale + c), ld4(beta + c));
     if (res) v += ld4(res + r * ldr + c);
     if (relu) {
@@ -431,11 +428,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int relu, float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres,
                                                            int dres_acc, unsigned* __restrict__ amax) {
   const int cpt = C >> 2;
-  const long long total = rows * cpt;
   unsigned m = 0;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / cpt;
-    const int c = (int)(i - r * cpt) * 4;
+  CS_QUAD_LOOP(rows, cpt, r, c) {
     f32x4 g = ld4(dz + r * lddz + c);
     const f32x4 inv = ld4(stats + C + c), mean = ld4(stats + c);
     const f32x4 yy = ld4(y + r * ldy + c);

@@ -38,10 +38,7 @@ __global__ void stem_unpack_kernel(const float* __restrict__ pk, float* __restri
 __global__ void axpy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, long long rows, int C,
                               float alpha, int acc) {
   const int cpt = C >> 2;
-  const long long total = rows * cpt;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / cpt;
-    const int c = (int)(i - r * cpt) * 4;
+  CS_QUAD_LOOP(rows, cpt, r, c) {
     f32x4 v = *(const f32x4*)(src + r * lds + c) * alpha;
     f32x4* d = (f32x4*)(dst + r * ldd + c);
     *d = acc ? (*d + v) : v;
@@ -67,11 +64,8 @@ struct AddArgs {
 };
 __global__ void add_n_act_kernel(AddArgs a, float* __restrict__ out, int ldo, long long rows, int C, int relu, unsigned* __restrict__ amax) {
   const int cpt = C >> 2;
-  const long long total = rows * cpt;
   unsigned m = 0;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / cpt;
-    const int c = (int)(i - r * cpt) * 4;
+  CS_QUAD_LOOP(rows, cpt, r, c) {
     f32x4 v = *(const f32x4*)(a.in[0] + r * a.ld[0] + c);
     for (int k = 1; k < a.n; ++k) v += *(const f32x4*)(a.in[k] + r * a.ld[k] + c);
     if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
@@ -131,10 +125,7 @@ __global__ __launch_bounds__(256) void add_n_act_planes_kernel(AddArgs a, AddRec
 __global__ void relu_bwd_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz, float* __restrict__ g, int ldg,
                                 long long rows, int C) {
   const int cpt = C >> 2;
-  const long long total = rows * cpt;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / cpt;
-    const int c = (int)(i - r * cpt) * 4;
+  CS_QUAD_LOOP(rows, cpt, r, c) {
     f32x4 d = *(const f32x4*)(dz + r * lddz + c);
     const f32x4 zz = *(const f32x4*)(z + r * ldz + c);
 #pragma unroll

@@ -69,6 +69,18 @@ def make_desc(xshape, ldx, Cout, ldy, kh, kw, stride, pad, dil, stem4=False, gro
 
 PROFILE = None  # bench.py sets this to a list: every implicit-GEMM launch is bracketed by HIP events
 
+# roctx ranges: CATSEG_ROCTX=1 brackets every timed C-ABI call with roctxRangePush(kind) / roctxRangePop(), so that a
+# `rocprofv3 --marker-trace --kernel-trace` timeline shows which layer operation a kernel belongs to.  Off by default (two ctypes calls per launch).
+_roctx = None
+if __import__("os").environ.get("CATSEG_ROCTX", "0") == "1":
+    for _name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+        try:
+            _roctx = ctypes.CDLL(_name)
+            _roctx.roctxRangePushA.argtypes = [ctypes.c_char_p]
+            break
+        except (OSError, AttributeError):
+            _roctx = None
+
 
 class _Timed:
     """HIP events on the launch stream around one C-ABI call (algorithmic FLOPs = 2*M*N*K)."""
@@ -77,6 +89,8 @@ class _Timed:
         self.kind, self.flops = kind, flops
 
     def __enter__(self):
+        if _roctx is not None:
+            _roctx.roctxRangePushA(self.kind.encode())
         if PROFILE is not None:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
@@ -86,6 +100,8 @@ class _Timed:
         if PROFILE is not None:
             self.e1.record()
             PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+        if _roctx is not None:
+            _roctx.roctxRangePop()
 
 
 # Arithmetic of the large convolutions: "fp32" = v_mfma_f32_32x32x2_f32 (an exact fp32 FMA chain), "bf16x3" = every fp32

@@ -1,4 +1,6 @@
 """Host-side utilities against fixtures generated from the reference (CPU only)."""
+import os
+
 import numpy as np
 import torch
 
@@ -186,3 +188,19 @@ def test_amax_record_scopes():
     finally:
         ops.AMAX_SCOPE_RECORDS = saved
         ops.set_amax_scope(None)
+
+
+def test_roctx_ranges_are_optional_and_balanced():
+    """CATSEG_ROCTX=1: every timed C-ABI call is bracketed by roctxRangePush(kind) / roctxRangePop(); off by default"""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); from miccai2021_cataract_semantic_segmentation_amd import ops\n"
+            "assert (ops._roctx is not None) == (os.environ.get('CATSEG_ROCTX') == '1')\n"
+            "if ops._roctx is not None:\n"
+            "    with ops._Timed('fwd', 1.0):\n"
+            "        pass\n"
+            "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for flag in ("0", "1"):
+        env = dict(os.environ, CATSEG_ROCTX=flag)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-500:]
