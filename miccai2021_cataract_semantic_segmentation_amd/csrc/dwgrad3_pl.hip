@@ -274,7 +274,11 @@ __global__ __launch_bounds__(256) void dwgrad3_pl_reduce_kernel(const float* __r
 }
 
 using Wp48 = WpCfg<48, 48, 3, 1, 4, 4, 2>;   // one block: all 48 x 432 accumulators, tiles 4 x 16, two image buffers of 33 KB
-using Wp96 = WpCfg<96, 48, 1, 2, 2, 2, 2>;   // block = 96 co x (one filter row x 48 ci), tiles 2 x 16, two image buffers of 21.5 KB (three: a tile is
+#ifdef WP_ALT96
+using Wp96 = WpCfg<48, 48, 1, 1, 4, 4, 2>;   // A/B: 48 co x (one filter row x 48 ci), tiles 4 x 16
+#else
+using Wp96 = WpCfg<96, 48, 1, 2, 2, 2, 2>;
+#endif   // block = 96 co x (one filter row x 48 ci), tiles 2 x 16, two image buffers of 21.5 KB (three: a tile is
                                              // 45 MFMAs per wave, shorter than an LDS-DMA round trip -- were measured: 60 -> 92 us, not adopted)
 
 struct WpPlan { int kind, variants, splits, TH; };
@@ -282,7 +286,7 @@ struct WpPlan { int kind, variants, splits, TH; };
 WpPlan wp_plan(int C, int B, int H, int W) {
   WpPlan p = {0, 0, 0, 0};
   if (C == 48) { p.kind = 1; p.variants = 1; p.TH = Wp48::TH; }
-  else if (C == 96 || C == 192 || C == 384) { p.kind = 2; p.variants = (C / 96) * (C / 48) * 3; p.TH = Wp96::TH; }
+  else if (C == 96 || C == 192 || C == 384) { p.kind = 2; p.variants = (C / Wp96::COT) * (C / Wp96::NCI) * 3; p.TH = Wp96::TH; }
   else return p;
   const int ntile = B * ((H + p.TH - 1) / p.TH) * ((W + 15) / 16);
   int s = catseg_g_wg_blocks / p.variants;

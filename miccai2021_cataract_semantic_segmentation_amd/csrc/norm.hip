@@ -99,7 +99,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   const bool live = c < C;
   const double n_full = (double)rpb, inv_full = 1.0 / n_full;
   const double n_last = (double)(rows - (long long)(nrb - 1) * rpb), inv_last = 1.0 / n_last;
-  __shared__ double sh0[256][5], sh1[256][5];
+  __shared__ double sh0[16][5], sh1[16][5];
   double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
   if (live) {
     auto one = [&](int b, double& s0, double& s1) {
@@ -116,28 +116,34 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
       s0 += nb * mb;
       s1 += (t2 - t1 * t1 * inv) + nb * mb * mb;
     };
-    int b = rl;
-    for (; b + 768 < nrb; b += 1024) {
+    // four independent load chains per round, ALSO in the last, ragged round (a serial tail of up to three dependent L2 round trips was
+    // most of these launches' 10 us)
+    for (int b = rl; b < nrb; b += 1024) {
       one(b, a0[0], a1[0]);
-      one(b + 256, a0[1], a1[1]);
-      one(b + 512, a0[2], a1[2]);
-      one(b + 768, a0[3], a1[3]);
+      if (b + 256 < nrb) one(b + 256, a0[1], a1[1]);
+      if (b + 512 < nrb) one(b + 512, a0[2], a1[2]);
+      if (b + 768 < nrb) one(b + 768, a0[3], a1[3]);
     }
-    for (; b < nrb; b += 256) one(b, a0[0], a1[0]);
   }
-  sh0[rl][cl] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
-  sh1[rl][cl] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+  // merge over the 256 row lanes in a fixed order (deterministic): the 16 row lanes of a wave by lane shuffles (lane = 4 row lane + channel),
+  // the 16 waves through LDS -- two block barriers instead of the nine of a shared-memory tree (these launches are pure latency: 628 per step)
+  double r0 = (a0[0] + a0[1]) + (a0[2] + a0[3]), r1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+#pragma unroll
+  for (int o = 4; o <= 32; o <<= 1) {
+    r0 += __shfl_xor(r0, o, 64);
+    r1 += __shfl_xor(r1, o, 64);
+  }
+  if ((threadIdx.x & 63) < 4) {
+    sh0[threadIdx.x >> 6][cl] = r0;
+    sh1[threadIdx.x >> 6][cl] = r1;
+  }
   __syncthreads();
-  // tree over the 256 row lanes (fixed order: deterministic)
-  for (int st = 128; st >= 1; st >>= 1) {
-    if (rl < st) {
-      sh0[rl][cl] += sh0[rl + st][cl];
-      sh1[rl][cl] += sh1[rl + st][cl];
-    }
-    __syncthreads();
-  }
   if (rl != 0 || !live) return;
-  const double t0 = sh0[0][cl], t1 = sh1[0][cl];
+  double t0 = 0, t1 = 0;
+  for (int w = 0; w < 16; ++w) {
+    t0 += sh0[w][cl];
+    t1 += sh1[w][cl];
+  }
   const double mean = t0 / (double)rows;
   double m2 = t1 - (double)rows * mean * mean;
   if (m2 < 0) m2 = 0;
@@ -343,11 +349,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
       sg += o[c];
       sgx += o[C + c];
     }
-  __shared__ double s1[64][16], s2[64][16];
-  s1[rl][cl] = sg; s2[rl][cl] = sgx;
+  // the 4 row lanes of a wave by lane shuffles (lane = 16 row lane + channel), the 16 waves through LDS (fixed order)
+  sg += __shfl_xor(sg, 16, 64);
+  sgx += __shfl_xor(sgx, 16, 64);
+  sg += __shfl_xor(sg, 32, 64);
+  sgx += __shfl_xor(sgx, 32, 64);
+  __shared__ double s1[16][16], s2[16][16];
+  if ((threadIdx.x & 63) < 16) { s1[threadIdx.x >> 6][cl] = sg; s2[threadIdx.x >> 6][cl] = sgx; }
   __syncthreads();
   if (rl != 0 || c >= C) return;
-  for (int k = 1; k < 64; ++k) { sg += s1[k][cl]; sgx += s2[k][cl]; }
+  sg = 0; sgx = 0;
+  for (int k = 0; k < 16; ++k) { sg += s1[k][cl]; sgx += s2[k][cl]; }
   if (dbeta) dbeta[c] = (float)sg;
   if (dgamma) dgamma[c] = (float)sgx;
   coef[c] = (float)(sg / (double)rows);
