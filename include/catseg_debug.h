@@ -38,6 +38,8 @@ int catseg_debug_set_dconv3_spec(int on);
 int catseg_debug_set_dconv3_alt96(int on);
 /* tuning hook: blocks per launch of the direct backward-weight kernel (csrc/dwgrad3_b3.hip; 0 restores the default 512) */
 int catseg_debug_set_dwgrad3_blocks(int blocks);
+/* persistent blocks of the planes kernel csrc/dconv3_pl.hip (default 512 = two per CU) */
+int catseg_debug_set_dconv3_pl_slots(int slots);
 
 /* tuning hook: bf16x3 block tile: 0 = heuristic, 1 = 256x256, 2 = 256x128, 3 = 128x256, 4 = 256x192, 5 = 256x96, 6 = 256x64 */
 int catseg_debug_set_b3_tile(int t);

@@ -19,8 +19,13 @@
 // Arithmetic: exactly dconv3_f16x2's (v_mfma_f32_16x16x32_f16, products hl, lh, hh into one fp32 accumulator, result scaled by
 // 2^-(e_x + e_w)); the weight images and their records are the ones catseg_dconv3_f16x2_prep_batch writes.
 #include <type_traits>
-#include <stdlib.h>
 #include "planes.h"
+
+int catseg_g_pl_slots = 512;
+extern "C" int catseg_debug_set_dconv3_pl_slots(int slots) {
+  catseg_g_pl_slots = slots > 0 ? slots : 512;
+  return CATSEG_OK;
+}
 
 namespace {
 
@@ -588,11 +593,7 @@ PlPlan pl_plan(int C) {
 template <class G>
 void pl_launch(const PlArgs& a, int C, hipStream_t st) {
   const int ntile = a.B * a.tiles_y * a.tiles_x;
-  static int slots = 0;      // two blocks per CU (CATSEG_PL_SLOTS: tuning runs)
-  if (!slots) {
-    const char* e = getenv("CATSEG_PL_SLOTS");
-    slots = e && atoi(e) > 0 ? atoi(e) : 512;
-  }
+  const int slots = catseg_g_pl_slots;      // two blocks per CU (catseg_debug_set_dconv3_pl_slots: tuning runs)
   // a block per tile while the tiles fit the block slots about once or twice; beyond that persistent blocks walking runs of tiles
   const int nb = ntile * (C / G::NT) > 2 * slots ? slots / (C / G::NT) : ntile;
   if (a.bq_part) hipLaunchKernelGGL((dconv3_pl_kernel<G, true>), dim3(nb, C / G::NT), dim3(512), 0, st, a);

@@ -96,12 +96,15 @@ class FlatParams:
 _side_streams = {}
 
 
+BRANCH_PRIORITY = int(__import__("os").environ.get("CATSEG_BRANCH_PRIORITY", "0"))   # A/B: -1 = the first branch's stream at high priority
+
+
 def side_streams(device, n):
     """a small pool of HIP streams per device for the parallel-branch regions (HRNet's branches are independent)"""
     key = (device.type, device.index)
     pool = _side_streams.setdefault(key, [])
     while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=device))
+        pool.append(torch.cuda.Stream(device=device, priority=BRANCH_PRIORITY if len(pool) == 0 else 0))
     return pool[:n]
 
 
