@@ -214,6 +214,13 @@ size_t catseg_dwgrad3_workspace(int B, int H, int W, int C);
 int catseg_dwgrad3(int B, int H, int W, int C, const float* x, int ldx, const float* dy, int ldy, float* dw, void* workspace,
                    size_t workspace_bytes, catseg_stream_t stream);
 
+/* ---- FCN-8s pieces (models/FCN.py:7-61 of the reference): F.max_pool2d(x, 2) with its argmax (idx: uint8 [B, H/2, W/2, C]) and backward
+ * (models/FCN.py:44-53); catseg_bias_rows: out[r][0..C) = bias -- the rows nn.ConvTranspose2d's bias initialises before the transposed
+ * convolution (= catseg_conv2d_bwd_data with the same weight tensor, models/FCN.py:35-38) accumulates into them */
+int catseg_maxpool2x2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int B, int H, int W, int C, catseg_stream_t stream);
+int catseg_maxpool2x2_bwd(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx, int B, int H, int W, int C, catseg_stream_t stream);
+int catseg_bias_rows(const float* bias, float* out, int ld, long long rows, int C, catseg_stream_t stream);
+
 /* ---- fp16 x 2 OPERAND PLANES written by the producer of a tensor, and the direct 3x3 kernels that stream them (round 4;
  * csrc/planes.h, csrc/dconv3_pl.hip).  Replaces, for the same reference layers as catseg_dconv3_f16x2 (conv3x3(planes, planes) of
  * models/HRNetv2.py:22-65), the in-kernel fp32 -> 2 x fp16 split: planes = [plane h / l][C / 8 channel groups][pixel][8] fp16,

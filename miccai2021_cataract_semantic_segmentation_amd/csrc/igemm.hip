@@ -1139,7 +1139,14 @@ extern "C" int catseg_conv2d_bwd_data(const catseg_conv_desc* d, const float* dy
   // stride s > 1: one dense launch per parity class (py, px) of the input pixels.  Input row iy = a*s + py only
   // receives taps ky with (py + pad - ky*dil) % s == 0, from output row a + (py + pad - ky*dil) / s: no wasted MACs.
   const int sdv = d->stride;
-  if (d->kh * d->kw > 32) return launch_igemm<L_NN>(a, 1, 1, (hipStream_t)stream);   // generic (slow) path
+  {
+    // taps that reach ONE parity class (FCN's ConvTranspose2d 16x16 / stride 8, models/FCN.py:38: 2 x 2 of the 256); the tap table of a
+    // launch holds 32
+    int gd = sdv, v = d->dil;
+    while (v) { const int t = gd % v; gd = v; v = t; }
+    const int ks = sdv / gd;
+    if (((d->kh + ks - 1) / ks) * ((d->kw + ks - 1) / ks) > 32) return launch_igemm<L_NN>(a, 1, 1, (hipStream_t)stream);   // generic (slow) path
+  }
   IgemmArgs cls[4];
   int ncls = 0;
   const bool multi = sdv == 2 && g_strided_multi;

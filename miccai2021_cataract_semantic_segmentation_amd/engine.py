@@ -476,6 +476,101 @@ def conv_bias(cx, x, conv, pad_to=32):
     return y
 
 
+def conv_act(cx, x, conv, relu=True):
+    """conv + bias (+ ReLU) without normalisation -- the VGG-style layers of models/FCN.py:42-55 of the reference: bias and ReLU run in
+    the convolution's epilogue.  x NHWC (or the raw NCHW image for a 3-channel first layer)."""
+    w = conv.weight
+    Cout = w.shape[0]
+    kh, kw = conv.kernel_size
+    s, p, d = conv.stride[0], conv.padding[0], conv.dilation[0]
+    pad3 = w.shape[1] == 3
+    if pad3:
+        x_in = x if is_nhwc4(x) else ops.nchw3_to_nhwc4(x)
+        wk = ops.weight_pad_cin(w.data, Cout, kh * kw, 3, 4)
+    else:
+        x_in, wk = x, w.data
+    bias = conv.bias.data if conv.bias is not None else None
+    cx.claim(w, conv.bias)
+    z = ops.conv_fwd_fused(x_in, wk, bias, None, relu, Cout, kh, kw, s, p, d)
+    if cx.record:
+        def bwd():
+            dz = cx.take(z)
+            if dz is None:
+                return
+            dy = ops.relu_bwd(dz, z) if relu else dz
+            del dz
+            dbias = cx.pgrad(conv.bias) if conv.bias is not None else None
+            if pad3:
+                dpk = torch.empty_like(wk)
+                ops.conv_bwd_weight(x_in, dy, dpk, dbias, kh, kw, s, p, d)
+                ops.weight_unpad_cin(dpk, cx.pgrad(w), Cout, kh * kw, 3, 4)
+            else:
+                ops.conv_bwd_weight(x_in, dy, cx.pgrad(w), dbias, kh, kw, s, p, d)
+                dx, acc = cx.dest(x)
+                ops.conv_bwd_data(dy, w.data, tuple(x.shape), kh, kw, s, p, d, out=dx, accumulate=acc)
+            cx.done(w, conv.bias)
+        cx.push(bwd)
+    return z
+
+
+def maxpool2(cx, x):
+    """F.max_pool2d(x, 2) (models/FCN.py:44-53 of the reference)"""
+    y, idx = ops.maxpool2_fwd(x)
+    if cx.record:
+        def bwd():
+            dy = cx.take(y)
+            if dy is None:
+                return
+            dx, acc = cx.dest(x)
+            ops.maxpool2_bwd(dy, idx, dx, acc)
+        cx.push(bwd)
+    return y
+
+
+class ConvTranspose2d(nn.ConvTranspose2d):
+    """Parameter container with nn.ConvTranspose2d's init / state-dict behaviour (weight [Cin, Cout, k, k]); runs on the HIP engine."""
+
+    def forward(self, x, output_size=None):  # pragma: no cover
+        raise RuntimeError("engine ConvTranspose2d is executed by the owning network, not called directly")
+
+
+def conv_transpose(cx, x, deconv):
+    """nn.ConvTranspose2d on a class-logit tensor (rows zero padded to 32 floats: conv_bias's output).  The transposed convolution IS the
+    backward-data pass of the convolution with the same weight tensor; its own backward is that convolution's forward / backward-weight."""
+    w = deconv.weight
+    Cin, Cout = w.shape[0], w.shape[1]
+    k, s, p = deconv.kernel_size[0], deconv.stride[0], deconv.padding[0]
+    assert deconv.kernel_size[0] == deconv.kernel_size[1] and deconv.output_padding[0] == 0 and deconv.dilation[0] == 1 and deconv.groups == 1
+    bias = deconv.bias.data if deconv.bias is not None else None
+    cx.claim(w, deconv.bias)
+    y, wp = ops.conv_transpose_fwd(x, w.data, bias, Cout, k, s, p)
+    if cx.record:
+        def bwd():
+            dy = cx.take(y)
+            if dy is None:
+                return
+            dx, acc = cx.dest(x)
+            ops.conv_transpose_bwd(dy, x, wp, cx.pgrad(w), cx.pgrad(deconv.bias) if deconv.bias is not None else None, k, s, p, dx, acc)
+            cx.done(w, deconv.bias)
+        cx.push(bwd)
+    return y
+
+
+def add_classes(cx, a, b):
+    """a + b of two class-logit tensors (models/FCN.py:57,60 of the reference); rows zero padded to the same stride"""
+    K = a.shape[-1]
+    yw = ops.add_n_act([ops.widen(a), ops.widen(b)], False)
+    y = yw[..., :K]
+    if cx.record:
+        def bwd():
+            dy = cx.take(y)
+            if dy is not None:
+                cx.give(a, dy, shared=True)
+                cx.give(b, dy, shared=True)
+        cx.push(bwd)
+    return y
+
+
 def add_n(cx, terms, relu=True):
     """y = act(sum(terms)) — the HRNet fuse (models/HRNetv2.py:237-261); terms share one shape"""
     y = ops.add_n_act(terms, relu)

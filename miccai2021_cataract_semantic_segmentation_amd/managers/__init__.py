@@ -1,3 +1,3 @@
 from .base import BaseManager, merge_defaults  # noqa: F401
-from .segmentation import (DeepLabv3Manager, DeepLabv3PlusManager, EncDecManager, HRNetv2Manager, OCRNetManager,  # noqa: F401
+from .segmentation import (DeepLabv3Manager, DeepLabv3PlusManager, EncDecManager, FCNManager, HRNetv2Manager, OCRNetManager,  # noqa: F401
                            SyntheticCataractDataset)

@@ -38,6 +38,17 @@ class HRNetv2Manager(DeepLabv3PlusManager):
     """(build-side name: the reference has no HRNetv2 manager; its HRNetv2 is a single-output net like DeepLabv3+)"""
 
 
+class FCNManager(DeepLabv3PlusManager):
+    """managers/FCN_Manager.py:10-17 of the reference: image in, logits out; Adam with a CONSTANT learning rate, or an exponential decay
+    by config['train']['lr_decay_gamma'] per epoch (the other managers' polynomial schedule is not used)."""
+
+    def load_optimiser(self):
+        from ..optim import FusedAdam
+        tc = self.config["train"]
+        self.optimiser = FusedAdam(self.model, lr=tc["learning_rate"], grad_scale=self.grad_scale)
+        self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimiser, tc["lr_decay_gamma"]) if "lr_decay_gamma" in tc else None
+
+
 class EncDecManager(BaseManager):
     """managers/EncDec_Manager.py:14-274: the model is built from the TOP-LEVEL 'encoder' / 'decoder' config entries
     (:16-21, configs/UPN_rf_lvsz.json has no 'graph'), the loss is always a LossWrapper (:23-29), and the step is

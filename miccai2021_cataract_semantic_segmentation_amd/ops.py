@@ -911,6 +911,70 @@ def maxpool_bwd(dy, idx, xshape):
     return dx
 
 
+def maxpool2_fwd(x):
+    """F.max_pool2d(x, 2) (models/FCN.py:44-53 of the reference) -> (y, argmax position inside the window)"""
+    B, H, W, C = x.shape
+    y = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+    idx = torch.empty((B, H // 2, W // 2, C), dtype=torch.uint8, device=x.device)
+    check(lib.catseg_maxpool2x2_fwd(ptr(x), ld_of(x), ptr(y), C, ptr(idx), B, H, W, C, stream()))
+    return y, idx
+
+
+def maxpool2_bwd(dy, idx, out, accumulate=False):
+    B, H, W, C = out.shape
+    dst = torch.empty(out.shape, dtype=torch.float32, device=dy.device) if accumulate else out
+    check(lib.catseg_maxpool2x2_bwd(ptr(dy), ld_of(dy), ptr(idx), ptr(dst), ld_of(dst), B, H, W, C, stream()))
+    if accumulate:
+        axpy(dst, out, 1.0, True)
+    return out
+
+
+def widen(t):
+    """the [B, H, W, ld] tensor behind a class-logit view [B, H, W, K] whose rows are zero padded to ld floats (conv_fwd(zero_to=),
+    engine.Ctx.dest): the 16-byte-granular kernels run on all ld columns"""
+    B, H, W, _ = t.shape
+    ld = ld_of(t)
+    return t if ld == t.shape[-1] else torch.as_strided(t, (B, H, W, ld), (H * W * ld, W * ld, ld, 1))
+
+
+def conv_transpose_fwd(x, w, bias, Cout, k, stride, pad, ld=32):
+    """nn.ConvTranspose2d(Cin, Cout, k, stride, pad) on class-logit tensors (models/FCN.py:35-38, utils/torch_utils.py:151-168 of the
+    reference): y = bias + backward-data of the convolution that has the same weight tensor (physical layout [Cin][k][k][Cout] = that
+    convolution's OHWI).  x: [B, H, W, Cin] view with zero-padded rows of ld floats; returns the same kind of view of the output and the
+    padded weight image the backward pass reuses."""
+    B, H, W, Cin = x.shape
+    Ho, Wo = (H - 1) * stride - 2 * pad + k, (W - 1) * stride - 2 * pad + k
+    assert ld_of(x) == ld and Cout <= ld and Cin <= ld
+    wp = weight_pad_cin(w, Cin, k * k, Cout, ld)
+    y = new_act(B, Ho, Wo, Cout, x.device, ld=ld, zero=True)
+    if bias is not None:
+        check(lib.catseg_bias_rows(ptr(bias), ptr(y), ld, rows_of(y), Cout, stream()))
+    conv_bwd_data(x, wp, (B, Ho, Wo, ld), k, k, stride, pad, 1, out=widen(y), accumulate=True)
+    return y, wp
+
+
+def conv_transpose_bwd(dy, x, wp, dw, dbias, k, stride, pad, dx, accumulate, ld=32):
+    """gradients of conv_transpose_fwd: dw = backward-weight of the same convolution with the roles of input and output gradient swapped,
+    dx = that convolution's FORWARD pass over dy"""
+    Cin, Cout = x.shape[-1], dy.shape[-1]
+    if ld_of(dy) != ld:     # the loss hands the gradient of the network's output over as a dense [B, H, W, K] tensor: re-pitch it (a copy)
+        padded = new_act(dy.shape[0], dy.shape[1], dy.shape[2], Cout, dy.device, ld=ld, zero=True)
+        padded.copy_(dy)
+        dy = padded
+    dyw = widen(dy)
+    dwp = torch.empty_like(wp)
+    conv_bwd_weight(dyw, x, dwp, None, k, k, stride, pad, 1)
+    weight_unpad_cin(dwp, dw, Cin, k * k, Cout, ld)
+    if dbias is not None:
+        ws = workspace(256 * Cout * 4 + 1024, dy.device)
+        check(lib.catseg_bias_grad(ptr(dy), ld_of(dy), rows_of(dy), Cout, ptr(dbias), ptr(ws), ws.numel(), stream()))
+    if dx is not None:
+        dst = new_act(x.shape[0], x.shape[1], x.shape[2], Cin, x.device, ld=ld, zero=True) if accumulate else dx
+        conv_fwd(dyw, wp, None, Cin, k, k, stride, pad, 1, out=dst, zero_to=ld)
+        if accumulate:
+            axpy(widen(dst), widen(dx), 1.0, True)
+
+
 def bilinear_fwd(x, Ho, Wo, align_corners, out=None, accumulate=False):
     B, H, W, C = x.shape
     if out is None:

@@ -183,3 +183,20 @@ def deeplabv3_forward(S, x, backbone="resnet50", out_stride=8, train=True):
     f = resnet_features(S, x, backbone, rswd_for(out_stride), train)
     logits = conv(S, "conv_out", aspp(S, "aspp.", f[4], 1 if out_stride >= 16 else 2, train))
     return F.interpolate(logits, size=size, mode="bilinear", align_corners=True)
+
+
+def fcn_forward(S, x):
+    """models/FCN.py:40-61 of the reference (FCN-8s; no normalisation layers, so training and inference run the same arithmetic).
+    Paddings from utils/torch_utils.py:130-168: 3x3 -> 1, 1x1 -> 0; ConvTranspose2d 4 / stride 2 -> 1, 16 / stride 8 -> 4."""
+    def deconv(p, t, stride, pad):
+        return F.conv_transpose2d(t, S[p + ".weight"], S.get(p + ".bias"), stride, pad)
+
+    p1 = F.max_pool2d(F.relu(conv(S, "conv1", x, 1, 1)), 2)
+    p2 = F.max_pool2d(F.relu(conv(S, "conv2", p1, 1, 1)), 2)
+    p3 = F.max_pool2d(F.relu(conv(S, "conv3", p2, 1, 1)), 2)
+    p4 = F.max_pool2d(F.relu(conv(S, "conv4", p3, 1, 1)), 2)
+    p5 = F.max_pool2d(F.relu(conv(S, "conv5", p4, 1, 1)), 2)
+    c7 = F.relu(conv(S, "conv7", F.relu(conv(S, "conv6", p5, 1, 1))))
+    fcn_16s = deconv("deconv32", conv(S, "conv8", c7), 2, 1) + conv(S, "p4_conv", p4)
+    fcn_8s = deconv("deconv16", fcn_16s, 2, 1) + conv(S, "p3_conv", p3)
+    return deconv("deconv8", fcn_8s, 8, 4)

@@ -88,3 +88,26 @@ def test_shipped_config_managers_train_validate_infer(tmp_path, name):
     inf = cls(dict(cfg, mode="inference", load_checkpoint=m.run_id), None, va)
     miou = inf.infer()[0]
     assert abs(round(miou, 4) - metrics["best_miou"]) < 2e-3
+
+
+def test_fcn_manager_constant_and_decayed_rate(tmp_path):
+    """FCNManager (managers/FCN_Manager.py:10-17 of the reference): Adam at a constant rate unless 'lr_decay_gamma' names an exponential decay"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from miccai2021_cataract_semantic_segmentation_amd import managers
+    cfg = {"name": "fcn", "mode": "training", "manager": "FCN", "log_path": str(tmp_path), "graph": {"model": "FCN", "width": 0.25},
+           "data": {"experiment": 2, "batch_size": 2}, "loss": {"name": "LovaszSoftmax"},
+           "train": {"learning_rate": 1e-3, "epochs": 3}, "log_every_n_epochs": 1, "seed": 0}
+    tr = managers.SyntheticCataractDataset(8, 64, 96, 17, seed=1)
+    va = managers.SyntheticCataractDataset(2, 64, 96, 17, seed=2)
+    m = managers.FCNManager(cfg, tr, va)
+    assert m.scheduler is None
+    m.train()
+    h = m.history
+    assert len(h) == 3 and h[-1]["train_loss"] < h[0]["train_loss"] and all(abs(r["lr"] - 1e-3) < 1e-12 for r in h)
+    assert set(m.model.state_dict()) >= {"conv1.weight", "deconv32.weight", "deconv8.bias", "p3_conv.weight"}
+    assert m.model.state_dict()["deconv8.weight"].shape == (17, 17, 16, 16)
+    cfg2 = dict(cfg, train={"learning_rate": 1e-3, "lr_decay_gamma": 0.5, "epochs": 2})
+    m2 = managers.FCNManager(cfg2, tr, va)
+    m2.train()
+    assert abs(m2.history[1]["lr"] - 2.5e-4) < 1e-12         # (recorded after the epoch's scheduler step)
