@@ -101,20 +101,35 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   const double n_last = (double)(rows - (long long)(nrb - 1) * rpb), inv_last = 1.0 / n_last;
   __shared__ double sh0[16][5], sh1[16][5];
   double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+  // what the channel's LAST lane needs after the merge is fetched now, in the shadow of the partial loads (these launches are a chain of
+  // dependent memory round trips; every one taken off the tail is ~1 us of 10)
+  float gam = 0.f, bet = 0.f, rm = 0.f, rv = 0.f;
+  unsigned ym = 0;
+  if (live && rl == 0) {
+    gam = gamma[c];
+    if (running_mean) { rm = running_mean[c]; rv = running_var[c]; }
+    if (z_rec) {
+      bet = beta[c];
+      for (int i = 0; i < CS_AMAX_SLOTS; ++i) ym = max(ym, y_rec[i * CS_AMAX_STRIDE]);
+    }
+  }
   if (live) {
     auto one = [&](int b, double& s0, double& s1) {
       const float* o = part + ((long long)b * 3) * C;
       const bool last = b == nrb - 1;
       double nb = last ? n_last : n_full, inv = last ? inv_last : inv_full;
-      if (counts) {                         // per-block row counts (2-D pixel tiles with ragged edges: csrc/dconv3_b3.hip)
-        if (counts[b] == 0) return;         // (a wave of csrc/dconv3_pl.hip whose pixel rows all lie below the image)
-        nb = (double)counts[b];
-        inv = 1.0 / nb;
-      }
+      // the count and the partial row are fetched TOGETHER (the row of an empty tile -- a wave of csrc/dconv3_pl.hip whose pixel rows all
+      // lie below the image -- is allocated but never written: whatever it holds is discarded by the selects below, never multiplied in)
+      const int cnt = counts ? counts[b] : 1;   // per-block row counts (2-D pixel tiles with ragged edges: csrc/dconv3_b3.hip)
       const double K = o[c], t1 = o[C + c], t2 = o[2 * C + c];
+      if (counts) {
+        nb = (double)cnt;
+        inv = 1.0 / (cnt > 0 ? nb : 1.0);
+      }
       const double mb = K + t1 * inv;
-      s0 += nb * mb;
-      s1 += (t2 - t1 * t1 * inv) + nb * mb * mb;
+      const double u0 = nb * mb, u1 = (t2 - t1 * t1 * inv) + nb * mb * mb;
+      s0 += cnt > 0 ? u0 : 0.0;
+      s1 += cnt > 0 ? u1 : 0.0;
     };
     // four independent load chains per round, ALSO in the last, ragged round (a serial tail of up to three dependent L2 round trips was
     // most of these launches' 10 us)
@@ -152,20 +167,18 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   const float invstd = 1.0f / sqrtf(var + eps);
   stats[c] = (float)mean;
   stats[C + c] = invstd;
-  scale[c] = gamma[c] * invstd;
+  scale[c] = gam * invstd;
   if (z_rec) {
     // bound of the normalised output of this channel, BEFORE the pass that computes it: |fma(y - mean, scale, beta)| <= |scale| (max|y| +
     // |mean|) + |beta|, with max|y| from the convolution's epilogue (csrc/dconv3_pl.hip).  The maximum over the channels (positive floats
     // order like their bit patterns) is what catseg_bn_apply_planes derives the planes' exponent from (csrc/planes.h).
-    unsigned ym = 0;
-    for (int i = 0; i < CS_AMAX_SLOTS; ++i) ym = max(ym, y_rec[i * CS_AMAX_STRIDE]);
-    const float bound = (fabsf(gamma[c] * invstd) * (__uint_as_float(ym) + fabsf((float)mean)) + fabsf(beta[c])) * 1.001f;
+    const float bound = (fabsf(gam * invstd) * (__uint_as_float(ym) + fabsf((float)mean)) + fabsf(bet)) * 1.001f;
     atomicMax(z_rec + CS_REC_BOUND, __float_as_uint(bound));
   }
   if (running_mean) {
     const float unb = (float)(m2 / (n > 1 ? n - 1 : 1));
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    running_mean[c] = (1.f - momentum) * rm + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * rv + momentum * unb;
   }
 }
 
@@ -332,48 +345,61 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   if (gmax_rec) cs_amax_commit(gm, gmax_rec);     // max |masked gradient|: the bound of the output's planes needs it (bn_bwd_finalize_kernel)
 }
 
-// 16 channels x 64 row lanes per block: up to 2040 partial rows (one per pixel tile of the direct kernels) are ~8 loads deep per
-// thread (with 64 channels x 16 row lanes they were 32 deep: a latency chain of ~10 us on 1 - 6 blocks); fixed summation order
+// 4 channels x 256 row lanes per block (the geometry of bn_finalize_kernel): up to 2040 partial rows (one per pixel tile of the direct
+// kernels) are two rounds of four INDEPENDENT loads per thread (with 16 channels x 64 row lanes they were 32 deep, four in flight: a chain
+// of ~8 L2 round trips on 3 - 24 blocks); fixed summation order
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nrb, long long rows, int C,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
                                                                const unsigned* __restrict__ gmax_rec = nullptr,
                                                                const unsigned* __restrict__ y_rec = nullptr, const float* __restrict__ stats = nullptr,
                                                                const float* __restrict__ gamma = nullptr, unsigned* __restrict__ dy_rec = nullptr) {
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
-  double sg = 0, sgx = 0;
-  if (c < C)
-#pragma unroll 4
-    for (int b = rl; b < nrb; b += 64) {
-      const float* o = part + ((long long)b * 2) * C;
-      sg += o[c];
-      sgx += o[C + c];
-    }
-  // the 4 row lanes of a wave by lane shuffles (lane = 16 row lane + channel), the 16 waves through LDS (fixed order)
-  sg += __shfl_xor(sg, 16, 64);
-  sgx += __shfl_xor(sgx, 16, 64);
-  sg += __shfl_xor(sg, 32, 64);
-  sgx += __shfl_xor(sgx, 32, 64);
-  __shared__ double s1[16][16], s2[16][16];
-  if ((threadIdx.x & 63) < 16) { s1[threadIdx.x >> 6][cl] = sg; s2[threadIdx.x >> 6][cl] = sgx; }
-  __syncthreads();
-  if (rl != 0 || c >= C) return;
-  sg = 0; sgx = 0;
-  for (int k = 0; k < 16; ++k) { sg += s1[k][cl]; sgx += s2[k][cl]; }
-  if (dbeta) dbeta[c] = (float)sg;
-  if (dgamma) dgamma[c] = (float)sgx;
-  coef[c] = (float)(sg / (double)rows);
-  coef[C + c] = (float)(sgx / (double)rows);
-  if (dy_rec) {
-    // bound of dy = gamma invstd (g - mean(g) - xhat mean(g xhat)) for this channel, before the pass that computes it:
-    //   |dy| <= |gamma invstd| (max|g| + |mean(g)| + max|xhat| |mean(g xhat)|),   max|xhat| <= (max|y| + |mean|) invstd
-    unsigned gm = 0, ym = 0;
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
+  const bool live = c < C;
+  // (the tail's inputs fetched in the shadow of the partial loads, as in bn_finalize_kernel)
+  unsigned gm = 0, ym = 0;
+  float st_mean = 0.f, st_inv = 0.f, gam = 0.f;
+  if (dy_rec && rl == 0 && live) {
     for (int i = 0; i < CS_AMAX_SLOTS; ++i) {
       gm = max(gm, gmax_rec[i * CS_AMAX_STRIDE]);
       ym = max(ym, y_rec[i * CS_AMAX_STRIDE]);
     }
-    const float inv = stats[C + c], xh = (__uint_as_float(ym) + fabsf(stats[c])) * inv;
-    const float bound = fabsf(gamma[c] * inv) * (__uint_as_float(gm) + fabsf(coef[c]) + xh * fabsf(coef[C + c])) * 1.001f;
+    st_mean = stats[c]; st_inv = stats[C + c]; gam = gamma[c];
+  }
+  double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+  if (live)
+    for (int b = rl; b < nrb; b += 1024) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (b + 256 * u < nrb) {
+          const float* o = part + ((long long)(b + 256 * u) * 2) * C;
+          a0[u] += o[c];
+          a1[u] += o[C + c];
+        }
+    }
+  double sg = (a0[0] + a0[1]) + (a0[2] + a0[3]), sgx = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+  // the 16 row lanes of a wave by lane shuffles (lane = 4 row lane + channel), the 16 waves through LDS (fixed order)
+#pragma unroll
+  for (int o = 4; o <= 32; o <<= 1) {
+    sg += __shfl_xor(sg, o, 64);
+    sgx += __shfl_xor(sgx, o, 64);
+  }
+  __shared__ double s1[16][5], s2[16][5];
+  if ((threadIdx.x & 63) < 4) { s1[threadIdx.x >> 6][cl] = sg; s2[threadIdx.x >> 6][cl] = sgx; }
+  __syncthreads();
+  if (rl != 0 || !live) return;
+  sg = 0; sgx = 0;
+  for (int k = 0; k < 16; ++k) { sg += s1[k][cl]; sgx += s2[k][cl]; }
+  if (dbeta) dbeta[c] = (float)sg;
+  if (dgamma) dgamma[c] = (float)sgx;
+  const float mg = (float)(sg / (double)rows), mgx = (float)(sgx / (double)rows);
+  coef[c] = mg;
+  coef[C + c] = mgx;
+  if (dy_rec) {
+    // bound of dy = gamma invstd (g - mean(g) - xhat mean(g xhat)) for this channel, before the pass that computes it:
+    //   |dy| <= |gamma invstd| (max|g| + |mean(g)| + max|xhat| |mean(g xhat)|),   max|xhat| <= (max|y| + |mean|) invstd
+    const float inv = st_inv, xh = (__uint_as_float(ym) + fabsf(st_mean)) * inv;
+    const float bound = fabsf(gam * inv) * (__uint_as_float(gm) + fabsf(mg) + xh * fabsf(mgx)) * 1.001f;
     atomicMax(dy_rec + CS_REC_BOUND, __float_as_uint(bound));
   }
 }
@@ -603,10 +629,10 @@ extern "C" int catseg_bn_backward_amax(const float* dz, int lddz, const float* z
   float* part = (float*)workspace;
   float* coef = part + (size_t)kMaxRowBlocks * 3 * ((C + 3) & ~3);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma, beta, rows, C, relu, s, part);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
 #ifdef BN_AB_DOUBLE_FINALIZE   // (TIMING-ONLY build: the finalize launches issued twice; the added time = their cost in the step.  NOT result
                                //  preserving on the forward side: running_mean / running_var receive the momentum update twice)
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
 #endif
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma,
                      beta, (const float*)coef, rows, C, relu, dy, lddy, dres, lddres, dres_accumulate, (unsigned*)amax_record);
@@ -639,7 +665,7 @@ extern "C" int catseg_bn_backward_pre_amax(const float* g, int ldg, const float*
   }
   hipStream_t st = (hipStream_t)stream;
   float* coef = (float*)workspace;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partials, n_blocks, rows, C, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, st, partials, n_blocks, rows, C, dgamma, dbeta, coef);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, st, g, ldg, (const float*)nullptr, 0, q, ldq, stats,
                      gamma, (const float*)nullptr, (const float*)coef, rows, C, 0, dq, lddq, (float*)nullptr, 0, 0, (unsigned*)amax_record);
   CS_LAUNCH_CHECK();
@@ -698,7 +724,7 @@ extern "C" int catseg_bn_backward_planes(const float* dz, int lddz, const float*
   float* coef = part + (size_t)kMaxRowBlocks * 3 * ((C + 3) & ~3);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma, beta, rows, C, relu, s, part,
                      (unsigned*)g_record);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef,
                      (const unsigned*)g_record, (const unsigned*)y_record, stats, gamma, (unsigned*)dy_record);
   const long long tiles = ((rows + 127) / 128) * ((C / 8 + 7) / 8);
   hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3((int)(tiles > 8192 ? 8192 : tiles)), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma,
@@ -722,7 +748,7 @@ extern "C" int catseg_bn_backward_pre_planes(const float* g, int ldg, const floa
   }
   hipStream_t st = (hipStream_t)stream;
   float* coef = (float*)workspace;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partials, n_blocks, rows, C, dgamma, dbeta, coef,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, st, partials, n_blocks, rows, C, dgamma, dbeta, coef,
                      (const unsigned*)g_record, (const unsigned*)y_record, stats, gamma, (unsigned*)dq_record);
   const long long tiles = ((rows + 127) / 128) * ((C / 8 + 7) / 8);
   hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3((int)(tiles > 8192 ? 8192 : tiles)), dim3(256), 0, st, g, ldg, (const float*)nullptr, 0, q, ldq,
