@@ -163,7 +163,11 @@ __global__ __launch_bounds__(G::NTHR, 2) void dwgrad3_pl_kernel(const WpArgs a) 
 
   auto tread = [&](int addr) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + addr)); };
   auto frag = [&](int addr, int hstride) {   // k = 0..3: the group's 4 pixels of tile row 2 ks, k = 4..7: of row 2 ks + 1
+#ifdef WP_NO_DSREAD
+    const s16x4 lo = {(short)addr, (short)lane, 1, 2}, hi = {(short)hstride, 3, (short)tid, 4};
+#else
     const s16x4 lo = tread(addr), hi = tread(addr + hstride);
+#endif
     const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(h8, v8);
   };
@@ -196,7 +200,9 @@ __global__ __launch_bounds__(G::NTHR, 2) void dwgrad3_pl_kernel(const WpArgs a) 
 #pragma unroll 1
   for (int tile = t_begin; tile < t_end; ++tile) {
     // (its buffer held tile - 1, whose last fragment reads are behind the barrier that closed that tile)
+#ifndef WP_NO_DMA       // (differential-timing builds, tools/ab_wp.sh: wrong results, the time difference is the ingredient's cost)
     if (tile + G::NBUF - 1 < t_end) dma(tile + G::NBUF - 1, nbuf);
+#endif
     const int bo = buf * G::BUF;
 #pragma unroll
     for (int ks = 0; ks < G::NKS; ++ks) {
@@ -214,9 +220,13 @@ __global__ __launch_bounds__(G::NTHR, 2) void dwgrad3_pl_kernel(const WpArgs a) 
 #pragma unroll
           for (int mt = 0; mt < G::MT; ++mt) {
             f32x4 c = acc[mt][j];
+#ifdef WP_NO_MFMA
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][0] + af[mt][1], bf[1] + bf[0], c, 0, 0, 0);
+#else
             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][0], bf[1], c, 0, 0, 0);   // h l
             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][1], bf[0], c, 0, 0, 0);   // l h
             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][0], bf[0], c, 0, 0, 0);   // h h
+#endif
             acc[mt][j] = c;
           }
         }
@@ -233,6 +243,17 @@ __global__ __launch_bounds__(G::NTHR, 2) void dwgrad3_pl_kernel(const WpArgs a) 
 
   // ---- this block's partial sums: slab[split][o][ky][kx][c] --------------------------------------------------------------------
   float* out = a.slabs + (long long)split * a.slab_stride;
+#ifdef WP_NO_STORE
+  if (a.splits > 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < G::NTW; ++j) t += acc[mt][j][0] + acc[mt][j][1] + acc[mt][j][2] + acc[mt][j][3];
+    if (t == 1.2345e-30f) out[0] = t;
+    return;
+  }
+#endif
 #pragma unroll
   for (int mt = 0; mt < G::MT; ++mt)
 #pragma unroll
@@ -276,17 +297,23 @@ __global__ __launch_bounds__(256) void dwgrad3_pl_reduce_kernel(const float* __r
 using Wp48 = WpCfg<48, 48, 3, 1, 4, 4, 2>;   // one block: all 48 x 432 accumulators, tiles 4 x 16, two image buffers of 33 KB
 #ifdef WP_ALT96
 using Wp96 = WpCfg<48, 48, 1, 1, 4, 4, 2>;   // A/B: 48 co x (one filter row x 48 ci), tiles 4 x 16
+#elif defined(WP_ROW96)
+using Wp96 = WpCfg<96, 48, 1, 2, 2, 2, 2>;   // A/B (the first form of this kernel): block = 96 co x (ONE filter row x 48 ci), 15 accumulators per wave
 #else
-using Wp96 = WpCfg<96, 48, 1, 2, 2, 2, 2>;
-#endif   // block = 96 co x (one filter row x 48 ci), tiles 2 x 16, two image buffers of 21.5 KB (three: a tile is
-                                             // 45 MFMAs per wave, shorter than an LDS-DMA round trip -- were measured: 60 -> 92 us, not adopted)
+// block = 96 co x (all three filter rows x 48 ci), tiles 2 x 16: 42 accumulators per wave (224 registers: four waves per block, two blocks per
+// CU = two waves per SIMD).  A tile is 126 MFMAs per wave, longer than an LDS-DMA round trip (with one filter row per block it was 45,
+// shorter than one: removing the LDS-DMA from that form gained 14 of its 53 us, tools/ab_wp.sh), dy is fetched by 2 variants of a split
+// instead of 6 and x once per channel half: 61.6 -> 59.0 us (96 channels, reduction included), 59.8 -> 58.3 (192), 66.7 -> 56.4 (384).
+// Three image buffers were measured on the one-row form: 60 -> 92 us, not adopted.
+using Wp96 = WpCfg<96, 48, 3, 2, 2, 2, 2>;
+#endif
 
 struct WpPlan { int kind, variants, splits, TH; };
 
 WpPlan wp_plan(int C, int B, int H, int W) {
   WpPlan p = {0, 0, 0, 0};
   if (C == 48) { p.kind = 1; p.variants = 1; p.TH = Wp48::TH; }
-  else if (C == 96 || C == 192 || C == 384) { p.kind = 2; p.variants = (C / Wp96::COT) * (C / Wp96::NCI) * 3; p.TH = Wp96::TH; }
+  else if (C == 96 || C == 192 || C == 384) { p.kind = 2; p.variants = (C / Wp96::COT) * (C / Wp96::NCI) * (Wp96::NTY == 3 ? 1 : 3); p.TH = Wp96::TH; }
   else return p;
   const int ntile = B * ((H + p.TH - 1) / p.TH) * ((W + 15) / 16);
   int s = catseg_g_wg_blocks / p.variants;
