@@ -297,15 +297,17 @@ __global__ __launch_bounds__(256) void dwgrad3_pl_reduce_kernel(const float* __r
 using Wp48 = WpCfg<48, 48, 3, 1, 4, 4, 2>;   // one block: all 48 x 432 accumulators, tiles 4 x 16, two image buffers of 33 KB
 #ifdef WP_ALT96
 using Wp96 = WpCfg<48, 48, 1, 1, 4, 4, 2>;   // A/B: 48 co x (one filter row x 48 ci), tiles 4 x 16
-#elif defined(WP_ROW96)
-using Wp96 = WpCfg<96, 48, 1, 2, 2, 2, 2>;   // A/B (the first form of this kernel): block = 96 co x (ONE filter row x 48 ci), 15 accumulators per wave
-#else
-// block = 96 co x (all three filter rows x 48 ci), tiles 2 x 16: 42 accumulators per wave (224 registers: four waves per block, two blocks per
-// CU = two waves per SIMD).  A tile is 126 MFMAs per wave, longer than an LDS-DMA round trip (with one filter row per block it was 45,
-// shorter than one: removing the LDS-DMA from that form gained 14 of its 53 us, tools/ab_wp.sh), dy is fetched by 2 variants of a split
-// instead of 6 and x once per channel half: 61.6 -> 59.0 us (96 channels, reduction included), 59.8 -> 58.3 (192), 66.7 -> 56.4 (384).
-// Three image buffers were measured on the one-row form: 60 -> 92 us, not adopted.
+#elif defined(WP_ROWS3)
+// A/B: block = 96 co x (ALL THREE filter rows x 48 ci): 42 accumulators per wave (224 registers), a tile is 126 MFMAs per wave and dy is
+// fetched by 2 variants of a split instead of 6.  Standalone it wins (reduction included: 61.6 -> 59.0 us at 96 channels, 59.8 -> 58.3 at 192,
+// 66.7 -> 56.4 at 384; the kernel alone 61.7 -> 55.2 us in the step), but its slabs are 3 x (85 MB per layer; reduction 8.6 -> 21 us), and the
+// whole step LOSES 1.7 - 2 ms with it (tools/ab_lib_bench.sh, three alternating rounds on one box: 118.1 - 118.6 against 119.8 - 121.9 ms).
 using Wp96 = WpCfg<96, 48, 3, 2, 2, 2, 2>;
+#else
+// block = 96 co x (one filter row x 48 ci), tiles 2 x 16, two image buffers of 21.5 KB (three: a tile is 45 MFMAs per wave, shorter than an
+// LDS-DMA round trip -- were measured: 60 -> 92 us, not adopted).  Differential builds (tools/ab_wp.sh) price its LDS-DMA at 14 of 53 us
+// (MFMAs alone 28, fragment reads 5, slab store 3).
+using Wp96 = WpCfg<96, 48, 1, 2, 2, 2, 2>;
 #endif
 
 struct WpPlan { int kind, variants, splits, TH; };
