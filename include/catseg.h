@@ -143,6 +143,10 @@ size_t catseg_split2h_blocked_elems(long long rows, int C);   /* [2][ceil(C/16)]
 size_t catseg_split2h_planar_elems(long long rows, int C);    /* [2][rows][roundup(C, 8)]: backward-weight operand */
 int catseg_split2h(const float* x, long long rows, int C, int ld, void* blocked_planes, void* planar_planes, void* scale,
                    catseg_stream_t stream);                   /* either layout may be NULL; one pass over x for both */
+/* catseg_split2h without the pass over x that finds max|x|: the maximum over up to four amax records the producers of x (or of its channel
+ * slices) left (null = unused); a record may be an upper bound */
+int catseg_split2h_bound(const float* x, long long rows, int C, int ld, void* blocked_planes, void* planar_planes, void* scale,
+                         const void* rec0, const void* rec1, const void* rec2, const void* rec3, catseg_stream_t stream);
 int catseg_split2h_weight_blocked(const float* w, int O, int taps, int Cin, void* planes, void* scale, catseg_stream_t stream);
 int catseg_split2h_weight_t_blocked(const float* w, int O, int taps, int Cin, void* planes, void* scale, catseg_stream_t stream);
 int catseg_conv2d_fwd_f16x2_blocked(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* w_planes,

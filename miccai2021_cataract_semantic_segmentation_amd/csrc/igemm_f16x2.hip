@@ -771,6 +771,18 @@ int amax_launch(const float* x, int ld, long long rows, int C, unsigned* amax_bi
   return CATSEG_OK;
 }
 
+// max|x| of a tensor whose producers left amax records (csrc/common.h: 16 slots each): the maximum over up to four records (the channel
+// slices of a concatenation have one producer each) instead of a pass over the tensor
+struct AmaxRecs { const unsigned* r[4]; };
+__global__ void amax_merge_kernel(AmaxRecs recs, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  const int i = threadIdx.x >> 4, s = threadIdx.x & 15;      // 64 threads: record i, slot s
+  if (recs.r[i]) m = recs.r[i][s * CS_AMAX_STRIDE];
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if (threadIdx.x == 0) *out = m;
+}
+
 }  // namespace
 
 // scale (device, 8 bytes: {uint32 amax bits, int32 exponent}) is working storage + result of the split calls below
@@ -788,6 +800,27 @@ extern "C" int catseg_split2h(const float* x, long long rows, int C, int ld, voi
   hipStream_t st = (hipStream_t)stream;
   unsigned* ab = (unsigned*)scale;
   if (int rc = amax_launch(x, ld, rows, C, ab, st)) return rc;
+  const int c16 = (C + 15) / 16, ldp = (C + 7) & ~7;
+  hipLaunchKernelGGL(split2h_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((c16 * 16 + 127) / 128)), dim3(256), 0, st, x, ld, rows, C, ldp,
+                     (const unsigned*)ab, (u16*)blocked_planes, (long long)c16 * rows * 16, (u16*)planar_planes, rows * ldp, (int*)(ab + 1));
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// catseg_split2h without its pass over x for max|x|: the producers of x left amax records (catseg_bn_apply_amax, catseg_bn_backward_amax,
+// catseg_add_n_act_amax ...; bilinear resizing and copies keep their input's), up to four of them for the channel slices of a concatenation
+// (null = unused).  The records must bound |x| (an exact maximum or an upper bound: the exponent only has to keep x * 2^e inside fp16).
+extern "C" int catseg_split2h_bound(const float* x, long long rows, int C, int ld, void* blocked_planes, void* planar_planes, void* scale,
+                                    const void* rec0, const void* rec1, const void* rec2, const void* rec3, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && ld >= C && ld % 4 == 0 && cs_aligned16(x) && cs_aligned16(blocked_planes) && cs_aligned16(planar_planes) &&
+                 (blocked_planes || planar_planes) && scale && (((uintptr_t)scale) & 7) == 0,
+             "split2h_bound: bad args (ld must be a multiple of 4, pointers 16-byte aligned)");
+  CS_REQUIRE(rec0 || rec1 || rec2 || rec3, "split2h_bound: no amax record");
+  CS_REQUIRE((rows + 63) / 64 < (1ll << 31), "split2h_bound: too many rows");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* ab = (unsigned*)scale;
+  AmaxRecs recs = {{(const unsigned*)rec0, (const unsigned*)rec1, (const unsigned*)rec2, (const unsigned*)rec3}};
+  hipLaunchKernelGGL(amax_merge_kernel, dim3(1), dim3(64), 0, st, recs, ab);
   const int c16 = (C + 15) / 16, ldp = (C + 7) & ~7;
   hipLaunchKernelGGL(split2h_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((c16 * 16 + 127) / 128)), dim3(256), 0, st, x, ld, rows, C, ldp,
                      (const unsigned*)ab, (u16*)blocked_planes, (long long)c16 * rows * 16, (u16*)planar_planes, rows * ldp, (int*)(ab + 1));

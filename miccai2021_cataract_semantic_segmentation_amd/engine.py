@@ -628,7 +628,10 @@ def adaptive_avgpool(cx, x, S):
 
 def copy_into(cx, src, dst):
     """dst (a channel slice of a concat buffer) = src; the gradient of dst flows back to src"""
+    rec = ops.amax_of(src)
     ops.axpy(src, dst, 1.0, False)
+    if rec is not None:
+        dst._amax = rec                 # (a copy: the source's record bounds it)
     if cx.record:
         def bwd():
             g = cx.take(dst)
@@ -653,6 +656,9 @@ def global_avgpool(cx, x):
 
 def concat_views(cx, cat, parts):
     """parts: [(tensor written as a channel slice of `cat`, c0, c1)] — backward hands out slices."""
+    recs = [ops.amax_of(t) for t, _, _ in parts]
+    if recs and all(r is not None for r in recs) and sum(c1 - c0 for _, c0, c1 in parts) == cat.shape[-1]:
+        cat._amax_parts = recs          # every channel of the buffer has a producer that left max|.|: the f16x2 split pass needs no amax pass
     if cx.record:
         def bwd():
             dcat = cx.take(cat)

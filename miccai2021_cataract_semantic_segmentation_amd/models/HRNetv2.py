@@ -288,7 +288,10 @@ def concat_branches(cx, ys):
         dst = cat[..., c0:c0 + c]
         if y is ys[0]:
             from .. import ops
+            rec = ops.amax_of(y)
             ops.axpy(y, dst, 1.0, False)
+            if rec is not None:
+                dst._amax = rec         # (a copy: the source's record bounds it; concat_views collects the slices' records)
             part = dst
             if cx.record:
                 def bwd(src=y, d=dst):

@@ -341,6 +341,19 @@ def amax_of(t):
     return getattr(t, "_amax", None)
 
 
+SPLIT_BOUND = _os.environ.get("CATSEG_SPLIT_BOUND", "1") != "0"    # f16x2 split passes take max|x| from the producers' records when they exist
+
+
+def amax_records_of(t):
+    """the amax records that bound |t|: its own, or those of the channel slices of a concatenation buffer (engine.concat_views); None if
+    unknown or more than four"""
+    r = getattr(t, "_amax", None)
+    if r is not None:
+        return [r]
+    parts = getattr(t, "_amax_parts", None)
+    return parts if parts and len(parts) <= 4 else None
+
+
 def drop_amax(t):
     """a tensor that is about to be modified IN PLACE (an accumulating launch) loses the amax record its producer attached: the record
     would underestimate the new contents, and an underestimate overflows the fp16 planes of the trunk kernels (their prescale leaves one
@@ -349,6 +362,8 @@ def drop_amax(t):
         t._amax = None
     if t is not None and getattr(t, "_planes", None) is not None:
         t._planes = None           # (planes describe the old contents)
+    if t is not None and getattr(t, "_amax_parts", None) is not None:
+        t._amax_parts = None
     return t
 
 
@@ -1283,7 +1298,12 @@ def split2h(x, blocked=True, planar=False):
     blk = torch.empty((2, (C + 15) // 16, rows, 16), dtype=torch.int16, device=x.device) if blocked else None
     pl = torch.empty((2, rows, (C + 7) // 8 * 8), dtype=torch.int16, device=x.device) if planar else None
     scale = torch.empty(2, dtype=torch.int32, device=x.device)
-    check(lib.catseg_split2h(ptr(x), rows, C, ld, ptr(blk), ptr(pl), ptr(scale), stream()))
+    recs = amax_records_of(x) if SPLIT_BOUND else None
+    if recs:        # the producers of x left max|x|: no pass over x to find it (csrc/igemm_f16x2.hip: catseg_split2h_bound)
+        r = list(recs) + [None] * (4 - len(recs))
+        check(lib.catseg_split2h_bound(ptr(x), rows, C, ld, ptr(blk), ptr(pl), ptr(scale), ptr(r[0]), ptr(r[1]), ptr(r[2]), ptr(r[3]), stream()))
+    else:
+        check(lib.catseg_split2h(ptr(x), rows, C, ld, ptr(blk), ptr(pl), ptr(scale), stream()))
     return blk, pl, scale
 
 

@@ -1,0 +1,47 @@
+"""f16x2 split passes of the head convolutions: max|x| from the producers' amax records instead of a pass over the tensor
+(csrc/igemm_f16x2.hip: catseg_split2h_bound)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def test_split2h_bound_takes_max_from_producer_records():
+    """catseg_split2h_bound: the exponent comes from up to four amax records instead of a pass over x; with the exact maximum in the records the
+    planes are bit-identical to catseg_split2h's, with an upper bound one power of two looser they still reproduce x to 2^-21 of the bound"""
+    _need_gpu()
+    from miccai2021_cataract_semantic_segmentation_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(3, 9, 17, 80, generator=g) * torch.exp(torch.randn(80, generator=g))).to(dev)
+    blk0, pl0, sc0 = ops.split2h(x, True, True)
+    parts = [x[..., :16], x[..., 16:48], x[..., 48:]]
+    recs = []
+    for p in parts:
+        r = ops.new_amax(dev)
+        r[32 * (len(recs) + 3)] = p.abs().max().reshape(1).view(torch.int32)[0]      # any slot of the record may hold the maximum
+        recs.append(r)
+    x._amax_parts = recs
+    blk1, pl1, sc1 = ops.split2h(x, True, True)
+    assert int(sc1[1]) == int(sc0[1]) and torch.equal(blk0, blk1) and torch.equal(pl0, pl1)
+    x._amax_parts = None
+    r = ops.new_amax(dev)
+    r[0] = (x.abs().max() * 2.5).reshape(1).view(torch.int32)[0]
+    x._amax = r
+    blk2, pl2, sc2 = ops.split2h(x, True, True)
+    e = int(sc2[1])
+    assert e in (int(sc0[1]) - 1, int(sc0[1]) - 2)
+    hl = pl2.view(torch.float16).float()                       # [2, rows, 80]
+    back = (hl[0] + hl[1]).reshape(3, 9, 17, 80) * 2.0 ** (-e)
+    assert float((back - x).abs().max()) <= float(x.abs().max()) * 2.5 * 2.0 ** -21
+    ops.SPLIT_BOUND = False
+    try:
+        blk3, _, sc3 = ops.split2h(x, True, False)
+    finally:
+        ops.SPLIT_BOUND = True
+    assert torch.equal(blk3, blk0) and int(sc3[1]) == int(sc0[1])
