@@ -22,6 +22,11 @@
 #include "planes.h"
 
 int catseg_g_pl_slots = 512;
+int catseg_g_pl_pair = 0;          // bit mask (2: 96 channels, 4: 192, 8: 384): launch the two-tiles-per-block form of the kernel
+extern "C" int catseg_debug_set_dconv3_pl_pair(int mask) {
+  catseg_g_pl_pair = mask;
+  return CATSEG_OK;
+}
 extern "C" int catseg_debug_set_dconv3_pl_slots(int slots) {
   catseg_g_pl_slots = slots > 0 ? slots : 512;
   return CATSEG_OK;
@@ -41,9 +46,12 @@ constexpr PlUnit pl_unit_of(int step, int half) {
 }
 constexpr int pl_steps_of(int KC) { return KC == 32 ? 9 : 14; }
 
-template <int C_, int NT_, int WC_, int WP_, int PB_, int TPH_, int TPW_>
+// NT2_: pixel tiles a block works on SIDE BY SIDE (1: four compute waves, two blocks per CU; 2: eight compute waves on two tiles that SHARE the
+// weight slots -- one stream of weights per CU instead of two -- and one block per CU)
+template <int C_, int NT_, int WC_, int WP_, int PB_, int TPH_, int TPW_, int NT2_ = 1>
 struct PlCfg {
-  static constexpr int C = C_, NT = NT_, WC = WC_, WP = WP_, PB = PB_, TPH = TPH_, TPW = TPW_;
+  static constexpr int C = C_, NT = NT_, WC = WC_, WP = WP_, PB = PB_, TPH = TPH_, TPW = TPW_, NT2 = NT2_;
+  static constexpr int NCW = 4 * NT2, NTHR = 64 * (NCW + 4), MINW = NT2 == 1 ? 4 : 3;
   static constexpr int KC = C == 48 ? 48 : 32;            // channel chunk of the WEIGHT image (as dconv3_f16x2 lays it out)
   static_assert(WC * WP == 4 && C % KC == 0 && C % NT == 0 && NT % (16 * WC) == 0 && TPH * TPW == WP * PB, "tiling");
   static constexpr int NG = C / 8;                        // channel groups of the planes
@@ -57,18 +65,21 @@ struct PlCfg {
   // X sub-chunks of a weight chunk: KC = 32: one (4 groups, 9 K-steps); KC = 48: (4 groups, steps 0-8) + (2 groups, steps 9-13)
   static constexpr int NSUB = KC == 48 ? 2 : 1;
   static constexpr int NXB = 2;
+  static constexpr int RING = NT2 * XBUF;                   // one ring buffer holds the halo images of the block's NT2 tiles
+  static constexpr int BUDGET = (NT2 == 1 ? 80 : 128) * 1024;
   // weight slots: as many (3 .. 5) as fit two blocks per CU (80 KB each).  With NWB slots the weights of K-step s + NWB are issued in step s
   // and must have landed NWB - 2 steps later: the helpers' counted waits then cover an L2 round trip under load (~1 - 2 K-steps)
 #ifdef PL_NWB
   static constexpr int NWB = PL_NWB;
 #else
-  static constexpr int NWB = (NXB * XBUF + 5 * WSTEP <= 80 * 1024) ? 5 : ((NXB * XBUF + 4 * WSTEP <= 80 * 1024) ? 4 : 3);
+  static constexpr int NWB = (NXB * RING + 5 * WSTEP <= BUDGET) ? 5 : ((NXB * RING + 4 * WSTEP <= BUDGET) ? 4 : 3);
 #endif
-  static constexpr int LDS = NXB * XBUF + NWB * WSTEP;
+  static constexpr int LDS = NXB * RING + NWB * WSTEP;
   static_assert(WSTEP % 1024 == 0 && KGS % 256 == 0, "LDS image strides");
   static constexpr int sub_steps(int u) { return u == 0 ? 9 : 5; }
   static constexpr int sub_groups(int u) { return u == 0 ? 4 : 2; }
-  static constexpr int sub_items(int u) { return u == 0 ? 2 * NJ : NJ; }   // X LDS-DMA instructions per helper wave
+  static constexpr int tile_items(int u) { return u == 0 ? 2 * NJ : NJ; }  // X LDS-DMA instructions per helper wave and tile
+  static constexpr int sub_items(int u) { return NT2 * tile_items(u); }
 };
 
 struct PlArgs {
@@ -121,12 +132,13 @@ __device__ __forceinline__ void pl_wait_vm(int n) {
 }
 
 template <class G, bool BQ>
-__global__ __launch_bounds__(512, 4) void dconv3_pl_kernel(const PlArgs a) {
+__global__ __launch_bounds__(G::NTHR, G::MINW) void dconv3_pl_kernel(const PlArgs a) {
   __shared__ __attribute__((aligned(256))) unsigned char smem[G::LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cob = blockIdx.y;
-  const int ntile = a.B * a.tiles_y * a.tiles_x;
+  const int ntile_all = a.B * a.tiles_y * a.tiles_x;
+  const int ntile = (ntile_all + G::NT2 - 1) / G::NT2;          // units of NT2 tiles: unit u = tiles NT2 u .. NT2 u + NT2 - 1
   int t_begin, t_end;
   {   // the blocks that share an XCD (equal blockIdx.x % 8) get neighbouring runs of tiles
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -137,9 +149,9 @@ __global__ __launch_bounds__(512, 4) void dconv3_pl_kernel(const PlArgs a) {
   if (t_begin >= t_end) return;
   const int total = (t_end - t_begin) * G::TSTEPS;          // K-steps of this block
 
-  if (wave >= 4) {
+  if (wave >= G::NCW) {
     // ================================================== helper role: every LDS-DMA of the block ==================================================
-    const int hw = wave - 4;
+    const int hw = wave - G::NCW;
     // halo slot of this lane in the j-th instruction of a (plane, group): slot = 64 j + lane -> (row, column) of the halo tile
     int rel[G::NJ], hr[G::NJ], hc[G::NJ];
 #pragma unroll
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(512, 4) void dconv3_pl_kernel(const PlArgs a) {
     const unsigned char* wsrc = (const unsigned char*)a.wimg + (long long)cob * G::TSTEPS * G::WSTEP + hw * Q + lane * 16;
     auto wfill = [&](int q, int slot) {
 #ifndef PL_NO_WDMA
-      unsigned char* dst = smem + G::NXB * G::XBUF + slot * G::WSTEP + hw * Q;
+      unsigned char* dst = smem + G::NXB * G::RING + slot * G::WSTEP + hw * Q;
       const unsigned char* src = wsrc + (long long)q * G::WSTEP;
 #pragma unroll
       for (int i = 0; i < NW; ++i)
@@ -168,29 +180,36 @@ __global__ __launch_bounds__(512, 4) void dconv3_pl_kernel(const PlArgs a) {
     };
     // ---- the NEXT sub-chunk to fetch: (tile, weight chunk, sub-chunk) -> image offset, tile origin, first channel group, ring buffer
     int f_tile = t_begin, f_chunk = 0, f_buf = 0;
-    int f_y0 = 0, f_x0 = 0, f_org = 0;
-    unsigned f_img = 0;
+    int f_y0[G::NT2], f_x0[G::NT2], f_org[G::NT2];
+    unsigned f_img[G::NT2];
     auto f_geom = [&]() {
-      const int tx = f_tile % a.tiles_x, ty = (f_tile / a.tiles_x) % a.tiles_y, b = f_tile / (a.tiles_x * a.tiles_y);
-      f_y0 = ty * G::TH;
-      f_x0 = tx * G::TW;
-      f_org = (f_y0 * a.W + f_x0) * 16;
-      f_img = (unsigned)(b * a.H * a.W) * 16u;
+#pragma unroll
+      for (int h = 0; h < G::NT2; ++h) {
+        int t = f_tile * G::NT2 + h;
+        if (t >= ntile_all) t = ntile_all - 1;              // (an odd tile count: the last unit fetches its one tile twice)
+        const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, b = t / (a.tiles_x * a.tiles_y);
+        f_y0[h] = ty * G::TH;
+        f_x0[h] = tx * G::TW;
+        f_org[h] = (f_y0[h] * a.W + f_x0[h]) * 16;
+        f_img[h] = (unsigned)(b * a.H * a.W) * 16u;
+      }
     };
     f_geom();
     // item m of sub-chunk type U for this helper: U = 0 (4 groups): group = hw, plane = m & 1, j = m >> 1;  U = 1 (2 groups): group = hw & 1,
     // plane = hw >> 1, j = m  (j is a compile-time constant either way: rel[] / hr[] / hc[] are indexed statically)
-    auto xissue = [&](auto U_, auto M_) {
-      constexpr int U = decltype(U_)::value, M = decltype(M_)::value;
+    auto xissue = [&](auto U_, auto MM_) {
+      constexpr int U = decltype(U_)::value, MM = decltype(MM_)::value;
+      constexpr int TH_ = MM / G::tile_items(U) < G::NT2 ? MM / G::tile_items(U) : 0, M = MM % G::tile_items(U);     // (tile of the unit, item)
+      if constexpr (MM / G::tile_items(U) >= G::NT2) return;
       constexpr int j = (U == 0 ? (M >> 1) : M) < G::NJ ? (U == 0 ? (M >> 1) : M) : 0;
       if constexpr ((U == 0 ? (M >> 1) : M) >= G::NJ) return;
       const int plane = U == 0 ? (M & 1) : (hw >> 1);
       const int lg = U == 0 ? hw : (hw & 1);
       const int g0 = f_chunk * (G::KC / 8) + (U == 0 ? 0 : 4);
-      const bool ok = (unsigned)(f_y0 + hr[j]) < (unsigned)a.H && (unsigned)(f_x0 + hc[j]) < (unsigned)a.W;
-      const unsigned voff = ok ? (unsigned)(f_org + rel[j]) : 0xFFFFFFF0u;
-      const unsigned soff = (unsigned)(plane * G::NG + g0 + lg) * a.P16 + f_img;
-      unsigned char* dst = smem + f_buf * G::XBUF + plane * G::XPS + lg * G::KGS + j * 1024;
+      const bool ok = (unsigned)(f_y0[TH_] + hr[j]) < (unsigned)a.H && (unsigned)(f_x0[TH_] + hc[j]) < (unsigned)a.W;
+      const unsigned voff = ok ? (unsigned)(f_org[TH_] + rel[j]) : 0xFFFFFFF0u;
+      const unsigned soff = (unsigned)(plane * G::NG + g0 + lg) * a.P16 + f_img[TH_];
+      unsigned char* dst = smem + f_buf * G::RING + TH_ * G::XBUF + plane * G::XPS + lg * G::KGS + j * 1024;
       if (j * 64 + lane < G::HP)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
     };
@@ -218,7 +237,13 @@ __global__ __launch_bounds__(512, 4) void dconv3_pl_kernel(const PlArgs a) {
         case 2: issue(std::integral_constant<int, 2>{}); break;
         case 3: issue(std::integral_constant<int, 3>{}); break;
         case 4: issue(std::integral_constant<int, 4>{}); break;
-        default: issue(std::integral_constant<int, 5>{}); break;
+        case 5: issue(std::integral_constant<int, 5>{}); break;
+        case 6: issue(std::integral_constant<int, 6>{}); break;
+        case 7: issue(std::integral_constant<int, 7>{}); break;
+        case 8: issue(std::integral_constant<int, 8>{}); break;
+        case 9: issue(std::integral_constant<int, 9>{}); break;
+        case 10: issue(std::integral_constant<int, 10>{}); break;
+        default: issue(std::integral_constant<int, 11>{}); break;
       }
     }
     f_advance(std::integral_constant<int, 0>{});
@@ -288,7 +313,8 @@ __global__ __launch_bounds__(512, 4) void dconv3_pl_kernel(const PlArgs a) {
 
   // ==================================================== compute role: fragment reads + MFMAs ====================================================
   const int i16 = lane & 15, kg = lane >> 4;
-  const int wc = wave / G::WP, wp = wave % G::WP;
+  const int half = wave >> 2, w4 = wave & 3;     // (tile of the unit this wave works on; wave within the tile's four)
+  const int wc = w4 / G::WP, wp = w4 % G::WP;
 #ifndef PL_NO_SCALE
   const int ex_x = __builtin_amdgcn_readfirstlane(a.x_rec[CS_REC_EXP]);
   const int ex_w = __builtin_amdgcn_readfirstlane(a.w_rec[1]);
@@ -299,10 +325,10 @@ __global__ __launch_bounds__(512, 4) void dconv3_pl_kernel(const PlArgs a) {
 #pragma unroll
   for (int pt = 0; pt < G::PB; ++pt) {
     const int px = (prow(pt) * G::HW + pcol(pt)) * 16;
-    xa[pt] = kg * G::KGS + px;
-    xs1[pt] = (kg & 1) * G::KGS + px;
+    xa[pt] = half * G::XBUF + kg * G::KGS + px;
+    xs1[pt] = half * G::XBUF + (kg & 1) * G::KGS + px;
   }
-  const int wb = G::NXB * G::XBUF + kg * (G::NT * 16) + (wc * G::CB * 16 + i16) * 16;
+  const int wb = G::NXB * G::RING + kg * (G::NT * 16) + (wc * G::CB * 16 + i16) * 16;
   h8 xf[G::PB][2], wf[G::CB][2];
   int xbase = 0;                 // ring buffer of the sub-chunk being computed (byte offset)
   // pixel fragments of weight-chunk step WS from the image at byte offset `base`
@@ -370,7 +396,7 @@ __global__ __launch_bounds__(512, 4) void dconv3_pl_kernel(const PlArgs a) {
 #ifndef PL_NO_DSREAD
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (LS + 1 < NS) xread1(std::integral_constant<int, WS0 + LS + 1>{}, xbase, pt);
-        else xread1(std::integral_constant<int, WSN>{}, xbase ^ G::XBUF, pt);
+        else xread1(std::integral_constant<int, WSN>{}, xbase ^ G::RING, pt);
         __builtin_amdgcn_sched_barrier(0);
 #endif
       }
@@ -392,12 +418,14 @@ __global__ __launch_bounds__(512, 4) void dconv3_pl_kernel(const PlArgs a) {
       one_step(std::integral_constant<int, 7>{});
       one_step(std::integral_constant<int, 8>{});
     }
-    xbase ^= G::XBUF;
+    xbase ^= G::RING;
   };
-  static_assert((G::XBUF & (G::XBUF - 1)) != 0 || true, "");
 
 #pragma unroll 1
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  for (int unit = t_begin; unit < t_end; ++unit) {
+    const int tile_raw = unit * G::NT2 + half;
+    const bool t_ok = tile_raw < ntile_all;                  // (the second tile of the last unit of an odd tile count does not exist)
+    const int tile = t_ok ? tile_raw : ntile_all - 1;
     const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
     const int y0 = ty * G::TH, x0 = tx * G::TW;
     const long long img0 = (long long)b * a.H * a.W;
@@ -432,7 +460,7 @@ __global__ __launch_bounds__(512, 4) void dconv3_pl_kernel(const PlArgs a) {
     int nvalid = 0;
 #pragma unroll
     for (int pt = 0; pt < G::PB; ++pt) {
-      p_ok[pt] = y0 + prow(pt) < a.H && x0 + pcol(pt) < a.W;
+      p_ok[pt] = t_ok && y0 + prow(pt) < a.H && x0 + pcol(pt) < a.W;
       nvalid += __builtin_popcountll(__builtin_amdgcn_ballot_w64(p_ok[pt]) & 0xFFFFull);
     }
     const int cl = wc * G::CB * 16 + 4 * kg;              // block-local channel of (ct = 0, r = 0)
@@ -467,7 +495,7 @@ __global__ __launch_bounds__(512, 4) void dconv3_pl_kernel(const PlArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v1 = pl_row16_sum(sg[r]), v2 = pl_row16_sum(sgx[r]);
-          if (i16 == 0) {
+          if (i16 == 0 && t_ok) {
             part[cl + ct * 16 + r] = v1;
             part[G::C + cl + ct * 16 + r] = v2;
           }
@@ -514,14 +542,14 @@ __global__ __launch_bounds__(512, 4) void dconv3_pl_kernel(const PlArgs a) {
             }
             d1 = pl_row16_sum(d1);
             d2 = pl_row16_sum(d2);
-            if (i16 == 0) {
+            if (i16 == 0 && t_ok) {
               const int c = cl + ct * 16 + r;
               part[c] = nvalid > 0 ? K : 0.f;
               part[G::C + c] = d1;
               part[2 * G::C + c] = d2;
             }
           }
-        if (lane == 0 && cob == 0 && wc == 0) a.bn_cnt[prw] = nvalid;
+        if (lane == 0 && cob == 0 && wc == 0 && t_ok) a.bn_cnt[prw] = nvalid;
       }
     }
     if (a.out_rec) {     // max |stored value| of this wave -> one of the record's 16 slots (order-independent: deterministic)
@@ -579,6 +607,10 @@ using Pl64 = PlCfg<64, 64, 2, 2, 2, 4, 1>;     // tile 4 x 16, wave = 32 co x 32
 using Pl96 = PlCfg<96, 96, 2, 2, 2, 4, 1>;     // tile 4 x 16, wave = 48 co x 32 px
 using Pl192 = PlCfg<192, 96, 2, 2, 2, 2, 2>;   // tile 2 x 32, two co blocks
 using Pl384 = PlCfg<384, 96, 2, 2, 2, 2, 2>;   // four co blocks
+// the same tiles, two per block: eight compute waves share one stream of weights (half the LDS-DMA bytes of the weights per output), one block per CU
+using Pl96P = PlCfg<96, 96, 2, 2, 2, 4, 1, 2>;
+using Pl192P = PlCfg<192, 96, 2, 2, 2, 2, 2, 2>;
+using Pl384P = PlCfg<384, 96, 2, 2, 2, 2, 2, 2>;
 
 struct PlPlan { int kind, NT, TH, TW, WP; };
 PlPlan pl_plan(int C) {
@@ -592,12 +624,12 @@ PlPlan pl_plan(int C) {
 
 template <class G>
 void pl_launch(const PlArgs& a, int C, hipStream_t st) {
-  const int ntile = a.B * a.tiles_y * a.tiles_x;
-  const int slots = catseg_g_pl_slots;      // two blocks per CU (catseg_debug_set_dconv3_pl_slots: tuning runs)
+  const int ntile = (a.B * a.tiles_y * a.tiles_x + G::NT2 - 1) / G::NT2;        // units of NT2 tiles
+  const int slots = catseg_g_pl_slots / G::NT2;      // two blocks per CU, or one of twice the size (catseg_debug_set_dconv3_pl_slots: tuning runs)
   // a block per tile while the tiles fit the block slots about once or twice; beyond that persistent blocks walking runs of tiles
   const int nb = ntile * (C / G::NT) > 2 * slots ? slots / (C / G::NT) : ntile;
-  if (a.bq_part) hipLaunchKernelGGL((dconv3_pl_kernel<G, true>), dim3(nb, C / G::NT), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((dconv3_pl_kernel<G, false>), dim3(nb, C / G::NT), dim3(512), 0, st, a);
+  if (a.bq_part) hipLaunchKernelGGL((dconv3_pl_kernel<G, true>), dim3(nb, C / G::NT), dim3(G::NTHR), 0, st, a);
+  else hipLaunchKernelGGL((dconv3_pl_kernel<G, false>), dim3(nb, C / G::NT), dim3(G::NTHR), 0, st, a);
 }
 
 int pl_run(int B, int H, int W, int C, const void* planes, const void* x_rec, const void* wimg, const void* w_rec, const float* bias, float* y,
@@ -623,11 +655,12 @@ int pl_run(int B, int H, int W, int C, const void* planes, const void* x_rec, co
   if (bn_part) CS_REQUIRE(bn_counts && bn_part_floats >= (size_t)nrow * 3 * C, "dconv3 (planes): BatchNorm partial buffer too small");
   if (bq_part) CS_REQUIRE(bq_part_floats >= (size_t)nrow * 2 * C, "dconv3 bnbwd (planes): partial buffer too small");
   hipStream_t st = (hipStream_t)stream;
-  if (p.kind == 1) pl_launch<Pl48>(a, C, st);
+  const int pair = catseg_g_pl_pair;
+  if (p.kind == 1) pl_launch<Pl48>(a, C, st);       // (two tiles of 48 channels would need four halo pieces per helper and K-step)
   else if (p.kind == 2) pl_launch<Pl64>(a, C, st);
-  else if (p.kind == 3) pl_launch<Pl96>(a, C, st);
-  else if (p.kind == 4) pl_launch<Pl192>(a, C, st);
-  else pl_launch<Pl384>(a, C, st);
+  else if (p.kind == 3) { if (pair & 2) pl_launch<Pl96P>(a, C, st); else pl_launch<Pl96>(a, C, st); }
+  else if (p.kind == 4) { if (pair & 4) pl_launch<Pl192P>(a, C, st); else pl_launch<Pl192>(a, C, st); }
+  else { if (pair & 8) pl_launch<Pl384P>(a, C, st); else pl_launch<Pl384>(a, C, st); }
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

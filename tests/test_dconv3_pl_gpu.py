@@ -90,3 +90,34 @@ def test_planes_layout_and_exactness(C):
         xf = x.reshape(P, C)
         assert float(((rebuilt - xf).abs() - xf.abs() * 2.0 ** -22).max()) <= 2.0 ** (-25 - e)      # (l is subnormal below 2^-17 max|x|)
         assert 2.0 ** 13 <= float(x.abs().max()) * over * 2.0 ** e < 2.0 ** 15
+
+
+@pytest.mark.parametrize("shape", [(96, 2, 19, 37), (96, 1, 4, 16), (96, 3, 9, 50), (192, 2, 7, 45), (192, 1, 2, 32), (384, 2, 5, 30), (384, 1, 3, 70)])
+def test_two_tiles_per_block_form_is_bit_identical(shape):
+    """catseg_debug_set_dconv3_pl_pair: eight compute waves on two tiles that share the weight slots (one block per CU) -- the same per-wave
+    arithmetic in the same order, so outputs, BatchNorm partials and the amax record equal the default form bit for bit; odd tile counts
+    (a last unit with one tile) included"""
+    _need_gpu()
+    from miccai2021_cataract_semantic_segmentation_amd import ops
+    C, B, H, W = shape
+    dev = torch.device("cuda")
+    x, w = _inputs(C, B, H, W, 3 * C + W)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.to(dev).contiguous(memory_format=torch.channels_last)
+    try:
+        wimg = ops.dconv3_weight_image(wd, h2=True)
+        xp = ops.planes_from_f32(xd)
+        outs = []
+        for mask in (0, 14):
+            ops.lib.catseg_debug_set_dconv3_pl_pair(mask)
+            rec = ops.new_amax(dev)
+            y, (part, nr, _, cnt) = ops.dconv3_pl(xp, wimg, None, out=torch.full_like(xd, float("nan")), bn_stats=True, out_rec=rec)
+            torch.cuda.synchronize()
+            outs.append((y, part[:nr * 3 * C].clone(), cnt[:nr].clone(), float(rec.view(torch.float32)[::32].max())))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2]) and outs[0][3] == outs[1][3]
+        live = outs[0][2] > 0                                      # (rows of empty waves are never written)
+        pa, pb = outs[0][1].view(-1, 3 * C)[live], outs[1][1].view(-1, 3 * C)[live]
+        assert torch.equal(pa, pb)
+    finally:
+        ops.lib.catseg_debug_set_dconv3_pl_pair(0)
+        ops.release_b3_cache()
