@@ -43,6 +43,9 @@ int catseg_debug_set_dconv3_pl_slots(int slots);
 /* tuning hook: bit mask of channel counts (2: 96, 4: 192, 8: 384) whose planes kernel runs in the two-tiles-per-block form (eight
  * compute waves sharing one stream of weights, one block per CU) */
 int catseg_debug_set_dconv3_pl_pair(int mask);
+/* occupancy queries (blocks per CU the runtime grants the planes kernels; needs a GPU): the designs assume two, or one for pair != 0 */
+int catseg_debug_dconv3_pl_occupancy(int C, int pair);
+int catseg_debug_dwgrad3_pl_occupancy(int C);
 
 /* tuning hook: bf16x3 block tile: 0 = heuristic, 1 = 256x256, 2 = 256x128, 3 = 128x256, 4 = 256x192, 5 = 256x96, 6 = 256x64 */
 int catseg_debug_set_b3_tile(int t);

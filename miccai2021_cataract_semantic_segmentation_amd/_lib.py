@@ -89,6 +89,8 @@ _SIGS = {
     "catseg_debug_set_dconv3_blocks": (I, [I]),
     "catseg_debug_set_dconv3_pl_slots": (I, [I]),
     "catseg_debug_set_dconv3_pl_pair": (I, [I]),
+    "catseg_debug_dconv3_pl_occupancy": (I, [I, I]),
+    "catseg_debug_dwgrad3_pl_occupancy": (I, [I]),
     "catseg_debug_set_dconv3_spec": (I, [I]),
     "catseg_debug_set_dconv3_alt96": (I, [I]),
     "catseg_aug_pad_flip_u8": (I, [P, P, I, I, I, I, P, I, I, P]),

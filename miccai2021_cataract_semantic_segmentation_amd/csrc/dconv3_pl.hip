@@ -669,6 +669,22 @@ int pl_run(int B, int H, int W, int C, const void* planes, const void* x_rec, co
 
 extern "C" int catseg_dconv3_pl_supported(int C) { return pl_plan(C).kind != 0; }
 
+// blocks of the planes kernel the runtime places on one CU (hipOccupancyMaxActiveBlocksPerMultiprocessor): the two-blocks-per-CU design of the
+// default form is a property of the LDS and register footprint, checked by tests/test_dconv3_pl_gpu.py.  pair != 0: the two-tiles-per-block form.
+extern "C" int catseg_debug_dconv3_pl_occupancy(int C, int pair) {
+  int n = -1;
+  hipError_t e = hipErrorInvalidValue;
+  if (C == 48) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dconv3_pl_kernel<Pl48, false>, Pl48::NTHR, 0);
+  else if (C == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dconv3_pl_kernel<Pl64, false>, Pl64::NTHR, 0);
+  else if (C == 96) e = pair ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dconv3_pl_kernel<Pl96P, false>, Pl96P::NTHR, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dconv3_pl_kernel<Pl96, false>, Pl96::NTHR, 0);
+  else if (C == 192) e = pair ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dconv3_pl_kernel<Pl192P, false>, Pl192P::NTHR, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dconv3_pl_kernel<Pl192, false>, Pl192::NTHR, 0);
+  else if (C == 384) e = pair ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dconv3_pl_kernel<Pl384P, false>, Pl384P::NTHR, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dconv3_pl_kernel<Pl384, false>, Pl384::NTHR, 0);
+  return e == hipSuccess ? n : -1;
+}
+
 // rows of the per-wave BatchNorm partial buffers of a launch: tiles x pixel groups per tile
 extern "C" int catseg_dconv3_pl_rows(int C, int B, int H, int W) {
   const PlPlan p = pl_plan(C);

@@ -297,6 +297,8 @@ __global__ __launch_bounds__(256) void dwgrad3_pl_reduce_kernel(const float* __r
 using Wp48 = WpCfg<48, 48, 3, 1, 4, 4, 2>;   // one block: all 48 x 432 accumulators, tiles 4 x 16, two image buffers of 33 KB
 #ifdef WP_ALT96
 using Wp96 = WpCfg<48, 48, 1, 1, 4, 4, 2>;   // A/B: 48 co x (one filter row x 48 ci), tiles 4 x 16
+#elif defined(WP_NBUF3)
+using Wp96 = WpCfg<96, 48, 1, 2, 2, 2, 3>;   // A/B: three image buffers (the LDS-DMA of tile t + 2 in flight behind tile t's MFMAs)
 #elif defined(WP_ROWS3)
 // A/B: block = 96 co x (ALL THREE filter rows x 48 ci): 42 accumulators per wave (224 registers), a tile is 126 MFMAs per wave and dy is
 // fetched by 2 variants of a split instead of 6.  Standalone it wins (reduction included: 61.6 -> 59.0 us at 96 channels, 59.8 -> 58.3 at 192,
@@ -328,6 +330,14 @@ WpPlan wp_plan(int C, int B, int H, int W) {
 }  // namespace
 
 extern "C" int catseg_dwgrad3_pl_supported(int C) { return C == 48 || C == 96 || C == 192 || C == 384; }
+
+// blocks of the backward-weight kernel the runtime places on one CU (two by design: four waves per block, two waves per SIMD)
+extern "C" int catseg_debug_dwgrad3_pl_occupancy(int C) {
+  int n = -1;
+  hipError_t e = C == 48 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dwgrad3_pl_kernel<Wp48>, Wp48::NTHR, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dwgrad3_pl_kernel<Wp96>, Wp96::NTHR, 0);
+  return e == hipSuccess ? n : -1;
+}
 
 extern "C" size_t catseg_dwgrad3_pl_workspace(int B, int H, int W, int C) {
   const WpPlan p = wp_plan(C, B, H, W);

@@ -1,8 +1,8 @@
-"""Host code of the C-ABI library under AddressSanitizer + UndefinedBehaviorSanitizer (the reference has no sanitizer run; GPU
-ASan is not available on the target pool, so this is the HOST side only): csrc/Makefile's `asan` target builds the library with
--fsanitize=address,undefined for the host pass, tests/host_asan/driver.cpp walks every size / plan / capability query over the bench
-model's shapes and a set of hostile arguments, and every compute entry point's argument validation (which must fail before the first HIP
-call).  No GPU needed; the first run compiles for ~1.5 min, later runs are incremental."""
+"""Host code of the C-ABI library under a sanitizer build (the reference has no sanitizer run; GPU sanitizers are not available on the
+target pool, so this is the HOST side only): tests/host_asan/build.sh compiles every translation unit of csrc/ with the host pass instrumented
+(address + undefined-behaviour checks), tests/host_asan/driver.cpp walks every size / plan / capability query over the bench model's shapes
+and a set of hostile arguments, and every compute entry point's argument validation (which must fail before the first HIP call).  No GPU
+needed; the first run compiles for ~1.5 min, later runs are incremental.  The recipe lives in tests/host_asan/ (not shipped to the GPU box)."""
 import os
 import shutil
 import subprocess
@@ -10,26 +10,14 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "miccai2021_cataract_semantic_segmentation_amd", "csrc")
-CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+SCRIPT = os.path.join(ROOT, "tests", "host_asan", "build.sh")
 
 
-@pytest.mark.timeout(1200)
-def test_host_paths_clean_under_asan_ubsan():
-    if shutil.which("hipcc") is None or not os.path.exists(CLANG):
-        pytest.skip("needs the ROCm toolchain")
-    out = os.path.join(CSRC, "build_asan")
-    r = subprocess.run(["make", "-C", CSRC, "-j8", "asan"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    rt = os.path.dirname(subprocess.run([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip())
-    exe = os.path.join(out, "host_driver")
-    r = subprocess.run([CLANG, "-std=c++17", "-g", "-O1", "-Wno-comment", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-                        "-shared-libsan", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "host_asan", "driver.cpp"), "-o", exe,
-                        "-L" + out, "-lcatseg_hip_asan", "-Wl,-rpath," + out, "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath," + rt],
-                       capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-4000:]
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
-    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+@pytest.mark.timeout(1500)
+def test_host_paths_clean_under_sanitizers():
+    if shutil.which("hipcc") is None or not os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or not os.path.exists(SCRIPT):
+        pytest.skip("needs the ROCm toolchain and tests/host_asan/ (CPU-side only)")
+    r = subprocess.run(["bash", SCRIPT], capture_output=True, text=True, timeout=1400)
     tail = (r.stdout + r.stderr)[-4000:]
     assert r.returncode == 0, tail
     assert "ERROR: AddressSanitizer" not in tail and "runtime error" not in tail, tail

@@ -15,7 +15,15 @@ dev = torch.device("cuda")
 x = torch.randn(B, H, W, C, device=dev)
 w = (torch.randn(C, C, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
 y = torch.empty_like(x)
-if kind.startswith("pl"):       # the planes kernel (csrc/dconv3_pl.hip): producer-written planes of eight inputs in turn
+if kind == "plwgrad":            # backward-weight on planes (csrc/dwgrad3_pl.hip), eight tensor pairs in turn
+    xs = [torch.randn(B, H, W, C, device="cuda") for _ in range(8)]
+    dys = [torch.randn(B, H, W, C, device="cuda") * 1e-3 for _ in range(8)]
+    xps = [ops.planes_from_f32(x) for x in xs]
+    dps = [ops.planes_from_f32(d) for d in dys]
+    dw = torch.empty(C, C, 3, 3, device="cuda").contiguous(memory_format=torch.channels_last)
+    for i in range(n):
+        ops.dwgrad3_pl(xps[i % 8], dps[i % 8], dw)
+elif kind.startswith("pl"):       # the planes kernel (csrc/dconv3_pl.hip): producer-written planes of eight inputs in turn
     xs = [torch.randn(B, H, W, C, device=dev) for _ in range(8)]
     xps = [ops.planes_from_f32(t) for t in xs]
     wimg = ops.dconv3_weight_image(w, backward_data=(kind == "pldgrad"), h2=True)
