@@ -297,8 +297,6 @@ __global__ __launch_bounds__(256) void dwgrad3_pl_reduce_kernel(const float* __r
 using Wp48 = WpCfg<48, 48, 3, 1, 4, 4, 2>;   // one block: all 48 x 432 accumulators, tiles 4 x 16, two image buffers of 33 KB
 #ifdef WP_ALT96
 using Wp96 = WpCfg<48, 48, 1, 1, 4, 4, 2>;   // A/B: 48 co x (one filter row x 48 ci), tiles 4 x 16
-#elif defined(WP_NBUF3)
-using Wp96 = WpCfg<96, 48, 1, 2, 2, 2, 3>;   // A/B: three image buffers (the LDS-DMA of tile t + 2 in flight behind tile t's MFMAs)
 #elif defined(WP_ROWS3)
 // A/B: block = 96 co x (ALL THREE filter rows x 48 ci): 42 accumulators per wave (224 registers), a tile is 126 MFMAs per wave and dy is
 // fetched by 2 variants of a split instead of 6.  Standalone it wins (reduction included: 61.6 -> 59.0 us at 96 channels, 59.8 -> 58.3 at 192,
@@ -306,8 +304,9 @@ using Wp96 = WpCfg<96, 48, 1, 2, 2, 2, 3>;   // A/B: three image buffers (the LD
 // whole step LOSES 1.7 - 2 ms with it (tools/ab_lib_bench.sh, three alternating rounds on one box: 118.1 - 118.6 against 119.8 - 121.9 ms).
 using Wp96 = WpCfg<96, 48, 3, 2, 2, 2, 2>;
 #else
-// block = 96 co x (one filter row x 48 ci), tiles 2 x 16, two image buffers of 21.5 KB (three: a tile is 45 MFMAs per wave, shorter than an
-// LDS-DMA round trip -- were measured: 60 -> 92 us, not adopted).  Differential builds (tools/ab_wp.sh) price its LDS-DMA at 14 of 53 us
+// block = 96 co x (one filter row x 48 ci), tiles 2 x 16, two image buffers of 23 KB: THREE blocks fit a CU (catseg_debug_dwgrad3_pl_occupancy),
+// which is what hides the LDS-DMA round trip behind a 45-MFMA tile.  A third image buffer costs the third block: 60 -> 92 us (PMC: the same
+// wave cycles over 1.5 x the wall time), not adopted.  Differential builds (tools/ab_wp.sh) price its LDS-DMA at 14 of 53 us
 // (MFMAs alone 28, fragment reads 5, slab store 3).
 using Wp96 = WpCfg<96, 48, 1, 2, 2, 2, 2>;
 #endif

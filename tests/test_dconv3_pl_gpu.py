@@ -121,3 +121,17 @@ def test_two_tiles_per_block_form_is_bit_identical(shape):
     finally:
         ops.lib.catseg_debug_set_dconv3_pl_pair(0)
         ops.release_b3_cache()
+
+
+def test_planes_kernels_keep_their_blocks_per_cu():
+    """the designs rest on co-residency: two blocks of the forward / backward-data kernel per CU (one in the two-tiles-per-block form), at least
+    two of the backward-weight kernel (three at 96+ channels: a third image buffer would cost one, and did: 60 -> 92 us)"""
+    _need_gpu()
+    from miccai2021_cataract_semantic_segmentation_amd import ops
+    torch.cuda.init()
+    for C in (48, 64, 96, 192, 384):
+        assert ops.lib.catseg_debug_dconv3_pl_occupancy(C, 0) == 2, C
+    for C in (96, 192, 384):
+        assert ops.lib.catseg_debug_dconv3_pl_occupancy(C, 1) == 1, C
+        assert ops.lib.catseg_debug_dwgrad3_pl_occupancy(C) >= 3, C
+    assert ops.lib.catseg_debug_dwgrad3_pl_occupancy(48) >= 2
