@@ -89,6 +89,7 @@ _SIGS = {
     "catseg_debug_set_dconv3_blocks": (I, [I]),
     "catseg_debug_set_dconv3_pl_slots": (I, [I]),
     "catseg_debug_set_dconv3_pl_pair": (I, [I]),
+    "catseg_debug_set_dwgrad3_pl_blocks": (I, [I]),
     "catseg_debug_dconv3_pl_occupancy": (I, [I, I]),
     "catseg_debug_dwgrad3_pl_occupancy": (I, [I]),
     "catseg_debug_set_dconv3_spec": (I, [I]),

@@ -11,7 +11,14 @@
 // bit-identical to it for equal exponents (tests/test_dwgrad3_pl_gpu.py).
 #include "planes.h"
 
-extern int catseg_g_wg_blocks;      // csrc/dwgrad3_b3.hip (catseg_debug_set_dwgrad3_blocks)
+extern int catseg_g_wg_blocks;      // csrc/dwgrad3_b3.hip (catseg_debug_set_dwgrad3_blocks): the 48-channel form (two blocks per CU)
+// blocks of the 96+ channel form: THREE fit a CU (46 KB of LDS, four waves), and the third is what hides the LDS-DMA round trips: standalone,
+// reduction included, 61.7 -> 52.9 us (96 channels), 58.9 -> 49.6 (192), 67.5 -> 50.1 (384) from 512 to 768 blocks; 1024 is slower again
+int catseg_g_wp96_blocks = 768;
+extern "C" int catseg_debug_set_dwgrad3_pl_blocks(int blocks) {
+  catseg_g_wp96_blocks = blocks > 0 ? blocks : 768;
+  return CATSEG_OK;
+}
 
 namespace {
 
@@ -319,7 +326,7 @@ WpPlan wp_plan(int C, int B, int H, int W) {
   else if (C == 96 || C == 192 || C == 384) { p.kind = 2; p.variants = (C / Wp96::COT) * (C / Wp96::NCI) * (Wp96::NTY == 3 ? 1 : 3); p.TH = Wp96::TH; }
   else return p;
   const int ntile = B * ((H + p.TH - 1) / p.TH) * ((W + 15) / 16);
-  int s = catseg_g_wg_blocks / p.variants;
+  int s = (p.kind == 2 ? catseg_g_wp96_blocks : catseg_g_wg_blocks) / p.variants;
   if (s < 1) s = 1;
   if (s > ntile) s = ntile;
   p.splits = s;

@@ -172,7 +172,8 @@ def _h2():
 # A/B hooks (tools/ab_env_bench.sh): launch-shape knobs of the library's debug interface (include/catseg_debug.h) from the environment, so that
 # a whole bench process can run under another setting.  Unset = the library's defaults.
 for _var, _setter in (("CATSEG_WG_BLOCKS", "catseg_debug_set_dwgrad3_blocks"), ("CATSEG_DC_BLOCKS", "catseg_debug_set_dconv3_blocks"),
-                      ("CATSEG_PL_SLOTS", "catseg_debug_set_dconv3_pl_slots"), ("CATSEG_PL_PAIR", "catseg_debug_set_dconv3_pl_pair"), ("CATSEG_IGEMM_SPLITS", "catseg_debug_set_splits")):
+                      ("CATSEG_PL_SLOTS", "catseg_debug_set_dconv3_pl_slots"), ("CATSEG_PL_PAIR", "catseg_debug_set_dconv3_pl_pair"),
+                      ("CATSEG_WP96_BLOCKS", "catseg_debug_set_dwgrad3_pl_blocks"), ("CATSEG_IGEMM_SPLITS", "catseg_debug_set_splits")):
     if _os.environ.get(_var):
         getattr(lib, _setter)(int(_os.environ[_var]))
 
