@@ -39,7 +39,7 @@ int catseg_debug_set_dconv3_alt96(int on);
 /* tuning hook: blocks per launch of the direct backward-weight kernel (csrc/dwgrad3_b3.hip; 0 restores the default 512) */
 int catseg_debug_set_dwgrad3_blocks(int blocks);
 /* persistent blocks of the planes kernel csrc/dconv3_pl.hip (default 512 = two per CU) */
-/* tuning hook: blocks of the 96+ channel backward-weight kernel on planes (0 = default 768: three per CU) */
+/* tuning hook: blocks of the 96+ channel backward-weight kernel on planes (0 = default 512; 768 = three per CU: faster standalone, more slab traffic, neutral in the step) */
 int catseg_debug_set_dwgrad3_pl_blocks(int blocks);
 int catseg_debug_set_dconv3_pl_slots(int slots);
 /* tuning hook: bit mask of channel counts (2: 96, 4: 192, 8: 384) whose planes kernel runs in the two-tiles-per-block form (eight

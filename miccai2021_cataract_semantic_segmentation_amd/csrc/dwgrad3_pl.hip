@@ -12,11 +12,13 @@
 #include "planes.h"
 
 extern int catseg_g_wg_blocks;      // csrc/dwgrad3_b3.hip (catseg_debug_set_dwgrad3_blocks): the 48-channel form (two blocks per CU)
-// blocks of the 96+ channel form: THREE fit a CU (46 KB of LDS, four waves), and the third is what hides the LDS-DMA round trips: standalone,
-// reduction included, 61.7 -> 52.9 us (96 channels), 58.9 -> 49.6 (192), 67.5 -> 50.1 (384) from 512 to 768 blocks; 1024 is slower again
-int catseg_g_wp96_blocks = 768;
+// blocks of the 96+ channel form: THREE fit a CU (46 KB of LDS, four waves).  With 768 blocks a launch uses the third slot and hides its LDS-DMA
+// round trips: standalone, reduction included, 61.7 -> 52.9 us (96 channels), 58.9 -> 49.6 (192), 67.5 -> 50.1 (384); 1024 is slower again.
+// In the step the kernels of sibling streams fill that slot anyway (118.5 ms either way) and 768 blocks mean 1.5 x the slabs (PMC: 99 -> 132 MB
+// of fabric traffic per layer): the default stays 512.
+int catseg_g_wp96_blocks = 512;
 extern "C" int catseg_debug_set_dwgrad3_pl_blocks(int blocks) {
-  catseg_g_wp96_blocks = blocks > 0 ? blocks : 768;
+  catseg_g_wp96_blocks = blocks > 0 ? blocks : 512;
   return CATSEG_OK;
 }
 
