@@ -45,3 +45,39 @@ def test_split2h_bound_takes_max_from_producer_records():
     finally:
         ops.SPLIT_BOUND = True
     assert torch.equal(blk3, blk0) and int(sc3[1]) == int(sc0[1])
+
+
+def test_concat_records_follow_the_engine_and_die_with_in_place_updates():
+    """engine.concat_views collects the slices' amax records (copies and bilinear resizes keep their source's); an accumulating launch into the
+    buffer drops them (a stale bound would overflow the fp16 planes), and the split pass then takes its own maximum again"""
+    _need_gpu()
+    from miccai2021_cataract_semantic_segmentation_amd import engine, ops
+    dev = torch.device("cuda")
+    saved = ops.TRUNK
+    ops.TRUNK = "f16x2"
+    try:
+        scope = ops.AmaxScope(dev, 64)
+        ops.set_amax_scope(scope)
+        cx = engine.Ctx(train=True, record=False)
+        a = torch.randn(2, 8, 12, 16, device=dev) * 3.0
+        b = torch.randn(2, 4, 6, 32, device=dev) * 5.0
+        for t in (a, b):
+            t._amax = ops.new_amax(dev)
+            t._amax[0:1] = t.abs().max().reshape(1).view(torch.int32)
+        cat = torch.empty(2, 8, 12, 48, device=dev)
+        p0 = engine.copy_into(cx, a, cat[..., :16])
+        p1 = engine.bilinear(cx, b, 8, 12, False, out=cat[..., 16:])
+        engine.concat_views(cx, cat, [(p0, 0, 16), (p1, 16, 48)])
+        recs = ops.amax_records_of(cat)
+        assert recs is not None and len(recs) == 2
+        blk, _, sc = ops.split2h(cat, True, False)
+        bound = max(float(a.abs().max()), float(b.abs().max()))
+        assert float(sc.view(torch.float32)[0]) == bound                      # the merged records, not a pass over the buffer
+        assert float(cat.abs().max()) <= bound
+        ops.axpy(torch.full_like(cat, 100.0), cat, 1.0, True)                 # in-place update: the records no longer bound the contents
+        assert ops.amax_records_of(cat) is None
+        _, _, sc2 = ops.split2h(cat, True, False)
+        assert float(sc2.view(torch.float32)[0]) == float(cat.abs().max())
+    finally:
+        ops.TRUNK = saved
+        ops.set_amax_scope(None)
