@@ -87,6 +87,10 @@ int catseg_conv2d_bwd_weight(const catseg_conv_desc* d, const float* x, const fl
 #define CATSEG_GEMM_NT 0
 #define CATSEG_GEMM_NN 1
 #define CATSEG_GEMM_TN 2
+/* second stage of a K-split reduction: out[b][i] (+)= sum_s slabs[b][s][i] in a fixed order (slabs [batch][splits][n], n % 4 == 0).  The
+ * OCR head's reductions over all N = H * W pixels into a K x C result (models/OCR.py:158-170 spatial gather, the value / key gradients of
+ * :266-274) run as catseg_gemm_batched over batch * splits row chunks followed by this sum */
+int catseg_sum_slabs(const float* slabs, float* out, long long n, int splits, int batch, int accumulate, catseg_stream_t stream);
 int catseg_gemm_batched(int layout, int batch, int M, int N, int K, const float* A, int lda,
                         long long strideA, const float* Bm, int ldb, long long strideB, float* C,
                         int ldc, long long strideC, int zero_to, int accumulate,

@@ -79,6 +79,7 @@ _SIGS = {
     "catseg_conv2d_bwd_weight_workspace": (SZ, [P]),
     "catseg_conv2d_bwd_weight": (I, [P, P, P, P, P, P, SZ, P]),
     "catseg_gemm_batched": (I, [I, I, I, I, I, P, I, L, P, I, L, P, I, L, I, I, P]),
+    "catseg_sum_slabs": (I, [P, P, L, I, I, I, P]),
     "catseg_debug_set_tile": (I, [I, I]),
     "catseg_debug_set_splits": (I, [I]),
     "catseg_debug_set_strided_multi": (I, [I]),

@@ -631,6 +631,39 @@ extern "C" int catseg_add_n_act_planes(const float* const* in, const int* ld, co
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
+namespace {
+// out[b][i] (+)= sum_s slabs[b][s][i], s in a fixed order (four independent chains, combined the same way every time: deterministic)
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const f32x4* __restrict__ slabs, f32x4* __restrict__ out, long long n4, int splits,
+                                                        int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4* p = slabs + (long long)blockIdx.y * splits * n4 + i;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int k = 0;
+  for (; k + 3 < splits; k += 4) {
+    s0 += p[(long long)k * n4];
+    s1 += p[(long long)(k + 1) * n4];
+    s2 += p[(long long)(k + 2) * n4];
+    s3 += p[(long long)(k + 3) * n4];
+  }
+  for (; k < splits; ++k) s0 += p[(long long)k * n4];
+  f32x4 r = (s0 + s1) + (s2 + s3);
+  f32x4* o = out + (long long)blockIdx.y * n4 + i;
+  if (accumulate) r += *o;
+  *o = r;
+}
+}  // namespace
+
+// second stage of a split reduction (the K-split batched GEMMs of the OCR head: ops.gemm_tn_split): slabs [batch][splits][n] -> out [batch][n]
+extern "C" int catseg_sum_slabs(const float* slabs, float* out, long long n, int splits, int batch, int accumulate, catseg_stream_t stream) {
+  CS_REQUIRE(slabs && out && n > 0 && n % 4 == 0 && splits > 0 && batch > 0 && cs_aligned16(slabs) && cs_aligned16(out), "sum_slabs: bad args");
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n4 + 255) / 256), (unsigned)batch), dim3(256), 0, (hipStream_t)stream, (const f32x4*)slabs,
+                     (f32x4*)out, n4, splits, accumulate);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
 extern "C" int catseg_relu_bwd(const float* dz, int lddz, const float* z, int ldz, float* g, int ldg, long long rows, int C,
                                catseg_stream_t stream) {
   CS_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && lddz % 4 == 0 && ldz % 4 == 0 && ldg % 4 == 0 && cs_aligned16(dz) && cs_aligned16(z) && cs_aligned16(g),

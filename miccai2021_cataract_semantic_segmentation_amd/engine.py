@@ -314,7 +314,21 @@ def image_hw(x):
 TAPS = None   # diagnostic hook (tools/error_growth.py): a dict collects named intermediate activations (CPU copies, NCHW)
 
 
+MARKS = None   # diagnostic hook (tools/stage_times.py): a list collects (direction, name, HIP event) at every tap of a pass and of its backward
+_cur_cx = None  # the Ctx of the forward pass being recorded (EngineNet._run)
+
+
 def tap(name, t):
+    if MARKS is not None and t.is_cuda:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        MARKS.append(("fwd", name, ev))
+        if _cur_cx is not None and _cur_cx.record:
+            def mark():
+                e2 = torch.cuda.Event(enable_timing=True)
+                e2.record()
+                MARKS.append(("bwd", name, e2))
+            _cur_cx.push(mark)
     if TAPS is not None:
         if getattr(t, "_planes_only", False):       # (exists as fp16 x 2 planes only: h + l, rescaled)
             pl = t._planes
@@ -679,7 +693,7 @@ def spatial_gather(cx, feats, logits, K):
     probs = ops.softmax_spatial_fwd(lbuf, K)
     proxy = torch.empty((B, K, 1, C), dtype=torch.float32, device=feats.device)
     ldf = ops.ld_of(feats)
-    ops.gemm(ops.TN, B, K, C, N, probs, ldl, N * ldl, feats, ldf, N * ldf, proxy, C, K * C)
+    ops.gemm_tn_split(B, K, C, N, probs, ldl, feats, ldf, proxy)
     if cx.record:
         def bwd():
             dproxy = cx.take(proxy)
@@ -717,12 +731,12 @@ def object_attention_core(cx, q, key, val, K, key_channels):
             dp = torch.empty_like(p)
             ops.gemm(ops.NT, B, N, K, Ck, dctx, Ck, N * Ck, val, Ck, K * Ck, dp, ld, N * ld, zero_to=ld)
             dv, accv = cx.dest(val)
-            ops.gemm(ops.TN, B, K, Ck, N, p, ld, N * ld, dctx, Ck, N * Ck, dv, Ck, K * Ck, accumulate=accv)
+            ops.gemm_tn_split(B, K, Ck, N, p, ld, dctx, Ck, dv, accumulate=accv)
             dsim = ops.softmax_rows_bwd(p, dp, K, scale)
             dq, accq = cx.dest(q)
             ops.gemm(ops.NN, B, N, Ck, K, dsim, ld, N * ld, key, Ck, K * Ck, dq, Ck, N * Ck, accumulate=accq)
             dk, acck = cx.dest(key)
-            ops.gemm(ops.TN, B, K, Ck, N, dsim, ld, N * ld, q, Ck, N * Ck, dk, Ck, K * Ck, accumulate=acck)
+            ops.gemm_tn_split(B, K, Ck, N, dsim, ld, q, Ck, dk, accumulate=acck)
         cx.push(bwd)
     return ctx
 
@@ -806,7 +820,12 @@ class EngineNet(nn.Module):
             cx.amax_scope = ops.AmaxScope(x.device, max(ops.AMAX_SCOPE_RECORDS, int(1.25 * getattr(self, "_amax_records", 0)) + 64))
             self._amax_scope_live = cx.amax_scope
             ops.set_amax_scope(cx.amax_scope)
-        outs = self._body(cx, x)
+        global _cur_cx
+        _cur_cx = cx
+        try:
+            outs = self._body(cx, x)
+        finally:
+            _cur_cx = None
         if not record:
             ops.release_b3_cache()      # a recorded forward keeps its split planes for the backward-weight pass (_end_backward frees them)
         return cx, outs

@@ -81,3 +81,41 @@ def test_concat_records_follow_the_engine_and_die_with_in_place_updates():
     finally:
         ops.TRUNK = saved
         ops.set_amax_scope(None)
+
+
+@pytest.mark.parametrize("shape", [(2, 25, 512, 32640), (1, 17, 256, 8160), (3, 25, 256, 4100), (2, 8, 64, 1000)])
+def test_gemm_tn_split_matches_fp64(shape):
+    """the K-split form of the OCR head's long reductions (ops.gemm_tn_split: batch * splits chunk GEMMs + catseg_sum_slabs) against fp64, with
+    and without accumulation, deterministic; shapes that do not split (indivisible or short K) take the one-launch path"""
+    _need_gpu()
+    from miccai2021_cataract_semantic_segmentation_amd import ops
+    B, M, N, K = shape
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(K + M)
+    lda = (M + 7) // 8 * 8
+    A = torch.zeros(B, K, lda)
+    A[..., :M] = torch.rand(B, K, M, generator=g)              # (softmax-like non-negative weights: no cancellation to hide a wrong chunking)
+    Bm = torch.randn(B, K, N, generator=g)
+    ref = torch.einsum("bkm,bkn->bmn", A[..., :M].double(), Bm.double())
+    Ad, Bd = A.to(dev), Bm.to(dev)
+    C0 = torch.full((B, M, N), float("nan"), device=dev)
+    ops.gemm_tn_split(B, M, N, K, Ad, lda, Bd, N, C0)
+    err = float((C0.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-6, err
+    C1 = torch.full((B, M, N), float("nan"), device=dev)
+    ops.gemm_tn_split(B, M, N, K, Ad, lda, Bd, N, C1)
+    assert torch.equal(C0, C1)
+    base = torch.randn(B, M, N, generator=g)
+    C2 = base.to(dev)
+    ops.gemm_tn_split(B, M, N, K, Ad, lda, Bd, N, C2, accumulate=True)
+    err = float((C2.cpu().double() - (ref + base.double())).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-6, err
+    saved = ops.GEMM_TN_SPLIT
+    ops.GEMM_TN_SPLIT = False
+    try:
+        C3 = torch.empty((B, M, N), device=dev)
+        ops.gemm_tn_split(B, M, N, K, Ad, lda, Bd, N, C3)
+    finally:
+        ops.GEMM_TN_SPLIT = saved
+    # (the one-launch form: ONE fp32 chain over all K rows per output -- 32 640 of them at the bench shape: measurably less accurate than the split)
+    assert float((C3.cpu().double() - ref).abs().max()) / float(ref.abs().max()) <= 3e-5

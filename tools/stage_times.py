@@ -1,0 +1,68 @@
+"""Where the untraced step spends its time: HIP events at the network's named taps (engine.MARKS: stem, stage 1 ... 4, concat, heads) in the
+forward pass and, through marker closures on the tape, at the same points of the backward pass; plus step begin, loss, Adam.  Main-stream
+events only: a stage's interval is its wall time, parallel regions included.   python3 tools/stage_times.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from miccai2021_cataract_semantic_segmentation_amd import engine
+from miccai2021_cataract_semantic_segmentation_amd.models import OCRNet
+from miccai2021_cataract_semantic_segmentation_amd.losses import TwoScaleLoss
+from miccai2021_cataract_semantic_segmentation_amd.optim import FusedAdam
+dev = torch.device("cuda")
+torch.manual_seed(0)
+model = OCRNet(dict(bench.MODELS["ocrnet_hrnet48"][0]), 3).to(dev).train()
+crit = TwoScaleLoss({"experiment": 3, "interm": {"name": "LovaszSoftmax", "args": [], "weight": 0.4}, "final": {"name": "LovaszSoftmax", "args": [], "weight": 1.0}})
+opt = FusedAdam(model, lr=1e-4)
+batches = [bench.synth_batch(8, 544, 960, 25, 1000 + i, dev) for i in range(4)]
+
+
+def ev():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def step(i, marks=None):
+    img, lbl = batches[i % 4]
+    engine.MARKS = marks
+    if marks is not None:
+        marks.append(("fwd", "begin", ev()))
+    opt.zero_grad()
+    a, f = model(img)
+    if marks is not None:
+        marks.append(("fwd", "forward done", ev()))
+    loss = crit(a, f, lbl)
+    if marks is not None:
+        marks.append(("bwd", "loss done", ev()))
+    loss.backward()
+    if marks is not None:
+        marks.append(("bwd", "backward done", ev()))
+    opt.step()
+    if marks is not None:
+        marks.append(("bwd", "adam done", ev()))
+    engine.MARKS = None
+
+
+for i in range(4):
+    step(i)
+torch.cuda.synchronize()
+agg, N = {}, 6
+for i in range(N):
+    marks = []
+    for j in range(3):          # the host must be AHEAD of the GPU when the marked step starts (a drained queue makes its first stages host-bound)
+        step(4 * i + j)
+    step(4 * i + 3, marks)
+    torch.cuda.synchronize()
+    order = []
+    for (d0, n0, e0), (d1, n1, e1) in zip(marks, marks[1:]):
+        key = "%s: %s -> %s" % (d1, n0, n1)
+        if key not in agg:
+            agg[key] = 0.0
+        order.append(key)
+        agg[key] += e0.elapsed_time(e1)
+    total = marks[0][2].elapsed_time(marks[-1][2])
+    agg["TOTAL"] = agg.get("TOTAL", 0.0) + total
+for k in order:
+    print("%-58s %7.2f ms" % (k, agg[k] / N))
+print("%-58s %7.2f ms" % ("TOTAL (begin -> adam done)", agg["TOTAL"] / N))
