@@ -109,6 +109,8 @@ def side_streams(device, n):
 
 
 PARALLEL_BRANCHES = True   # run independent branches (HRNet stages) on separate HIP streams, forward and backward
+# streams a parallel region spreads its branches over (branch i runs on stream i % BRANCH_STREAMS): A/B knob, CATSEG_BRANCH_STREAMS
+BRANCH_STREAMS = int(__import__("os").environ.get("CATSEG_BRANCH_STREAMS", "4"))
 
 
 class _Region:
@@ -166,9 +168,10 @@ class Ctx:
                 if not self_.on:
                     return self_
                 self_.main = torch.cuda.current_stream(device)
-                self_.streams = side_streams(device, n)
-                ev = torch.cuda.Event()
+                self_.streams = side_streams(device, max(1, min(n, BRANCH_STREAMS)))
+                ev = torch.cuda.Event(enable_timing=MARKS is not None)
                 ev.record(self_.main)
+                self_.t0 = ev
                 for st in self_.streams:
                     st.wait_event(ev)
                 cx.region = _Region(self_.streams)
@@ -182,10 +185,14 @@ class Ctx:
             def __exit__(self_, *exc):
                 if not self_.on:
                     return False
+                ends = []
                 for st in self_.streams:
-                    ev = torch.cuda.Event()
+                    ev = torch.cuda.Event(enable_timing=MARKS is not None)
                     ev.record(st)
                     self_.main.wait_event(ev)
+                    ends.append(ev)
+                if MARKS is not None:
+                    MARKS.append(("region_fwd", self_.t0, ends))
                 if cx.record:
                     cx.tape.append(("region_end", cx.region))
                 cx.region = None
@@ -197,9 +204,10 @@ class Ctx:
 
             def __enter__(self_):
                 if self_.par.on:
-                    self_.ctxm = torch.cuda.stream(self_.par.streams[self_.i])
+                    st = self_.par.streams[self_.i % len(self_.par.streams)]
+                    self_.ctxm = torch.cuda.stream(st)
                     self_.ctxm.__enter__()
-                    cx.branch_stream = self_.par.streams[self_.i]
+                    cx.branch_stream = st
                 return self_
 
             def __exit__(self_, *exc):
@@ -267,6 +275,7 @@ class Ctx:
     def backward(self):
         tape = self.tape
         main = None
+        region_t0 = None
         while tape:
             fn, tag = tape.pop()
             if isinstance(fn, str):
@@ -274,16 +283,21 @@ class Ctx:
                 if main is None:
                     main = torch.cuda.current_stream(region.streams[0].device)
                 if fn == "region_end":          # (reverse order) entering the region: the side streams wait for the main stream
-                    ev = torch.cuda.Event()
+                    ev = torch.cuda.Event(enable_timing=MARKS is not None)
                     ev.record(main)
                     for st in region.streams:
                         st.wait_event(ev)
                     self._region_depth += 1
+                    region_t0 = ev
                 else:                           # leaving it: the main stream waits for every branch
+                    ends = []
                     for st in region.streams:
-                        ev = torch.cuda.Event()
+                        ev = torch.cuda.Event(enable_timing=MARKS is not None)
                         ev.record(st)
                         main.wait_event(ev)
+                        ends.append(ev)
+                    if MARKS is not None:       # (tools/stage_times.py: how long each branch stream of this region's backward ran)
+                        MARKS.append(("region_bwd", region_t0, ends))
                     self._region_depth -= 1
                     if self._region_depth == 0 and self._deferred:
                         ready, self._deferred = self._deferred, []

@@ -47,13 +47,21 @@ def step(i, marks=None):
 for i in range(4):
     step(i)
 torch.cuda.synchronize()
-agg, N = {}, 6
+agg, ragg, N = {}, {}, 6
 for i in range(N):
     marks = []
     for j in range(3):          # the host must be AHEAD of the GPU when the marked step starts (a drained queue makes its first stages host-bound)
         step(4 * i + j)
     step(4 * i + 3, marks)
     torch.cuda.synchronize()
+    regions = [m for m in marks if m[0].startswith("region")]
+    marks = [m for m in marks if not m[0].startswith("region")]
+    for ri, (kind, t0, ends) in enumerate(regions):
+        key = "%s #%02d" % (kind, ri)
+        durs = [t0.elapsed_time(e) for e in ends]
+        cur = ragg.setdefault(key, [0.0] * len(durs))
+        for j, d in enumerate(durs):
+            cur[j] += d
     order = []
     for (d0, n0, e0), (d1, n1, e1) in zip(marks, marks[1:]):
         key = "%s: %s -> %s" % (d1, n0, n1)
@@ -66,3 +74,6 @@ for i in range(N):
 for k in order:
     print("%-58s %7.2f ms" % (k, agg[k] / N))
 print("%-58s %7.2f ms" % ("TOTAL (begin -> adam done)", agg["TOTAL"] / N))
+print("parallel regions (one per HRNet module): time from the fork to the end of each branch stream, ms")
+for k, v in ragg.items():
+    print("  %-16s %s   (max - min %.2f)" % (k, "  ".join("%.2f" % (x / N) for x in v), (max(v) - min(v)) / N))
