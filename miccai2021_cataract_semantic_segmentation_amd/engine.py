@@ -94,6 +94,8 @@ class FlatParams:
 
 # --------------------------------------------------------------------------- tape
 _side_streams = {}
+_skew_streams = []
+STREAM_SKEW = int(__import__("os").environ.get("CATSEG_STREAM_SKEW", "0"))
 
 
 BRANCH_PRIORITY = int(__import__("os").environ.get("CATSEG_BRANCH_PRIORITY", "0"))   # A/B: -1 = the first branch's stream at high priority
@@ -103,6 +105,8 @@ def side_streams(device, n):
     """a small pool of HIP streams per device for the parallel-branch regions (HRNet's branches are independent)"""
     key = (device.type, device.index)
     pool = _side_streams.setdefault(key, [])
+    if not pool and STREAM_SKEW > 0:            # A/B (CATSEG_STREAM_SKEW): shift the pool's position in the runtime's round-robin over hardware queues
+        _skew_streams.extend(torch.cuda.Stream(device=device) for _ in range(STREAM_SKEW))
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device, priority=BRANCH_PRIORITY if len(pool) == 0 else 0))
     return pool[:n]
@@ -111,6 +115,7 @@ def side_streams(device, n):
 PARALLEL_BRANCHES = True   # run independent branches (HRNet stages) on separate HIP streams, forward and backward
 # streams a parallel region spreads its branches over (branch i runs on stream i % BRANCH_STREAMS): A/B knob, CATSEG_BRANCH_STREAMS
 BRANCH_STREAMS = int(__import__("os").environ.get("CATSEG_BRANCH_STREAMS", "4"))
+LAST_BRANCH_ON_MAIN = __import__("os").environ.get("CATSEG_LAST_BRANCH_ON_MAIN", "1") != "0"
 
 
 class _Region:
@@ -168,7 +173,17 @@ class Ctx:
                 if not self_.on:
                     return self_
                 self_.main = torch.cuda.current_stream(device)
-                self_.streams = side_streams(device, max(1, min(n, BRANCH_STREAMS)))
+                ns = max(1, min(n, BRANCH_STREAMS))
+                if LAST_BRANCH_ON_MAIN and ns >= 4 and cx.record:
+                    # The runtime spreads streams over FOUR hardware queues: the main stream holds one, so of four side streams two share a
+                    # queue and run one after the other (rocprofv3 kernel trace: streams 3 and 4 on queue 4; per-branch stream times of a
+                    # stage-4 module 4.4 / 4.1 / 5.4 / 5.4 ms backward).  The main stream idles during a region: the last branch runs on it.
+                    # Only for a RECORDED pass: its tape keeps every tensor a side stream reads alive until the backward has used it, so that
+                    # main-stream allocations inside the region cannot be handed a block a side stream still reads (an inference pass frees
+                    # a module's inputs as it goes: there the main stream launches nothing between fork and join, as before).
+                    self_.streams = side_streams(device, ns - 1) + [self_.main]
+                else:
+                    self_.streams = side_streams(device, ns)
                 ev = torch.cuda.Event(enable_timing=MARKS is not None)
                 ev.record(self_.main)
                 self_.t0 = ev
