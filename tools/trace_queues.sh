@@ -6,5 +6,5 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d "$O/trace_q" -- python3 "$R/bench.py" --steps 2 --warmup 2 --no-cpu-baseline --no-side-figures --no-roofline > /dev/null 2> "$O/trace_q.err"
 f=$(find "$O/trace_q" -name "*kernel_trace.csv" | head -1)
 head -1 "$f"
-python3 "$R/tools/trace_queues.py" "$f"
+python3 "$R/tools/trace_queues.py" "$f"; python3 "$R/tools/trace_small_grids.py" "$f"
 rm -rf "$O/trace_q"
