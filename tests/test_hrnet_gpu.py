@@ -104,10 +104,11 @@ def test_parallel_regions_bit_identical():
     lbl = torch.randint(0, 26, (2, 12, 20), generator=gen).repeat_interleave(8, 1).repeat_interleave(8, 2).cuda()
     crit = TwoScaleLoss({"experiment": 3, "interm": {"name": "LovaszSoftmax", "args": []}, "final": {"name": "LovaszSoftmax", "args": []}})
     res = []
-    old = engine.PARALLEL_BRANCHES
+    old, old_last = engine.PARALLEL_BRANCHES, engine.LAST_BRANCH_ON_MAIN
     try:
-        for par in (True, False, True):
-            engine.PARALLEL_BRANCHES = par
+        # (parallel with the fourth branch on the main stream's hardware queue -- the default --, sequential, parallel on four side streams)
+        for par, last in ((True, True), (False, True), (True, False)):
+            engine.PARALLEL_BRANCHES, engine.LAST_BRANCH_ON_MAIN = par, last
             model = OCRNet(dict(cfg), 3)
             model.load_state_dict(fill_state(spec_of(model.state_dict()), 3))
             model.cuda().train()
@@ -117,7 +118,7 @@ def test_parallel_regions_bit_identical():
             res.append((final.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()},
                         {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
     finally:
-        engine.PARALLEL_BRANCHES = old
+        engine.PARALLEL_BRANCHES, engine.LAST_BRANCH_ON_MAIN = old, old_last
     for other in res[1:]:
         assert torch.equal(res[0][0], other[0])
         for k in res[0][1]:
