@@ -746,17 +746,22 @@ def gemm(layout, batch, M, N, K, A, lda, sA, Bm, ldb, sB, Cm, ldc, sC, zero_to=0
 GEMM_TN_SPLIT = _os.environ.get("CATSEG_GEMM_TN_SPLIT", "1") != "0"
 
 
+def tn_splits(M, N, K):
+    """row chunks of a long reduction into a small M x N result: the largest divisor of K up to 32 that leaves chunks of >= 512 rows (a
+    multiple of 4: the chunk's byte offset stays 16-byte aligned); 1 = do not split (short K, a large result, no suitable divisor)"""
+    if K >= 4096 and M * N <= 64 * 1024:
+        for s in (32, 24, 20, 16, 15, 12, 10, 8, 6, 5, 4, 3, 2):
+            if K % s == 0 and K // s >= 512 and (K // s) % 4 == 0:
+                return s
+    return 1
+
+
 def gemm_tn_split(batch, M, N, K, A, lda, Bm, ldb, Cm, accumulate=False):
     """C[b] (+)= A[b]^T B[b] for a LONG reduction K into a SMALL result M x N (the OCR head: all H * W pixels of an image into K_classes x C;
     models/OCR.py:158-170, and the value / key gradients of :266-274): with one block chain per (image, column tile) the 32 640-row
     reduction of the bench shape runs on 64 of the chip's 256 CUs for ~2 ms; the rows are cut into `splits` chunks that run as batch * splits
     independent GEMMs and are summed in a fixed order (catseg_sum_slabs).  A, Bm: [batch, K, ld] contiguous; Cm: [batch, M, N] contiguous."""
-    splits = 1
-    if GEMM_TN_SPLIT and K >= 4096 and M * N <= 64 * 1024:
-        for s in (32, 24, 20, 16, 15, 12, 10, 8, 6, 5, 4, 3, 2):
-            if K % s == 0 and K // s >= 512 and (K // s) % 4 == 0:
-                splits = s
-                break
+    splits = tn_splits(M, N, K) if GEMM_TN_SPLIT else 1
     if splits == 1:
         return gemm(TN, batch, M, N, K, A, lda, K * lda, Bm, ldb, K * ldb, Cm, N, M * N, accumulate=accumulate)
     kc = K // splits

@@ -204,3 +204,18 @@ def test_roctx_ranges_are_optional_and_balanced():
         env = dict(os.environ, CATSEG_ROCTX=flag)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-500:]
+
+
+def test_tn_split_selection():
+    """ops.tn_splits: the OCR head's reductions over all pixels (bench shape 136 x 240 = 32 640 rows -> 32 chunks of 1 020; the ResNet50 models'
+    68 x 120 = 8 160 -> 15 of 544); short reductions, large results and row counts without a suitable divisor stay one launch"""
+    from miccai2021_cataract_semantic_segmentation_amd import ops
+    assert ops.tn_splits(25, 512, 32640) == 32 and 32640 // 32 == 1020
+    assert ops.tn_splits(25, 256, 32640) == 32
+    assert ops.tn_splits(17, 512, 8160) == 15 and 8160 // 15 == 544
+    assert ops.tn_splits(25, 512, 4095) == 1            # short
+    assert ops.tn_splits(25, 512, 4099) == 1            # prime: no divisor
+    assert ops.tn_splits(512, 512, 32640) == 1          # a large result is already output-parallel
+    for K in range(4096, 40000, 977):
+        s = ops.tn_splits(25, 512, K)
+        assert s == 1 or (K % s == 0 and K // s >= 512 and (K // s) % 4 == 0)
