@@ -15,20 +15,35 @@ import torch.distributed as dist
 import torch.utils.data
 
 
+COMM_HIGH_PRIORITY = os.environ.get("CATSEG_COMM_PRIORITY", "high") != "normal"
+
+
+def init_group(backend, rank, world, local=0):
+    """creates the default process group.  RCCL ('nccl'): bound to this rank's device, and with a HIGH-PRIORITY communicator stream
+    (CATSEG_COMM_PRIORITY=normal: the default priority) -- the all-reduce kernels of a gradient bucket are launched while the trunk
+    kernels of the remaining backward pass hold every CU with persistent blocks (csrc/dconv3_pl.hip: 512 blocks, all registers of their
+    SIMDs); the hardware scheduler serves a high-priority queue first whenever a workgroup slot frees, so a bucket's few-CU ring kernel
+    starts beside them instead of behind the queue of the compute streams."""
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        opts = None
+        if COMM_HIGH_PRIORITY:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local), pg_options=opts)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+
+
 def init_from_env(backend=None):
-    """torchrun-style bootstrap; returns (rank, local_rank, world)."""
+    """torchrun-style bootstrap; returns (rank, local_rank, world).  A world of one creates no group unless CATSEG_DIST_SINGLE=1 asks
+    for it (tests/_rccl_worker.py: RCCL itself exercised on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("CATSEG_DIST_SINGLE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = resolve_backend(backend)
-        if backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        init_group(resolve_backend(backend), rank, world, local)
     return rank, local, world
 
 
@@ -57,7 +72,10 @@ class GradSync:
     LAST (the lowest offsets: stem and first stage, whose gradients the backward pass writes at its very end) is kept small
     (tail_bytes), because its all-reduce cannot overlap with anything."""
 
-    def __init__(self, bucket_bytes=None, group=None, tail_bytes=None):
+    def __init__(self, bucket_bytes=None, group=None, tail_bytes=None, force=None):
+        # force: launch the all-reduces even in a world of one (CATSEG_FORCE_ALLREDUCE=1): the collective then runs through the whole
+        # RCCL path -- communicator, its stream, the event hand-over from and to the launch stream -- with nothing to add
+        self.force = (os.environ.get("CATSEG_FORCE_ALLREDUCE") == "1") if force is None else bool(force)
         self.bucket_bytes = int(bucket_bytes) if bucket_bytes else default_bucket_bytes()
         self.tail_bytes = int(tail_bytes) if tail_bytes else min(self.bucket_bytes, int(float(os.environ.get("CATSEG_TAIL_BUCKET_MB", "4")) * (1 << 20)))
         self.group = group
@@ -114,7 +132,7 @@ class GradSync:
             return
         self.launched[b] = True
         s, e, _ = self.buckets[b]
-        if self.world > 1:
+        if self.world > 1 or (self.force and dist.is_initialized()):
             self.handles.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.bytes_reduced += (e - s) * 4
 
@@ -130,7 +148,7 @@ class GradSync:
         import time
         for b in range(len(self.buckets)):   # parameters that received no gradient this step
             self._launch(b)
-        cuda = self.grad.is_cuda and self.world > 1
+        cuda = self.grad.is_cuda and bool(self.handles)
         if cuda:
             if self._ev is not None:         # (read last step's pair here: no synchronisation on the hot path)
                 e0, e1 = self._ev
@@ -161,12 +179,14 @@ class GradSync:
                 "tail_bucket_MB": self.tail_bytes / (1 << 20),
                 "bucket_sizes_MB": [round((e - s) * 4 / (1 << 20), 2) for (s, e, _) in self.buckets],
                 "bytes_reduced_per_step": self.bytes_reduced // n, "exposed_wait_ms": self.exposed_ms / n,
-                "host_wait_ms": self.host_wait_ms / n, "steps": self.steps}
+                "host_wait_ms": self.host_wait_ms / n, "steps": self.steps,
+                "comm_stream_priority": "high" if (COMM_HIGH_PRIORITY and dist.is_initialized() and dist.get_backend(self.group) == "nccl")
+                else "default", "forced_in_world_of_one": bool(self.force and self.world == 1)}
 
 
-def attach(model, bucket_bytes=None):
+def attach(model, bucket_bytes=None, force=None):
     """Enable data-parallel gradient averaging on an EngineNet; returns 1/world for FusedAdam.grad_scale."""
-    sync = GradSync(bucket_bytes)
+    sync = GradSync(bucket_bytes, force=force)
     model._grad_sync = sync
     return 1.0 / sync.world
 

@@ -869,10 +869,17 @@ class EngineNet(nn.Module):
     def _begin_backward(self, cx):
         fp = self.flat()
         if self._grads_pending:
-            if all(p.grad is None for p in fp.params):
+            detached = sum(1 for p in fp.params if p.grad is None)
+            if detached == len(fp.params) or detached > 0:
                 # optimiser.zero_grad(set_to_none=True) of a stock torch optimiser (torch.optim.Adam(model.parameters()) in the reference's
-                # loop, managers/OCRNet_Manager.py:80-90) detached every .grad: that IS the zero_grad between two backward passes
+                # loop, managers/OCRNet_Manager.py:80-90) detached every .grad: that IS the zero_grad between two backward passes.  An
+                # optimiser over a SUBSET of the parameters detaches only its own: the others' gradients are read by nobody (torch would
+                # accumulate them unseen; the tape overwrites them), so a partly detached set counts as cleared as well.
                 fp.grad.zero_()
+                self._grads_pending = False
+            elif not bool(fp.grad.any()):
+                # zero_grad(set_to_none=False): the .grad views were zeroed in place, i.e. the flat buffer is all zero (checked on this
+                # rare path only: one reduction + a host synchronisation)
                 self._grads_pending = False
             else:
                 raise RuntimeError("second backward() before zero_grad(): the HIP engine's tape overwrites parameter gradients "

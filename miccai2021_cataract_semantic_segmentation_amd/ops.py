@@ -517,6 +517,15 @@ def _bn_part_buffer(nfloats, device):
     return buf
 
 
+def _refuse_placeholder(t, what):
+    """a planes-only activation (bn_apply(planes_only=True)) is an UNWRITTEN fp32 placeholder: only the plane-streaming kernels may consume
+    it.  Every other route of the convolution wrappers refuses it instead of reading uninitialised memory (a consumer with
+    exact_operands, a failed _d3_ok, a bias, or CATSEG_PLANES_WIDTHS / DCONV3 toggled between producer and consumer would get here)."""
+    if getattr(t, "_planes_only", False):
+        raise RuntimeError("a planes-only activation reached %s, which reads fp32: its fp32 tensor was never written "
+                           "(engine.conv_bn_act(sole_conv_out=True) requires the planes route on the consumer)" % what)
+
+
 def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False, groups=1, bn_stats=False, train=False,
              exact=False):
     """train=True (the engine's recorded forward): a backward pass will follow -- the split planes of x are written in both layouts
@@ -548,13 +557,13 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
                 res = dconv3_pl(xp, dconv3_weight_image(w_ptr_tensor, h2=True), None, out=out, bn_stats=bn_stats, out_rec=yrec)
             (res[0] if bn_stats else res)._yrec = yrec
             return res
-        if getattr(x, "_planes_only", False):
-            raise RuntimeError("a planes-only activation reached a convolution that does not stream planes")
+        _refuse_placeholder(x, "the in-kernel-split direct 3x3 kernel")
         rec = amax_of(x) if _trunk_h2() else None
         wimg = dconv3_weight_image(w_ptr_tensor, h2=rec is not None)
         with _Timed("fwd_d3h" if rec is not None else "fwd_d3", flops):
             res = dconv3(x, wimg, bias, out=out, bn_stats=bn_stats, x_amax=rec)
         return res
+    _refuse_placeholder(x, "a convolution forward outside the planes route")
     if not exact and "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(rows, Cout, kh * kw, Cin):
         d = make_desc(x.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
         blk = _b3_blocked_ok(max(zero_to, Cout), Cin, B * H * W, Cout, kh * kw)
@@ -624,6 +633,7 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
     call returns (g, (partials, n_tiles)) for bn_backward_pre; otherwise it returns dx alone, as without bn_src."""
     B, H, W, Cin = xshape
     Cout = dy.shape[-1]
+    _refuse_placeholder(dy, "conv_bwd_data (fp32 output gradient)")
     if out is None:
         out = new_act(B, H, W, Cin, dy.device)
         accumulate = False
@@ -675,6 +685,8 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
 def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=False, groups=1):
     """dw: destination tensor (physical OHWI, or packed [O][7][8][4] for the stem)."""
     Cout, Cin = dy.shape[-1], x.shape[-1]
+    _refuse_placeholder(x, "conv_bwd_weight (fp32 input)")
+    _refuse_placeholder(dy, "conv_bwd_weight (fp32 output gradient)")
     flops = 2.0 * rows_of(dy) * Cout * (3 if stem4 else Cin // groups) * kh * kw
     if (not stem4 and x.dim() == 4 and _d3_ok(rows_of(dy), Cin, Cout, kh, kw, stride, pad, dil, groups)
             and lib.catseg_dwgrad3_supported(Cin)):

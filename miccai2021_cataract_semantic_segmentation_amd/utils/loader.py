@@ -29,6 +29,8 @@ from .ingest import GpuIngest, sample_flips
 def _worker_main(conn, dataset, slots, widx, nworkers):
     """a loader worker PROCESS (forked, never exec'ed; it never touches the GPU): for every task (slot, ids, token) it reads frames
     widx, widx + nworkers, ... of the batch from the dataset and writes them into the SHARED staging slot, then answers with the token"""
+    code = 0
+    token = None
     try:
         torch.set_num_threads(1)
         while True:
@@ -44,14 +46,24 @@ def _worker_main(conn, dataset, slots, widx, nworkers):
             conn.send(token)
     except (EOFError, KeyboardInterrupt, BrokenPipeError):
         pass
+    except BaseException:       # noqa: BLE001  a dataset error, a corrupt frame, a shape mismatch: the parent re-raises it with this traceback
+        code = 1                # (torch's DataLoader does the same for its workers; a silent exit 0 left the parent with a bare EOFError)
+        try:
+            import traceback
+            conn.send(("error", token, widx, traceback.format_exc()))
+        except (BrokenPipeError, OSError):
+            pass
     finally:
-        os._exit(0)            # (no interpreter shutdown in a forked copy of a process that has initialised the GPU)
+        os._exit(code)         # (no interpreter shutdown in a forked copy of a process that has initialised the GPU)
 
 
 class _WorkerPool:
     """worker processes filling shared, pinned staging slots (the reference's DataLoader(num_workers=...),
     managers/BaseManager.py:298-305).  The processes are FORKED from the loader's process (as torch's DataLoader forks its workers): no
-    exec of a GPU-initialised process, the dataset needs no pickling; they only read the dataset and write host memory."""
+    exec of a GPU-initialised process, the dataset needs no pickling; they only read the dataset and write host memory.
+    The fork is PERSISTENT (torch's `persistent_workers=True`): the workers hold the copy of the dataset object they inherited when the
+    pool was created, so a later change of the parent's dataset state does not reach them -- PinnedFrameLoader.close() (or a frame-shape
+    change) ends the pool and the next iteration forks a new one."""
 
     def __init__(self, dataset, slots, n):
         ctx = multiprocessing.get_context("fork")
@@ -73,9 +85,20 @@ class _WorkerPool:
     def wait(self, token):
         """blocks (interpreter lock released while polling the pipes) until every worker has answered `token`"""
         while self.pending.get(token, 0) > 0:
-            for c in self.conns:
-                while c.poll(0):
-                    self.pending[c.recv()] -= 1
+            if not self.conns:
+                raise RuntimeError("loader worker pool was closed while batch %r was pending" % (token,))
+            for w, c in enumerate(self.conns):
+                try:
+                    while c.poll(0):
+                        msg = c.recv()
+                        if isinstance(msg, tuple) and msg and msg[0] == "error":
+                            raise RuntimeError("loader worker %d failed on batch token %r:\n%s" % (msg[2], msg[1], msg[3]))
+                        self.pending[msg] -= 1
+                except (EOFError, OSError) as e:
+                    p = self.procs[w]
+                    p.join(timeout=1.0)
+                    raise RuntimeError("loader worker %d (pid %s) died without a report, exit code %s"
+                                       % (w, p.pid, p.exitcode)) from e
             if self.pending[token] > 0:
                 multiprocessing.connection.wait(self.conns, timeout=0.05)
         self.pending.pop(token, None)
@@ -94,6 +117,7 @@ class _WorkerPool:
         for c in self.conns:
             c.close()
         self.conns, self.procs = [], []
+        self.pending = {}
 
 
 class PinnedFrameLoader:
@@ -130,6 +154,17 @@ class PinnedFrameLoader:
         if self._pool is not None:
             self._pool.close()
             self._pool = None
+        self._unregister()
+
+    def _unregister(self):
+        """the shared staging slots were page-locked with hipHostRegister: un-register them (after the copy stream has drained) before the
+        tensors are dropped -- a registration that outlives its pages can make a later hipHostRegister of a reused address range fail"""
+        regs, self._registered = getattr(self, "_registered", []), []
+        if regs:
+            self.copy_stream.synchronize()
+            rt = torch.cuda.cudart()
+            for t in regs:
+                rt.cudaHostUnregister(t.data_ptr())
 
     def __del__(self):
         try:
@@ -163,11 +198,13 @@ class PinnedFrameLoader:
                             torch.empty((self.batch, h, w), dtype=torch.uint8).share_memory_()) for _ in range(self.prefetch + 1)]
             self._pool = _WorkerPool(self.dataset, self._slots, self.nproc)
             rt = torch.cuda.cudart()
+            self._registered = []
             for pair in self._slots:
                 for t in pair:
                     err = rt.cudaHostRegister(t.data_ptr(), t.numel(), 0)
                     if int(err) != 0:
                         raise RuntimeError("hipHostRegister of a shared staging slot failed: %s" % (err,))
+                    self._registered.append(t)      # (keeps the pages alive until _unregister)
             return
         self._slots = [(torch.empty((self.batch, h, w, 3), dtype=torch.uint8).pin_memory(),
                         torch.empty((self.batch, h, w), dtype=torch.uint8).pin_memory()) for _ in range(self.prefetch + 1)]
@@ -217,9 +254,13 @@ class PinnedFrameLoader:
                 bi += 1
                 yield x, labels
         finally:
-            for t in range(base, base + submitted):       # (abandoned iteration: the workers finish what they were given)
-                if t in pool.pending:
-                    pool.wait(t)
+            if pool.conns:                                 # (close() / __del__ may already have ended the pool)
+                for t in range(base, base + submitted):   # (abandoned iteration: the workers finish what they were given)
+                    if t in pool.pending:
+                        try:
+                            pool.wait(t)
+                        except RuntimeError:
+                            break                          # (a dead worker: its error has been / is being raised by the consumer's wait)
             for ev, _ in in_copy:
                 ev.synchronize()
 

@@ -62,3 +62,32 @@ def encdec_forward(S, x, encoder="ResNet18", train=True):
     """models/EncDec.py:43-53 -> (deep_features, prediction)"""
     feats = resnet_basic_stages(S, x, encoder, train)
     return feats[-1], upernet_forward(S, feats, train)
+
+
+def resnext_features_eval(S, x, layers=(3, 4, 23, 3), groups=32, prefix="enc_model."):
+    """torchvision resnext101_32x8d trunk in eval mode behind the reference's wrapper (models/ResNeXt.py:46-60: the four stage outputs at
+    strides 4 / 8 / 16 / 32): Bottleneck v1.5 with the stride on the grouped 3x3, expansion 4, 1x1 + BatchNorm downsample.  torchvision is
+    an unpinned, un-vendored dependency of the reference: parity unpinned for this trunk."""
+    def bn(p, t):
+        return F.batch_norm(t, S[p + ".running_mean"], S[p + ".running_var"], S[p + ".weight"], S[p + ".bias"], False, 0.1, 1e-5)
+    t = F.max_pool2d(F.relu(bn(prefix + "bn1", F.conv2d(x, S[prefix + "conv1.weight"], None, 2, 3))), 3, 2, 1)
+    outs = []
+    for li, n in enumerate(layers):
+        for b in range(n):
+            p = "%slayer%d.%d" % (prefix, li + 1, b)
+            s = 2 if (li > 0 and b == 0) else 1
+            idt = t
+            if (p + ".downsample.0.weight") in S:
+                idt = bn(p + ".downsample.1", F.conv2d(t, S[p + ".downsample.0.weight"], None, s))
+            o = F.relu(bn(p + ".bn1", F.conv2d(t, S[p + ".conv1.weight"])))
+            o = F.relu(bn(p + ".bn2", F.conv2d(o, S[p + ".conv2.weight"], None, s, 1, 1, groups)))
+            o = bn(p + ".bn3", F.conv2d(o, S[p + ".conv3.weight"]))
+            t = F.relu(o + idt)
+        outs.append(t)
+    return outs
+
+
+def resnext101_upernet_infer(S, x):
+    """EncDec(ResNeXt101_32x8d + UPerNet) eval-mode forward (BASELINE config 5; reference models/EncDec.py:43-53, UPerNet.py:108-145)"""
+    out = upernet_forward(S, resnext_features_eval(S, x), False)
+    return out[0] if isinstance(out, (tuple, list)) else out

@@ -196,3 +196,73 @@ def test_gloo_is_refused_on_gpus_unless_the_environment_asks_for_it(monkeypatch)
     monkeypatch.setenv("CATSEG_DIST_BACKEND", "nccl")
     with pytest.raises(RuntimeError, match="RCCL"):
         D.resolve_backend("gloo", cuda=True)
+
+
+def test_bench_self_launch_relays_one_json_line(monkeypatch, capsys):
+    """`python bench.py --gpus N` without a torchrun environment: the launcher starts torch.distributed.run with N ranks on 127.0.0.1,
+    relays exactly the result line on stdout (everything else to stderr) and returns the job's exit code (bench.self_launch)"""
+    import subprocess
+    import bench
+    assert bench._gpus_arg(["--steps", "3"]) == 1 and bench._gpus_arg(["--gpus", "8", "--infer"]) == 8 and bench._gpus_arg(["--gpus=4"]) == 4
+    seen = {}
+
+    class _P:
+        returncode = 0
+        stdout = b'rank chatter\n{"metric": "train frames/sec", "value": 1.0, "n_gpus": 4}\nmore chatter\n'
+
+    def fake_run(cmd, stdout=None, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return _P()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    rc = bench.self_launch(["--gpus", "4", "--steps", "2"])
+    cap = capsys.readouterr()
+    assert rc == 0
+    assert cap.out.strip().splitlines() == ['{"metric": "train frames/sec", "value": 1.0, "n_gpus": 4}']
+    assert "rank chatter" in cap.err and "more chatter" in cap.err
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    _P.returncode, _P.stdout = 3, b"boom\n"
+    assert bench.self_launch(["--gpus", "2"]) == 3
+    assert capsys.readouterr().out == ""
+    _P.returncode, _P.stdout = 0, b"no result\n"
+    assert bench.self_launch(["--gpus", "2"]) == 1      # a job that printed nothing is a failure, not an empty success
+
+
+def test_forced_exchange_in_a_world_of_one_is_the_identity(tmp_path):
+    """GradSync(force=True) (tests/_rccl_worker.py drives RCCL with it on the GPU box): every bucket is launched even with one rank; over
+    gloo on the CPU the flat gradient comes back unchanged and the byte count covers the whole buffer"""
+    from miccai2021_cataract_semantic_segmentation_amd import dist as D
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        class FP:
+            ALIGN = 64
+        fp = FP()
+        fp.params = [torch.nn.Parameter(torch.randn(n)) for n in (1000, 64, 5000, 129)]
+        off, fp.offsets = 0, {}
+        for p in fp.params:
+            fp.offsets[id(p)] = off
+            off += (p.numel() + 63) // 64 * 64
+        fp.grad = torch.randn(off)
+        want = fp.grad.clone()
+        sync = D.GradSync(bucket_bytes=8192, tail_bytes=1024, force=True)
+        assert sync.world == 1
+        sync.begin(fp)
+        for p in reversed(fp.params):
+            sync.param_ready(p)
+        assert all(sync.launched) and len(sync.handles) == len(sync.buckets) >= 2
+        sync.finish()
+        assert torch.equal(fp.grad, want) and sync.stats()["bytes_reduced_per_step"] == off * 4
+        assert sync.stats()["forced_in_world_of_one"]
+        plain = D.GradSync(bucket_bytes=8192, force=False)
+        plain.begin(fp)
+        plain.finish()
+        assert plain.bytes_reduced == 0
+    finally:
+        dist.destroy_process_group()

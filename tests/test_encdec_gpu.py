@@ -91,25 +91,9 @@ def test_encdec_resnet18_upernet_matches_reference_fixture(golden):
                           lambda o, l: OL.lovasz_softmax(o, l), T(g["x"]), T(g["lbl"]), label="EncDec(ResNet18+UPerNet)")
 
 
-def _resnext_oracle(S, x, layers=(3, 4, 23, 3), groups=32, wpg=8):
-    """torchvision resnext101_32x8d trunk in eval mode (the reference's models/ResNeXt.py:46-60 wrapper)"""
-    def bn(p, t):
-        return F.batch_norm(t, S[p + ".running_mean"], S[p + ".running_var"], S[p + ".weight"], S[p + ".bias"], False, 0.1, 1e-5)
-    t = F.max_pool2d(F.relu(bn("enc_model.bn1", F.conv2d(x, S["enc_model.conv1.weight"], None, 2, 3))), 3, 2, 1)
-    outs = []
-    for li, n in enumerate(layers):
-        for b in range(n):
-            p = "enc_model.layer%d.%d" % (li + 1, b)
-            s = 2 if (li > 0 and b == 0) else 1
-            idt = t
-            if (p + ".downsample.0.weight") in S:
-                idt = bn(p + ".downsample.1", F.conv2d(t, S[p + ".downsample.0.weight"], None, s))
-            o = F.relu(bn(p + ".bn1", F.conv2d(t, S[p + ".conv1.weight"])))
-            o = F.relu(bn(p + ".bn2", F.conv2d(o, S[p + ".conv2.weight"], None, s, 1, 1, groups)))
-            o = bn(p + ".bn3", F.conv2d(o, S[p + ".conv3.weight"]))
-            t = F.relu(o + idt)
-        outs.append(t)
-    return outs
+def _resnext_oracle(S, x):
+    from oracle.upernet import resnext_features_eval
+    return resnext_features_eval(S, x)
 
 
 def test_resnext101_upernet_inference_vs_oracle():
