@@ -468,6 +468,13 @@ int catseg_confusion_matrix(const float* logits, const int64_t* labels, long lon
 /* torch.optim.Adam(lr) step over a flat parameter buffer (managers/BaseManager.py:441) */
 int catseg_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
                      float beta2, float eps, int step, float grad_scale, catseg_stream_t stream);
+/* the same step with its step-dependent scalars in DEVICE memory -- hyper = {lr, 1 - beta1^step, sqrt(1 - beta2^step), grad_scale}, the
+   values catseg_adam_hyper (host, no GPU call) computes exactly as catseg_adam_step does -- so that a launch captured in a hipGraph
+   (the whole training step of managers/OCRNet_Manager.py:80-90 replayed as one graph) follows the learning-rate schedule and the bias
+   correction of torch.optim.Adam from step to step; bit-identical to catseg_adam_step for equal values */
+void catseg_adam_hyper(float lr, float beta1, float beta2, int step, float grad_scale, float* hyper4);
+int catseg_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1,
+                         float beta2, float eps, catseg_stream_t stream);
 
 #ifdef __cplusplus
 }

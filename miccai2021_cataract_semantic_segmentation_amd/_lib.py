@@ -161,6 +161,8 @@ _SIGS = {
     "catseg_resize_nearest": (I, [P, I, P, I, I, I, I, I, I, I, I, I, F, P]),
     "catseg_confusion_matrix": (I, [P, P, L, I, P, P]),
     "catseg_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, F, P]),
+    "catseg_adam_hyper": (None, [F, F, F, I, F, P]),
+    "catseg_adam_step_dev": (I, [P, P, P, P, L, P, F, F, F, P]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)  # AttributeError here = header / library mismatch

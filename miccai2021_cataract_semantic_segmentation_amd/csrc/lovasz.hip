@@ -754,7 +754,11 @@ __global__ __launch_bounds__(PIX) void confusion_kernel(const float* __restrict_
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n4,
-                            long long n, float lr, float b1, float b2, float eps, float bc1, float bc2s, float gscale) {
+                            long long n, float lr, float b1, float b2, float eps, float bc1, float bc2s, float gscale,
+                            const float* __restrict__ hyper) {
+  if (hyper) {      // step-dependent scalars from device memory (a captured launch replays with new values): {lr, bc1, sqrt(bc2), grad scale}
+    lr = hyper[0]; bc1 = hyper[1]; bc2s = hyper[2]; gscale = hyper[3];
+  }
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const long long e = i * 4;
     if (e + 3 < n) {
@@ -882,7 +886,26 @@ extern "C" int catseg_adam_step(float* p, const float* g, float* m, float* v, lo
   long long blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, lr, beta1, beta2, eps, (float)bc1,
-                     (float)sqrt(bc2), grad_scale);
+                     (float)sqrt(bc2), grad_scale, (const float*)nullptr);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+extern "C" void catseg_adam_hyper(float lr, float beta1, float beta2, int step, float grad_scale, float* hyper4) {
+  hyper4[0] = lr;
+  hyper4[1] = (float)(1.0 - pow((double)beta1, step));
+  hyper4[2] = (float)sqrt(1.0 - pow((double)beta2, step));
+  hyper4[3] = grad_scale;
+}
+
+extern "C" int catseg_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1,
+                                    float beta2, float eps, catseg_stream_t stream) {
+  CS_REQUIRE(n > 0 && hyper && cs_aligned16(p) && cs_aligned16(g) && cs_aligned16(m) && cs_aligned16(v), "adam: bad args");
+  const long long n4 = (n + 3) / 4;
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, 0.f, beta1, beta2, eps, 1.f, 1.f, 1.f,
+                     hyper);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

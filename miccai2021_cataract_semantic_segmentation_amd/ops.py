@@ -1206,6 +1206,12 @@ def _adam_step(p, g, m, v, lr, step, beta1, beta2, eps, grad_scale):
     check(lib.catseg_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, stream()))
 
 
+def adam_step_dev(p, g, m, v, hyper, beta1=0.9, beta2=0.999, eps=1e-8):
+    """adam_step with {lr, bias corrections, gradient scale} in device memory (hyper: float32[4], optim.FusedAdam.upload_hyper)"""
+    with _Timed("hbm:adam", 28.0 * p.numel()):
+        check(lib.catseg_adam_step_dev(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(hyper), beta1, beta2, eps, stream()))
+
+
 def add_n_act(terms, relu, out=None):
     """out = act(sum(terms)); terms: up to 4 NHWC tensors of one shape (row strides may differ)"""
     t0 = terms[0]

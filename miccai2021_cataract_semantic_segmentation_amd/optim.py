@@ -22,6 +22,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._m = self._v = None
         self._steps = 0
         self.grad_scale = grad_scale
+        self._hyper_dev = self._hyper_host = None      # device_hyper(): the step-dependent scalars live in device memory
 
     def zero_grad(self, set_to_none=True):
         """The backward tape OVERWRITES each parameter's slice of the flat gradient buffer (it does not accumulate over
@@ -47,9 +48,40 @@ class FusedAdam(torch.optim.Optimizer):
         if g.get("weight_decay", 0) or g.get("amsgrad", False):
             raise NotImplementedError("FusedAdam implements torch.optim.Adam(lr, betas, eps) without weight decay / amsgrad "
                                       "(managers/BaseManager.py:441 of the reference)")
+        if self._hyper_dev is not None:
+            # device-scalar form (graph.GraphedTrainStep): a launch recorded into a hipGraph reads {lr, bias corrections, gradient scale}
+            # from device memory; outside a capture this call advances the step and uploads them itself
+            if not torch.cuda.is_current_stream_capturing():
+                self._steps += 1
+                self.upload_hyper()
+            ops.adam_step_dev(fp.flat, fp.grad, m, v, self._hyper_dev, g["betas"][0], g["betas"][1], g["eps"])
+            return
         self._steps += 1
         ops.adam_step(fp.flat, fp.grad, m, v, float(g["lr"]), self._steps, g["betas"][0], g["betas"][1], g["eps"],
                       self.grad_scale)
+
+    def device_hyper(self):
+        """switch to the device-scalar kernel form (include/catseg.h: catseg_adam_step_dev); bit-identical updates"""
+        if self._hyper_dev is None:
+            fp = self.model.flat()
+            self._hyper_host = torch.zeros((16, 4), dtype=torch.float32).pin_memory()     # a ring: the host may run steps ahead of the GPU
+            self._hyper_events = [None] * 16
+            self._hyper_dev = torch.zeros(4, dtype=torch.float32, device=fp.flat.device)
+        return self
+
+    def upload_hyper(self):
+        """{lr, 1 - beta1^step, sqrt(1 - beta2^step), grad_scale} of the CURRENT step count -> device (asynchronous copy from pinned memory
+        on the current stream: ordered in front of the next launch / graph replay on it)"""
+        g = self.param_groups[0]
+        slot = self._steps % 16
+        if self._hyper_events[slot] is not None:
+            self._hyper_events[slot].synchronize()         # (the copy that last read this pinned slot, 16 steps ago)
+        row = self._hyper_host[slot]
+        ops.lib.catseg_adam_hyper(float(g["lr"]), g["betas"][0], g["betas"][1], max(self._steps, 1), self.grad_scale, row.data_ptr())
+        self._hyper_dev.copy_(row, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._hyper_events[slot] = ev
 
     # ------------------------------------------------------------------ torch.optim.Adam-compatible (de)serialisation
     def state_dict(self):

@@ -1,0 +1,90 @@
+"""The whole training step replayed as one hipGraph (graph.GraphedTrainStep) against the eager launch loop: the same kernels in the same
+order on the same streams -> bit-identical losses, parameters, Adam moments, BatchNorm statistics and confusion matrices over several
+steps with changing batches and a changing learning rate (reference loop: managers/OCRNet_Manager.py:80-113)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _setup(name, B, H, W):
+    import bench
+    from miccai2021_cataract_semantic_segmentation_amd.losses import TwoScaleLoss
+    from miccai2021_cataract_semantic_segmentation_amd.models import OCRNet
+    from miccai2021_cataract_semantic_segmentation_amd.optim import FusedAdam
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    model = OCRNet(dict(bench.MODELS[name][0]), 3).to(dev).train()
+    crit = TwoScaleLoss({"experiment": 3, "interm": {"name": "LovaszSoftmax", "args": [], "weight": 0.4},
+                         "final": {"name": "LovaszSoftmax", "args": [], "weight": 1.0}})
+    opt = FusedAdam(model, lr=1e-3)
+    batches = [bench.synth_batch(B, H, W, 25, 300 + i, dev) for i in range(4)]
+    return model, crit, opt, batches
+
+
+@pytest.mark.parametrize("name,shape", [("ocrnet_hrnet48", (2, 128, 192)), ("ocrnet_r50", (2, 64, 96))])
+def test_graphed_step_is_bit_identical_to_the_eager_step(name, shape):
+    _need_gpu()
+    from miccai2021_cataract_semantic_segmentation_amd.graph import GraphedTrainStep
+    from miccai2021_cataract_semantic_segmentation_amd.utils.metrics import t_get_confusion_matrix
+    B, H, W = shape
+    model, crit, opt, batches = _setup(name, B, H, W)
+    fp = model.flat()
+    w0 = fp.flat.clone()
+    bufs0 = [b.clone() for b in model.buffers()]
+    lrs = [1e-3, 1e-3, 5e-4, 2.5e-4, 2.5e-4]
+    # ---- eager
+    cm_e = torch.zeros((25, 25), dtype=torch.int32, device="cuda")
+    losses_e = []
+    for i, lr in enumerate(lrs):
+        opt.param_groups[0]["lr"] = lr
+        x, y = batches[i % 4]
+        opt.zero_grad()
+        out = model(x)
+        loss = crit(*out, y)
+        loss.backward()
+        opt.step()
+        t_get_confusion_matrix(out[1].detach(), y, cm_e)
+        losses_e.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    w_e, m_e, v_e = fp.flat.clone(), opt._m.clone(), opt._v.clone()
+    bufs_e = [b.clone() for b in model.buffers()]
+    logits_e = out[1].detach().clone()
+    # ---- the same five steps from the same state through the graph
+    with torch.no_grad():
+        fp.flat.copy_(w0)
+        opt._m.zero_()
+        opt._v.zero_()
+        for b, s in zip(model.buffers(), bufs0):
+            b.copy_(s)
+    opt._steps = 0
+    cm_g = torch.zeros((25, 25), dtype=torch.int32, device="cuda")
+    step = GraphedTrainStep(model, lambda o, l: crit(*o, l), opt, *batches[0], confusion=cm_g)
+    assert opt._steps == 0 and torch.equal(fp.flat, w0) and int(cm_g.sum()) == 0          # the warm-up left no trace
+    losses_g = []
+    for i, lr in enumerate(lrs):
+        opt.param_groups[0]["lr"] = lr
+        losses_g.append(float(step(*batches[i % 4])))
+    torch.cuda.synchronize()
+    assert losses_g == losses_e
+    assert torch.equal(fp.flat, w_e) and torch.equal(opt._m, m_e) and torch.equal(opt._v, v_e)
+    for b, s in zip(model.buffers(), bufs_e):
+        assert torch.equal(b, s)
+    assert torch.equal(cm_g, cm_e) and int(cm_e.sum()) > 0
+    assert torch.equal(step.outputs[1].detach(), logits_e)
+    assert opt._steps == len(lrs) and step.replays == len(lrs)
+    sd = model.state_dict()                                     # lazily flushed BatchNorm step counters follow the replays
+    k = [k for k in sd if k.endswith("num_batches_tracked")][0]
+    assert int(sd[k]) == 2 * len(lrs)
+    # an eager step after the graph keeps working (and needs its zero_grad, as after any backward)
+    opt.zero_grad()
+    loss = crit(*model(batches[1][0]), batches[1][1])
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
