@@ -383,6 +383,9 @@ def main():
                                                                  "profiles/r03_cpu_thread_sweep.json; all 128 cores are 5x slower)")
     ap.add_argument("--no-side-figures", action="store_true",
                     help="skip the side figures measured after the timed region (exact-fp32 arithmetic, unpadded 540x960 frames, through the uint8 loader)")
+    ap.add_argument("--eager", action="store_true",
+                    help="run the timed steps through the Python launch loop (~3000 ctypes launches per step) instead of replaying the step as "
+                         "one hipGraph (graph.GraphedTrainStep; bit-identical results)")
     ap.add_argument("--with-h2d", action="store_true",
                     help="side measurement (never the reported `value` of the contract): every step also copies its batch from "
                          "pinned host memory, float32 image + int64 labels as the reference's loader hands them over")
@@ -430,6 +433,18 @@ def main():
     from miccai2021_cataract_semantic_segmentation_amd.utils.metrics import t_get_confusion_matrix
     cm = torch.zeros((K, K), dtype=torch.int32, device=dev)
 
+    # Execution mode of the timed region: the whole step recorded once into a hipGraph and replayed (graph.GraphedTrainStep: the same
+    # launches on the same streams, bit-identical results, one host call per step instead of ~3000), or --eager: the Python launch loop.
+    # The instrumented roofline steps (HIP events around single launches) always run eagerly.
+    from miccai2021_cataract_semantic_segmentation_amd.graph import GraphedTrainStep
+    graphed = {"step": None, "key": None, "captures": 0, "capture_s": 0.0}
+    use_graph = [not args.eager and not args.with_h2d]
+
+    def drop_graph():
+        if graphed["step"] is not None:
+            graphed["step"].release()
+            graphed["step"], graphed["key"] = None, None
+
     def step(batch=None):
         """one training step as the reference's manager runs it (managers/OCRNet_Manager.py:80-113): zero_grad, forward, loss, backward,
         (gradient exchange,) Adam, and the per-step training metric: the confusion matrix of the batch's predictions"""
@@ -442,6 +457,18 @@ def main():
         else:
             x, y = batches[counter[0] % NBATCH]
             counter[0] += 1
+        if use_graph[0] and ops.PROFILE is None:
+            key = (tuple(x.shape), tuple(y.shape), ops.PRECISION)
+            if graphed["key"] != key:
+                drop_graph()
+                t_c = time.perf_counter()
+                graphed["step"] = GraphedTrainStep(model, (lambda o, l: crit(None, o, l)) if deeplab else (lambda o, l: crit(o[0], o[1], l)),
+                                                   opt, x, y, confusion=cm)
+                graphed["key"] = key
+                graphed["captures"] += 1
+                graphed["capture_s"] += time.perf_counter() - t_c
+            return graphed["step"](x, y)
+        drop_graph()
         opt.zero_grad()
         out = model(x)
         interm, final = (None, out) if deeplab else out
@@ -482,6 +509,7 @@ def main():
         from miccai2021_cataract_semantic_segmentation_amd.losses import two_scale
         par, engine.PARALLEL_BRANCHES = engine.PARALLEL_BRANCHES, False
         conc, two_scale.CONCURRENT = two_scale.CONCURRENT, False
+        was_graph, use_graph[0] = use_graph[0], False
         step()
         torch.cuda.synchronize()
         ops.PROFILE = [] if rank == 0 else None
@@ -490,6 +518,7 @@ def main():
         torch.cuda.synchronize()
         engine.PARALLEL_BRANCHES = par
         two_scale.CONCURRENT = conc
+        use_graph[0] = was_graph
     if not args.no_roofline and rank == 0:
         prof, ops.PROFILE = ops.PROFILE, None
         agg = {}
@@ -600,7 +629,11 @@ def main():
                               "fp32_tflop_per_step": sum(v[0] for k, v in mm.items() if not k.endswith(("_b3", "_d3", "_h2", "_d3h", "_d3p"))) / 2 / 1e12}
     comm = None
     if world > 1:
-        comm = model._grad_sync.stats()          # every rank (it synchronises its device); rank 0 prints
+        drop_graph()                             # (hands the reducer back to the model)
+        comm = model._grad_sync.stats()
+        comm["overlap"] = ("none: the exchange runs behind the replayed graph of zero_grad .. backward (graph.GraphedTrainStep); exposed_wait_ms is "
+                           "the whole all-reduce" if (not args.eager and not args.with_h2d) else
+                           "buckets are launched from the backward tape as their last gradient is written")          # every rank (it synchronises its device); rank 0 prints
         comm["payload_MB_per_step"] = round(comm["bytes_reduced_per_step"] / 1e6, 1)
         if comm["backend"] != "nccl":
             comm["note"] = "FUNCTIONAL ARTEFACT: backend %s asked for through CATSEG_DIST_BACKEND -- not an RCCL / xGMI measurement, not a scaling figure" % comm["backend"]
@@ -732,6 +765,12 @@ def main():
         if side:
             out["side_figures"] = side
         out["config"]["step"] = "zero_grad, forward, loss, backward, Adam, confusion matrix of the batch (the reference's per-step training metric)"
+        out["config"]["execution"] = (("the step recorded once by stream capture and replayed as one hipGraph per step (graph.GraphedTrainStep: same "
+                                       "launches, same streams, bit-identical results; %d capture(s), %.1f s, outside the timed region)%s"
+                                       % (graphed["captures"], graphed["capture_s"],
+                                          "; data parallel: graph = zero_grad .. backward, then bucketed RCCL all-reduce, Adam, confusion matrix as "
+                                          "ordinary launches" if world > 1 else ""))
+                                      if (not args.eager and not args.with_h2d) else "eager: one ctypes launch per kernel (--eager)")
         _emit(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

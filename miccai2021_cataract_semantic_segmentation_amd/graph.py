@@ -15,7 +15,10 @@ hipGraph through stream capture and replayed with one launch per step:
 What a replay must not freeze is kept out of the graph's kernel arguments: the Adam kernel reads {lr, bias corrections, gradient scale}
 from device memory (catseg_adam_step_dev; uploaded in front of each replay: LambdaLR and the step count keep working), inputs are copied
 into static buffers.  The arithmetic is the eager step's, launch for launch: results are bit-identical (tests/test_graph_gpu.py).
-Data-parallel runs: the bucket all-reduces are launched from the tape, i.e. inside the capture; RCCL's collectives are capturable.
+Data-parallel runs (model._grad_sync attached): the graph ends with the backward pass; the bucketed all-reduce of the flat gradient
+buffer, Adam and the confusion matrix follow as ordinary launches (three to a dozen calls) -- the collectives stay OUTSIDE the capture
+(a captured RCCL collective cannot be validated on the one-GPU boxes this was built on), at the price of an exchange that no longer
+overlaps the backward pass: 293 MB over xGMI, ~2 ms at 8 GPUs, against ~3000 launches less host work per step.
 """
 import torch
 
@@ -24,8 +27,9 @@ from .optim import FusedAdam
 
 
 class GraphedTrainStep:
-    def __init__(self, model, loss_fn, optimiser, img, lbl, confusion=None, warmup=2, keep_state=True):
-        """model: an EngineNet in training mode; loss_fn(model_output, labels) -> scalar loss tensor; optimiser: FusedAdam over the model;
+    def __init__(self, model, loss_fn, optimiser, img, lbl, confusion=None, warmup=2, keep_state=True, forward_loss=None):
+        """model: an EngineNet in training mode; loss_fn(model_output, labels) -> scalar loss tensor (or forward_loss(img, labels) ->
+        (loss, final logits), the managers' method, instead of model + loss_fn); optimiser: FusedAdam over the model;
         img / lbl: a batch of the shapes every later call will have; confusion: optional int32 [K, K] matrix the step accumulates its
         batch's confusion matrix into (the reference's per-step training metric).
         Warm-up: `warmup` eager steps on the capture stream (workspaces, weight images, allocator pools reach their steady state);
@@ -36,6 +40,10 @@ class GraphedTrainStep:
         if not model.training:
             raise RuntimeError("GraphedTrainStep captures a TRAINING step: call model.train() first")
         self.model, self.loss_fn, self.opt, self.confusion = model, loss_fn, optimiser, confusion
+        self.forward_loss = forward_loss
+        # data parallel: the reducer is taken off the tape; the exchange runs behind the replayed graph
+        self.sync, model._grad_sync = model._grad_sync, None
+        self.split = self.sync is not None
         dev = img.device
         self.img = torch.empty_like(img).copy_(img)
         self.lbl = torch.empty_like(lbl).copy_(lbl)
@@ -75,17 +83,31 @@ class GraphedTrainStep:
             mod._pending_batches = n
         self.replays = 0
 
+    def release(self):
+        """gives the reducer back to the model (eager steps may follow) and drops the graph with its memory pool"""
+        if self.sync is not None:
+            self.model._grad_sync = self.sync
+        self.graph = None
+        self.loss = self.outputs = None
+
     def _body(self):
         self.opt.zero_grad()
-        out = self.model(self.img)
-        loss = self.loss_fn(out, self.lbl)
+        if self.forward_loss is not None:
+            loss, out = self.forward_loss(self.img, self.lbl)
+        else:
+            out = self.model(self.img)
+            loss = self.loss_fn(out, self.lbl)
         loss.backward()
+        if not self.split:
+            self._tail(out)
+        return loss.detach(), out
+
+    def _tail(self, out):
         self.opt.step()
         if self.confusion is not None:
             from .utils.metrics import t_get_confusion_matrix
             final = out[-1] if isinstance(out, (tuple, list)) else out
             t_get_confusion_matrix(final.detach(), self.lbl, self.confusion)
-        return loss.detach(), out
 
     def __call__(self, img, lbl):
         """one training step on (img, lbl); returns the loss (a static device tensor: read or copy it before the next call)"""
@@ -94,9 +116,17 @@ class GraphedTrainStep:
             self.img.copy_(img, non_blocking=True)
         if lbl is not self.lbl:
             self.lbl.copy_(lbl, non_blocking=True)
-        self.opt._steps += 1
-        self.opt.upload_hyper()
-        self.graph.replay()                          # (launched on the current stream, behind the copies above)
+        if self.split:
+            self.graph.replay()
+            self.sync.begin(self.model.flat())       # every bucket, highest offsets first as the tape would have released them
+            for b in reversed(range(len(self.sync.buckets))):
+                self.sync._launch(b)
+            self.sync.finish()
+            self._tail(self.outputs)                 # (eager Adam: advances the step count and uploads its scalars itself)
+        else:
+            self.opt._steps += 1
+            self.opt.upload_hyper()
+            self.graph.replay()                      # (launched on the current stream, behind the copies above)
         for mod in self._bns:
             mod._pending_batches += 1
         self.model._grads_pending = True

@@ -156,16 +156,33 @@ class BaseManager:
         n = 0
         if getattr(self, "shard_sampler", None) is not None:
             self.shard_sampler.set_epoch(self.epoch + self.start_epoch)
+        # config['train']['hip_graph'] (build-side key, default off): the step -- zero_grad, forward, loss, backward, Adam, confusion matrix --
+        # is recorded once per epoch into a hipGraph and replayed (graph.GraphedTrainStep: bit-identical to this loop, one host call per
+        # step instead of ~3000 launches); batches of another shape (a ragged last batch) run the loop below
+        graphed = None
+        use_graph = bool(self.config.get("train", {}).get("hip_graph", False)) and isinstance(self.optimiser, FusedAdam)
         for img, lbl, _ in self.train_loader:
             img, lbl = img.to(self.device, non_blocking=True), lbl.to(self.device, non_blocking=True)
-            self.optimiser.zero_grad()
-            loss, out = self.forward_loss(img, lbl)
-            loss.backward()
-            self.optimiser.step()
-            t_get_confusion_matrix(out.detach(), lbl, running_cm)      # accumulates on the device
-            loss_sum += loss.detach()
+            if use_graph and graphed is None:
+                from ..graph import GraphedTrainStep
+                img, lbl = img.float().contiguous(), lbl.long().contiguous()
+                graphed = GraphedTrainStep(self.model, None, self.optimiser, img, lbl, confusion=running_cm, forward_loss=self.forward_loss)
+            if graphed is not None and img.shape == graphed.img.shape and lbl.shape == graphed.lbl.shape:
+                loss_sum += graphed(img, lbl)
+            else:
+                if graphed is not None:
+                    graphed.release()
+                    graphed, use_graph = None, False
+                self.optimiser.zero_grad()
+                loss, out = self.forward_loss(img, lbl)
+                loss.backward()
+                self.optimiser.step()
+                t_get_confusion_matrix(out.detach(), lbl, running_cm)      # accumulates on the device
+                loss_sum += loss.detach()
             n += 1
             self.global_step += 1
+        if graphed is not None:
+            graphed.release()
         if self.scheduler is not None:
             self.scheduler.step()
         if self.world > 1:                       # logged training metrics are GLOBAL: one exchange per epoch

@@ -88,3 +88,31 @@ def test_graphed_step_is_bit_identical_to_the_eager_step(name, shape):
     opt.step()
     torch.cuda.synchronize()
     assert torch.isfinite(loss)
+
+
+def test_manager_epochs_through_the_graph_equal_the_eager_loop(tmp_path):
+    """config['train']['hip_graph'] = True: the manager records its step once per epoch and replays it -- two epochs (the second at the
+    scheduler's next learning rate) give the history, the weights and the BatchNorm statistics of the eager loop, bit for bit"""
+    _need_gpu()
+    from miccai2021_cataract_semantic_segmentation_amd.managers import OCRNetManager, SyntheticCataractDataset
+
+    def run(hip_graph, sub):
+        cfg = {"name": "t", "mode": "training", "manager": "OCRNet", "log_path": str(tmp_path / sub),
+               "graph": {"model": "OCRNet", "backbone": "resnet50", "out_stride": 8, "pretrained": False},
+               "data": {"experiment": 2, "batch_size": 2},
+               "loss": {"name": "TwoScaleLoss", "interm": {"name": "LovaszSoftmax", "args": [], "weight": 0.4},
+                        "final": {"name": "LovaszSoftmax", "args": [], "weight": 1.0}},
+               "train": {"learning_rate": 1e-3, "epochs": 2, "hip_graph": hip_graph}, "log_every_n_epochs": 1, "seed": 0}
+        torch.manual_seed(123)                                  # (the model's default initialisation draws from the global generator)
+        m = OCRNetManager(cfg, SyntheticCataractDataset(8, 64, 96, 17, seed=1), SyntheticCataractDataset(2, 64, 96, 17, seed=2))
+        m.train()
+        torch.cuda.synchronize()
+        return m.history, m.model.flat().flat.clone(), [b.clone() for b in m.model.buffers()], m.optimiser._steps
+    h_e, w_e, b_e, s_e = run(False, "eager")
+    h_g, w_g, b_g, s_g = run(True, "graph")
+    assert s_e == s_g == 8
+    assert [(r["train_loss"], r["train_miou"], r["lr"]) for r in h_e] == [(r["train_loss"], r["train_miou"], r["lr"]) for r in h_g]
+    assert [r.get("valid_miou") for r in h_e] == [r.get("valid_miou") for r in h_g]
+    assert torch.equal(w_e, w_g)
+    for a, b in zip(b_e, b_g):
+        assert torch.equal(a, b)
