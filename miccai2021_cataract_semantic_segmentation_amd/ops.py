@@ -682,6 +682,45 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
     return out
 
 
+def _wgrad_split_route(x, dy, kh, kw, stride, stem4, groups):
+    """backward-weight of this layer runs the split-precision implicit GEMM (igemm_h2t / igemm_b3t) on planes of x and dy"""
+    Cout, Cin = dy.shape[-1], x.shape[-1]
+    return bool(groups == 1 and "wgrad" in B3_OPS and not stem4 and PRECISION == "bf16x3" and Cin % 8 == 0 and
+                rows_of(x) * Cin < B3_INDEX_LIMIT and rows_of(dy) * ((Cout + 7) // 8 * 8) < B3_INDEX_LIMIT and
+                ((B3_MIN_TAPS <= kh * kw and kh * kw * Cin >= B3_MIN_K and Cout >= B3_MIN_N and rows_of(dy) >= B3_MIN_WGRAD_ROWS)
+                 or (stride == 1 and _b3_wide_1x1(rows_of(dy), Cout, kh * kw, Cin))))
+
+
+def _wgrad_dgrad_blk(x, dy, kh, kw, stride):
+    """the layer's backward-data will read BLOCKED planes of dy: the backward-weight's split pass writes them as well"""
+    Cout, Cin = dy.shape[-1], x.shape[-1]
+    return bool(stride == 1 and "dgrad" in B3_OPS and _b3_eligible(rows_of(x), Cin, kh * kw, (Cout + 7) // 8 * 8)
+                and _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16, rows_of(dy), Cin, kh * kw))
+
+
+def _wgrad_h2_route(x, dy):
+    Cout, Cin = dy.shape[-1], x.shape[-1]
+    return bool(_h2() and 4 * rows_of(x) * Cin < B3_PLANE_LIMIT and 4 * rows_of(dy) * ((Cout + 7) // 8 * 8) < B3_PLANE_LIMIT)
+
+
+def wgrad_presplit(x, dy, kh, kw, stride=1, pad=0, dil=1, stem4=False, groups=1):
+    """engine.Ctx.async_wgrad: the split passes conv_bwd_weight would run, issued on the CURRENT stream ahead of it -- the backward-weight
+    kernel itself then runs on another stream while this stream goes on to the layer's backward-data, which reads the blocked planes of dy
+    that the same pass wrote.  Returns the plane tensors the other stream will read (for record_stream), or None: no split route."""
+    if (not stem4 and x.dim() == 4 and _d3_ok(rows_of(dy), x.shape[-1], dy.shape[-1], kh, kw, stride, pad, dil, groups)
+            and lib.catseg_dwgrad3_supported(x.shape[-1])):
+        return None
+    if not _wgrad_split_route(x, dy, kh, kw, stride, stem4, groups):
+        return None
+    dgrad_blk = _wgrad_dgrad_blk(x, dy, kh, kw, stride)
+    with _Timed("split3", 0.0):
+        if _wgrad_h2_route(x, dy):
+            xp, xsc = _split3_cached(x, "h2p")
+            dyp, dysc = _split3_cached_dy(dy, "h2p", both=dgrad_blk)
+            return [xp, xsc, dyp, dysc]
+        return [_split3_cached(x, "planar"), _split3_cached_dy(dy, "planar", both=dgrad_blk)]
+
+
 def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=False, groups=1):
     """dw: destination tensor (physical OHWI, or packed [O][7][8][4] for the stem)."""
     Cout, Cin = dy.shape[-1], x.shape[-1]
@@ -692,15 +731,11 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
             and lib.catseg_dwgrad3_supported(Cin)):
         dwgrad3(x, dy, dw, dbias, flops)
         return dw
-    if (groups == 1 and "wgrad" in B3_OPS and not stem4 and PRECISION == "bf16x3" and Cin % 8 == 0 and
-            rows_of(x) * Cin < B3_INDEX_LIMIT and rows_of(dy) * ((Cout + 7) // 8 * 8) < B3_INDEX_LIMIT and
-            ((B3_MIN_TAPS <= kh * kw and kh * kw * Cin >= B3_MIN_K and Cout >= B3_MIN_N and rows_of(dy) >= B3_MIN_WGRAD_ROWS)
-             or (stride == 1 and _b3_wide_1x1(rows_of(dy), Cout, kh * kw, Cin)))):
+    if _wgrad_split_route(x, dy, kh, kw, stride, stem4, groups):
         d = make_desc(x.shape, Cin, Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         ws = workspace(lib.catseg_conv2d_bwd_weight_bf16x3_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
-        dgrad_blk = (stride == 1 and "dgrad" in B3_OPS and _b3_eligible(rows_of(x), Cin, kh * kw, (Cout + 7) // 8 * 8)
-                     and _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16, rows_of(dy), Cin, kh * kw))
-        if _h2() and 4 * rows_of(x) * Cin < B3_PLANE_LIMIT and 4 * rows_of(dy) * ((Cout + 7) // 8 * 8) < B3_PLANE_LIMIT:
+        dgrad_blk = _wgrad_dgrad_blk(x, dy, kh, kw, stride)
+        if _wgrad_h2_route(x, dy):
             # two fp16 planes per operand (csrc/igemm_f16x2.hip; each operand's planes behind one 32-bit-offset buffer resource); dy's
             # blocked planes for this layer's backward-data from the same pass
             wsb = workspace(lib.catseg_conv2d_bwd_weight_f16x2_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
