@@ -115,8 +115,11 @@ def side_streams(device, n):
 
 # Backward-weight of the layers marked Conv2d.async_wgrad (the three head convolutions of OCRNet: 9.3 ms of matrix work per HRNet-W48 step
 # whose result nothing reads before the optimiser / the gradient exchange) on ONE extra stream: the launch stream goes straight on to the
-# layer's backward-data and to the HBM-bound kernels behind it.  CATSEG_ASYNC_WGRAD=0: in line, as before.
-ASYNC_WGRAD = __import__("os").environ.get("CATSEG_ASYNC_WGRAD", "1") != "0"
+# layer's backward-data and to the HBM-bound kernels behind it.  Measured (tools/ab_modes.sh, two alternating rounds on one box, graph replay):
+# 113.39 / 112.42 ms with it against 113.19 / 112.93 ms in line; eager 115.5 / 119.7 against 116.2 / 117.8 -- NO gain: igemm_h2t_kernel runs one
+# wave per SIMD with all 512 registers, so a CU that holds one of its blocks holds nothing else, and beside the layer's backward-data (the
+# same matrix pipes at the power ceiling) it only time-slices.  Off by default (CATSEG_ASYNC_WGRAD=1 enables it); kept with its test.
+ASYNC_WGRAD = __import__("os").environ.get("CATSEG_ASYNC_WGRAD", "0") == "1"
 _wgrad_streams = {}
 
 
