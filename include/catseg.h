@@ -476,6 +476,27 @@ void catseg_adam_hyper(float lr, float beta1, float beta2, int step, float grad_
 int catseg_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1,
                          float beta2, float eps, catseg_stream_t stream);
 
+/* ---- pointwise (1 x 1, stride 1) convolutions in split precision with the split in registers (csrc/pconv1.hip) ----
+   Replaces the ATen 1 x 1 conv2d calls (forward, and their autograd backward) of the stage-1 bottlenecks (models/HRNetv2.py:68-106), of the
+   object-attention block (models/OCR.py:186-235: f_pixel / f_up) and of the HRNet fuse layers (models/HRNetv2.py:237-261) -- layers too
+   small for the blocked-plane kernels above, HBM-bound GEMMs with K = 64 ... 512.  The activation operand is the fp32 NHWC tensor itself
+   plus the amax record its producer left (CATSEG_AMAX_RECORD_BYTES); the weight operand is a pre-split image.
+   catseg_pconv1_prep_batch: entries = DEVICE array of n records {int64 weight offset (floats, relative to flat), int64 image offset (bytes,
+   relative to wimg_base), int32 O, int32 I, int32 transposed, int32 pad}; records = n x {uint32 bits of max|w|, int32 exponent} (DEVICE).
+   catseg_pconv1: y[M][N] (+)= x[M][K] . B^T (+ bias); B = image of (N, K) = the layer's [O][I] weights (forward: N = O, K = I) or, with
+   transposed != 0 at preparation, their transpose (backward-data: N = I, K = O).  bn_part as catseg_conv2d_fwd_bnstats.
+   catseg_pconv1_wgrad: dw[Cout][Cin] = dy^T . x over P pixels (slabs + fixed-order sum: deterministic). */
+int catseg_pconv1_supported(int N, int K);
+size_t catseg_pconv1_wimg_bytes(int N, int K);
+int catseg_pconv1_prep_batch(const float* flat, int n, const void* entries, void* wimg_base, void* records, catseg_stream_t stream);
+int catseg_pconv1(long long M, int N, int K, const float* x, int ldx, const void* x_rec, const void* wimg, const void* w_rec,
+                  const float* bias, float* y, int ldy, int accumulate, float* bn_part, size_t bn_part_floats, int* tile_rows,
+                  int* n_tiles, catseg_stream_t stream);
+int catseg_pconv1_wgrad_supported(int Cout, int Cin);
+size_t catseg_pconv1_wgrad_workspace(long long P, int Cout, int Cin);
+int catseg_pconv1_wgrad(long long P, int Cout, int Cin, const float* dy, int lddy, const void* dy_rec, const float* x, int ldx,
+                        const void* x_rec, float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

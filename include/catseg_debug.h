@@ -57,6 +57,9 @@ int catseg_debug_set_b3_tile(int t);
  *     in N / M; 3 / 4 = 16 / 32 wide), splits, direct (1 = the direct backward-weight kernel handles it). */
 int catseg_debug_plan_conv(const catseg_conv_desc* d, int op, int* out);
 
+/* csrc/pconv1.hip: blocks of a backward-weight launch of the pointwise kernels (default 256: one per CU) */
+int catseg_debug_set_pconv1_wgrad_blocks(int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -161,6 +161,14 @@ _SIGS = {
     "catseg_resize_nearest": (I, [P, I, P, I, I, I, I, I, I, I, I, I, F, P]),
     "catseg_confusion_matrix": (I, [P, P, L, I, P, P]),
     "catseg_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, F, P]),
+    "catseg_pconv1_supported": (I, [I, I]),
+    "catseg_pconv1_wimg_bytes": (SZ, [I, I]),
+    "catseg_pconv1_prep_batch": (I, [P, I, P, P, P, P]),
+    "catseg_pconv1": (I, [L, I, I, P, I, P, P, P, P, P, I, I, P, SZ, P, P, P]),
+    "catseg_pconv1_wgrad_supported": (I, [I, I]),
+    "catseg_pconv1_wgrad_workspace": (SZ, [L, I, I]),
+    "catseg_pconv1_wgrad": (I, [L, I, I, P, I, P, P, I, P, P, P, SZ, P]),
+    "catseg_debug_set_pconv1_wgrad_blocks": (I, [I]),
     "catseg_adam_hyper": (None, [F, F, F, I, F, P]),
     "catseg_adam_step_dev": (I, [P, P, P, P, L, P, F, F, F, P]),
 }

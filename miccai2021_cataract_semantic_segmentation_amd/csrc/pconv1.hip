@@ -1,0 +1,600 @@
+// Pointwise (1 x 1, stride 1) convolution of the layers that are NOT large enough for the blocked-plane kernel of igemm_f16x2.hip and were
+// the bulk of the fp32-MFMA residue of an OCRNet-HRNet-W48 step: the stage-1 bottlenecks (models/HRNetv2.py:68-106 of the reference: 1 x 1
+// 64 -> 64 / 64 -> 256 / 256 -> 64 on 261 120 pixels), the object-attention block of the OCR head (models/OCR.py:186-235: f_pixel 512 -> 256
+// -> 256, f_up 256 -> 512) and the 1 x 1 fuse layers of the HRNet modules (models/HRNetv2.py:237-261).  With K = Cin of 64 ... 512 these
+// GEMMs are HBM-bound (25 ... 85 FLOP per byte), and a separate split pass over the activation costs what the fp16 matrix cores gain
+// (tools/ab_1x1_hr.py, round 4).  Here the split happens IN REGISTERS:
+//
+//   * arithmetic of igemm_f16x2.hip: xs = x * 2^e (e from the tensor's amax record, left by its producer),  h = fp16(xs),  l = fp16(xs - h),
+//     a.b ~ hh + hl + lh into one fp32 accumulator (three v_mfma_f32_32x32x16_f16), result scaled back by 2^-(e_x + e_w);
+//   * A operand (pixel rows): a lane of the 32 x 32 x 16 MFMA owns 8 consecutive k of one row = 32 contiguous bytes of the fp32 NHWC row --
+//     it loads them straight from global memory (two 16-byte buffer loads, rows past M and channels past K come back as zeros), scales,
+//     splits and holds the two fragments: no LDS, no barrier on the activation's path, 4 bytes read per element, nothing written;
+//   * B operand (weights): a pre-split image per layer and direction (p1_prep_batch_kernel: all layers of a network in one launch per
+//     step) streams through three LDS slots by LDS-DMA, one 32-deep k-group per slot, shared by the block's eight waves;
+//   * block = 256 rows x up to 256 columns, 8 waves of 32 rows (two per SIMD, <= 256 registers), one barrier per k-group;
+//   * epilogue: bias, accumulate, BatchNorm partials per (row tile, channel) (common.h: cs_tile_bn_partials) as the other forward kernels.
+//
+// Backward-data of the same layers is the same kernel on dy with the transposed weight image.  Backward-weight: p1t_kernel below.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+// prescale exponent from the bits of a tensor's max |x| (igemm_f16x2.hip: h2_exponent): amax * 2^e in [2^14, 2^15)
+__host__ __device__ inline int p1_exponent(unsigned amax_bits) {
+  const int ex = (int)((amax_bits >> 23) & 0xFF);
+  if (ex == 0 || ex == 255) return 0;
+  const int e = 14 - (ex - 127);
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+
+__host__ __device__ constexpr int p1_bn(int N) { return N >= 256 ? 256 : (N + 31) / 32 * 32; }   // columns of a block tile
+__host__ __device__ constexpr int p1_ntn(int N) { return (N + p1_bn(N) - 1) / p1_bn(N); }
+__host__ __device__ constexpr int p1_groups(int K) { return ((K + 31) / 32 + 1) / 2 * 2; }        // 32-deep k-groups, an even count (the K loop is unrolled twice)
+
+// ---- weight image: [k-group][n tile][k-tile 0/1][plane h/l][BN][16 halves], the two 8-half chunks of a row swapped where (n >> 3) & 1
+// (conflict-free ds_read_b128 of the B fragments), zero beyond N / K.  transposed: B[n][k] = w[k][n] (backward-data: n = input channel)
+struct P1Entry { long long w_off, img_off; int O, I, transposed, pad; };
+
+__global__ __launch_bounds__(256) void p1_amax_batch_kernel(const float* __restrict__ flat, const P1Entry* __restrict__ ent, unsigned* __restrict__ recs) {
+  const P1Entry e = ent[blockIdx.y];
+  const float* w = flat + e.w_off;
+  const long long n = (long long)e.O * e.I;
+  unsigned m = 0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    m = max(m, __float_as_uint(w[i]) & 0x7FFFFFFFu);
+  cs_amax_commit1(m, recs + 2 * blockIdx.y);
+}
+
+__global__ __launch_bounds__(256) void p1_prep_batch_kernel(const float* __restrict__ flat, const P1Entry* __restrict__ ent,
+                                                            unsigned char* __restrict__ img_base, unsigned* __restrict__ recs) {
+  const P1Entry e = ent[blockIdx.y];
+  const int ex = p1_exponent(recs[2 * blockIdx.y]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) ((int*)recs)[2 * blockIdx.y + 1] = ex;
+  const float* w = flat + e.w_off;
+  const int N = e.transposed ? e.I : e.O, K = e.transposed ? e.O : e.I;
+  const int BN = p1_bn(N), ntn = p1_ntn(N), G = p1_groups(K);
+  half8* img = (half8*)(img_base + e.img_off);
+  const long long pieces = (long long)G * ntn * 2 * BN * 2;          // (g, nt, kt, nn, chunk): one thread writes the h and the l piece
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < pieces; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i & 1);
+    long long r = i >> 1;
+    const int nn = (int)(r % BN); r /= BN;
+    const int kt = (int)(r & 1); r >>= 1;
+    const int nt = (int)(r % ntn);
+    const int g = (int)(r / ntn);
+    const int n = nt * BN + nn, k0 = 32 * g + 16 * kt + 8 * c;
+    half8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      float v = 0.f;
+      if (n < N && k < K) v = e.transposed ? w[(long long)k * e.I + n] : w[(long long)n * e.I + k];
+      const float xs = __builtin_ldexpf(v, ex);
+      const _Float16 hh = (_Float16)xs;
+      h[j] = hh;
+      l[j] = (_Float16)(xs - (float)hh);
+    }
+    const int pc = c ^ ((nn >> 3) & 1);
+    const long long row0 = (((long long)(g * ntn + nt) * 2 + kt) * 2) * BN;      // plane 0 rows of this (g, nt, kt)
+    img[(row0 + nn) * 2 + pc] = h;
+    img[(row0 + BN + nn) * 2 + pc] = l;
+  }
+}
+
+struct P1Args {
+  const float* x; int ldx;            // A: [M][ldx] fp32, columns [0, K)
+  const unsigned* xrec;               // amax record of A (CS_AMAX_SLOTS slots)
+  const unsigned char* wimg;          // weight image of (N, K)
+  const int* wrec;                    // {amax bits, exponent} of the weights
+  float* y; int ldy;
+  const float* bias;
+  int M, N, K;
+  int tilesM, ntn;
+  int accumulate;
+  float* bn_part;                     // [tilesM][3][N] or null
+  unsigned long long x_bytes, img_bytes;
+};
+
+constexpr int p1_waitcnt(int vm) { return (vm & 15) | (7 << 4) | (15 << 8) | ((vm >> 4) << 14); }     // vmcnt only (expcnt / lgkmcnt: no wait)
+
+template <int NT>
+__global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
+  constexpr int BN = 32 * NT;
+  constexpr int GB = 4 * BN * 32;                   // bytes of one k-group of B: k-tile (2) x plane (2) x BN rows x 32 bytes
+  constexpr int PIECES = GB / 16;                   // = 256 NT: a multiple of 64
+  constexpr int PB = (PIECES + 511) / 512;          // LDS-DMA instructions per wave per k-group
+  constexpr int NBUF = 3;
+  constexpr int EPI = 2 * 8 * BN * 4;               // floats the BatchNorm-partials exchange needs, in bytes
+  constexpr int SMEM = (NBUF * GB > EPI ? NBUF * GB : EPI) + 1024;   // + a 1 KB sink for the idle waves' (zero-filled) trailing pieces
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  // block -> (row tile, column tile): the column tiles of one row tile sit 8 block ids apart, i.e. on the SAME XCD (blocks are dealt
+  // round-robin over the eight XCDs): the second read of the activation rows hits that XCD's L2
+  int tile_m = blockIdx.x, tile_n = 0;
+  if (p.ntn > 1) {
+    const int per = 8 * p.ntn, grp = blockIdx.x / per, r = blockIdx.x - grp * per;
+    tile_n = r >> 3;
+    tile_m = grp * 8 + (r & 7);
+  }
+  if (tile_m >= p.tilesM) return;
+  const int m0 = tile_m * 256, n0 = tile_n * BN;
+
+  const int ex = p1_exponent(cs_amax_read(p.xrec));
+  const int G = p1_groups(p.K);
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+
+  // A: a raw buffer over the activation (rows past M are past its end: zeros); a lane's k-group = four 16-byte loads
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)(unsigned)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.wimg, (short)0, (int)(unsigned)p.img_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const int row = m0 + wave * 32 + l31;
+  const unsigned a_row = (unsigned)row * (unsigned)p.ldx * 4u + (unsigned)hh * 32u;
+  const unsigned klim = row < p.M ? (unsigned)p.K : 0u;          // rows past M: every k is "past K" (branch-free: the loads are issued
+  auto a_off = [&](int g, int kt, int c) -> unsigned {           //  unconditionally, the vmcnt bookkeeping below counts on it)
+    const unsigned k = (unsigned)(32 * g + 16 * kt + 8 * hh + 4 * c);
+    const unsigned m = (unsigned)-(int)(k < klim);
+    return ((a_row + (unsigned)(32 * g + 16 * kt) * 4u + 16u * c) & m) | (OOB & ~m);
+  };
+  // B: k-group g of column tile tile_n is one contiguous run of GB bytes of the image
+  const unsigned b_lane = (unsigned)(wave * 64 + lane) * 16u;
+  auto issueB = [&](int g, int buf) {
+    const unsigned src0 = (unsigned)((g * p.ntn + tile_n)) * (unsigned)GB;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const bool live = i * 512 + wave * 64 < PIECES;              // (wave-uniform)
+      const unsigned voff = live ? src0 + (unsigned)i * 8192u + b_lane : OOB;
+      char* dst = live ? smem + buf * GB + (i * 512 + wave * 64) * 16 : smem + SMEM - 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
+    }
+  };
+
+  f32x4 ra[2][4];       // raw fp32 of the two k-groups in flight: [parity][kt * 2 + c]
+  auto loadA = [&](int g, int par) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ra[par][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off(g, q >> 1, q & 1), 0, 0));
+  };
+  half8 Ah[2], Al[2];
+  auto splitA = [&](int par) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const f32x4 v0 = ra[par][kt * 2], v1 = ra[par][kt * 2 + 1];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xs = __builtin_ldexpf(j < 4 ? v0[j & 3] : v1[j & 3], ex);
+        const _Float16 h = (_Float16)xs;
+        Ah[kt][j] = h;
+        Al[kt][j] = (_Float16)(xs - (float)h);
+      }
+    }
+  };
+  const int boff = l31 * 32 + ((hh ^ ((l31 >> 3) & 1)) << 4);
+  // B fragments of (k-tile, column pair) q = 0 .. 2 NP - 1 are read one pair AHEAD of the MFMAs that use them
+  constexpr int NP = (NT + 1) / 2;                   // column pairs per k-tile
+  auto compute = [&](int buf) {
+    const char* bb = smem + buf * GB + boff;
+    half8 bh[2][2], bl[2][2];
+    auto rd = [&](int q, int st) {
+      const int kt = q / NP, u = 2 * (q - kt * NP);
+      bh[st][0] = *(const half8*)(bb + ((kt * 2 + 0) * BN + 32 * u) * 32);
+      bl[st][0] = *(const half8*)(bb + ((kt * 2 + 1) * BN + 32 * u) * 32);
+      if (u + 1 < NT) {
+        bh[st][1] = *(const half8*)(bb + ((kt * 2 + 0) * BN + 32 * (u + 1)) * 32);
+        bl[st][1] = *(const half8*)(bb + ((kt * 2 + 1) * BN + 32 * (u + 1)) * 32);
+      }
+    };
+    rd(0, 0);
+#pragma unroll
+    for (int q = 0; q < 2 * NP; ++q) {
+      const int st = q & 1, kt = q / NP, u = 2 * (q - kt * NP);
+      if (q + 1 < 2 * NP) rd(q + 1, st ^ 1);
+      if (u + 1 < NT) {
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[kt], bh[st][0], acc[u], 0, 0, 0);
+        acc[u + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[kt], bh[st][1], acc[u + 1], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[kt], bh[st][0], acc[u], 0, 0, 0);
+        acc[u + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[kt], bh[st][1], acc[u + 1], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[kt], bl[st][0], acc[u], 0, 0, 0);
+        acc[u + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[kt], bl[st][1], acc[u + 1], 0, 0, 0);
+      } else {
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[kt], bh[st][0], acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[kt], bh[st][0], acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[kt], bl[st][0], acc[u], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);             // (keeps the next pair's reads in front of this pair's MFMAs, not behind them)
+    }
+  };
+
+  // Order of the vector-memory operations (vmcnt retires them in order): A(0) B(0) A(1) B(1) | A(2) [wait] B(2) | A(3) [wait] B(3) | ...
+  // At the wait of iteration g everything but the newest A(g+1) B(g+1) A(g+2) may be outstanding: 8 + PB operations.
+  loadA(0, 0);
+  issueB(0, 0);
+  loadA(1, 1);
+  issueB(1, 1);
+  for (int g = 0; g < G; g += 2) {
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int gg = g + par;
+      splitA(par);                                   // (the compiler waits for A(gg) here)
+      loadA(gg + 2, par);                            // past the last group: out of range = zeros, never used
+      __builtin_amdgcn_sched_barrier(0);             // (the count below assumes the four loads above have been issued)
+      __builtin_amdgcn_s_waitcnt(p1_waitcnt(8 + PB));
+      __builtin_amdgcn_s_barrier();                  // B(gg) of every wave has landed; every wave is done with slot (gg + 2) % 3 (step gg - 1)
+      asm volatile("" ::: "memory");
+      issueB(gg + 2, (gg + 2) % NBUF);
+      compute(gg % NBUF);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(p1_waitcnt(0));
+  __syncthreads();
+
+  // back to the operands' scale: 2^-(e_x + e_w) in two exact steps
+  {
+    const int ea = -ex, ew = -p.wrec[1];
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][r] = __builtin_ldexpf(__builtin_ldexpf(acc[u][r], ea), ew);
+  }
+  float bv[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const int col = n0 + 32 * u + l31;
+    bv[u] = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+  }
+  const int rbase = m0 + wave * 32 + 4 * hh;
+  if (p.bn_part != nullptr) {
+    int colv[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) colv[u] = 32 * u + l31;
+    cs_tile_bn_partials<NT, 16, 8, false>(
+        (float*)smem, BN, colv, hh == 0, wave, min(256, p.M - m0),
+        [&](int j, int i) { return acc[j][i] + bv[j]; },
+        [&](int i) { return rbase + (i & 3) + 8 * (i >> 2) < p.M; }, p.bn_part + (long long)tile_m * 3 * p.N, p.N, n0);
+  }
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const int col = n0 + 32 * u + l31;
+    float add[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rw = rbase + (r & 3) + 8 * (r >> 2);
+      add[r] = (p.accumulate && rw < p.M && col < p.N) ? p.y[(long long)rw * p.ldy + col] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rw = rbase + (r & 3) + 8 * (r >> 2);
+      if (rw < p.M && col < p.N) p.y[(long long)rw * p.ldy + col] = (acc[u][r] + bv[u]) + add[r];
+    }
+  }
+}
+
+template <int NT>
+void p1_launch(const P1Args& a, hipStream_t st) {
+  const int per = 8 * a.ntn;
+  const int blocks = a.ntn > 1 ? (a.tilesM + 7) / 8 * per : a.tilesM;
+  hipLaunchKernelGGL(p1_kernel<NT>, dim3(blocks), dim3(512), 0, st, a);
+}
+
+// ---- backward-weight: dW[o][c] = sum_p dy[p][o] x[p][c] ------------------------------------------------------------------------------
+// M = Cout (dy columns), N = Cin (x columns), reduction over the pixels: both operands are k-strided in memory.  A block owns a run of
+// 32-pixel steps and an (MP x NP) tile of the result; per step the eight waves read the fp32 rows of dy and x coalesced (16 bytes per
+// lane), split them in registers and write the two fp16 planes pixel-major into LDS; the MFMA fragments (8 consecutive pixels of one
+// channel) come out of the hardware transpose ds_read_b64_tr_b16 (a 16-lane group turns 4 pixels x 16 channels around).  Each wave
+// accumulates a (32 TM) x (32 TN) piece over the block's whole run; partial results go to slabs that p1t_reduce_kernel adds in a fixed
+// order (deterministic).  Pixel row stride = 64 (mod 128) bytes: the four pixel rows one LDS cycle serves (64 bytes each: two 16-lane
+// groups side by side) fall into four different 64-byte bank groups.
+struct P1TArgs {
+  const float* dy; int lddy; const unsigned* dyrec;
+  const float* x; int ldx; const unsigned* xrec;
+  float* slabs;                       // [gridDim.x][Mtot][Ntot] partial results (Mtot = nbm * MP, Ntot = nbn * NP)
+  long long P;                        // pixels
+  int M, N;                           // Cout, Cin
+  int nbn, Mtot, Ntot;                // blockIdx.y = bm * nbn + bn
+  int steps_per_block;                // 32-pixel steps per block
+  unsigned long long dy_bytes, x_bytes;
+};
+
+typedef short p1_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) p1_s16x4 p1_lds_s16x4;
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(512) void p1t_kernel(const P1TArgs p) {
+  static_assert(WM * WN == 8, "eight waves");
+  constexpr int MP = 32 * TM * WM, NP = 32 * TN * WN;
+  constexpr int CH = MP + NP;                               // 16-bit columns of one LDS pixel row: dy channels, then x channels
+  constexpr int RS = (CH * 2 + 63) / 128 * 128 + 64;        // row stride in bytes, = 64 (mod 128)
+  constexpr int PL = 32 * RS;                               // one plane of a 32-pixel step
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * PL];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int edy = p1_exponent(cs_amax_read(p.dyrec)), ex = p1_exponent(cs_amax_read(p.xrec));
+  const int bm = blockIdx.y / p.nbn, bn = blockIdx.y - bm * p.nbn;
+  const int mo = bm * MP, no = bn * NP;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, (short)0, (int)(unsigned)p.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)(unsigned)p.x_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  // staging: a step's 32 pixels x (MP + NP) channels in 4-float items, item q = (pixel, quad): consecutive lanes take consecutive quads
+  // of one pixel row (coalesced)
+  constexpr int QM = MP / 4, QT = (MP + NP) / 4;
+  constexpr int ITEMS = (32 * QT + 511) / 512;
+  const long long step0 = (long long)blockIdx.x * p.steps_per_block;
+  f32x4 raw[ITEMS];
+  auto load = [&](long long s) {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int q = i * 512 + tid;
+      const int px = q / QT, c4 = q - px * QT;
+      const long long pix = s * 32 + px;
+      const bool isx = c4 >= QM;
+      unsigned off = OOB;
+      if (q < 32 * QT && pix < p.P) {
+        if (!isx) {
+          if (mo + c4 * 4 < p.M) off = (unsigned)(pix * p.lddy + mo + c4 * 4) * 4u;
+        } else if (no + (c4 - QM) * 4 < p.N) {
+          off = (unsigned)(pix * p.ldx + no + (c4 - QM) * 4) * 4u;
+        }
+      }
+      const f32x4 vd = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, isx ? OOB : off, 0, 0));
+      const f32x4 vx = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, isx ? off : OOB, 0, 0));
+      raw[i] = isx ? vx : vd;
+    }
+  };
+  auto stash = [&](int buf) {
+    char* base = smem + buf * 2 * PL;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int q = i * 512 + tid;
+      if (q < 32 * QT) {
+        const int px = q / QT, c4 = q - px * QT;
+        const int e = c4 >= QM ? ex : edy;
+        const f32x4 v = raw[i];
+        u16 h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xs = __builtin_ldexpf(v[j], e);
+          const _Float16 hv = (_Float16)xs;
+          h[j] = __builtin_bit_cast(u16, hv);
+          l[j] = __builtin_bit_cast(u16, (_Float16)(xs - (float)hv));
+        }
+        char* d = base + px * RS + c4 * 8;
+        *(unsigned long long*)d = (unsigned long long)h[0] | ((unsigned long long)h[1] << 16) | ((unsigned long long)h[2] << 32) | ((unsigned long long)h[3] << 48);
+        *(unsigned long long*)(d + PL) = (unsigned long long)l[0] | ((unsigned long long)l[1] << 16) | ((unsigned long long)l[2] << 32) | ((unsigned long long)l[3] << 48);
+      }
+    }
+  };
+  // fragment of a 32-column tile: lane (j = lane & 31, g = lane >> 5) needs pixels 16 kt + 8 g .. + 8 of column col0 + j.  The 16-lane
+  // group of the lane (columns col0 + 16 (j >> 4) .. + 16) transposes 4 pixels x 16 columns per read: lane li of the group supplies the
+  // address of (pixel li >> 2 of the four, columns 4 (li & 3) .. + 4) and receives the four pixels of column li
+  const int fr_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * RS + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  auto frag = [&](const char* plane, int col0, int kt) -> half8 {
+    const char* src = plane + fr_off + 16 * kt * RS + col0 * 2;
+    const p1_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((p1_lds_s16x4*)src);
+    const p1_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((p1_lds_s16x4*)(src + 4 * RS));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(half8, v8);
+  };
+
+  const int nsteps = p.steps_per_block;
+  load(step0);
+#pragma unroll 1
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    stash(buf);                                     // (waits for the loads of step s; buffer s & 1 was last read in step s - 2: behind the barrier of step s - 1)
+    if (s + 1 < nsteps) load(step0 + s + 1);
+    __syncthreads();
+    const char* hp = smem + buf * 2 * PL;
+    const char* lp = hp + PL;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      half8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = frag(hp, 32 * (wm * TM + i), kt);
+        al[i] = frag(lp, 32 * (wm * TM + i), kt);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = frag(hp, MP + 32 * (wn * TN + j), kt);
+        bl[j] = frag(lp, MP + 32 * (wn * TN + j), kt);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // this block's tile of its slab, scaled back
+  float* slab = p.slabs + (long long)blockIdx.x * p.Mtot * p.Ntot;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int sa = -edy, sb = -ex;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rw = mo + 32 * (wm * TM + i) + (r & 3) + 8 * (r >> 2) + 4 * hh, col = no + 32 * (wn * TN + j) + l31;
+        slab[(long long)rw * p.Ntot + col] = __builtin_ldexpf(__builtin_ldexpf(acc[i][j][r], sa), sb);
+      }
+}
+
+// dw[o][c] = sum over slabs, fixed order (four independent chains)
+__global__ __launch_bounds__(256) void p1t_reduce_kernel(const float* __restrict__ slabs, int nslabs, int Mtot, int Ntot, int M, int N, float* __restrict__ dw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const int o = i / N, c = i - o * N;
+  const float* s = slabs + (long long)o * Ntot + c;
+  const long long stride = (long long)Mtot * Ntot;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int k = 0;
+  for (; k + 3 < nslabs; k += 4) {
+    a0 += s[(long long)k * stride];
+    a1 += s[(long long)(k + 1) * stride];
+    a2 += s[(long long)(k + 2) * stride];
+    a3 += s[(long long)(k + 3) * stride];
+  }
+  for (; k < nslabs; ++k) a0 += s[(long long)k * stride];
+  dw[i] = (a0 + a1) + (a2 + a3);
+}
+
+struct P1TPlan { int kind, MP, NP; };
+// block tile of the result by shape: kind -> (WM, WN, TM, TN); at most 128 accumulator registers per wave
+P1TPlan p1t_plan(int M, int N) {
+  if (M <= 0 || N <= 0 || M > 1024 || N > 1024) return {0, 0, 0};
+  if (M <= 64 && N <= 128) return {8, 64, 128};         // 2 x 4 waves of 32 x 32
+  if (M <= 64) return {1, 64, 256};                     // 2 x 4 waves of 32 x 64
+  if (N <= 64) return {2, 256, 64};                     // 4 x 2 waves of 64 x 32
+  if (M <= 128 && N <= 128) return {3, 128, 128};       // 2 x 4 waves of 64 x 32
+  if (M <= 128) return {9, 128, 256};                   // 2 x 4 waves of 64 x 64
+  return {4, 256, 256};                                 // 2 x 4 waves of 128 x 64
+}
+
+int g_p1t_blocks = 256;
+
+}  // namespace
+
+extern "C" int catseg_pconv1_supported(int N, int K) {
+  return (N >= 32 && K >= 32 && K % 8 == 0 && N <= 512 && K <= 1024) ? 1 : 0;
+}
+
+extern "C" size_t catseg_pconv1_wimg_bytes(int N, int K) {
+  return (size_t)p1_groups(K) * p1_ntn(N) * 4 * p1_bn(N) * 32;
+}
+
+// entries: DEVICE array of n records {int64 weight offset (floats, relative to flat), int64 image offset (bytes, relative to wimg_base),
+// int32 O, int32 I, int32 transposed, int32 pad}: the image of (N = O, K = I), or with transposed != 0 of (N = I, K = O) (backward-data);
+// records = n x {uint32 bits of max|w|, int32 exponent} (DEVICE): zeroed, filled by the amax launch, completed by the image launch
+extern "C" int catseg_pconv1_prep_batch(const float* flat, int n, const void* entries, void* wimg_base, void* records, catseg_stream_t stream) {
+  CS_REQUIRE(flat && entries && wimg_base && records && n > 0, "pconv1 prep batch: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(records, 0, (size_t)n * 8, st) != hipSuccess) { catseg_set_error("pconv1 prep: memset failed"); return CATSEG_EHIP; }
+  hipLaunchKernelGGL(p1_amax_batch_kernel, dim3(8, n), dim3(256), 0, st, flat, (const P1Entry*)entries, (unsigned*)records);
+  hipLaunchKernelGGL(p1_prep_batch_kernel, dim3(32, n), dim3(256), 0, st, flat, (const P1Entry*)entries, (unsigned char*)wimg_base, (unsigned*)records);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// y[M][N] (+)= x[M][K] . B^T (+ bias) with B = the weight image of (N, K); x_rec: the amax record of x (its producer's); w_rec: the
+// image's {amax bits, exponent}.  bn_part may be null; otherwise per-(256-row tile, channel) BatchNorm partials as catseg_conv2d_fwd_bnstats.
+extern "C" int catseg_pconv1(long long M, int N, int K, const float* x, int ldx, const void* x_rec, const void* wimg, const void* w_rec,
+                             const float* bias, float* y, int ldy, int accumulate, float* bn_part, size_t bn_part_floats, int* tile_rows,
+                             int* n_tiles, catseg_stream_t stream) {
+  CS_REQUIRE(M > 0 && catseg_pconv1_supported(N, K) && x && x_rec && wimg && w_rec && y, "pconv1: unsupported shape or null argument");
+  CS_REQUIRE(ldx >= K && ldx % 4 == 0 && ldy >= N && cs_aligned16(x) && cs_aligned16(wimg) && ((uintptr_t)y & 3) == 0, "pconv1: alignment / row strides");
+  CS_REQUIRE((unsigned long long)M * (unsigned long long)ldx * 4ull < 0xFFFFFFF0ull && M < (1ll << 31) - 256, "pconv1: activation beyond one 4 GB buffer resource");
+  P1Args a = {};
+  a.x = x; a.ldx = ldx; a.xrec = (const unsigned*)x_rec; a.wimg = (const unsigned char*)wimg; a.wrec = (const int*)w_rec;
+  a.y = y; a.ldy = ldy; a.bias = bias; a.M = (int)M; a.N = N; a.K = K;
+  a.tilesM = (int)((M + 255) / 256); a.ntn = p1_ntn(N); a.accumulate = accumulate;
+  a.x_bytes = (unsigned long long)M * ldx * 4ull; a.img_bytes = catseg_pconv1_wimg_bytes(N, K);
+  if (bn_part != nullptr) {
+    CS_REQUIRE(tile_rows && n_tiles, "pconv1: tile_rows / n_tiles");
+    *tile_rows = 0; *n_tiles = 0;
+    if ((size_t)a.tilesM * 3 * N <= bn_part_floats) {
+      a.bn_part = bn_part;
+      *tile_rows = 256; *n_tiles = a.tilesM;
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (p1_bn(N) / 32) {
+    case 1: p1_launch<1>(a, st); break;
+    case 2: p1_launch<2>(a, st); break;
+    case 3: p1_launch<3>(a, st); break;
+    case 4: p1_launch<4>(a, st); break;
+    case 5: p1_launch<5>(a, st); break;
+    case 6: p1_launch<6>(a, st); break;
+    case 7: p1_launch<7>(a, st); break;
+    default: p1_launch<8>(a, st); break;
+  }
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+extern "C" int catseg_pconv1_wgrad_supported(int Cout, int Cin) { return p1t_plan(Cout, Cin).kind != 0 && Cout % 4 == 0 && Cin % 4 == 0 ? 1 : 0; }
+
+namespace {
+struct P1TGrid { P1TPlan pl; int nbm, nbn, Mtot, Ntot, blocks, steps_per_block; };
+P1TGrid p1t_grid(long long P, int Cout, int Cin) {
+  P1TGrid g = {};
+  g.pl = p1t_plan(Cout, Cin);
+  if (!g.pl.kind) return g;
+  g.nbm = (Cout + g.pl.MP - 1) / g.pl.MP; g.nbn = (Cin + g.pl.NP - 1) / g.pl.NP;
+  g.Mtot = g.nbm * g.pl.MP; g.Ntot = g.nbn * g.pl.NP;
+  const long long steps = (P + 31) / 32;
+  long long want = g_p1t_blocks / (g.nbm * g.nbn);
+  if (want < 1) want = 1;
+  if (want > steps) want = steps;
+  g.steps_per_block = (int)((steps + want - 1) / want);
+  g.blocks = (int)((steps + g.steps_per_block - 1) / g.steps_per_block);
+  return g;
+}
+}  // namespace
+
+extern "C" size_t catseg_pconv1_wgrad_workspace(long long P, int Cout, int Cin) {
+  const P1TGrid g = p1t_grid(P, Cout, Cin);
+  if (!g.pl.kind) return 0;
+  return (size_t)g.blocks * g.Mtot * g.Ntot * 4;
+}
+
+extern "C" int catseg_debug_set_pconv1_wgrad_blocks(int n) { g_p1t_blocks = n > 0 ? n : 256; return CATSEG_OK; }
+
+// dw[Cout][Cin] = dy^T . x over P pixels; both operands fp32 rows with their producers' amax records
+extern "C" int catseg_pconv1_wgrad(long long P, int Cout, int Cin, const float* dy, int lddy, const void* dy_rec, const float* x, int ldx,
+                                   const void* x_rec, float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+  const P1TGrid g = p1t_grid(P, Cout, Cin);
+  CS_REQUIRE(P > 0 && g.pl.kind && Cout % 4 == 0 && Cin % 4 == 0 && dy && x && dy_rec && x_rec && dw && workspace, "pconv1 wgrad: unsupported shape or null argument");
+  CS_REQUIRE(lddy >= Cout && ldx >= Cin && lddy % 4 == 0 && ldx % 4 == 0 && cs_aligned16(dy) && cs_aligned16(x) && cs_aligned16(workspace),
+             "pconv1 wgrad: alignment / row strides");
+  CS_REQUIRE((unsigned long long)P * lddy * 4ull < 0xFFFFFFF0ull && (unsigned long long)P * ldx * 4ull < 0xFFFFFFF0ull, "pconv1 wgrad: operand beyond 4 GB");
+  CS_REQUIRE(workspace_bytes >= catseg_pconv1_wgrad_workspace(P, Cout, Cin), "pconv1 wgrad: workspace too small");
+  P1TArgs a = {};
+  a.dy = dy; a.lddy = lddy; a.dyrec = (const unsigned*)dy_rec; a.x = x; a.ldx = ldx; a.xrec = (const unsigned*)x_rec;
+  a.slabs = (float*)workspace; a.P = P; a.M = Cout; a.N = Cin; a.nbn = g.nbn; a.Mtot = g.Mtot; a.Ntot = g.Ntot;
+  a.steps_per_block = g.steps_per_block;
+  a.dy_bytes = (unsigned long long)P * lddy * 4ull; a.x_bytes = (unsigned long long)P * ldx * 4ull;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(g.blocks, g.nbm * g.nbn);
+  switch (g.pl.kind) {
+    case 8: hipLaunchKernelGGL((p1t_kernel<2, 4, 1, 1>), grid, dim3(512), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((p1t_kernel<2, 4, 1, 2>), grid, dim3(512), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((p1t_kernel<4, 2, 2, 1>), grid, dim3(512), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((p1t_kernel<2, 4, 2, 1>), grid, dim3(512), 0, st, a); break;
+    case 9: hipLaunchKernelGGL((p1t_kernel<2, 4, 2, 2>), grid, dim3(512), 0, st, a); break;
+    default: hipLaunchKernelGGL((p1t_kernel<2, 4, 4, 2>), grid, dim3(512), 0, st, a); break;
+  }
+  hipLaunchKernelGGL(p1t_reduce_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, st, (const float*)workspace, g.blocks, g.Mtot, g.Ntot, Cout, Cin, dw);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}

@@ -812,6 +812,8 @@ def object_attention_core(cx, q, key, val, K, key_channels):
     del sim
     ctx = torch.empty((B, H, W, Ck), dtype=torch.float32, device=q.device)
     ops.gemm(ops.NN, B, N, Ck, K, p, ld, N * ld, val, Ck, K * Ck, ctx, Ck, N * Ck)
+    if ops.amax_of(val) is not None:
+        ctx._amax = ops.amax_of(val)    # every row of ctx is a convex combination of val's rows (softmax weights): max|ctx| <= max|val|
     if cx.record:
         def bwd():
             dctx = cx.take(ctx)
@@ -896,10 +898,29 @@ class EngineNet(nn.Module):
             self._d3bank = bank
         return bank
 
+    def _p1_bank(self):
+        """weight images of the pointwise (1 x 1) layers for csrc/pconv1.hip (ops.P1Bank): every eligible layer, two launches per step"""
+        fp = self.flat()
+        bank = getattr(self, "_p1bank", None)
+        if bank is None or (bank is not False and bank.flat is not fp.flat):
+            ws = []
+            for m in self.modules():
+                if (isinstance(m, Conv2d) and not m.stem and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0)
+                        and m.groups == 1 and ops.lib.catseg_pconv1_supported(m.out_channels, m.in_channels)
+                        and ops.lib.catseg_pconv1_supported(m.in_channels, m.out_channels) and id(m.weight) in fp.offsets):
+                    ws.append((m.weight.data, fp.offsets[id(m.weight)]))
+            bank = ops.P1Bank(fp.flat, ws) if ws else False
+            self._p1bank = bank
+        return bank
+
     def _run(self, x, record):
         ops.release_b3_cache()          # (planes left over from a recorded forward that never saw its backward)
         if ops.DCONV3 and ops.PRECISION == "bf16x3" and self.training:
             bank = self._d3_bank()
+            if bank:
+                bank.refresh()
+        if ops.P1 and ops._trunk_h2() and self.training:
+            bank = self._p1_bank()
             if bank:
                 bank.refresh()
         cx = Ctx(self.training, record, None)

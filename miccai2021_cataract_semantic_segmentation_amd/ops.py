@@ -237,6 +237,8 @@ def release_b3_cache():
     _b3_cache_dy.update(key=None, x=None, planar=None, blk=None, h2=None, h2p=None)
     _b3_kept.clear()
     _d3_wimg.clear()
+    _p1_wimg.clear()
+    del _p1_keep[:]
 
 
 # Direct 3x3 / stride 1 / pad 1 convolution of the HRNet trunk widths in split precision (csrc/dconv3_b3.hip): the fp32 activation is
@@ -423,6 +425,79 @@ class Dconv3Bank:
             _d3_wimg[(w.data_ptr(), bool(dg), False)] = self.images[off:off + nbytes]
 
 
+# Pointwise (1 x 1, stride 1) convolutions in split precision with the split in registers (csrc/pconv1.hip): every dense 1 x 1 layer whose
+# input carries an amax record and that is too small for the blocked-plane kernels (ops._b3_wide_1x1) -- the stage-1 bottlenecks, the
+# object-attention block of the OCR head, the HRNet fuse layers.  CATSEG_P1=0: the fp32 MFMA kernels, as in round 4.
+P1 = _os.environ.get("CATSEG_P1", "1") != "0"
+P1_MIN_ROWS = 2048
+P1_OPS = tuple(v for v in _os.environ.get("CATSEG_P1_OPS", "fwd,dgrad,wgrad").split(",") if v)
+_p1_wimg = {}
+
+
+def _p1_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
+    return (P1 and _trunk_h2() and kh == 1 and kw == 1 and stride == 1 and pad == 0 and groups == 1 and rows >= P1_MIN_ROWS
+            and not _b3_wide_1x1(rows, Cout, 1, Cin))
+
+
+class P1Bank:
+    """the weight images of every pointwise layer of one network (forward image of (N = O, K = I) and the transposed image of backward-data),
+    written by ONE amax + ONE image launch per step over the flat parameter buffer (catseg_pconv1_prep_batch)"""
+
+    def __init__(self, flat, weights):
+        """weights: [(parameter tensor [O, I, 1, 1] (a view into flat), offset in floats)]"""
+        import numpy as np
+        self.flat = flat
+        rec = np.zeros(2 * len(weights), dtype=[("w", "<i8"), ("img", "<i8"), ("O", "<i4"), ("I", "<i4"), ("t", "<i4"), ("pad", "<i4")])
+        off = 0
+        self.slices = []
+        for i, (w, woff) in enumerate(weights):
+            O, I = w.shape[0], w.shape[1]
+            for t in (0, 1):
+                nbytes = lib.catseg_pconv1_wimg_bytes(I if t else O, O if t else I)
+                rec[2 * i + t] = (woff, off, O, I, t, 0)
+                self.slices.append((w, t, off, nbytes, 2 * i + t))
+                off += (nbytes + 255) // 256 * 256
+        self.entries = torch.from_numpy(rec.view(np.uint8).copy()).to(flat.device)
+        self.n = len(rec)
+        self.images = torch.empty(max(off, 256), dtype=torch.uint8, device=flat.device)
+        self.records = torch.zeros(2 * self.n, dtype=torch.int32, device=flat.device)
+
+    def refresh(self):
+        check(lib.catseg_pconv1_prep_batch(ptr(self.flat), self.n, ptr(self.entries), ptr(self.images), ptr(self.records), stream()))
+        for w, t, off, nbytes, k in self.slices:
+            _p1_wimg[(w.data_ptr(), bool(t))] = (self.images[off:off + nbytes], self.records[2 * k:2 * k + 2])
+
+
+def p1_weight_image(w, transposed=False):
+    """(image, record) of a pointwise layer's weights [O, I, 1, 1] (physical OHWI = [O][I]); layers outside a P1Bank get a one-layer bank"""
+    key = (w.data_ptr(), bool(transposed))
+    img = _p1_wimg.get(key)
+    if img is None:
+        bank = P1Bank(w, [(w, 0)])
+        bank.refresh()
+        _p1_keep.append(bank)
+        img = _p1_wimg[key]
+    return img
+
+
+_p1_keep = []
+
+
+def pconv1(x, wimg, bias, N, out, accumulate=False, bn_stats=False):
+    """out[rows][N] (+)= x[rows][K] . B^T (+ bias) through csrc/pconv1.hip; x carries an amax record; wimg = p1_weight_image(...)"""
+    rows, K = rows_of(x), x.shape[-1]
+    part = tr = nt = None
+    if bn_stats:
+        part = _bn_part_buffer(3 * ((rows + 255) // 256) * N, x.device)
+        tr, nt = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib.catseg_pconv1(rows, N, K, ptr(x), ld_of(x), ptr(amax_of(x)), ptr(wimg[0]), ptr(wimg[1]), ptr(bias), ptr(out), ld_of(out),
+                            1 if accumulate else 0, ptr(part), part.numel() if part is not None else 0,
+                            ctypes.byref(tr) if bn_stats else None, ctypes.byref(nt) if bn_stats else None, stream()))
+    if bn_stats:
+        return out, ((part, nt.value, tr.value) if tr.value > 0 else None)
+    return out
+
+
 def dconv3(x, wimg, bias=None, out=None, accumulate=False, bn_stats=False, x_amax=None):
     """y (+)= conv3x3(x) from a weight image; bn_stats: also returns (partials, n_tiles, 0, counts) for bn_finalize.
     x_amax: the input's amax record -> the two-plane fp16 kernel; wimg is then (image, record) of dconv3_weight_image(..., h2=True)"""
@@ -564,6 +639,13 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
             res = dconv3(x, wimg, bias, out=out, bn_stats=bn_stats, x_amax=rec)
         return res
     _refuse_placeholder(x, "a convolution forward outside the planes route")
+    if (not exact and not stem4 and zero_to == 0 and w_ptr_tensor.dim() == 4 and "fwd" in P1_OPS and amax_of(x) is not None
+            and _p1_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups) and lib.catseg_pconv1_supported(Cout, Cin)
+            and rows * ld_of(x) * 4 < B3_PLANE_LIMIT):
+        with _Timed("fwd_p1", flops):
+            res = pconv1(x, p1_weight_image(w_ptr_tensor), bias, Cout, out, bn_stats=bn_stats)
+        drop_amax(out)
+        return res
     if not exact and "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(rows, Cout, kh * kw, Cin):
         d = make_desc(x.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
         blk = _b3_blocked_ok(max(zero_to, Cout), Cin, B * H * W, Cout, kh * kw)
@@ -658,6 +740,11 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
         with _Timed(kind, flops):
             dconv3(dy, wimg, None, out=out, accumulate=accumulate, x_amax=rec)
         return out
+    if (w.dim() == 4 and "dgrad" in P1_OPS and amax_of(dy) is not None and _p1_ok(B * H * W, Cout, Cin, kh, kw, stride, pad, dil, groups)
+            and lib.catseg_pconv1_supported(Cin, Cout) and rows_of(dy) * ld_of(dy) * 4 < B3_PLANE_LIMIT):
+        with _Timed("dgrad_p1", flops):
+            pconv1(dy, p1_weight_image(w, transposed=True), None, Cin, out, accumulate=accumulate)
+        return out
     if groups == 1 and "dgrad" in B3_OPS and _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1):
         d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         blk = _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16, rows_of(dy), Cin, kh * kw)
@@ -730,6 +817,17 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
     if (not stem4 and x.dim() == 4 and _d3_ok(rows_of(dy), Cin, Cout, kh, kw, stride, pad, dil, groups)
             and lib.catseg_dwgrad3_supported(Cin)):
         dwgrad3(x, dy, dw, dbias, flops)
+        return dw
+    if (not stem4 and x.dim() == 4 and dw.dim() == 4 and "wgrad" in P1_OPS and amax_of(x) is not None and amax_of(dy) is not None
+            and _p1_ok(rows_of(dy), Cin, Cout, kh, kw, stride, pad, dil, groups) and lib.catseg_pconv1_wgrad_supported(Cout, Cin)
+            and rows_of(x) * ld_of(x) * 4 < B3_PLANE_LIMIT and rows_of(dy) * ld_of(dy) * 4 < B3_PLANE_LIMIT):
+        need = lib.catseg_pconv1_wgrad_workspace(rows_of(dy), Cout, Cin)
+        ws = workspace(need + 256 * Cout * 4, x.device)
+        with _Timed("wgrad_p1", flops):
+            check(lib.catseg_pconv1_wgrad(rows_of(dy), Cout, Cin, ptr(dy), ld_of(dy), ptr(amax_of(dy)), ptr(x), ld_of(x), ptr(amax_of(x)), ptr(dw),
+                                          ptr(ws), need, stream()))
+        if dbias is not None:
+            check(lib.catseg_bias_grad(ptr(dy), ld_of(dy), rows_of(dy), Cout, ptr(dbias), ptr(ws), ws.numel(), stream()))
         return dw
     if _wgrad_split_route(x, dy, kh, kw, stride, stem4, groups):
         d = make_desc(x.shape, Cin, Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
