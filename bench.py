@@ -533,7 +533,7 @@ def main():
         PEAK_F32, PEAK_B3, PEAK_H2 = 157.3, 2500.0 / 6.0, 2500.0 / 3.0
 
         def peak_of(kind):
-            if kind.endswith(("_h2", "_d3h", "_d3p")) or kind in ("h2w", "d3h", "wgrad_d3h", "d3p"):
+            if kind.endswith(("_h2", "_d3h", "_d3p", "_p1", "_s2p")) or kind in ("h2w", "d3h", "wgrad_d3h", "d3p", "p1", "s2p"):
                 return PEAK_H2
             return PEAK_B3 if kind.endswith(("_b3", "_d3")) or kind in ("b3w", "d3") else PEAK_F32
         mm = {k: v for k, v in agg.items() if not k.startswith("hbm:") and k != "split3" and v[1] > 0}
@@ -577,6 +577,9 @@ def main():
                            for k in groups if k in kern and kern[k].get("hbm_bytes_per_step") and groups[k][2] >= 2}
         LABELS = {"f32": "igemm_f32_kernel / igemm_f32_multi_kernel (every layer outside the split-precision routes: NT forward, NN backward-data, "
                          "TN backward-weight + wgrad_direct_kernel incl. slab reduction; exact fp32 MFMA chains)",
+                 "p1": "p1_kernel (pointwise 1x1 conv2d forward and backward-data: fp32 rows split into two fp16 planes in registers straight from "
+                       "global memory, weight image through LDS, three MFMA products; csrc/pconv1.hip)",
+                 "wgrad_p1": "p1t_kernel (pointwise 1x1 conv2d backward-weight, in-register split, transposed LDS reads, incl. slab reduction)",
                  "b3w": "igemm_b3w_kernel (conv2d forward and backward-data of the large layers, bf16x3 split precision)",
                  "h2w": "igemm_h2w_kernel (conv2d forward and backward-data of the large layers, f16x2 split precision: two fp16 planes "
                         "per operand, three MFMA products)",
@@ -624,9 +627,10 @@ def main():
         lb_ms = (sum(v[0] / (peak_of(k) * 1e12) for k, v in mm.items())
                  + sum(v[0] for k, v in agg.items() if k.startswith("hbm:")) / 8e12) / 2 * 1e3
         roof["whole_step"] = {"lower_bound_ms": lb_ms, "measured_ms": dt / args.steps * 1e3, "frac": lb_ms / (dt / args.steps * 1e3),
-                              "f16x2_tflop_per_step": sum(v[0] for k, v in mm.items() if k.endswith(("_h2", "_d3h", "_d3p"))) / 2 / 1e12,
+                              "f16x2_tflop_per_step": sum(v[0] for k, v in mm.items() if k.endswith(("_h2", "_d3h", "_d3p", "_p1", "_s2p"))) / 2 / 1e12,
                               "bf16x3_tflop_per_step": sum(v[0] for k, v in mm.items() if k.endswith(("_b3", "_d3"))) / 2 / 1e12,
-                              "fp32_tflop_per_step": sum(v[0] for k, v in mm.items() if not k.endswith(("_b3", "_d3", "_h2", "_d3h", "_d3p"))) / 2 / 1e12}
+                              "fp32_tflop_per_step": sum(v[0] for k, v in mm.items()
+                                                         if not k.endswith(("_b3", "_d3", "_h2", "_d3h", "_d3p", "_p1", "_s2p"))) / 2 / 1e12}
     comm = None
     if world > 1:
         drop_graph()                             # (hands the reducer back to the model)

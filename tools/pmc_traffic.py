@@ -18,6 +18,12 @@ def group(name):
     m = re.search(r"igemm_f32_kernel<(\d)", name)
     if m:
         return LAY[m.group(1)]
+    if "p1t_kernel" in name or "p1t_reduce" in name:
+        return "wgrad_p1"       # pointwise backward-weight + its slab sum (round 5, csrc/pconv1.hip)
+    if "p1_kernel" in name:
+        return "p1"             # pointwise forward AND backward-data
+    if "p1_prep" in name or "p1_amax" in name:
+        return "d3_prep"
     if "dwgrad3_pl" in name:
         return "wgrad_d3p"      # backward-weight on producer-written planes + its slab reduction (round 4)
     if "dconv3_pl_kernel" in name:
