@@ -428,8 +428,16 @@ class Dconv3Bank:
 # Pointwise (1 x 1, stride 1) convolutions in split precision with the split in registers (csrc/pconv1.hip): every dense 1 x 1 layer whose
 # input carries an amax record and that is too small for the blocked-plane kernels (ops._b3_wide_1x1) -- the stage-1 bottlenecks, the
 # object-attention block of the OCR head, the HRNet fuse layers.  CATSEG_P1=0: the fp32 MFMA kernels, as in round 4.
+# Measured (tools/time_p1.py, four tensors in turn, fp32 MFMA kernel -> this route, us per launch at the bench size): stage-1 64 -> 256 forward
+# 178 -> 138, backward-data 113 -> 85; 256 -> 64 129 -> 81 / 135 -> 119; f_pixel 512 -> 256 609 -> 264 / 597 -> 326; 256 -> 256 337 -> 191 / 308 -> 176;
+# f_up 256 -> 512 643 -> 354 / 555 -> 252 (2.3 - 4.1 TB/s of algorithmic bytes).  The fuse layers of the low-resolution branches (8 160 ... 65 280
+# pixels: 32 ... 255 blocks of 256 rows) are no faster or slower (0.55 - 1.2 x): P1_MIN_ROWS keeps them on the fp32 kernels.  Backward-weight
+# (p1t_kernel: LDS-bound, both operands pass through the transposing reads) pays for the 256 / 512-channel layers only (619 -> 492, 343 -> 276 us;
+# 64-channel layers 0.82 - 0.89 x): P1_WGRAD_MIN_DIM.  HRNet-W48 step (tools/ab_p1.sh, graph replay, two alternating rounds): 109.06 / 109.97 ms
+# without, 108.24 / 108.09 with all three operations on every layer, 107.72 / 107.65 with forward + backward-data only.
 P1 = _os.environ.get("CATSEG_P1", "1") != "0"
-P1_MIN_ROWS = 2048
+P1_MIN_ROWS = 100000
+P1_WGRAD_MIN_DIM = 256
 P1_OPS = tuple(v for v in _os.environ.get("CATSEG_P1_OPS", "fwd,dgrad,wgrad").split(",") if v)
 _p1_wimg = {}
 
@@ -819,6 +827,7 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
         dwgrad3(x, dy, dw, dbias, flops)
         return dw
     if (not stem4 and x.dim() == 4 and dw.dim() == 4 and "wgrad" in P1_OPS and amax_of(x) is not None and amax_of(dy) is not None
+            and min(Cout, Cin) >= P1_WGRAD_MIN_DIM
             and _p1_ok(rows_of(dy), Cin, Cout, kh, kw, stride, pad, dil, groups) and lib.catseg_pconv1_wgrad_supported(Cout, Cin)
             and rows_of(x) * ld_of(x) * 4 < B3_PLANE_LIMIT and rows_of(dy) * ld_of(dy) * 4 < B3_PLANE_LIMIT):
         need = lib.catseg_pconv1_wgrad_workspace(rows_of(dy), Cout, Cin)

@@ -119,6 +119,8 @@ def test_conv_wrappers_take_the_pointwise_route_and_match_the_fp32_kernels():
     w = (torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1).cuda().contiguous(memory_format=torch.channels_last)
     dy = (torch.randn(B, H, W, Cout, generator=g) * 1e-5).cuda()
     prof, ops.PROFILE = ops.PROFILE, []
+    saved = (ops.P1_MIN_ROWS, ops.P1_WGRAD_MIN_DIM)
+    ops.P1_MIN_ROWS, ops.P1_WGRAD_MIN_DIM = 1, 1
     try:
         y0 = ops.conv_fwd(x, w, None, Cout, 1, 1)
         dx0 = ops.conv_bwd_data(dy, w, tuple(x.shape), 1, 1)
@@ -132,6 +134,7 @@ def test_conv_wrappers_take_the_pointwise_route_and_match_the_fp32_kernels():
         kinds1 = [k[0] for k in ops.PROFILE]
     finally:
         ops.PROFILE = prof
+        ops.P1_MIN_ROWS, ops.P1_WGRAD_MIN_DIM = saved
         ops.release_b3_cache()
     torch.cuda.synchronize()
     assert kinds0 == ["fwd", "dgrad", "wgrad"] and kinds1 == ["fwd_p1", "dgrad_p1", "wgrad_p1"]
