@@ -192,3 +192,72 @@ def test_resnext101_upernet_fullres_inference_vs_oracle():
     # (b) with factor 4: the fused inference path folds BatchNorm into the weights (one more rounding of every weight) and runs the wide
     # layers on three bf16 planes; measured 3.5e-6 of the logit scale against the fp32 CPU oracle's 1.1e-6, label maps identical
     _logit_bar("resnext101_upernet_1x1088x1920_inference", "production", out_h, ref, f64, True, noise_factor=4.0)
+
+
+def test_config3_batch8_production_vs_exact_fp32_cross_plan():
+    """configuration 3 at its REAL batch (8 x 3 x 544 x 960, TwoScale-Lovasz, the bench model): the production arithmetic against an
+    INDEPENDENT one -- CATSEG_PRECISION=fp32, exact fp32 MFMA chains in every layer -- on the HIP path itself (no CPU oracle can be afforded
+    at this size: ~3 minutes and 30 GB per evaluation).  Both plans are held to 1e-3 absolute of fp64 at batch 2 by the tests above; at
+    batch 8 they must agree with each other to the sum of those bars, give the same loss, the same label maps up to ties, and gradients of
+    the same size and direction.  The production step is then replayed as a hipGraph and must reproduce its own bits."""
+    _need_gpu()
+    import bench
+    from oracle.state import fill_state, spec_of
+    from miccai2021_cataract_semantic_segmentation_amd import ops
+    from miccai2021_cataract_semantic_segmentation_amd.graph import GraphedTrainStep
+    from miccai2021_cataract_semantic_segmentation_amd.losses import TwoScaleLoss
+    from miccai2021_cataract_semantic_segmentation_amd.models import OCRNet
+    from miccai2021_cataract_semantic_segmentation_amd.optim import FusedAdam
+    cfg = dict(bench.MODELS["ocrnet_hrnet48"][0])
+    spec = spec_of(OCRNet(dict(cfg), 3).state_dict())
+    x, lbl = bench.synth_batch(8, 544, 960, 25, 77, torch.device("cuda"))
+    crit = TwoScaleLoss({"experiment": 3, "interm": {"name": "LovaszSoftmax", "args": [], "weight": 0.4},
+                         "final": {"name": "LovaszSoftmax", "args": [], "weight": 1.0}})
+    keys = ["backbone.conv1.weight", "backbone.layer1.0.conv1.weight", "backbone.stage2.0.branches.1.0.conv1.weight",
+            "backbone.stage3.1.fuse_layers.2.0.0.0.weight", "backbone.stage4.2.branches.3.3.conv2.weight", "conv_high_map.0.weight",
+            "interm_prediction_head.0.weight", "spatial_ocr_head.object_context_block.f_pixel.0.weight",
+            "spatial_ocr_head.object_context_block.f_up.0.weight", "spatial_ocr_head.conv_bn_dropout.0.weight", "conv_out.weight"]
+    res = {}
+    for plan in ("production", "fp32"):
+        with FR.set_plan(plan):
+            model = OCRNet(dict(cfg), 3)
+            model.load_state_dict(fill_state(spec, 41))
+            model.cuda().train()
+            interm, final = model(x)
+            loss = crit(interm, final, lbl)
+            loss.backward()
+            torch.cuda.synchronize()
+            named = dict(model.named_parameters())
+            res[plan] = (final.detach().float().clone(), float(loss.detach()), {k: named[k].grad.detach().clone() for k in keys if k in named})
+            if plan == "production":
+                # the same step through the graph: identical logits, loss and flat gradient, bit for bit
+                g_eager = model.flat().grad.clone()
+                opt = FusedAdam(model, lr=0.0)
+                step = GraphedTrainStep(model, lambda o, l: crit(*o, l), opt, x, lbl)
+                l_g = float(step(x, lbl))
+                torch.cuda.synchronize()
+                assert l_g == res[plan][1] and torch.equal(step.outputs[1].detach(), res[plan][0]) and torch.equal(model.flat().grad, g_eager)
+                step.release()
+            del model, interm, final, loss
+            torch.cuda.empty_cache()
+    (fp, lp, gp), (f3, l3, g3) = res["production"], res["fp32"]
+    d = float((fp - f3).abs().max())
+    scale = float(f3.abs().max())
+    lab = int((fp.argmax(1) != f3.argmax(1)).sum())
+    top2 = f3.topk(2, dim=1).values
+    outside = int(((fp.argmax(1) != f3.argmax(1)) & ((top2[:, 0] - top2[:, 1]) > 2.2 * d)).sum())
+    fig = {"max_abs_logit_difference": d, "logit_scale": scale, "loss_production": lp, "loss_exact_fp32": l3, "label_disagreements": lab,
+           "pixels": int(fp[:, 0].numel()), "label_disagreements_outside_the_error_band": outside}
+    rows = []
+    for k in gp:
+        a, b = gp[k].double().reshape(-1), g3[k].double().reshape(-1)
+        rows.append((k, float(a.norm() / (b.norm() + 1e-300)), float((a * b).sum() / (a.norm() * b.norm() + 1e-300))))
+    fig["gradients"] = {k: {"norm_ratio": r, "cosine": c} for k, r, c in rows}
+    FR.record("ocrnet_hrnet48_8x544x960", "production_vs_exact_fp32", fig)
+    print(fig)
+    assert len(rows) >= 8
+    assert d <= 2e-3, fig                                  # each plan within 1e-3 absolute of fp64 (asserted at batch 2 above)
+    assert abs(lp - l3) <= 1e-5 * max(1.0, abs(l3)), fig
+    assert outside == 0 and lab <= 4e-4 * fig["pixels"], fig
+    for k, r, c in rows:
+        assert abs(r - 1) < 2e-2 and c > 0.999, (k, r, c)
