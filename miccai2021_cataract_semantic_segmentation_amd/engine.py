@@ -156,6 +156,7 @@ class Ctx:
         self._region_depth = 0         # backward: parallel regions entered and not yet joined
         self._deferred = []            # backward: parameters whose 'gradient ready' signal waits for the join
         self._async = None             # backward: (side stream, [parameters whose gradient it writes]) of async_wgrad launches not yet joined
+        self._gstream = {}             # backward, inside a parallel region: id(activation) -> stream that last touched its gradient buffer
         self.bn_src = {}               # id(z) -> (y, stats, gamma, beta) of a conv_bn_act output z = relu(bn(y))
         self.bn_pre = {}               # backward: id(z) -> per-tile sums of the already masked gradient of z (conv_bn_act private_in)
 
@@ -189,6 +190,7 @@ class Ctx:
         class _Par:
             def __enter__(self_):
                 self_.on = PARALLEL_BRANCHES and n > 1 and device.type == "cuda"
+                self_.marks = {}
                 if not self_.on:
                     return self_
                 self_.main = torch.cuda.current_stream(device)
@@ -215,6 +217,21 @@ class Ctx:
 
             def branch(self_, i):
                 return _Branch(self_, i)
+
+            def mark(self_, key):
+                """(inside a branch) an event behind everything the current branch stream has enqueued: `key` names what is now complete"""
+                if self_.on:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(device))
+                    self_.marks[key] = (ev, torch.cuda.current_stream(device))
+
+            def wait(self_, key):
+                """(inside a branch) the current branch stream waits for mark(key) of a sibling branch"""
+                if self_.on and key in self_.marks:
+                    ev, st = self_.marks[key]
+                    cur = torch.cuda.current_stream(device)
+                    if st.cuda_stream != cur.cuda_stream:
+                        cur.wait_event(ev)
 
             def __exit__(self_, *exc):
                 if not self_.on:
@@ -252,7 +269,23 @@ class Ctx:
 
         return _Par()
 
+    def _order_grad(self, t):
+        """backward, inside a parallel region: the gradient buffer of activation t is about to be read / written on the current stream.
+        If another branch stream touched it last (a fuse chain that runs on its DESTINATION branch's stream accumulates into the gradient
+        of its source branch's output: HighResolutionModule.run), the current stream first waits for everything that stream has enqueued
+        so far -- accumulations from several streams into one buffer are thereby chained in tape order: deterministic, race free."""
+        if self._region_depth <= 0:
+            return
+        cur = torch.cuda.current_stream()
+        last = self._gstream.get(id(t))
+        if last is not None and last.cuda_stream != cur.cuda_stream:
+            ev = torch.cuda.Event()
+            ev.record(last)
+            cur.wait_event(ev)
+        self._gstream[id(t)] = cur
+
     def take(self, t):
+        self._order_grad(t)
         self.shared.discard(id(t))
         return self.grads.pop(id(t), None)
 
@@ -270,6 +303,7 @@ class Ctx:
 
     def give(self, t, g, shared=False):
         assert id(t) not in self.bn_pre, "conv_bn_act(private_in=True): the input has a second consumer"
+        self._order_grad(t)
         if id(t) not in self.grads:
             self.grads[id(t)] = g
             if shared:
@@ -280,6 +314,7 @@ class Ctx:
     def dest(self, t):
         """buffer the gradient of activation t must be written to: (buffer, accumulate?)"""
         assert id(t) not in self.bn_pre, "conv_bn_act(private_in=True): the input has a second consumer"
+        self._order_grad(t)
         if id(t) in self.grads:
             return self._own(t), True
         C = t.shape[-1]
@@ -362,6 +397,8 @@ class Ctx:
                     if MARKS is not None:       # (tools/stage_times.py: how long each branch stream of this region's backward ran)
                         MARKS.append(("region_bwd", region_t0, ends))
                     self._region_depth -= 1
+                    if self._region_depth == 0:
+                        self._gstream.clear()           # (every branch stream has joined the main stream)
                     if self._region_depth == 0 and self._deferred:
                         ready, self._deferred = self._deferred, []
                         for p in ready:         # (on the main stream, which now follows every branch of the region)

@@ -153,20 +153,35 @@ class HighResolutionModule(nn.Module):
         n_out = len(self.fuse_layers)
         terms = [[None] * self.num_branches for _ in range(n_out)]
         shapes = [tuple(x.shape) for x in xs]       # (branch outputs keep their input's spatial size)
+        # Round 5: the DOWN-sampling chains (j < i: one to three 3x3 / stride 2 convolutions) run on their DESTINATION branch's stream.  The
+        # branch of the highest resolution is the longest (its BatchNorm passes move twice the bytes of the next branch), and its stream also
+        # carried the six stride-2 convolutions that start from its output, one after the other; the streams of the low-resolution branches
+        # idle by then.  Stream i waits for branch j's blocks (par.wait) and runs f_ij; in the backward pass the chains' contributions to the
+        # gradient of x_j are chained in tape order by engine.Ctx._order_grad.  FUSE_DOWN_ON_DEST = False: the round-4 schedule.
         with cx.parallel(xs[0].device, self.num_branches) as par:
             for j in range(self.num_branches):
                 with par.branch(j):
                     xs[j] = _run_seq(cx, self.branches[j], xs[j])
+                    par.mark(j)
                     for i in range(n_out):
-                        if j == i:
+                        if j == i or (FUSE_DOWN_ON_DEST and j < i and par.on):
                             continue
                         t = _run_seq(cx, self.fuse_layers[i][j], xs[j])
                         terms[i][j] = bilinear(cx, t, shapes[i][1], shapes[i][2], False) if j > i else t
+            if FUSE_DOWN_ON_DEST and par.on:
+                for i in range(n_out):
+                    for j in range(min(i, self.num_branches)):
+                        with par.branch(i):
+                            par.wait(j)
+                            terms[i][j] = _run_seq(cx, self.fuse_layers[i][j], xs[j])
         outs = []
         for i in range(n_out):
             terms[i][i] = xs[i]
             outs.append(add_n(cx, terms[i], relu=True))
         return outs
+
+
+FUSE_DOWN_ON_DEST = __import__("os").environ.get("CATSEG_FUSE_DOWN_ON_DEST", "1") != "0"
 
 
 class HRNetBody(nn.Module):
