@@ -225,13 +225,17 @@ class Ctx:
                     ev.record(torch.cuda.current_stream(device))
                     self_.marks[key] = (ev, torch.cuda.current_stream(device))
 
-            def wait(self_, key):
-                """(inside a branch) the current branch stream waits for mark(key) of a sibling branch"""
+            def wait(self_, key, *tensors):
+                """(inside a branch) the current branch stream waits for mark(key) of a sibling branch; `tensors`: what it is going to read of
+                that sibling's (allocated on the sibling's stream: recorded for the caching allocator, forward and backward readers alike)"""
                 if self_.on and key in self_.marks:
                     ev, st = self_.marks[key]
                     cur = torch.cuda.current_stream(device)
                     if st.cuda_stream != cur.cuda_stream:
                         cur.wait_event(ev)
+                        for t in tensors:
+                            if t is not None and t.is_cuda:
+                                t.record_stream(cur)
 
             def __exit__(self_, *exc):
                 if not self_.on:
@@ -282,6 +286,12 @@ class Ctx:
             ev = torch.cuda.Event()
             ev.record(last)
             cur.wait_event(ev)
+            g = self.grads.get(id(t))
+            if g is not None:
+                # the buffer was allocated on another stream's pool: without this the caching allocator may hand it out again on that
+                # stream as soon as the last reference drops, while kernels of THIS stream still read or accumulate into it
+                g.record_stream(cur)
+                g.record_stream(last)
         self._gstream[id(t)] = cur
 
     def take(self, t):

@@ -172,7 +172,7 @@ class HighResolutionModule(nn.Module):
                 for i in range(n_out):
                     for j in range(min(i, self.num_branches)):
                         with par.branch(i):
-                            par.wait(j)
+                            par.wait(j, xs[j])
                             terms[i][j] = _run_seq(cx, self.fuse_layers[i][j], xs[j])
         outs = []
         for i in range(n_out):

@@ -216,7 +216,9 @@ def _split3_cached(x, want="planar", both=False, keep=False):
     the ASPP branches read one tensor); keep=True (a recorded training forward) holds on to the planes until release_b3_cache(),
     so that the layer's backward-weight pass reads what its forward produced instead of splitting x again (the planes of all
     bf16x3 layers of a step: 5.5 GB for OCRNet-HRNet-W48 at bs 8, of 288 GB)"""
-    key = (x.data_ptr(), x._version, tuple(x.shape), ld_of(x))
+    # (per stream: since round 5 a branch output may be read by fuse chains on SEVERAL branch streams -- each splits for itself; planes made
+    #  on one stream are never read on another without an ordering event)
+    key = (x.data_ptr(), x._version, tuple(x.shape), ld_of(x), torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0)
     ent = _b3_kept.get(key)
     if ent is not None and ent["x"] is x:
         return _cached(ent, x, key, want, both)
