@@ -102,6 +102,20 @@ STREAM_SKEW = int(__import__("os").environ.get("CATSEG_STREAM_SKEW", "0"))
 BRANCH_PRIORITY = int(__import__("os").environ.get("CATSEG_BRANCH_PRIORITY", "0"))   # A/B: -1 = the first branch's stream at high priority
 
 
+def cross_wait(cur, ev, main):
+    """stream `cur` waits for event `ev` of a SIBLING branch stream.  Outside a capture: directly.  While the step is being recorded into a
+    hipGraph (graph.GraphedTrainStep) the dependency is relayed through the region's origin stream -- origin waits for the event, records a
+    new one, `cur` waits for that: hipStreamEndCapture of ROCm 7.2 crashes (segmentation fault) on a capture in which one forked stream
+    waited directly on another forked stream's event; origin-waits-on-fork and fork-waits-on-origin are the patterns every join / fork uses."""
+    if main is not None and main.cuda_stream != cur.cuda_stream and torch.cuda.is_current_stream_capturing():
+        main.wait_event(ev)
+        ev2 = torch.cuda.Event()
+        ev2.record(main)
+        cur.wait_event(ev2)
+    else:
+        cur.wait_event(ev)
+
+
 def side_streams(device, n):
     """a small pool of HIP streams per device for the parallel-branch regions (HRNet's branches are independent)"""
     key = (device.type, device.index)
@@ -156,6 +170,7 @@ class Ctx:
         self._region_depth = 0         # backward: parallel regions entered and not yet joined
         self._deferred = []            # backward: parameters whose 'gradient ready' signal waits for the join
         self._async = None             # backward: (side stream, [parameters whose gradient it writes]) of async_wgrad launches not yet joined
+        self._main = None              # backward: the stream the tape is replayed from (the origin of its parallel regions)
         self._gstream = {}             # backward, inside a parallel region: id(activation) -> stream that last touched its gradient buffer
         self.bn_src = {}               # id(z) -> (y, stats, gamma, beta) of a conv_bn_act output z = relu(bn(y))
         self.bn_pre = {}               # backward: id(z) -> per-tile sums of the already masked gradient of z (conv_bn_act private_in)
@@ -195,13 +210,15 @@ class Ctx:
                     return self_
                 self_.main = torch.cuda.current_stream(device)
                 ns = max(1, min(n, BRANCH_STREAMS))
-                if LAST_BRANCH_ON_MAIN and ns >= 4 and cx.record:
+                if LAST_BRANCH_ON_MAIN and ns >= 4 and cx.record and not torch.cuda.is_current_stream_capturing():
                     # The runtime spreads streams over FOUR hardware queues: the main stream holds one, so of four side streams two share a
                     # queue and run one after the other (rocprofv3 kernel trace: streams 3 and 4 on queue 4; per-branch stream times of a
                     # stage-4 module 4.4 / 4.1 / 5.4 / 5.4 ms backward).  The main stream idles during a region: the last branch runs on it.
                     # Only for a RECORDED pass: its tape keeps every tensor a side stream reads alive until the backward has used it, so that
                     # main-stream allocations inside the region cannot be handed a block a side stream still reads (an inference pass frees
                     # a module's inputs as it goes: there the main stream launches nothing between fork and join, as before).
+                    # Not while a hipGraph is being recorded: a replay maps the branches onto queues by itself (measured: no difference),
+                    # and the origin stream is needed as the relay of cross-branch dependencies (cross_wait).
                     self_.streams = side_streams(device, ns - 1) + [self_.main]
                 else:
                     self_.streams = side_streams(device, ns)
@@ -232,7 +249,7 @@ class Ctx:
                     ev, st = self_.marks[key]
                     cur = torch.cuda.current_stream(device)
                     if st.cuda_stream != cur.cuda_stream:
-                        cur.wait_event(ev)
+                        cross_wait(cur, ev, self_.main)
                         for t in tensors:
                             if t is not None and t.is_cuda:
                                 t.record_stream(cur)
@@ -285,7 +302,7 @@ class Ctx:
         if last is not None and last.cuda_stream != cur.cuda_stream:
             ev = torch.cuda.Event()
             ev.record(last)
-            cur.wait_event(ev)
+            cross_wait(cur, ev, self._main)
             g = self.grads.get(id(t))
             if g is not None:
                 # the buffer was allocated on another stream's pool: without this the caching allocator may hand it out again on that
@@ -390,6 +407,7 @@ class Ctx:
                 region = tag
                 if main is None:
                     main = torch.cuda.current_stream(region.streams[0].device)
+                    self._main = main
                 if fn == "region_end":          # (reverse order) entering the region: the side streams wait for the main stream
                     ev = torch.cuda.Event(enable_timing=MARKS is not None)
                     ev.record(main)
