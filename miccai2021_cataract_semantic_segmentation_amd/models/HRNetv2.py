@@ -153,27 +153,28 @@ class HighResolutionModule(nn.Module):
         n_out = len(self.fuse_layers)
         terms = [[None] * self.num_branches for _ in range(n_out)]
         shapes = [tuple(x.shape) for x in xs]       # (branch outputs keep their input's spatial size)
-        # Round 5: the DOWN-sampling chains (j < i: one to three 3x3 / stride 2 convolutions) run on their DESTINATION branch's stream.  The
-        # branch of the highest resolution is the longest (its BatchNorm passes move twice the bytes of the next branch), and its stream also
-        # carried the six stride-2 convolutions that start from its output, one after the other; the streams of the low-resolution branches
-        # idle by then.  Stream i waits for branch j's blocks (par.wait) and runs f_ij; in the backward pass the chains' contributions to the
-        # gradient of x_j are chained in tape order by engine.Ctx._order_grad.  FUSE_DOWN_ON_DEST = False: the round-4 schedule.
+        # Round 5: the down-sampling chains that start from branch 0 (f_i0: one to three 3x3 / stride 2 convolutions) run on their
+        # DESTINATION branch's stream.  The branch of the highest resolution is the longest (its BatchNorm passes move twice the bytes of the
+        # next branch), and its stream also carried the six stride-2 convolutions that start from its output, one after the other, while
+        # the streams of the low-resolution branches idled.  Stream i waits for branch 0's blocks (par.wait) and runs f_i0; in the backward
+        # pass the chains' contributions to the gradient of x_0 are chained in tape order by engine.Ctx._order_grad.  (All down-sampling
+        # chains on their destination streams was measured too: 122.9 against 110.5 ms -- the chains from x_1 / x_2 then wait for branch 0 as
+        # well instead of running beside it.)  FUSE_DOWN_ON_DEST = False: the round-4 schedule.
         with cx.parallel(xs[0].device, self.num_branches) as par:
             for j in range(self.num_branches):
                 with par.branch(j):
                     xs[j] = _run_seq(cx, self.branches[j], xs[j])
                     par.mark(j)
                     for i in range(n_out):
-                        if j == i or (FUSE_DOWN_ON_DEST and j < i and par.on):
+                        if j == i or (FUSE_DOWN_ON_DEST and j == 0 and j < i and par.on):
                             continue
                         t = _run_seq(cx, self.fuse_layers[i][j], xs[j])
                         terms[i][j] = bilinear(cx, t, shapes[i][1], shapes[i][2], False) if j > i else t
             if FUSE_DOWN_ON_DEST and par.on:
-                for i in range(n_out):
-                    for j in range(min(i, self.num_branches)):
-                        with par.branch(i):
-                            par.wait(j, xs[j])
-                            terms[i][j] = _run_seq(cx, self.fuse_layers[i][j], xs[j])
+                for i in range(1, n_out):
+                    with par.branch(i):
+                        par.wait(0, xs[0])
+                        terms[i][0] = _run_seq(cx, self.fuse_layers[i][0], xs[0])
         outs = []
         for i in range(n_out):
             terms[i][i] = xs[i]
