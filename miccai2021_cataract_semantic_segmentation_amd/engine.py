@@ -102,20 +102,6 @@ STREAM_SKEW = int(__import__("os").environ.get("CATSEG_STREAM_SKEW", "0"))
 BRANCH_PRIORITY = int(__import__("os").environ.get("CATSEG_BRANCH_PRIORITY", "0"))   # A/B: -1 = the first branch's stream at high priority
 
 
-def cross_wait(cur, ev, main):
-    """stream `cur` waits for event `ev` of a SIBLING branch stream.  Outside a capture: directly.  While the step is being recorded into a
-    hipGraph (graph.GraphedTrainStep) the dependency is relayed through the region's origin stream -- origin waits for the event, records a
-    new one, `cur` waits for that: hipStreamEndCapture of ROCm 7.2 crashes (segmentation fault) on a capture in which one forked stream
-    waited directly on another forked stream's event; origin-waits-on-fork and fork-waits-on-origin are the patterns every join / fork uses."""
-    if main is not None and main.cuda_stream != cur.cuda_stream and torch.cuda.is_current_stream_capturing():
-        main.wait_event(ev)
-        ev2 = torch.cuda.Event()
-        ev2.record(main)
-        cur.wait_event(ev2)
-    else:
-        cur.wait_event(ev)
-
-
 def side_streams(device, n):
     """a small pool of HIP streams per device for the parallel-branch regions (HRNet's branches are independent)"""
     key = (device.type, device.index)
@@ -170,8 +156,6 @@ class Ctx:
         self._region_depth = 0         # backward: parallel regions entered and not yet joined
         self._deferred = []            # backward: parameters whose 'gradient ready' signal waits for the join
         self._async = None             # backward: (side stream, [parameters whose gradient it writes]) of async_wgrad launches not yet joined
-        self._main = None              # backward: the stream the tape is replayed from (the origin of its parallel regions)
-        self._gstream = {}             # backward, inside a parallel region: id(activation) -> stream that last touched its gradient buffer
         self.bn_src = {}               # id(z) -> (y, stats, gamma, beta) of a conv_bn_act output z = relu(bn(y))
         self.bn_pre = {}               # backward: id(z) -> per-tile sums of the already masked gradient of z (conv_bn_act private_in)
 
@@ -205,20 +189,17 @@ class Ctx:
         class _Par:
             def __enter__(self_):
                 self_.on = PARALLEL_BRANCHES and n > 1 and device.type == "cuda"
-                self_.marks = {}
                 if not self_.on:
                     return self_
                 self_.main = torch.cuda.current_stream(device)
                 ns = max(1, min(n, BRANCH_STREAMS))
-                if LAST_BRANCH_ON_MAIN and ns >= 4 and cx.record and not torch.cuda.is_current_stream_capturing():
+                if LAST_BRANCH_ON_MAIN and ns >= 4 and cx.record:
                     # The runtime spreads streams over FOUR hardware queues: the main stream holds one, so of four side streams two share a
                     # queue and run one after the other (rocprofv3 kernel trace: streams 3 and 4 on queue 4; per-branch stream times of a
                     # stage-4 module 4.4 / 4.1 / 5.4 / 5.4 ms backward).  The main stream idles during a region: the last branch runs on it.
                     # Only for a RECORDED pass: its tape keeps every tensor a side stream reads alive until the backward has used it, so that
                     # main-stream allocations inside the region cannot be handed a block a side stream still reads (an inference pass frees
                     # a module's inputs as it goes: there the main stream launches nothing between fork and join, as before).
-                    # Not while a hipGraph is being recorded: a replay maps the branches onto queues by itself (measured: no difference),
-                    # and the origin stream is needed as the relay of cross-branch dependencies (cross_wait).
                     self_.streams = side_streams(device, ns - 1) + [self_.main]
                 else:
                     self_.streams = side_streams(device, ns)
@@ -234,25 +215,6 @@ class Ctx:
 
             def branch(self_, i):
                 return _Branch(self_, i)
-
-            def mark(self_, key):
-                """(inside a branch) an event behind everything the current branch stream has enqueued: `key` names what is now complete"""
-                if self_.on:
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream(device))
-                    self_.marks[key] = (ev, torch.cuda.current_stream(device))
-
-            def wait(self_, key, *tensors):
-                """(inside a branch) the current branch stream waits for mark(key) of a sibling branch; `tensors`: what it is going to read of
-                that sibling's (allocated on the sibling's stream: recorded for the caching allocator, forward and backward readers alike)"""
-                if self_.on and key in self_.marks:
-                    ev, st = self_.marks[key]
-                    cur = torch.cuda.current_stream(device)
-                    if st.cuda_stream != cur.cuda_stream:
-                        cross_wait(cur, ev, self_.main)
-                        for t in tensors:
-                            if t is not None and t.is_cuda:
-                                t.record_stream(cur)
 
             def __exit__(self_, *exc):
                 if not self_.on:
@@ -290,29 +252,7 @@ class Ctx:
 
         return _Par()
 
-    def _order_grad(self, t):
-        """backward, inside a parallel region: the gradient buffer of activation t is about to be read / written on the current stream.
-        If another branch stream touched it last (a fuse chain that runs on its DESTINATION branch's stream accumulates into the gradient
-        of its source branch's output: HighResolutionModule.run), the current stream first waits for everything that stream has enqueued
-        so far -- accumulations from several streams into one buffer are thereby chained in tape order: deterministic, race free."""
-        if self._region_depth <= 0:
-            return
-        cur = torch.cuda.current_stream()
-        last = self._gstream.get(id(t))
-        if last is not None and last.cuda_stream != cur.cuda_stream:
-            ev = torch.cuda.Event()
-            ev.record(last)
-            cross_wait(cur, ev, self._main)
-            g = self.grads.get(id(t))
-            if g is not None:
-                # the buffer was allocated on another stream's pool: without this the caching allocator may hand it out again on that
-                # stream as soon as the last reference drops, while kernels of THIS stream still read or accumulate into it
-                g.record_stream(cur)
-                g.record_stream(last)
-        self._gstream[id(t)] = cur
-
     def take(self, t):
-        self._order_grad(t)
         self.shared.discard(id(t))
         return self.grads.pop(id(t), None)
 
@@ -330,7 +270,6 @@ class Ctx:
 
     def give(self, t, g, shared=False):
         assert id(t) not in self.bn_pre, "conv_bn_act(private_in=True): the input has a second consumer"
-        self._order_grad(t)
         if id(t) not in self.grads:
             self.grads[id(t)] = g
             if shared:
@@ -341,7 +280,6 @@ class Ctx:
     def dest(self, t):
         """buffer the gradient of activation t must be written to: (buffer, accumulate?)"""
         assert id(t) not in self.bn_pre, "conv_bn_act(private_in=True): the input has a second consumer"
-        self._order_grad(t)
         if id(t) in self.grads:
             return self._own(t), True
         C = t.shape[-1]
@@ -407,7 +345,6 @@ class Ctx:
                 region = tag
                 if main is None:
                     main = torch.cuda.current_stream(region.streams[0].device)
-                    self._main = main
                 if fn == "region_end":          # (reverse order) entering the region: the side streams wait for the main stream
                     ev = torch.cuda.Event(enable_timing=MARKS is not None)
                     ev.record(main)
@@ -425,8 +362,6 @@ class Ctx:
                     if MARKS is not None:       # (tools/stage_times.py: how long each branch stream of this region's backward ran)
                         MARKS.append(("region_bwd", region_t0, ends))
                     self._region_depth -= 1
-                    if self._region_depth == 0:
-                        self._gstream.clear()           # (every branch stream has joined the main stream)
                     if self._region_depth == 0 and self._deferred:
                         ready, self._deferred = self._deferred, []
                         for p in ready:         # (on the main stream, which now follows every branch of the region)

@@ -149,40 +149,28 @@ class HighResolutionModule(nn.Module):
         # THAT BRANCH'S STREAM, right behind the branch: chain f_ij needs nothing but x_j, so the region joins only once per module
         # (a join + fork between branches and fuse chains cost one cross-stream hand-over more: 252 -> ~130 idle gaps of ~24 us per
         # step); the gradient of x_j is accumulated by one stream, in a fixed order.  The sums follow on the main stream.
+        # (Round 5 measured the alternative placement -- the down-sampling chains f_i0 that start from branch 0 on their DESTINATION branch's
+        # stream, with the cross-stream ordering that needs: 118.5 - 120.6 against 111.9 - 112.3 ms eager, 121.7 against 113.5 ms as a graph
+        # replay.  The regions are throughput-bound, not bound by branch 0's chain: a kernel trace suggests otherwise -- 75 % of a traced step
+        # shows one kernel in flight -- because the tracer serialises dispatches; timings of the untraced step decide.)
         xs = list(xs)
         n_out = len(self.fuse_layers)
         terms = [[None] * self.num_branches for _ in range(n_out)]
         shapes = [tuple(x.shape) for x in xs]       # (branch outputs keep their input's spatial size)
-        # Round 5: the down-sampling chains that start from branch 0 (f_i0: one to three 3x3 / stride 2 convolutions) run on their
-        # DESTINATION branch's stream.  The branch of the highest resolution is the longest (its BatchNorm passes move twice the bytes of the
-        # next branch), and its stream also carried the six stride-2 convolutions that start from its output, one after the other, while
-        # the streams of the low-resolution branches idled.  Stream i waits for branch 0's blocks (par.wait) and runs f_i0; in the backward
-        # pass the chains' contributions to the gradient of x_0 are chained in tape order by engine.Ctx._order_grad.  (All down-sampling
-        # chains on their destination streams was measured too: 122.9 against 110.5 ms -- the chains from x_1 / x_2 then wait for branch 0 as
-        # well instead of running beside it.)  FUSE_DOWN_ON_DEST = False: the round-4 schedule.
         with cx.parallel(xs[0].device, self.num_branches) as par:
             for j in range(self.num_branches):
                 with par.branch(j):
                     xs[j] = _run_seq(cx, self.branches[j], xs[j])
-                    par.mark(j)
                     for i in range(n_out):
-                        if j == i or (FUSE_DOWN_ON_DEST and j == 0 and j < i and par.on):
+                        if j == i:
                             continue
                         t = _run_seq(cx, self.fuse_layers[i][j], xs[j])
                         terms[i][j] = bilinear(cx, t, shapes[i][1], shapes[i][2], False) if j > i else t
-            if FUSE_DOWN_ON_DEST and par.on:
-                for i in range(1, n_out):
-                    with par.branch(i):
-                        par.wait(0, xs[0])
-                        terms[i][0] = _run_seq(cx, self.fuse_layers[i][0], xs[0])
         outs = []
         for i in range(n_out):
             terms[i][i] = xs[i]
             outs.append(add_n(cx, terms[i], relu=True))
         return outs
-
-
-FUSE_DOWN_ON_DEST = __import__("os").environ.get("CATSEG_FUSE_DOWN_ON_DEST", "1") != "0"
 
 
 class HRNetBody(nn.Module):
