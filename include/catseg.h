@@ -481,8 +481,9 @@ int catseg_adam_step_dev(float* p, const float* g, float* m, float* v, long long
    object-attention block (models/OCR.py:186-235: f_pixel / f_up) and of the HRNet fuse layers (models/HRNetv2.py:237-261) -- layers too
    small for the blocked-plane kernels above, HBM-bound GEMMs with K = 64 ... 512.  The activation operand is the fp32 NHWC tensor itself
    plus the amax record its producer left (CATSEG_AMAX_RECORD_BYTES); the weight operand is a pre-split image.
-   catseg_pconv1_prep_batch: entries = DEVICE array of n records {int64 weight offset (floats, relative to flat), int64 image offset (bytes,
-   relative to wimg_base), int32 O, int32 I, int32 transposed, int32 pad}; records = n x {uint32 bits of max|w|, int32 exponent} (DEVICE).
+   catseg_pconv1_prep_batch: entries = DEVICE array of n 64-byte records {int64 weight offset (floats, relative to flat), int64 image offset
+   (bytes, relative to wimg_base), int32 O, I, kh, kw, transposed, ky0, kys, nky, kx0, kxs, nkx, pad} (a 1 x 1 layer: kh = kw = nky = nkx =
+   kys = kxs = 1, ky0 = kx0 = 0); records = n x {uint32 bits of max|w|, int32 exponent} (DEVICE).
    catseg_pconv1: y[M][N] (+)= x[M][K] . B^T (+ bias); B = image of (N, K) = the layer's [O][I] weights (forward: N = O, K = I) or, with
    transposed != 0 at preparation, their transpose (backward-data: N = I, K = O).  bn_part as catseg_conv2d_fwd_bnstats.
    catseg_pconv1_wgrad: dw[Cout][Cin] = dy^T . x over P pixels (slabs + fixed-order sum: deterministic). */
@@ -496,6 +497,24 @@ int catseg_pconv1_wgrad_supported(int Cout, int Cin);
 size_t catseg_pconv1_wgrad_workspace(long long P, int Cout, int Cin);
 int catseg_pconv1_wgrad(long long P, int Cout, int Cin, const float* dy, int lddy, const void* dy_rec, const float* x, int ldx,
                         const void* x_rec, float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
+/* The same kernels as "gather" launches for dense convolutions with kh x kw taps, stride 1 / 2, padding, dilation (stride 1) whose input
+   carries an amax record: the 3 x 3 / stride 2 layers of the HRNet fuse chains and transitions (models/HRNetv2.py:176-198,237-261: ATen
+   conv2d + its autograd backward), the 256 -> 48 transition, the stem's second convolution.  Weight images through
+   catseg_pconv1_prep_batch with the 64-byte entries catseg_gconv_entries fills (host memory; 1 entry forward, stride^2 entries -- one
+   per input-pixel parity class, catseg_gconv_class_bytes apart -- backward-data).  Results as the fp32 kernels' to split-precision accuracy. */
+int catseg_gconv_supported(const catseg_conv_desc* d);
+size_t catseg_gconv_class_bytes(const catseg_conv_desc* d);
+size_t catseg_gconv_wimg_bytes(const catseg_conv_desc* d, int backward_data);
+int catseg_gconv_entries(const catseg_conv_desc* d, int backward_data, long long w_off, long long img_off, void* entries_out);
+int catseg_gconv_fwd(const catseg_conv_desc* d, const float* x, const void* x_rec, const void* wimg, const void* w_rec,
+                     const float* bias, float* y, float* bn_part, size_t bn_part_floats, int* tile_rows, int* n_tiles,
+                     catseg_stream_t stream);
+int catseg_gconv_bwd_data(const catseg_conv_desc* d, const float* dy, const void* dy_rec, const void* wimg_classes, const void* w_rec,
+                          float* dx, int accumulate, catseg_stream_t stream);
+int catseg_gconv_wgrad_supported(const catseg_conv_desc* d);
+size_t catseg_gconv_wgrad_workspace(const catseg_conv_desc* d);
+int catseg_gconv_bwd_weight(const catseg_conv_desc* d, const float* dy, const void* dy_rec, const float* x, const void* x_rec,
+                            float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
 
 #ifdef __cplusplus
 }

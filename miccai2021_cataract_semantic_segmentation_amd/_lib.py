@@ -169,6 +169,15 @@ _SIGS = {
     "catseg_pconv1_wgrad_workspace": (SZ, [L, I, I]),
     "catseg_pconv1_wgrad": (I, [L, I, I, P, I, P, P, I, P, P, P, SZ, P]),
     "catseg_debug_set_pconv1_wgrad_blocks": (I, [I]),
+    "catseg_gconv_supported": (I, [P]),
+    "catseg_gconv_class_bytes": (SZ, [P]),
+    "catseg_gconv_wimg_bytes": (SZ, [P, I]),
+    "catseg_gconv_entries": (I, [P, I, L, L, P]),
+    "catseg_gconv_fwd": (I, [P, P, P, P, P, P, P, P, SZ, P, P, P]),
+    "catseg_gconv_bwd_data": (I, [P, P, P, P, P, P, I, P]),
+    "catseg_gconv_wgrad_supported": (I, [P]),
+    "catseg_gconv_wgrad_workspace": (SZ, [P]),
+    "catseg_gconv_bwd_weight": (I, [P, P, P, P, P, P, P, SZ, P]),
     "catseg_adam_hyper": (None, [F, F, F, I, F, P]),
     "catseg_adam_step_dev": (I, [P, P, P, P, L, P, F, F, F, P]),
 }

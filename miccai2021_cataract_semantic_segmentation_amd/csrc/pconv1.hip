@@ -37,12 +37,15 @@ __host__ __device__ constexpr int p1_groups(int K) { return ((K + 31) / 32 + 1) 
 
 // ---- weight image: [k-group][n tile][k-tile 0/1][plane h/l][BN][16 halves], the two 8-half chunks of a row swapped where (n >> 3) & 1
 // (conflict-free ds_read_b128 of the B fragments), zero beyond N / K.  transposed: B[n][k] = w[k][n] (backward-data: n = input channel)
-struct P1Entry { long long w_off, img_off; int O, I, transposed, pad; };
+// General form (round 5, the "gather" launches below): the weights are OHWI [O][kh][kw][I]; an image holds a SUB-GRID of the taps --
+// ky = ky0 + a kys (a < nky), kx = kx0 + b kxs (b < nkx) -- with k' = (a nkx + b) Ck + c: forward Ck = I, c = input channel, n = o;
+// transposed (backward-data) Ck = O, c = output channel, n = input channel.  1 x 1: kh = kw = nky = nkx = 1.
+struct P1Entry { long long w_off, img_off; int O, I, kh, kw, transposed, ky0, kys, nky, kx0, kxs, nkx, pad; };
 
 __global__ __launch_bounds__(256) void p1_amax_batch_kernel(const float* __restrict__ flat, const P1Entry* __restrict__ ent, unsigned* __restrict__ recs) {
   const P1Entry e = ent[blockIdx.y];
   const float* w = flat + e.w_off;
-  const long long n = (long long)e.O * e.I;
+  const long long n = (long long)e.O * e.I * e.kh * e.kw;
   unsigned m = 0;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     m = max(m, __float_as_uint(w[i]) & 0x7FFFFFFFu);
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void p1_prep_batch_kernel(const float* __restr
   const int ex = p1_exponent(recs[2 * blockIdx.y]);
   if (blockIdx.x == 0 && threadIdx.x == 0) ((int*)recs)[2 * blockIdx.y + 1] = ex;
   const float* w = flat + e.w_off;
-  const int N = e.transposed ? e.I : e.O, K = e.transposed ? e.O : e.I;
+  const int N = e.transposed ? e.I : e.O, Ck = e.transposed ? e.O : e.I, K = e.nky * e.nkx * Ck;
   const int BN = p1_bn(N), ntn = p1_ntn(N), G = p1_groups(K);
   half8* img = (half8*)(img_base + e.img_off);
   const long long pieces = (long long)G * ntn * 2 * BN * 2;          // (g, nt, kt, nn, chunk): one thread writes the h and the l piece
@@ -72,7 +75,13 @@ __global__ __launch_bounds__(256) void p1_prep_batch_kernel(const float* __restr
     for (int j = 0; j < 8; ++j) {
       const int k = k0 + j;
       float v = 0.f;
-      if (n < N && k < K) v = e.transposed ? w[(long long)k * e.I + n] : w[(long long)n * e.I + k];
+      if (n < N && k < K) {
+        const int t = k / Ck, c = k - t * Ck;
+        const int ta = t / e.nkx, tb = t - ta * e.nkx;
+        const int ky = e.ky0 + ta * e.kys, kx = e.kx0 + tb * e.kxs;
+        const int o = e.transposed ? c : n, ci = e.transposed ? n : c;
+        v = w[(((long long)o * e.kh + ky) * e.kw + kx) * e.I + ci];
+      }
       const float xs = __builtin_ldexpf(v, ex);
       const _Float16 hh = (_Float16)xs;
       h[j] = hh;
@@ -84,6 +93,17 @@ __global__ __launch_bounds__(256) void p1_prep_batch_kernel(const float* __restr
     img[(row0 + BN + nn) * 2 + pc] = l;
   }
 }
+
+// how a GEMM row and a k' index of a gather launch map to an element of the A tensor, and a row to an output pixel
+struct P1Geo {
+  int Wg, HWg;              // row grid: row -> (image, i, j) = (row / HWg, (row % HWg) / Wg, row % Wg)
+  int si, y0, x0;           // A pixel of tap (0, 0) at grid point (i, j): (i si + y0, j si + x0)
+  int ya, xa, nb;           // tap t = (a, b) = (t / nb, t % nb): A pixel += (a ya, b xa)
+  int Hi, Wi, C;            // A: images of Hi x Wi pixels with C channels (k' = t C + c)
+  unsigned mC, mnb;         // ceil(2^32 / C), ceil(2^32 / nb) (nb > 1)
+  int so, oy, ox, Ho, Wo;   // output pixel of grid point (i, j): (i so + oy, j so + ox) of an Ho x Wo image
+  int linear_out;           // the row grid IS the output image: output row = GEMM row
+};
 
 struct P1Args {
   const float* x; int ldx;            // A: [M][ldx] fp32, columns [0, K)
@@ -97,11 +117,12 @@ struct P1Args {
   int accumulate;
   float* bn_part;                     // [tilesM][3][N] or null
   unsigned long long x_bytes, img_bytes;
+  P1Geo geo;                          // (GEO launches)
 };
 
 constexpr int p1_waitcnt(int vm) { return (vm & 15) | (7 << 4) | (15 << 8) | ((vm >> 4) << 14); }     // vmcnt only (expcnt / lgkmcnt: no wait)
 
-template <int NT>
+template <int NT, bool GEO>
 __global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
   constexpr int BN = 32 * NT;
   constexpr int GB = 4 * BN * 32;                   // bytes of one k-group of B: k-tile (2) x plane (2) x BN rows x 32 bytes
@@ -142,11 +163,31 @@ __global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.wimg, (short)0, (int)(unsigned)p.img_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
   const int row = m0 + wave * 32 + l31;
-  const unsigned a_row = (unsigned)row * (unsigned)p.ldx * 4u + (unsigned)hh * 32u;
   const unsigned klim = row < p.M ? (unsigned)p.K : 0u;          // rows past M: every k is "past K" (branch-free: the loads are issued
-  auto a_off = [&](int g, int kt, int c) -> unsigned {           //  unconditionally, the vmcnt bookkeeping below counts on it)
-    const unsigned k = (unsigned)(32 * g + 16 * kt + 8 * hh + 4 * c);
-    const unsigned m = (unsigned)-(int)(k < klim);
+  unsigned a_row = 0;                                            //  unconditionally, the vmcnt bookkeeping below counts on it)
+  int ybase = 0, xbase = 0;
+  if (GEO) {
+    const int rr = row < p.M ? row : 0;
+    const int gb = rr / p.geo.HWg, rem = rr - gb * p.geo.HWg;
+    const int gi = rem / p.geo.Wg, gj = rem - gi * p.geo.Wg;
+    ybase = gi * p.geo.si + p.geo.y0;
+    xbase = gj * p.geo.si + p.geo.x0;
+    a_row = (unsigned)(gb * p.geo.Hi * p.geo.Wi);                // (pixel index of the image's origin)
+  } else {
+    a_row = (unsigned)row * (unsigned)p.ldx * 4u + (unsigned)hh * 32u;
+  }
+  auto a_off = [&](int g, int kt, int c) -> unsigned {
+    const unsigned k8 = (unsigned)(32 * g + 16 * kt + 8 * hh);
+    if (GEO) {
+      const unsigned tap = __umulhi(k8, p.geo.mC), cc = k8 - tap * (unsigned)p.geo.C;
+      const unsigned ta = p.geo.nb == 1 ? tap : __umulhi(tap, p.geo.mnb), tb = tap - ta * (unsigned)p.geo.nb;
+      const int yi = ybase + (int)ta * p.geo.ya, xi = xbase + (int)tb * p.geo.xa;
+      const bool ok = (int)(k8 + 4u * c < klim) & (int)((unsigned)yi < (unsigned)p.geo.Hi) & (int)((unsigned)xi < (unsigned)p.geo.Wi);
+      const unsigned m = (unsigned)-(int)ok;
+      const unsigned off = ((a_row + (unsigned)(yi * p.geo.Wi + xi)) * (unsigned)p.ldx + cc) * 4u + 16u * c;
+      return (off & m) | (OOB & ~m);
+    }
+    const unsigned m = (unsigned)-(int)(k8 + 4u * c < klim);
     return ((a_row + (unsigned)(32 * g + 16 * kt) * 4u + 16u * c) & m) | (OOB & ~m);
   };
   // B: k-group g of column tile tile_n is one contiguous run of GB bytes of the image
@@ -264,6 +305,19 @@ __global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
         [&](int j, int i) { return acc[j][i] + bv[j]; },
         [&](int i) { return rbase + (i & 3) + 8 * (i >> 2) < p.M; }, p.bn_part + (long long)tile_m * 3 * p.N, p.N, n0);
   }
+  long long orow[16];               // element offset of the output row of accumulator row r (GEO: the row's output pixel)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rw = rbase + (r & 3) + 8 * (r >> 2);
+    if (GEO && !p.geo.linear_out) {
+      const int rr = rw < p.M ? rw : 0;
+      const int gb = rr / p.geo.HWg, rem = rr - gb * p.geo.HWg;
+      const int gi = rem / p.geo.Wg, gj = rem - gi * p.geo.Wg;
+      orow[r] = ((long long)(gb * p.geo.Ho + gi * p.geo.so + p.geo.oy) * p.geo.Wo + gj * p.geo.so + p.geo.ox) * p.ldy;
+    } else {
+      orow[r] = (long long)rw * p.ldy;
+    }
+  }
 #pragma unroll
   for (int u = 0; u < NT; ++u) {
     const int col = n0 + 32 * u + l31;
@@ -271,21 +325,35 @@ __global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rw = rbase + (r & 3) + 8 * (r >> 2);
-      add[r] = (p.accumulate && rw < p.M && col < p.N) ? p.y[(long long)rw * p.ldy + col] : 0.f;
+      add[r] = (p.accumulate && rw < p.M && col < p.N) ? p.y[orow[r] + col] : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rw = rbase + (r & 3) + 8 * (r >> 2);
-      if (rw < p.M && col < p.N) p.y[(long long)rw * p.ldy + col] = (acc[u][r] + bv[u]) + add[r];
+      if (rw < p.M && col < p.N) p.y[orow[r] + col] = (acc[u][r] + bv[u]) + add[r];
     }
   }
 }
 
 template <int NT>
-void p1_launch(const P1Args& a, hipStream_t st) {
+void p1_launch(const P1Args& a, bool geo, hipStream_t st) {
   const int per = 8 * a.ntn;
   const int blocks = a.ntn > 1 ? (a.tilesM + 7) / 8 * per : a.tilesM;
-  hipLaunchKernelGGL(p1_kernel<NT>, dim3(blocks), dim3(512), 0, st, a);
+  if (geo) hipLaunchKernelGGL((p1_kernel<NT, true>), dim3(blocks), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((p1_kernel<NT, false>), dim3(blocks), dim3(512), 0, st, a);
+}
+
+void p1_dispatch(const P1Args& a, bool geo, hipStream_t st) {
+  switch (p1_bn(a.N) / 32) {
+    case 1: p1_launch<1>(a, geo, st); break;
+    case 2: p1_launch<2>(a, geo, st); break;
+    case 3: p1_launch<3>(a, geo, st); break;
+    case 4: p1_launch<4>(a, geo, st); break;
+    case 5: p1_launch<5>(a, geo, st); break;
+    case 6: p1_launch<6>(a, geo, st); break;
+    case 7: p1_launch<7>(a, geo, st); break;
+    default: p1_launch<8>(a, geo, st); break;
+  }
 }
 
 // ---- backward-weight: dW[o][c] = sum_p dy[p][o] x[p][c] ------------------------------------------------------------------------------
@@ -305,12 +373,14 @@ struct P1TArgs {
   int nbn, Mtot, Ntot;                // blockIdx.y = bm * nbn + bn
   int steps_per_block;                // 32-pixel steps per block
   unsigned long long dy_bytes, x_bytes;
+  // gather form (kh x kw taps, stride, pad, dil): N = taps * Cin virtual columns (tap, c); pixel p = (image, yo, xo) of the Ho x Wo output
+  int geo, Cin, kw, stride, pad, dil, Hi, Wi, Ho, Wo;
 };
 
 typedef short p1_s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) p1_s16x4 p1_lds_s16x4;
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool GEO>
 __global__ __launch_bounds__(512) void p1t_kernel(const P1TArgs p) {
   static_assert(WM * WN == 8, "eight waves");
   constexpr int MP = 32 * TM * WM, NP = 32 * TN * WN;
@@ -342,6 +412,29 @@ __global__ __launch_bounds__(512) void p1t_kernel(const P1TArgs p) {
   constexpr int ITEMS = (32 * QT + 511) / 512;
   const long long step0 = (long long)blockIdx.x * p.steps_per_block;
   f32x4 raw[ITEMS];
+  // gather form: what does not change from step to step is decoded ONCE per item -- the tap and channel of its column quad, packed
+  // ky | kx << 8 | c << 16 (-1: a dy item, or a column past N) -- the pixel of a step by two multiplications with float reciprocals
+  int itap[ITEMS];
+  const float r_hw = GEO ? 1.f / (float)(p.Ho * p.Wo) : 0.f, r_wo = GEO ? 1.f / (float)p.Wo : 0.f;
+  if (GEO) {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int q = i * 512 + tid;
+      const int px = q / QT, c4 = q - px * QT;
+      itap[i] = -1;
+      if (q < 32 * QT && c4 >= QM && no + (c4 - QM) * 4 < p.N) {
+        const int v = no + (c4 - QM) * 4, tap = v / p.Cin, c = v - tap * p.Cin;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        itap[i] = ky | (kx << 8) | (c << 16);
+      }
+    }
+  }
+  auto fdiv = [](int n, int d, float rd) -> int {      // n / d for 0 <= n < 2^23 (exact in float), one correction step each way
+    int q = (int)((float)n * rd);
+    q -= (int)(q * d > n);
+    q += (int)((q + 1) * d <= n);
+    return q;
+  };
   auto load = [&](long long s) {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -353,6 +446,14 @@ __global__ __launch_bounds__(512) void p1t_kernel(const P1TArgs p) {
       if (q < 32 * QT && pix < p.P) {
         if (!isx) {
           if (mo + c4 * 4 < p.M) off = (unsigned)(pix * p.lddy + mo + c4 * 4) * 4u;
+        } else if (GEO) {
+          if (itap[i] >= 0) {
+            const int hw = p.Ho * p.Wo, b = fdiv((int)pix, hw, r_hw), rem = (int)pix - b * hw;
+            const int yo = fdiv(rem, p.Wo, r_wo), xo = rem - yo * p.Wo;
+            const int yi = yo * p.stride - p.pad + (itap[i] & 255) * p.dil, xi = xo * p.stride - p.pad + ((itap[i] >> 8) & 255) * p.dil;
+            if ((unsigned)yi < (unsigned)p.Hi && (unsigned)xi < (unsigned)p.Wi)
+              off = (unsigned)(((long long)(b * p.Hi + yi) * p.Wi + xi) * p.ldx + (itap[i] >> 16)) * 4u;
+          }
         } else if (no + (c4 - QM) * 4 < p.N) {
           off = (unsigned)(pix * p.ldx + no + (c4 - QM) * 4) * 4u;
         }
@@ -471,13 +572,13 @@ __global__ __launch_bounds__(256) void p1t_reduce_kernel(const float* __restrict
 
 struct P1TPlan { int kind, MP, NP; };
 // block tile of the result by shape: kind -> (WM, WN, TM, TN); at most 128 accumulator registers per wave
-P1TPlan p1t_plan(int M, int N) {
-  if (M <= 0 || N <= 0 || M > 1024 || N > 1024) return {0, 0, 0};
+P1TPlan p1t_plan(int M, int N, bool geo = false) {
+  if (M <= 0 || N <= 0 || M > 1024 || N > (geo ? 16384 : 1024)) return {0, 0, 0};
   if (M <= 64 && N <= 128) return {8, 64, 128};         // 2 x 4 waves of 32 x 32
   if (M <= 64) return {1, 64, 256};                     // 2 x 4 waves of 32 x 64
   if (N <= 64) return {2, 256, 64};                     // 4 x 2 waves of 64 x 32
   if (M <= 128 && N <= 128) return {3, 128, 128};       // 2 x 4 waves of 64 x 32
-  if (M <= 128) return {9, 128, 256};                   // 2 x 4 waves of 64 x 64
+  if (M <= 128 || geo) return {9, 128, 256};            // 2 x 4 waves of 64 x 64 (gather form: the 256 x 256 tile would spill)
   return {4, 256, 256};                                 // 2 x 4 waves of 128 x 64
 }
 
@@ -527,17 +628,7 @@ extern "C" int catseg_pconv1(long long M, int N, int K, const float* x, int ldx,
       *tile_rows = 256; *n_tiles = a.tilesM;
     }
   }
-  hipStream_t st = (hipStream_t)stream;
-  switch (p1_bn(N) / 32) {
-    case 1: p1_launch<1>(a, st); break;
-    case 2: p1_launch<2>(a, st); break;
-    case 3: p1_launch<3>(a, st); break;
-    case 4: p1_launch<4>(a, st); break;
-    case 5: p1_launch<5>(a, st); break;
-    case 6: p1_launch<6>(a, st); break;
-    case 7: p1_launch<7>(a, st); break;
-    default: p1_launch<8>(a, st); break;
-  }
+  p1_dispatch(a, false, (hipStream_t)stream);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
@@ -546,9 +637,9 @@ extern "C" int catseg_pconv1_wgrad_supported(int Cout, int Cin) { return p1t_pla
 
 namespace {
 struct P1TGrid { P1TPlan pl; int nbm, nbn, Mtot, Ntot, blocks, steps_per_block; };
-P1TGrid p1t_grid(long long P, int Cout, int Cin) {
+P1TGrid p1t_grid(long long P, int Cout, int Cin, bool geo = false) {
   P1TGrid g = {};
-  g.pl = p1t_plan(Cout, Cin);
+  g.pl = p1t_plan(Cout, Cin, geo);
   if (!g.pl.kind) return g;
   g.nbm = (Cout + g.pl.MP - 1) / g.pl.MP; g.nbn = (Cin + g.pl.NP - 1) / g.pl.NP;
   g.Mtot = g.nbm * g.pl.MP; g.Ntot = g.nbn * g.pl.NP;
@@ -559,6 +650,25 @@ P1TGrid p1t_grid(long long P, int Cout, int Cin) {
   g.steps_per_block = (int)((steps + want - 1) / want);
   g.blocks = (int)((steps + g.steps_per_block - 1) / g.steps_per_block);
   return g;
+}
+}  // namespace
+
+namespace {
+template <bool GEO>
+void p1t_launch(const P1TArgs& a, const P1TGrid& g, hipStream_t st) {
+  const dim3 grid(g.blocks, g.nbm * g.nbn);
+  switch (g.pl.kind) {
+    case 8: hipLaunchKernelGGL((p1t_kernel<2, 4, 1, 1, GEO>), grid, dim3(512), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((p1t_kernel<2, 4, 1, 2, GEO>), grid, dim3(512), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((p1t_kernel<4, 2, 2, 1, GEO>), grid, dim3(512), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((p1t_kernel<2, 4, 2, 1, GEO>), grid, dim3(512), 0, st, a); break;
+    case 9: hipLaunchKernelGGL((p1t_kernel<2, 4, 2, 2, GEO>), grid, dim3(512), 0, st, a); break;
+    default: hipLaunchKernelGGL((p1t_kernel<2, 4, 4, 2, GEO>), grid, dim3(512), 0, st, a); break;
+  }
+}
+void p1t_dispatch(const P1TArgs& a, const P1TGrid& g, bool geo, hipStream_t st) {
+  if (geo) p1t_launch<true>(a, g, st);
+  else p1t_launch<false>(a, g, st);
 }
 }  // namespace
 
@@ -585,16 +695,171 @@ extern "C" int catseg_pconv1_wgrad(long long P, int Cout, int Cin, const float* 
   a.steps_per_block = g.steps_per_block;
   a.dy_bytes = (unsigned long long)P * lddy * 4ull; a.x_bytes = (unsigned long long)P * ldx * 4ull;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(g.blocks, g.nbm * g.nbn);
-  switch (g.pl.kind) {
-    case 8: hipLaunchKernelGGL((p1t_kernel<2, 4, 1, 1>), grid, dim3(512), 0, st, a); break;
-    case 1: hipLaunchKernelGGL((p1t_kernel<2, 4, 1, 2>), grid, dim3(512), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((p1t_kernel<4, 2, 2, 1>), grid, dim3(512), 0, st, a); break;
-    case 3: hipLaunchKernelGGL((p1t_kernel<2, 4, 2, 1>), grid, dim3(512), 0, st, a); break;
-    case 9: hipLaunchKernelGGL((p1t_kernel<2, 4, 2, 2>), grid, dim3(512), 0, st, a); break;
-    default: hipLaunchKernelGGL((p1t_kernel<2, 4, 4, 2>), grid, dim3(512), 0, st, a); break;
-  }
+  p1t_dispatch(a, g, false, st);
   hipLaunchKernelGGL(p1t_reduce_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, st, (const float*)workspace, g.blocks, g.Mtot, g.Ntot, Cout, Cin, dw);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+
+// =====================================================================================================================================
+// "gather" launches of the same two kernels: dense convolutions with kh x kw taps, stride, padding and dilation whose input carries an amax
+// record and that neither the direct 3x3 kernels (Cin = Cout, stride 1) nor the blocked-plane kernels (K >= 2048 with >= 192 columns) take:
+// the 3x3 / stride 2 layers of the HRNet fuse chains and transitions (models/HRNetv2.py:237-261, :176-198 of the reference), the
+// 256 -> 48 transition, the second stem convolution.  A lane's 8-deep k run lies inside ONE tap (Cin % 8 == 0), so its 32 bytes are still
+// contiguous in the NHWC row of the tap's input pixel; padding taps are out-of-range offsets (zeros).  Backward-data of a stride-s layer =
+// one launch per input-pixel parity class with that class's sub-grid of taps (no product with a structural zero), writing every s-th pixel.
+namespace {
+unsigned p1_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
+
+bool g1_shape_ok(const catseg_conv_desc* d) {
+  return d && !d->stem4 && d->groups <= 1 && d->Cin % 8 == 0 && d->Cout % 4 == 0 && d->kh >= 1 && d->kw >= 1 && d->kh * d->kw <= 25 &&
+         d->stride >= 1 && d->stride <= 2 && d->kh >= d->stride && d->kw >= d->stride && (d->stride == 1 || d->dil == 1);
+}
+
+// sub-grid of the taps that reach input-pixel parity py (one dimension): k = k0 + a * ks, a < nk; y0 = (py + pad - k0 dil) / s
+void g1_class(int k, int s, int pad, int dil, int py, int* k0, int* ks, int* nk, int* y0) {
+  *ks = s; *k0 = -1; *nk = 0; *y0 = 0;            // (dil == 1 whenever s > 1)
+  for (int kk = 0; kk < k; ++kk)
+    if ((py + pad - kk * dil) % s == 0 && py + pad - kk * dil >= -1000000) {
+      if (*k0 < 0) { *k0 = kk; *y0 = (py + pad - kk * dil) / s; }
+      ++*nk;
+      if (s == 1) break;
+    }
+  if (s == 1) { *k0 = 0; *ks = 1; *nk = k; *y0 = pad; }
+}
+}  // namespace
+
+extern "C" int catseg_gconv_supported(const catseg_conv_desc* d) {
+  if (!g1_shape_ok(d)) return 0;
+  return (catseg_pconv1_supported(d->Cout, d->kh * d->kw * d->Cin) && d->kh * d->kw * d->Cin <= 8192 - 32 && d->Cin <= 1024 && d->Cout <= 512) ? 1 : 0;
+}
+
+// bytes of the forward image (backward_data = 0) or of ALL class images of backward-data (class c = py * stride + px at offset
+// c * catseg_gconv_class_bytes)
+extern "C" size_t catseg_gconv_class_bytes(const catseg_conv_desc* d) {
+  // every class image is sized for the largest class (all taps of one parity in both dimensions)
+  const int s = d->stride, nky = (d->kh + s - 1) / s, nkx = (d->kw + s - 1) / s;
+  return catseg_pconv1_wimg_bytes(d->Cin, nky * nkx * d->Cout);
+}
+extern "C" size_t catseg_gconv_wimg_bytes(const catseg_conv_desc* d, int backward_data) {
+  if (!backward_data) return catseg_pconv1_wimg_bytes(d->Cout, d->kh * d->kw * d->Cin);
+  return (size_t)d->stride * d->stride * catseg_gconv_class_bytes(d);
+}
+
+// fills the host-side prep entries of a layer: entries[0] (forward) or entries[0 .. s*s) (backward-data classes); returns the count.
+// entry layout = P1Entry (64 bytes); w_off / img_off are written relative to the caller's bases (img_off: base + class offset)
+extern "C" int catseg_gconv_entries(const catseg_conv_desc* d, int backward_data, long long w_off, long long img_off, void* entries_out) {
+  if (!g1_shape_ok(d)) return 0;
+  P1Entry* e = (P1Entry*)entries_out;
+  if (!backward_data) {
+    e[0] = P1Entry{w_off, img_off, d->Cout, d->Cin, d->kh, d->kw, 0, 0, 1, d->kh, 0, 1, d->kw, 0};
+    return 1;
+  }
+  const int s = d->stride;
+  const size_t cb = catseg_gconv_class_bytes(d);
+  for (int py = 0; py < s; ++py)
+    for (int px = 0; px < s; ++px) {
+      int ky0, kys, nky, y0, kx0, kxs, nkx, x0;
+      g1_class(d->kh, s, d->pad, d->dil, py, &ky0, &kys, &nky, &y0);
+      g1_class(d->kw, s, d->pad, d->dil, px, &kx0, &kxs, &nkx, &x0);
+      e[py * s + px] = P1Entry{w_off, img_off + (long long)((py * s + px) * cb), d->Cout, d->Cin, d->kh, d->kw, 1, ky0, kys, nky, kx0, kxs, nkx, 0};
+    }
+  return s * s;
+}
+
+// y = conv(x, w) (+ bias) -- forward gather launch; wimg = forward image, BatchNorm partials as catseg_conv2d_fwd_bnstats
+extern "C" int catseg_gconv_fwd(const catseg_conv_desc* d, const float* x, const void* x_rec, const void* wimg, const void* w_rec,
+                                const float* bias, float* y, float* bn_part, size_t bn_part_floats, int* tile_rows, int* n_tiles,
+                                catseg_stream_t stream) {
+  CS_REQUIRE(catseg_gconv_supported(d) && x && x_rec && wimg && w_rec && y, "gconv fwd: unsupported shape or null argument");
+  CS_REQUIRE(d->ldx >= d->Cin && d->ldx % 4 == 0 && d->ldy >= d->Cout && cs_aligned16(x) && cs_aligned16(wimg), "gconv fwd: alignment / row strides");
+  const long long rows_in = (long long)d->B * d->H * d->W, M = (long long)d->B * d->Ho * d->Wo;
+  CS_REQUIRE((unsigned long long)rows_in * d->ldx * 4ull < 0xFFFFFFF0ull && M < (1ll << 31) - 256, "gconv fwd: activation beyond one 4 GB buffer resource");
+  P1Args a = {};
+  a.x = x; a.ldx = d->ldx; a.xrec = (const unsigned*)x_rec; a.wimg = (const unsigned char*)wimg; a.wrec = (const int*)w_rec;
+  a.y = y; a.ldy = d->ldy; a.bias = bias; a.M = (int)M; a.N = d->Cout; a.K = d->kh * d->kw * d->Cin;
+  a.tilesM = (int)((M + 255) / 256); a.ntn = p1_ntn(a.N);
+  a.x_bytes = (unsigned long long)rows_in * d->ldx * 4ull; a.img_bytes = catseg_pconv1_wimg_bytes(a.N, a.K);
+  P1Geo& g = a.geo;
+  g.Wg = d->Wo; g.HWg = d->Ho * d->Wo; g.si = d->stride; g.y0 = -d->pad; g.x0 = -d->pad; g.ya = d->dil; g.xa = d->dil; g.nb = d->kw;
+  g.Hi = d->H; g.Wi = d->W; g.C = d->Cin; g.mC = p1_magic(d->Cin); g.mnb = p1_magic(d->kw);
+  g.so = 1; g.oy = 0; g.ox = 0; g.Ho = d->Ho; g.Wo = d->Wo; g.linear_out = 1;
+  if (bn_part != nullptr) {
+    CS_REQUIRE(tile_rows && n_tiles, "gconv fwd: tile_rows / n_tiles");
+    *tile_rows = 0; *n_tiles = 0;
+    if ((size_t)a.tilesM * 3 * a.N <= bn_part_floats) {
+      a.bn_part = bn_part;
+      *tile_rows = 256; *n_tiles = a.tilesM;
+    }
+  }
+  p1_dispatch(a, true, (hipStream_t)stream);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// dx (+)= conv_transpose(dy, w): wimg_classes = the stride^2 class images (catseg_gconv_entries(backward_data = 1)), one launch per class
+extern "C" int catseg_gconv_bwd_data(const catseg_conv_desc* d, const float* dy, const void* dy_rec, const void* wimg_classes, const void* w_rec,
+                                     float* dx, int accumulate, catseg_stream_t stream) {
+  CS_REQUIRE(g1_shape_ok(d) && dy && dy_rec && wimg_classes && w_rec && dx, "gconv bwd_data: unsupported shape or null argument");
+  CS_REQUIRE(d->ldy >= d->Cout && d->ldy % 4 == 0 && d->ldx >= d->Cin && cs_aligned16(dy) && cs_aligned16(wimg_classes), "gconv bwd_data: alignment / row strides");
+  const long long rows_dy = (long long)d->B * d->Ho * d->Wo;
+  CS_REQUIRE((unsigned long long)rows_dy * d->ldy * 4ull < 0xFFFFFFF0ull && (long long)d->B * d->H * d->W < (1ll << 31) - 256, "gconv bwd_data: operand beyond 4 GB");
+  const int s = d->stride;
+  const size_t cb = catseg_gconv_class_bytes(d);
+  for (int py = 0; py < s; ++py)
+    for (int px = 0; px < s; ++px) {
+      int ky0, kys, nky, y0, kx0, kxs, nkx, x0;
+      g1_class(d->kh, s, d->pad, d->dil, py, &ky0, &kys, &nky, &y0);
+      g1_class(d->kw, s, d->pad, d->dil, px, &kx0, &kxs, &nkx, &x0);
+      const int Hg = (d->H - py + s - 1) / s, Wg = (d->W - px + s - 1) / s;
+      if (Hg <= 0 || Wg <= 0) continue;
+      CS_REQUIRE(nky > 0 && nkx > 0, "gconv bwd_data: a parity class without taps");
+      P1Args a = {};
+      a.x = dy; a.ldx = d->ldy; a.xrec = (const unsigned*)dy_rec;
+      a.wimg = (const unsigned char*)wimg_classes + (size_t)(py * s + px) * cb; a.wrec = (const int*)w_rec;
+      a.y = dx; a.ldy = d->ldx; a.bias = nullptr; a.M = d->B * Hg * Wg; a.N = d->Cin; a.K = nky * nkx * d->Cout;
+      a.tilesM = (a.M + 255) / 256; a.ntn = p1_ntn(a.N); a.accumulate = accumulate;
+      a.x_bytes = (unsigned long long)rows_dy * d->ldy * 4ull; a.img_bytes = catseg_pconv1_wimg_bytes(a.N, a.K);
+      P1Geo& g = a.geo;
+      g.Wg = Wg; g.HWg = Hg * Wg; g.si = 1; g.y0 = y0; g.x0 = x0;
+      g.ya = s == 1 ? -d->dil : -1; g.xa = g.ya; g.nb = nkx;
+      g.Hi = d->Ho; g.Wi = d->Wo; g.C = d->Cout; g.mC = p1_magic(d->Cout); g.mnb = p1_magic(nkx);
+      g.so = s; g.oy = py; g.ox = px; g.Ho = d->H; g.Wo = d->W; g.linear_out = (s == 1) ? 1 : 0;
+      p1_dispatch(a, true, (hipStream_t)stream);
+    }
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+extern "C" int catseg_gconv_wgrad_supported(const catseg_conv_desc* d) {
+  return (g1_shape_ok(d) && p1t_plan(d->Cout, d->kh * d->kw * d->Cin, true).kind != 0 && d->Cin % 4 == 0) ? 1 : 0;
+}
+extern "C" size_t catseg_gconv_wgrad_workspace(const catseg_conv_desc* d) {
+  const P1TGrid g = p1t_grid((long long)d->B * d->Ho * d->Wo, d->Cout, d->kh * d->kw * d->Cin, true);
+  return g.pl.kind ? (size_t)g.blocks * g.Mtot * g.Ntot * 4 : 0;
+}
+
+// dw[Cout][kh][kw][Cin] = sum over output pixels of dy (x) x(gathered): the OHWI layout IS [Cout][taps * Cin]
+extern "C" int catseg_gconv_bwd_weight(const catseg_conv_desc* d, const float* dy, const void* dy_rec, const float* x, const void* x_rec,
+                                       float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(catseg_gconv_wgrad_supported(d) && dy && x && dy_rec && x_rec && dw && workspace, "gconv wgrad: unsupported shape or null argument");
+  const long long P = (long long)d->B * d->Ho * d->Wo, rows_in = (long long)d->B * d->H * d->W;
+  const int N = d->kh * d->kw * d->Cin;
+  const P1TGrid g = p1t_grid(P, d->Cout, N, true);
+  CS_REQUIRE(d->ldy >= d->Cout && d->ldx >= d->Cin && d->ldy % 4 == 0 && d->ldx % 4 == 0 && cs_aligned16(dy) && cs_aligned16(x) && cs_aligned16(workspace),
+             "gconv wgrad: alignment / row strides");
+  CS_REQUIRE((unsigned long long)P * d->ldy * 4ull < 0xFFFFFFF0ull && (unsigned long long)rows_in * d->ldx * 4ull < 0xFFFFFFF0ull, "gconv wgrad: operand beyond 4 GB");
+  CS_REQUIRE(workspace_bytes >= catseg_gconv_wgrad_workspace(d), "gconv wgrad: workspace too small");
+  P1TArgs a = {};
+  a.dy = dy; a.lddy = d->ldy; a.dyrec = (const unsigned*)dy_rec; a.x = x; a.ldx = d->ldx; a.xrec = (const unsigned*)x_rec;
+  a.slabs = (float*)workspace; a.P = P; a.M = d->Cout; a.N = N; a.nbn = g.nbn; a.Mtot = g.Mtot; a.Ntot = g.Ntot;
+  a.steps_per_block = g.steps_per_block;
+  a.dy_bytes = (unsigned long long)P * d->ldy * 4ull; a.x_bytes = (unsigned long long)rows_in * d->ldx * 4ull;
+  a.geo = 1; a.Cin = d->Cin; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.Hi = d->H; a.Wi = d->W; a.Ho = d->Ho; a.Wo = d->Wo;
+  hipStream_t st = (hipStream_t)stream;
+  p1t_dispatch(a, g, true, st);
+  hipLaunchKernelGGL(p1t_reduce_kernel, dim3((d->Cout * N + 255) / 256), dim3(256), 0, st, (const float*)workspace, g.blocks, g.Mtot, g.Ntot, d->Cout, N, dw);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

@@ -905,10 +905,18 @@ class EngineNet(nn.Module):
         if bank is None or (bank is not False and bank.flat is not fp.flat):
             ws = []
             for m in self.modules():
-                if (isinstance(m, Conv2d) and not m.stem and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0)
-                        and m.groups == 1 and ops.lib.catseg_pconv1_supported(m.out_channels, m.in_channels)
-                        and ops.lib.catseg_pconv1_supported(m.in_channels, m.out_channels) and id(m.weight) in fp.offsets):
-                    ws.append((m.weight.data, fp.offsets[id(m.weight)]))
+                if not (isinstance(m, Conv2d) and not m.stem and m.groups == 1 and id(m.weight) in fp.offsets and m.in_channels % 8 == 0
+                        and m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1] and m.dilation[0] == m.dilation[1]):
+                    continue
+                O, I, (kh, kw), st, pd, dl = m.out_channels, m.in_channels, m.kernel_size, m.stride[0], m.padding[0], m.dilation[0]
+                if (kh, kw) == (1, 1) and st == 1 and pd == 0:
+                    if ops.lib.catseg_pconv1_supported(O, I) and ops.lib.catseg_pconv1_supported(I, O):
+                        ws.append((m.weight.data, fp.offsets[id(m.weight)], 1, 0, 1))
+                elif ops.G1 and not (kh == 3 and kw == 3 and st == 1 and pd == 1 and dl == 1 and I == O and ops.lib.catseg_dconv3_supported(I)):
+                    d = ops._g1_desc(I, O, kh, kw, st, pd, dl)
+                    if (ops.lib.catseg_gconv_supported(__import__("ctypes").byref(d))
+                            and ops.lib.catseg_pconv1_supported(I, ((kh + st - 1) // st) * ((kw + st - 1) // st) * O)):
+                        ws.append((m.weight.data, fp.offsets[id(m.weight)], st, pd, dl))
             bank = ops.P1Bank(fp.flat, ws) if ws else False
             self._p1bank = bank
         return bank

@@ -449,24 +449,44 @@ def _p1_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
             and not _b3_wide_1x1(rows, Cout, 1, Cin))
 
 
+_P1_ENTRY = [("w", "<i8"), ("img", "<i8"), ("O", "<i4"), ("I", "<i4"), ("kh", "<i4"), ("kw", "<i4"), ("t", "<i4"), ("ky0", "<i4"), ("kys", "<i4"),
+             ("nky", "<i4"), ("kx0", "<i4"), ("kxs", "<i4"), ("nkx", "<i4"), ("pad", "<i4")]      # csrc/pconv1.hip: P1Entry (64 bytes)
+
+
+def _g1_desc(Cin, Cout, kh, kw, stride, pad, dil):
+    """conv descriptor for the shape-independent queries of the gather launches (csrc/pconv1.hip: catseg_gconv_*)"""
+    return ConvDesc(0, 0, 0, Cin, 0, 0, Cout, kh, kw, stride, pad, dil, Cin, Cout, 0, 1)
+
+
 class P1Bank:
-    """the weight images of every pointwise layer of one network (forward image of (N = O, K = I) and the transposed image of backward-data),
-    written by ONE amax + ONE image launch per step over the flat parameter buffer (catseg_pconv1_prep_batch)"""
+    """the weight images of every pointwise AND gather layer of one network for csrc/pconv1.hip -- per layer the forward image and the image(s)
+    of backward-data (1 x 1: the transposed image; kh x kw / stride s: one image per input-pixel parity class) -- written by ONE amax + ONE
+    image launch per step over the flat parameter buffer (catseg_pconv1_prep_batch)"""
 
     def __init__(self, flat, weights):
-        """weights: [(parameter tensor [O, I, 1, 1] (a view into flat), offset in floats)]"""
+        """weights: [(parameter tensor [O, I, kh, kw] (a view into flat), offset in floats, stride, pad, dil)]"""
         import numpy as np
         self.flat = flat
-        rec = np.zeros(2 * len(weights), dtype=[("w", "<i8"), ("img", "<i8"), ("O", "<i4"), ("I", "<i4"), ("t", "<i4"), ("pad", "<i4")])
-        off = 0
-        self.slices = []
-        for i, (w, woff) in enumerate(weights):
-            O, I = w.shape[0], w.shape[1]
-            for t in (0, 1):
-                nbytes = lib.catseg_pconv1_wimg_bytes(I if t else O, O if t else I)
-                rec[2 * i + t] = (woff, off, O, I, t, 0)
-                self.slices.append((w, t, off, nbytes, 2 * i + t))
+        recs, self.slices, off = [], [], 0
+        for w, woff, stride, pad, dil in weights:
+            O, I, kh, kw = w.shape
+            if kh == 1 and kw == 1 and stride == 1:
+                for t in (0, 1):
+                    nbytes = lib.catseg_pconv1_wimg_bytes(I if t else O, O if t else I)
+                    self.slices.append(((w.data_ptr(), bool(t)), off, nbytes, len(recs)))
+                    recs.append((woff, off, O, I, 1, 1, t, 0, 1, 1, 0, 1, 1, 0))
+                    off += (nbytes + 255) // 256 * 256
+                continue
+            d = _g1_desc(I, O, kh, kw, stride, pad, dil)
+            for bwd in (0, 1):
+                nbytes = lib.catseg_gconv_wimg_bytes(ctypes.byref(d), bwd)
+                buf = np.zeros(4, dtype=_P1_ENTRY)
+                n = lib.catseg_gconv_entries(ctypes.byref(d), bwd, woff, off, buf.ctypes.data)
+                assert n >= 1
+                self.slices.append(((w.data_ptr(), "g", bool(bwd), stride, pad, dil), off, nbytes, len(recs)))
+                recs.extend(tuple(int(v) for v in buf[i]) for i in range(n))
                 off += (nbytes + 255) // 256 * 256
+        rec = np.array(recs, dtype=_P1_ENTRY)
         self.entries = torch.from_numpy(rec.view(np.uint8).copy()).to(flat.device)
         self.n = len(rec)
         self.images = torch.empty(max(off, 256), dtype=torch.uint8, device=flat.device)
@@ -474,8 +494,8 @@ class P1Bank:
 
     def refresh(self):
         check(lib.catseg_pconv1_prep_batch(ptr(self.flat), self.n, ptr(self.entries), ptr(self.images), ptr(self.records), stream()))
-        for w, t, off, nbytes, k in self.slices:
-            _p1_wimg[(w.data_ptr(), bool(t))] = (self.images[off:off + nbytes], self.records[2 * k:2 * k + 2])
+        for key, off, nbytes, k in self.slices:
+            _p1_wimg[key] = (self.images[off:off + nbytes], self.records[2 * k:2 * k + 2])
 
 
 def p1_weight_image(w, transposed=False):
@@ -483,7 +503,32 @@ def p1_weight_image(w, transposed=False):
     key = (w.data_ptr(), bool(transposed))
     img = _p1_wimg.get(key)
     if img is None:
-        bank = P1Bank(w, [(w, 0)])
+        bank = P1Bank(w, [(w, 0, 1, 0, 1)])
+        bank.refresh()
+        _p1_keep.append(bank)
+        img = _p1_wimg[key]
+    return img
+
+
+# Gather launches of the same kernels (csrc/pconv1.hip: catseg_gconv_*): dense kh x kw convolutions with stride 1 / 2 whose input carries an
+# amax record and that neither the direct 3x3 kernels nor the blocked-plane kernels take -- the stride-2 layers of the HRNet fuse chains and
+# transitions, the 256 -> 48 transition, the stem's second convolution.  CATSEG_G1=0: the fp32 MFMA kernels.
+G1 = _os.environ.get("CATSEG_G1", "1") != "0"
+G1_MIN_ROWS = int(_os.environ.get("CATSEG_G1_MIN_ROWS", "16384"))
+G1_OPS = tuple(v for v in _os.environ.get("CATSEG_G1_OPS", "fwd,dgrad,wgrad").split(",") if v)
+
+
+def _g1_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
+    return (G1 and _trunk_h2() and groups == 1 and (kh * kw > 1 or stride > 1) and rows >= G1_MIN_ROWS and Cin % 8 == 0
+            and not _b3_eligible(rows, Cout, kh * kw, Cin, stride == 1))
+
+
+def g1_weight_image(w, backward_data, stride, pad, dil):
+    """(image(s), record) of a gather layer: the forward image, or the stride^2 class images of backward-data back to back"""
+    key = (w.data_ptr(), "g", bool(backward_data), stride, pad, dil)
+    img = _p1_wimg.get(key)
+    if img is None:
+        bank = P1Bank(w, [(w, 0, stride, pad, dil)])
         bank.refresh()
         _p1_keep.append(bank)
         img = _p1_wimg[key]
@@ -656,6 +701,21 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
             res = pconv1(x, p1_weight_image(w_ptr_tensor), bias, Cout, out, bn_stats=bn_stats)
         drop_amax(out)
         return res
+    if (not exact and not stem4 and zero_to == 0 and w_ptr_tensor.dim() == 4 and "fwd" in G1_OPS and amax_of(x) is not None
+            and _g1_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups) and rows_of(x) * ld_of(x) * 4 < B3_PLANE_LIMIT):
+        d = make_desc(x.shape, ld_of(x), Cout, ld_of(out), kh, kw, stride, pad, dil)
+        if lib.catseg_gconv_supported(ctypes.byref(d)):
+            if bn_stats:
+                part = _bn_part_buffer(3 * ((rows + 255) // 256) * Cout, x.device)
+            wimg = g1_weight_image(w_ptr_tensor, False, stride, pad, dil)
+            with _Timed("fwd_s2p", flops):
+                check(lib.catseg_gconv_fwd(ctypes.byref(d), ptr(x), ptr(amax_of(x)), ptr(wimg[0]), ptr(wimg[1]), ptr(bias), ptr(out), ptr(part),
+                                           part.numel() if part is not None else 0, ctypes.byref(tr) if bn_stats else None,
+                                           ctypes.byref(nt) if bn_stats else None, stream()))
+            drop_amax(out)
+            if bn_stats:
+                return out, ((part, nt.value, tr.value) if tr.value > 0 else None)
+            return out
     if not exact and "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and _b3_eligible(rows, Cout, kh * kw, Cin):
         d = make_desc(x.shape, Cin, Cout, ld_of(out), kh, kw, stride, pad, dil)
         blk = _b3_blocked_ok(max(zero_to, Cout), Cin, B * H * W, Cout, kh * kw)
@@ -755,6 +815,18 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
         with _Timed("dgrad_p1", flops):
             pconv1(dy, p1_weight_image(w, transposed=True), None, Cin, out, accumulate=accumulate)
         return out
+    if (w.dim() == 4 and "dgrad" in G1_OPS and amax_of(dy) is not None and Cout % 8 == 0 and _g1_ok(rows_of(dy), Cin, Cout, kh, kw, stride, pad, dil, groups)
+            and not _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1) and rows_of(dy) * ld_of(dy) * 4 < B3_PLANE_LIMIT):
+        d = make_desc(xshape, ld_of(out), Cout, ld_of(dy), kh, kw, stride, pad, dil)
+        dT = _g1_desc(Cout, Cin, kh, kw, stride, pad, dil)      # (the class launches are GEMMs with N = Cin, K = taps * Cout)
+        if (lib.catseg_gconv_supported(ctypes.byref(d)) and lib.catseg_pconv1_supported(Cin, ((kh + stride - 1) // stride) * ((kw + stride - 1) // stride) * Cout)
+                and d.Ho == dy.shape[1] and d.Wo == dy.shape[2]):
+            wimg = g1_weight_image(w, True, stride, pad, dil)
+            with _Timed("dgrad_s2p", flops):
+                check(lib.catseg_gconv_bwd_data(ctypes.byref(d), ptr(dy), ptr(amax_of(dy)), ptr(wimg[0]), ptr(wimg[1]), ptr(out),
+                                                1 if accumulate else 0, stream()))
+            del dT
+            return out
     if groups == 1 and "dgrad" in B3_OPS and _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1):
         d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         blk = _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16, rows_of(dy), Cin, kh * kw)
@@ -840,6 +912,18 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
         if dbias is not None:
             check(lib.catseg_bias_grad(ptr(dy), ld_of(dy), rows_of(dy), Cout, ptr(dbias), ptr(ws), ws.numel(), stream()))
         return dw
+    if (not stem4 and x.dim() == 4 and dw.dim() == 4 and "wgrad" in G1_OPS and amax_of(x) is not None and amax_of(dy) is not None
+            and _g1_ok(rows_of(dy), Cin, Cout, kh, kw, stride, pad, dil, groups) and not _wgrad_split_route(x, dy, kh, kw, stride, stem4, groups)
+            and rows_of(x) * ld_of(x) * 4 < B3_PLANE_LIMIT and rows_of(dy) * ld_of(dy) * 4 < B3_PLANE_LIMIT):
+        d = make_desc(x.shape, ld_of(x), Cout, ld_of(dy), kh, kw, stride, pad, dil)
+        if lib.catseg_gconv_wgrad_supported(ctypes.byref(d)) and d.Ho == dy.shape[1] and d.Wo == dy.shape[2]:
+            need = lib.catseg_gconv_wgrad_workspace(ctypes.byref(d))
+            ws = workspace(need + 256 * Cout * 4, x.device)
+            with _Timed("wgrad_s2p", flops):
+                check(lib.catseg_gconv_bwd_weight(ctypes.byref(d), ptr(dy), ptr(amax_of(dy)), ptr(x), ptr(amax_of(x)), ptr(dw), ptr(ws), need, stream()))
+            if dbias is not None:
+                check(lib.catseg_bias_grad(ptr(dy), ld_of(dy), rows_of(dy), Cout, ptr(dbias), ptr(ws), ws.numel(), stream()))
+            return dw
     if _wgrad_split_route(x, dy, kh, kw, stride, stem4, groups):
         d = make_desc(x.shape, Cin, Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
         ws = workspace(lib.catseg_conv2d_bwd_weight_bf16x3_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)

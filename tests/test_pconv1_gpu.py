@@ -141,3 +141,60 @@ def test_conv_wrappers_take_the_pointwise_route_and_match_the_fp32_kernels():
     for a, b in ((y0, y1), (dx0, dx1), (dw0, dw1)):
         s = float(a.abs().max())
         assert float((a - b).abs().max()) <= 4e-5 * s
+
+
+CONVS = [  # (B, H, W, Cin, Cout, k, stride, pad, dil)
+    (2, 34, 50, 48, 96, 3, 2, 1, 1), (2, 33, 47, 48, 48, 3, 2, 1, 1), (1, 40, 64, 256, 48, 3, 1, 1, 1), (2, 36, 36, 64, 64, 3, 2, 1, 1),
+    (2, 20, 30, 96, 192, 3, 2, 1, 1), (1, 24, 24, 192, 384, 3, 2, 1, 1), (1, 30, 30, 64, 128, 3, 1, 2, 2), (1, 26, 38, 96, 96, 3, 2, 1, 1),
+    (1, 21, 35, 256, 96, 3, 2, 1, 1), (2, 16, 16, 48, 384, 3, 2, 1, 1)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad,dil", CONVS)
+def test_gather_launches_vs_float64_conv2d(B, H, W, Cin, Cout, k, stride, pad, dil):
+    """the gather launches of csrc/pconv1.hip (3x3 / stride 2 fuse and transition layers of models/HRNetv2.py:176-198,237-261, the
+    256 -> 48 transition, a dilated layer) through ops.conv_fwd / conv_bwd_data / conv_bwd_weight against float64 F.conv2d and its autograd:
+    forward with BatchNorm partials, backward-data per input-pixel parity class with accumulation, backward-weight"""
+    _need_gpu()
+    import torch.nn.functional as F
+    from miccai2021_cataract_semantic_segmentation_amd import ops
+    if not ops._trunk_h2():
+        pytest.skip("needs the f16x2 trunk arithmetic (amax records)")
+    g = torch.Generator().manual_seed(B * H + W + Cin + Cout)
+    x = (torch.randn(B, Cin, H, W, generator=g, dtype=torch.float64) * torch.exp(2 * torch.rand(1, Cin, 1, 1, generator=g, dtype=torch.float64) - 1)).relu() * 3e-2
+    w = torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) * 0.05
+    xr, wr = x.float().double().requires_grad_(), w.float().double().requires_grad_()
+    yr = F.conv2d(xr, wr, None, stride, pad, dil)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64) * 2e-6
+    gy = gy.float().double()
+    yr.backward(gy)
+    xd = x.float().permute(0, 2, 3, 1).contiguous().cuda()
+    wd = w.float().cuda().contiguous(memory_format=torch.channels_last)
+    dyd = gy.float().permute(0, 2, 3, 1).contiguous().cuda()
+    xd._amax, dyd._amax = _rec(xd, 1.5), _rec(dyd)
+    saved = (ops.G1_MIN_ROWS, ops.PROFILE)
+    ops.G1_MIN_ROWS, ops.PROFILE = 1, []
+    try:
+        y, part = ops.conv_fwd(xd, wd, None, Cout, k, k, stride, pad, dil, bn_stats=True)
+        base = torch.randn(xd.shape, generator=g).cuda() * 1e-8
+        dx = base.clone()
+        ops.conv_bwd_data(dyd, wd, tuple(xd.shape), k, k, stride, pad, dil, out=dx, accumulate=True)
+        dw = ops.conv_bwd_weight(xd, dyd, torch.full_like(wd, float("nan")), None, k, k, stride, pad, dil)
+        kinds = [q[0] for q in ops.PROFILE]
+    finally:
+        ops.G1_MIN_ROWS, ops.PROFILE = saved
+        ops.release_b3_cache()
+    torch.cuda.synchronize()
+    assert kinds == ["fwd_s2p", "dgrad_s2p", "wgrad_s2p"], kinds
+    ref = yr.detach().permute(0, 2, 3, 1)
+    s = float(ref.abs().max())
+    assert float((y.cpu().double() - ref).abs().max()) <= TOL * s, (float((y.cpu().double() - ref).abs().max()), s)
+    rows = ref.shape[0] * ref.shape[1] * ref.shape[2]
+    stats, _ = ops.bn_finalize(part, rows, Cout, torch.ones(Cout, device="cuda"), 1e-5, 0.1, torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda"))
+    assert torch.allclose(stats[:Cout].cpu().double(), ref.reshape(-1, Cout).mean(0), atol=2e-6 * s)
+    refx = xr.grad.permute(0, 2, 3, 1)
+    sx = float(refx.abs().max())
+    gotx = dx.cpu().double() - base.cpu().double()
+    assert float((gotx - refx).abs().max()) <= TOL * sx + 2e-7 * float(base.abs().max()), (float((gotx - refx).abs().max()), sx)
+    refw = wr.grad
+    sw = float(refw.abs().max())
+    assert float((dw.cpu().double() - refw).abs().max()) <= TOL * sw, (float((dw.cpu().double() - refw).abs().max()), sw)
