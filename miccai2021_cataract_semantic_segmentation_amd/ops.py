@@ -513,8 +513,14 @@ def p1_weight_image(w, transposed=False):
 # Gather launches of the same kernels (csrc/pconv1.hip: catseg_gconv_*): dense kh x kw convolutions with stride 1 / 2 whose input carries an
 # amax record and that neither the direct 3x3 kernels nor the blocked-plane kernels take -- the stride-2 layers of the HRNet fuse chains and
 # transitions, the 256 -> 48 transition, the stem's second convolution.  CATSEG_G1=0: the fp32 MFMA kernels.
+# Measured (tools/time_g1.py, fp32 MFMA kernel -> gather launch, us): 256 -> 48 3x3 at 8 x 136 x 240: forward 585 -> 398, backward-data 495 -> 249,
+# backward-weight 739 -> 651; 256 -> 96 / stride 2: 251 -> 129, 315 -> 200, 348 -> 230; stem 64 -> 64 / stride 2: 225 -> 143 forward; 48 -> 96 / stride 2:
+# 72 -> 46 forward, 107 -> 73 backward-weight -- but its backward-data (four parity-class launches with N = 48 columns) 88 -> 95 and 48 -> 48: 59 -> 76:
+# backward-data takes the route from G1_DGRAD_MIN_CIN input channels on.  HRNet-W48 step (graph replay, three alternating rounds): 108.1 - 108.8 ms
+# without, 107.9 - 108.2 with.
 G1 = _os.environ.get("CATSEG_G1", "1") != "0"
 G1_MIN_ROWS = int(_os.environ.get("CATSEG_G1_MIN_ROWS", "16384"))
+G1_DGRAD_MIN_CIN = int(_os.environ.get("CATSEG_G1_DGRAD_MIN_CIN", "128"))
 G1_OPS = tuple(v for v in _os.environ.get("CATSEG_G1_OPS", "fwd,dgrad,wgrad").split(",") if v)
 
 
@@ -815,7 +821,7 @@ def conv_bwd_data(dy, w, xshape, kh, kw, stride=1, pad=0, dil=1, out=None, accum
         with _Timed("dgrad_p1", flops):
             pconv1(dy, p1_weight_image(w, transposed=True), None, Cin, out, accumulate=accumulate)
         return out
-    if (w.dim() == 4 and "dgrad" in G1_OPS and amax_of(dy) is not None and Cout % 8 == 0 and _g1_ok(rows_of(dy), Cin, Cout, kh, kw, stride, pad, dil, groups)
+    if (w.dim() == 4 and "dgrad" in G1_OPS and amax_of(dy) is not None and Cout % 8 == 0 and Cin >= G1_DGRAD_MIN_CIN and _g1_ok(rows_of(dy), Cin, Cout, kh, kw, stride, pad, dil, groups)
             and not _b3_eligible(B * H * W, Cin, kh * kw, (Cout + 7) // 8 * 8, stride == 1) and rows_of(dy) * ld_of(dy) * 4 < B3_PLANE_LIMIT):
         d = make_desc(xshape, ld_of(out), Cout, ld_of(dy), kh, kw, stride, pad, dil)
         dT = _g1_desc(Cout, Cin, kh, kw, stride, pad, dil)      # (the class launches are GEMMs with N = Cin, K = taps * Cout)

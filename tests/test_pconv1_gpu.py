@@ -171,8 +171,8 @@ def test_gather_launches_vs_float64_conv2d(B, H, W, Cin, Cout, k, stride, pad, d
     wd = w.float().cuda().contiguous(memory_format=torch.channels_last)
     dyd = gy.float().permute(0, 2, 3, 1).contiguous().cuda()
     xd._amax, dyd._amax = _rec(xd, 1.5), _rec(dyd)
-    saved = (ops.G1_MIN_ROWS, ops.PROFILE)
-    ops.G1_MIN_ROWS, ops.PROFILE = 1, []
+    saved = (ops.G1_MIN_ROWS, ops.PROFILE, ops.G1_DGRAD_MIN_CIN)
+    ops.G1_MIN_ROWS, ops.PROFILE, ops.G1_DGRAD_MIN_CIN = 1, [], 1
     try:
         y, part = ops.conv_fwd(xd, wd, None, Cout, k, k, stride, pad, dil, bn_stats=True)
         base = torch.randn(xd.shape, generator=g).cuda() * 1e-8
@@ -181,7 +181,7 @@ def test_gather_launches_vs_float64_conv2d(B, H, W, Cin, Cout, k, stride, pad, d
         dw = ops.conv_bwd_weight(xd, dyd, torch.full_like(wd, float("nan")), None, k, k, stride, pad, dil)
         kinds = [q[0] for q in ops.PROFILE]
     finally:
-        ops.G1_MIN_ROWS, ops.PROFILE = saved
+        ops.G1_MIN_ROWS, ops.PROFILE, ops.G1_DGRAD_MIN_CIN = saved
         ops.release_b3_cache()
     torch.cuda.synchronize()
     assert kinds == ["fwd_s2p", "dgrad_s2p", "wgrad_s2p"], kinds
