@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--model $m --steps 1 --warmup 1 --no-roofline --no-cpu-baseline --no-side-figures"
+ARGS="--model $m --eager --steps 1 --warmup 1 --no-roofline --no-cpu-baseline --no-side-figures"
 if [ "$m" = "infer" ]; then ARGS="--infer --steps 1 --warmup 1 --no-roofline --no-cpu-baseline"; fi   # config 5: 2 forward steps of 4 frames
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch_$m" -- python3 "$R/bench.py" $ARGS > "$O/pmc_fetch_$m.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write_$m" -- python3 "$R/bench.py" $ARGS > "$O/pmc_write_$m.log" 2>&1
