@@ -410,6 +410,13 @@ size_t catseg_lovasz_workspace(long long P, int K);
 int catseg_lovasz_softmax(const float* logits, const int64_t* labels, long long P, int K, float weight,
                           float* loss_out, float* dlogits, int accumulate_dlogits, void* workspace,
                           size_t workspace_bytes, catseg_stream_t stream);
+/* the same pipeline in two calls around autograd (losses/LovaszSoftmax.py:19-32 + its backward): _fwd leaves d loss / d prob and the class
+   counts in `workspace` (catseg_lovasz_workspace bytes, kept untouched by the caller together with `logits`) when want_grad != 0; _bwd writes
+   (d loss / d logit) * upstream, upstream = a DEVICE scalar (autograd's grad_output; null = 1): no separate scaling pass over the gradient */
+int catseg_lovasz_softmax_fwd(const float* logits, const int64_t* labels, long long P, int K, float weight, float* loss_out,
+                              int want_grad, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
+int catseg_lovasz_softmax_bwd(const float* logits, long long P, int K, float weight, const float* upstream, float* dlogits,
+                              int accumulate_dlogits, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
 /* nn.CrossEntropyLoss(ignore_index) (losses/LossWrapper.py:17-24) fused with backward */
 size_t catseg_ce_workspace(long long P);
 int catseg_cross_entropy(const float* logits, const int64_t* labels, long long P, int K, long long ignore_index,

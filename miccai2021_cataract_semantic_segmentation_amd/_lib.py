@@ -153,6 +153,8 @@ _SIGS = {
     "catseg_softmax_rows_bwd": (I, [P, P, P, L, I, I, F, P]),
     "catseg_lovasz_workspace": (SZ, [L, I]),
     "catseg_lovasz_softmax": (I, [P, P, L, I, F, P, P, I, P, SZ, P]),
+    "catseg_lovasz_softmax_fwd": (I, [P, P, L, I, F, P, I, P, SZ, P]),
+    "catseg_lovasz_softmax_bwd": (I, [P, L, I, F, P, P, I, P, SZ, P]),
     "catseg_ce_workspace": (SZ, [L]),
     "catseg_cross_entropy": (I, [P, P, L, I, L, F, P, P, P, SZ, P]),
     "catseg_ohem_workspace": (SZ, [L]),

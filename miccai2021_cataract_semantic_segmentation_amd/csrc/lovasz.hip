@@ -602,7 +602,8 @@ __global__ __launch_bounds__(256) void lv_finalize_kernel(const uint32_t* __rest
 }
 
 __global__ __launch_bounds__(PIX) void lv_backward_kernel(const float* __restrict__ logits, long long P, int K, const uint32_t* __restrict__ counts,
-                                                          const float* __restrict__ dprob, float weight, float* __restrict__ dlogits, int acc) {
+                                                          const float* __restrict__ dprob, float weight, float* __restrict__ dlogits, int acc,
+                                                          const float* __restrict__ upstream = nullptr) {
   extern __shared__ float sh[];
   const int KS = K | 1;
   const long long p0 = (long long)blockIdx.x * PIX;
@@ -644,7 +645,13 @@ __global__ __launch_bounds__(PIX) void lv_backward_kernel(const float* __restric
         }
       }
     }
-    for (int c = 0; c < K; ++c) row[c] = row[c] * (grow[c] - dot);
+    // upstream: d(total loss) / d(this loss), a device scalar (autograd's grad_output): the product the separate scaling pass used to form,
+    // (d loss / d logit) * upstream, rounded the same way
+    const float up = upstream ? *upstream : 1.f;
+    for (int c = 0; c < K; ++c) {
+      const float v = row[c] * (grow[c] - dot);
+      row[c] = upstream ? v * up : v;
+    }
   }
   __syncthreads();
   unstage_rows(dlogits, p0, np, K, KS, sh, acc != 0);
@@ -792,9 +799,9 @@ extern "C" int catseg_debug_set_lovasz_prune(int on) {
 
 extern "C" size_t catseg_lovasz_workspace(long long P, int K) { return lv_layout(P, K, nullptr, nullptr); }
 
-extern "C" int catseg_lovasz_softmax(const float* logits, const int64_t* labels, long long P, int K, float weight,
-                                     float* loss_out, float* dlogits, int accumulate_dlogits, void* workspace,
-                                     size_t workspace_bytes, catseg_stream_t stream) {
+namespace {
+int lovasz_run(const float* logits, const int64_t* labels, long long P, int K, float weight, float* loss_out, float* dlogits, int want_grad,
+               int accumulate_dlogits, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
   CS_REQUIRE(P > 0 && P < (1ll << 31) && K > 0 && K <= MAXK, "lovasz: need 0 < P < 2^31 and K <= %d", MAXK);
   const size_t need = lv_layout(P, K, nullptr, nullptr);
   if (workspace_bytes < need || !workspace) {
@@ -819,7 +826,7 @@ extern "C" int catseg_lovasz_softmax(const float* logits, const int64_t* labels,
     hipLaunchKernelGGL(lv_blkscan_kernel, dim3(K), dim3(1024), 0, st, (const uint32_t*)w.counts, w.blkcnt, (long long)nb, w.nact);
     hipLaunchKernelGGL(lv_compact_kernel<true>, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, (const uint32_t*)w.counts,
                        (const uint32_t*)w.minfg, w.blkcnt, (long long)nb, w.keys[0], w.vals[0]);
-    if (dlogits && hipMemsetAsync(w.dprob, 0, (size_t)K * P * 4, st) != hipSuccess) { catseg_set_error("lovasz: memset failed"); return CATSEG_EHIP; }
+    if (want_grad && hipMemsetAsync(w.dprob, 0, (size_t)K * P * 4, st) != hipSuccess) { catseg_set_error("lovasz: memset failed"); return CATSEG_EHIP; }
   } else {
     hipLaunchKernelGGL(lv_fill_nact_kernel, dim3(1), dim3(64), 0, st, w.nact, (uint32_t)P);
     hipLaunchKernelGGL(lv_prep_kernel, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, (const uint32_t*)w.counts, w.keys[0], w.vals[0]);
@@ -837,11 +844,41 @@ extern "C" int catseg_lovasz_softmax(const float* logits, const int64_t* labels,
   hipLaunchKernelGGL(lv_fgsum_kernel, dim3((unsigned)ntiles, K), dim3(256), 0, st, (const uint32_t*)w.vals[cur], P, (const uint32_t*)w.counts, nact, w.fgsum, ntiles);
   hipLaunchKernelGGL(lv_fgscan_kernel, dim3(K), dim3(1024), 0, st, (const uint32_t*)w.counts, w.fgsum, ntiles);
   hipLaunchKernelGGL(lv_grad_kernel, dim3((unsigned)ntiles, K), dim3(256), 0, st, (const uint32_t*)w.keys[cur], (const uint32_t*)w.vals[cur], P,
-                     (const uint32_t*)w.counts, nact, (const uint32_t*)w.fgsum, ntiles, w.lpart, dlogits ? w.dprob : nullptr);
+                     (const uint32_t*)w.counts, nact, (const uint32_t*)w.fgsum, ntiles, w.lpart, want_grad ? w.dprob : nullptr);
   hipLaunchKernelGGL(lv_finalize_kernel, dim3(1), dim3(256), 0, st, (const uint32_t*)w.counts, (const float*)w.lpart, ntiles, K, weight, loss_out, 0);
   if (dlogits)
     hipLaunchKernelGGL(lv_backward_kernel, dim3(nb), dim3(PIX), 2 * shb, st, logits, P, K, (const uint32_t*)w.counts, (const float*)w.dprob, weight, dlogits,
                        accumulate_dlogits);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+}  // namespace
+
+extern "C" int catseg_lovasz_softmax(const float* logits, const int64_t* labels, long long P, int K, float weight,
+                                     float* loss_out, float* dlogits, int accumulate_dlogits, void* workspace,
+                                     size_t workspace_bytes, catseg_stream_t stream) {
+  return lovasz_run(logits, labels, P, K, weight, loss_out, dlogits, dlogits != nullptr, accumulate_dlogits, workspace, workspace_bytes, stream);
+}
+
+// The same pipeline in two calls around autograd: _fwd leaves d loss / d prob (class planes) and the class counts in `workspace` when
+// want_grad != 0; _bwd turns them into d loss / d logit times `upstream` (a DEVICE scalar: autograd's grad_output of the loss; null = 1) -- the
+// pass over 4 P K bytes that used to multiply the stored gradient by the upstream scalar disappears.  The caller keeps workspace and
+// logits untouched between the two calls.
+extern "C" int catseg_lovasz_softmax_fwd(const float* logits, const int64_t* labels, long long P, int K, float weight, float* loss_out,
+                                         int want_grad, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+  return lovasz_run(logits, labels, P, K, weight, loss_out, nullptr, want_grad, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int catseg_lovasz_softmax_bwd(const float* logits, long long P, int K, float weight, const float* upstream, float* dlogits,
+                                         int accumulate_dlogits, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(P > 0 && P < (1ll << 31) && K > 0 && K <= MAXK && logits && dlogits && workspace, "lovasz bwd: bad args");
+  CS_REQUIRE(workspace_bytes >= lv_layout(P, K, nullptr, nullptr), "lovasz bwd: workspace too small");
+  LvWs w;
+  lv_layout(P, K, (char*)workspace, &w);
+  const int nb = (int)((P + PIX - 1) / PIX);
+  const size_t shb = (size_t)PIX * (K | 1) * 4;
+  hipLaunchKernelGGL(lv_backward_kernel, dim3(nb), dim3(PIX), 2 * shb, (hipStream_t)stream, logits, P, K, (const uint32_t*)w.counts, (const float*)w.dprob, weight,
+                     dlogits, accumulate_dlogits, upstream);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

@@ -18,16 +18,20 @@ class _LovaszFn(torch.autograd.Function):
             lbl = lbl.long()
         lbl = lbl.contiguous()
         need_grad = pred.requires_grad
-        dl = torch.empty_like(rows) if need_grad else None
-        loss = ops.lovasz_softmax(rows, lbl, weight, dl)
-        ctx.dl = dl
+        # forward: loss + d loss / d prob (kept in the call's own workspace); the logits gradient is formed in backward(), already multiplied
+        # by the upstream scalar (round 5: the separate pass that scaled a stored gradient -- 418 MB read + written per loss -- is gone)
+        loss, ws = ops.lovasz_softmax_fwd(rows, lbl, weight, want_grad=need_grad)
+        ctx.rows, ctx.ws, ctx.weight = (rows, ws, weight) if need_grad else (None, None, weight)
         ctx.shape = pred.shape
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        dl = scale_by(ctx.dl, g)
-        ctx.dl = None
+        up = g.reshape(1)
+        if up.dtype != torch.float32 or not up.is_contiguous():
+            up = up.float().contiguous()
+        dl = ops.lovasz_softmax_bwd(ctx.rows, ctx.ws, up, ctx.weight)
+        ctx.rows = ctx.ws = None
         B, K, H, W = ctx.shape
         return dl.view(B, H, W, K).permute(0, 3, 1, 2), None, None
 

@@ -1367,6 +1367,31 @@ def _lovasz(logits, labels, Pn, K, weight, loss_out, dlogits, accumulate, ws):
     return loss_out
 
 
+def lovasz_softmax_fwd(logits, labels, weight=1.0, want_grad=True):
+    """forward half of lovasz_softmax for autograd: (loss, workspace) -- the workspace holds d loss / d prob for lovasz_softmax_bwd and is
+    a buffer of its own (not the stream's shared scratch: other launches run between the two halves)"""
+    Pn, K = logits.shape
+    assert logits.is_contiguous() and labels.dtype == torch.int64 and labels.is_contiguous()
+    loss_out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    need = lib.catseg_lovasz_workspace(Pn, K)
+    ws = torch.empty(need, dtype=torch.uint8, device=logits.device) if want_grad else workspace(need, logits.device)
+    with _Timed("hbm:lovasz", 4.0 * Pn * K * (2 if want_grad else 1) + 8.0 * Pn):
+        check(lib.catseg_lovasz_softmax_fwd(ptr(logits), ptr(labels), Pn, K, weight, ptr(loss_out), 1 if want_grad else 0, ptr(ws), need, stream()))
+    return loss_out, (ws if want_grad else None)
+
+
+def lovasz_softmax_bwd(logits, ws, upstream, weight=1.0, dlogits=None, accumulate=False):
+    """dlogits (+)= d loss / d logits * upstream (upstream: 1-element float32 device tensor, autograd's grad_output; None = 1)"""
+    Pn, K = logits.shape
+    if dlogits is None:
+        dlogits = torch.empty_like(logits)
+        accumulate = False
+    assert upstream is None or (upstream.numel() == 1 and upstream.dtype == torch.float32 and upstream.is_cuda)
+    with _Timed("hbm:lovasz", 0.0):
+        check(lib.catseg_lovasz_softmax_bwd(ptr(logits), Pn, K, weight, ptr(upstream), ptr(dlogits), 1 if accumulate else 0, ptr(ws), ws.numel(), stream()))
+    return dlogits
+
+
 def cross_entropy(logits, labels, ignore_index, weight=1.0, dlogits=None, loss_out=None):
     Pn, K = logits.shape
     assert logits.is_contiguous() and labels.dtype == torch.int64 and labels.is_contiguous()
