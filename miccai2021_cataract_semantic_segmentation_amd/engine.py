@@ -130,6 +130,17 @@ def wgrad_stream(device):
     return _wgrad_streams[key]
 
 
+PREP_ASYNC = __import__("os").environ.get("CATSEG_PREP_ASYNC", "1") != "0"
+_prep_streams = {}
+
+
+def prep_stream(device):
+    key = (device.type, device.index)
+    if key not in _prep_streams:
+        _prep_streams[key] = torch.cuda.Stream(device=device)
+    return _prep_streams[key]
+
+
 PARALLEL_BRANCHES = True   # run independent branches (HRNet stages) on separate HIP streams, forward and backward
 # streams a parallel region spreads its branches over (branch i runs on stream i % BRANCH_STREAMS): A/B knob, CATSEG_BRANCH_STREAMS
 BRANCH_STREAMS = int(__import__("os").environ.get("CATSEG_BRANCH_STREAMS", "4"))
@@ -192,6 +203,7 @@ class Ctx:
                 if not self_.on:
                     return self_
                 self_.main = torch.cuda.current_stream(device)
+                ops.images_ready()              # (the branch streams fork from here: they must not wait on the prep stream themselves)
                 ns = max(1, min(n, BRANCH_STREAMS))
                 if LAST_BRANCH_ON_MAIN and ns >= 4 and cx.record:
                     # The runtime spreads streams over FOUR hardware queues: the main stream holds one, so of four side streams two share a
@@ -923,14 +935,29 @@ class EngineNet(nn.Module):
 
     def _run(self, x, record):
         ops.release_b3_cache()          # (planes left over from a recorded forward that never saw its backward)
+        # The per-step weight images (direct 3x3 kernels: 459 MB written for OCRNet-HRNet-W48, 0.43 ms; pointwise / gather kernels) are not
+        # needed before stage 2: their launches run on a side stream beside the stem and stage 1; the launch stream waits for them at the
+        # first lookup of an image or in front of the first parallel region (ops.images_ready).  PREP_ASYNC = False: in line, as in round 4.
+        banks = []
         if ops.DCONV3 and ops.PRECISION == "bf16x3" and self.training:
-            bank = self._d3_bank()
-            if bank:
-                bank.refresh()
+            banks.append(self._d3_bank())
         if ops.P1 and ops._trunk_h2() and self.training:
-            bank = self._p1_bank()
-            if bank:
-                bank.refresh()
+            banks.append(self._p1_bank())
+        banks = [b for b in banks if b]
+        if banks:
+            if PREP_ASYNC and x.is_cuda:
+                main = torch.cuda.current_stream(x.device)
+                side = prep_stream(x.device)
+                side.wait_stream(main)          # (behind the optimiser's update of the weights and the last readers of the old images)
+                with torch.cuda.stream(side):
+                    for b in banks:
+                        b.refresh()
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                ops.images_pending(ev, main)
+            else:
+                for b in banks:
+                    b.refresh()
         cx = Ctx(self.training, record, None)
         if ops._trunk_h2() and self.training:
             # the per-tensor amax records of this forward pass and of its backward: ONE chunk, zeroed here on the main stream, sized from

@@ -372,9 +372,29 @@ def drop_amax(t):
     return t
 
 
+_images_event = None      # (event, origin stream): the step's weight images are being written on a side stream (engine.EngineNet._run)
+
+
+def images_pending(ev, origin):
+    global _images_event
+    _images_event = (ev, origin)
+
+
+def images_ready():
+    """the current stream waits for the weight-image launches of this step (once: every later stream forks from the origin stream)"""
+    global _images_event
+    if _images_event is not None:
+        ev, origin = _images_event
+        cur = torch.cuda.current_stream(origin.device)
+        cur.wait_event(ev)
+        if cur.cuda_stream == origin.cuda_stream:
+            _images_event = None
+
+
 def dconv3_weight_image(w, backward_data=False, h2=False):
     """pre-split weight image of the direct kernel (cached until release_b3_cache(): one per layer and direction per step);
     h2: the two-plane fp16 image and its scale record, (image, record)"""
+    images_ready()
     key = (w.data_ptr(), bool(backward_data), bool(h2))
     img = _d3_wimg.get(key)
     if img is None:
@@ -500,6 +520,7 @@ class P1Bank:
 
 def p1_weight_image(w, transposed=False):
     """(image, record) of a pointwise layer's weights [O, I, 1, 1] (physical OHWI = [O][I]); layers outside a P1Bank get a one-layer bank"""
+    images_ready()
     key = (w.data_ptr(), bool(transposed))
     img = _p1_wimg.get(key)
     if img is None:
@@ -531,6 +552,7 @@ def _g1_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
 
 def g1_weight_image(w, backward_data, stride, pad, dil):
     """(image(s), record) of a gather layer: the forward image, or the stride^2 class images of backward-data back to back"""
+    images_ready()
     key = (w.data_ptr(), "g", bool(backward_data), stride, pad, dil)
     img = _p1_wimg.get(key)
     if img is None:
