@@ -971,6 +971,7 @@ class EngineNet(nn.Module):
             outs = self._body(cx, x)
         finally:
             _cur_cx = None
+            ops.images_ready()          # (a pass that looked no image up -- small maps stay on the fp32 kernels -- still joins the prep stream)
         if not record:
             ops.release_b3_cache()      # a recorded forward keeps its split planes for the backward-weight pass (_end_backward frees them)
         return cx, outs
