@@ -462,8 +462,15 @@ def main():
             if graphed["key"] != key:
                 drop_graph()
                 t_c = time.perf_counter()
-                graphed["step"] = GraphedTrainStep(model, (lambda o, l: crit(None, o, l)) if deeplab else (lambda o, l: crit(o[0], o[1], l)),
-                                                   opt, x, y, confusion=cm)
+                try:
+                    graphed["step"] = GraphedTrainStep(model, (lambda o, l: crit(None, o, l)) if deeplab else (lambda o, l: crit(o[0], o[1], l)),
+                                                       opt, x, y, confusion=cm)
+                except Exception as e:      # noqa: BLE001  a capture the runtime refuses must not cost the line: the launch loop runs the same kernels
+                    graphed["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+                    print("bench: hipGraph capture failed (%s) -- falling back to the eager launch loop" % graphed["error"], file=sys.stderr)
+                    use_graph[0] = False
+                    torch.cuda.synchronize()
+                    return step(batch if batch is not None else (x, y))
                 graphed["key"] = key
                 graphed["captures"] += 1
                 graphed["capture_s"] += time.perf_counter() - t_c
@@ -774,7 +781,8 @@ def main():
                                        % (graphed["captures"], graphed["capture_s"],
                                           "; data parallel: graph = zero_grad .. backward, then bucketed RCCL all-reduce, Adam, confusion matrix as "
                                           "ordinary launches" if world > 1 else ""))
-                                      if (not args.eager and not args.with_h2d) else "eager: one ctypes launch per kernel (--eager)")
+                                      if (not args.eager and not args.with_h2d and "error" not in graphed) else
+                                      ("eager: one ctypes launch per kernel" + (" (hipGraph capture failed: %s)" % graphed["error"] if "error" in graphed else " (--eager)")))
         _emit(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -57,9 +57,13 @@ class GraphedTrainStep:
                      None if confusion is None else confusion.clone())
         self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(self.stream):
-            for _ in range(max(int(warmup), 1)):
-                self._body()
+        try:
+            with torch.cuda.stream(self.stream):
+                for _ in range(max(int(warmup), 1)):
+                    self._body()
+        except BaseException:
+            model._grad_sync = self.sync
+            raise
         torch.cuda.current_stream(dev).wait_stream(self.stream)
         torch.cuda.synchronize(dev)
         if saved is not None:
@@ -77,8 +81,13 @@ class GraphedTrainStep:
         self._bns = [mod for mod in model.modules() if isinstance(mod, engine.BatchNorm2d)]
         pend = [mod._pending_batches for mod in self._bns]
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
-            self.loss, self.outputs = self._body()
+        try:
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.loss, self.outputs = self._body()
+        except BaseException:
+            model._grad_sync = self.sync            # (hand the reducer back: the caller may go on with the eager loop)
+            self.graph = None
+            raise
         for mod, n in zip(self._bns, pend):          # (the capture ran the Python side of one step: undo its host-side counters)
             mod._pending_batches = n
         self.replays = 0
