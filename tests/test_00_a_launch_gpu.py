@@ -77,4 +77,6 @@ def test_rccl_world1_forced_gradient_exchange(tmp_path):
     assert st["buckets"] >= 5 and st["bytes_reduced_per_step"] >= 0.99 * r["flat_bytes"]
     assert st["steps"] == 3 and st["exposed_wait_ms"] >= 0.0 and st["host_wait_ms"] >= 0.0
     assert r["grad_norm"] > 0 and r["scale"] == 1.0
+    # the graph replay with the RCCL group (and its watchdog thread) alive: same gradients, one forced exchange per replayed step
+    assert r["graph_bit_identical"] and r["graph_steps_reduced"] == 2
     print("RCCL world-1 forced exchange:", json.dumps(st))
