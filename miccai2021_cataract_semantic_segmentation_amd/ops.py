@@ -542,11 +542,12 @@ def p1_weight_image(w, transposed=False):
 G1 = _os.environ.get("CATSEG_G1", "1") != "0"
 G1_MIN_ROWS = int(_os.environ.get("CATSEG_G1_MIN_ROWS", "16384"))
 G1_DGRAD_MIN_CIN = int(_os.environ.get("CATSEG_G1_DGRAD_MIN_CIN", "128"))
+G1_MIN_CIN = int(_os.environ.get("CATSEG_G1_MIN_CIN", "0"))
 G1_OPS = tuple(v for v in _os.environ.get("CATSEG_G1_OPS", "fwd,dgrad,wgrad").split(",") if v)
 
 
 def _g1_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
-    return (G1 and _trunk_h2() and groups == 1 and (kh * kw > 1 or stride > 1) and rows >= G1_MIN_ROWS and Cin % 8 == 0
+    return (G1 and _trunk_h2() and groups == 1 and (kh * kw > 1 or stride > 1) and rows >= G1_MIN_ROWS and Cin % 8 == 0 and Cin >= G1_MIN_CIN
             and not _b3_eligible(rows, Cout, kh * kw, Cin, stride == 1))
 
 
