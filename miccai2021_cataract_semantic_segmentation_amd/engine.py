@@ -937,7 +937,11 @@ class EngineNet(nn.Module):
         ops.release_b3_cache()          # (planes left over from a recorded forward that never saw its backward)
         # The per-step weight images (direct 3x3 kernels: 459 MB written for OCRNet-HRNet-W48, 0.43 ms; pointwise / gather kernels) are not
         # needed before stage 2: their launches run on a side stream beside the stem and stage 1; the launch stream waits for them at the
-        # first lookup of an image or in front of the first parallel region (ops.images_ready).  PREP_ASYNC = False: in line, as in round 4.
+        # first lookup of an image or in front of the first parallel region (ops.images_ready).  Only while the step is being RECORDED into a
+        # hipGraph (replay: 109.1 / 109.2 / 109.7 -> 108.5 / 109.2 / 109.0 ms): in the eager launch loop one more live stream shifts the runtime's
+        # round-robin of streams over its four hardware queues, two branch streams of the parallel regions then share a queue and the step
+        # LOSES 3 - 5 ms (116.4 / 119.5 against 113.5 / 114.3 ms; per-branch region times 1.9 / 2.7 / 2.7 / 2.7 instead of 2.2 / 2.3 / 2.0 / 2.3 ms).
+        # PREP_ASYNC = False: in line everywhere.
         banks = []
         if ops.DCONV3 and ops.PRECISION == "bf16x3" and self.training:
             banks.append(self._d3_bank())
@@ -945,7 +949,7 @@ class EngineNet(nn.Module):
             banks.append(self._p1_bank())
         banks = [b for b in banks if b]
         if banks:
-            if PREP_ASYNC and x.is_cuda:
+            if PREP_ASYNC and x.is_cuda and torch.cuda.is_current_stream_capturing():
                 main = torch.cuda.current_stream(x.device)
                 side = prep_stream(x.device)
                 side.wait_stream(main)          # (behind the optimiser's update of the weights and the last readers of the old images)
