@@ -255,7 +255,17 @@ def build_hrnet_trunk(net, width, stage1_width, modules):
     # The rounding error of the first layers is what the rest of the trunk amplifies (x 250 from the stem to the logits, x 100 from layer1,
     # x 40 from stage 2, x 12 from stage 3: tools/error_growth.py): the four 3x3 convolutions of layer1 run their forward pass on the fp32
     # kernel with two-level accumulation instead of the two-plane fp16 direct kernel (+0.4 ms per bs-8 step).
-    for part in (net.layer1,):
+    # Round 5: the same holds for the stem's second convolution and the first transition once the gather launches of csrc/pconv1.hip could
+    # take their FORWARD pass (tools/error_growth.py at 2 x 3 x 544 x 960: relative RMS error at the stem 2.2e-7 -> 3.7e-7 and 1.4 x at every later tap,
+    # 113 instead of 63 label disagreements with fp64 at the logits): they stay on the fp32 kernel forward (backward takes the gather route).
+    # CATSEG_EXACT_EARLY = "layer1" / "stem" / "all" (default) selects how far the rule reaches.
+    early = __import__("os").environ.get("CATSEG_EXACT_EARLY", "all")
+    parts = [net.layer1]
+    if early in ("stem", "all"):
+        parts.append(net.conv2)
+    if early == "all":
+        parts.append(net.transition1)
+    for part in parts:
         for m in part.modules():
             if isinstance(m, Conv2d):
                 m.exact_operands = True
