@@ -35,7 +35,7 @@ def main():
         ON.ocrnet_hrnet_forward(S64, x.double(), train=True)
         ON.TAPS = None
         for plan in plans:
-            with FR.set_plan(plan):
+            with FR.set_plan(plan, batch=2):
                 model = OCRNet(dict(cfg), 3)
                 model.load_state_dict(fill_state(spec, 41))
                 model.cuda().train()
