@@ -494,7 +494,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    w_start = None if args.no_side_figures else model.flat().flat.clone()     # the weights the timed region starts from (side figures)
+    w_start = None if (args.no_side_figures or world > 1) else model.flat().flat.clone()     # the weights the timed region starts from (side figures)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -661,7 +661,8 @@ def main():
 
     side = {}
     SIDE_STEPS = 10
-    if not args.no_side_figures and (B, H, W) == (8, 544, 960):
+    if not args.no_side_figures and (B, H, W) == (8, 544, 960) and world == 1:
+        # (N = 1 only: a scaling run measures the step, nothing else)
         # Every side figure runs from the weights the timed region started from, with lr = 0.  The cost of the Lovasz loss depends on the
         # predictions (active-set pruning, DESIGN.md 4.2: ONE confidently predicted foreground pixel decides whether a class's whole pixel
         # set enters the sort), so figures taken after 30 more training steps -- along trajectories that differ in the last bits between
