@@ -36,6 +36,7 @@ struct LvWs {
   uint32_t* minfg;    // [MAXK] bits of the smallest foreground error per class
   uint32_t* nact;     // [MAXK] length of the sorted sequence per class (P, or the active prefix when pruning)
   uint32_t* blkcnt;   // [K][nblk] active elements per 256-pixel block -> exclusive offsets
+  unsigned long long* actmask;   // [P] bit c = class c keeps this pixel in its sort (active-set pruning)
 };
 
 size_t lv_layout(long long P, int K, char* base, LvWs* w) {
@@ -60,6 +61,7 @@ size_t lv_layout(long long P, int K, char* base, LvWs* w) {
   t.minfg = (uint32_t*)take(MAXK * 4);
   t.nact = (uint32_t*)take(MAXK * 4);
   t.blkcnt = (uint32_t*)take((size_t)K * ((P + PIX - 1) / PIX) * 4);
+  t.actmask = (unsigned long long*)take((size_t)P * 8);
   if (w) *w = t;
   return off;
 }
@@ -216,12 +218,14 @@ __global__ __launch_bounds__(PIX) void lv_minfg_kernel(const float* __restrict__
   if (threadIdx.x < K && mn[threadIdx.x] != 0x7F7F7F7Fu) atomicMin(&minfg[threadIdx.x], mn[threadIdx.x]);
 }
 
-// WRITE = false: count the active elements of each (class, 256-pixel block); WRITE = true: write them compacted
-template <bool WRITE>
-__global__ __launch_bounds__(PIX) void lv_compact_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, long long P, int K,
-                                                         const uint32_t* __restrict__ counts, const uint32_t* __restrict__ minfg,
-                                                         uint32_t* __restrict__ blkcnt, long long nblk, uint32_t* __restrict__ keys,
-                                                         uint32_t* __restrict__ vals) {
+// ONE pass over the logits decides, counts and stashes: per (class, 256-pixel block) the active elements are compacted INSIDE the block, in
+// pixel order, into tmp[c][p0 + rank] = key | fg << 31 (keys have 30 significant bits), their number goes to blkcnt[c][block] and the pixel's
+// class bits to actmask[p].  After the scan of the counts, lv_gather_kernel moves each block's run to its place in the class's sequence -- it
+// reads the active elements only (round 4 ran this pass twice, count and write: a second read of the logits and a second softmax per pixel).
+__global__ __launch_bounds__(PIX) void lv_compact1_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, long long P, int K,
+                                                          const uint32_t* __restrict__ counts, const uint32_t* __restrict__ minfg,
+                                                          uint32_t* __restrict__ blkcnt, long long nblk, uint32_t* __restrict__ tmp,
+                                                          unsigned long long* __restrict__ actmask) {
   extern __shared__ float sh[];
   __shared__ uint32_t wcnt[4][MAXK];
   const int KS = K | 1;
@@ -239,37 +243,63 @@ __global__ __launch_bounds__(PIX) void lv_compact_kernel(const float* __restrict
     lab = labels[p0 + t];
   }
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  uint32_t act_bits = 0, act_bits_hi = 0;  // K <= 64: two words of "class c keeps this pixel"
-  // pass 1: per-wave counts
+  unsigned long long bits = 0;   // K <= 64
   for (int c = 0; c < K; ++c) {
     bool a = false;
     if (live && counts[c] != 0) {
       const uint32_t fg = (lab == c) ? 1u : 0u;
       const float err = fabsf((float)fg - row[c] / s);
       a = fg || __float_as_uint(err) >= minfg[c];
+      if (a) row[c] = err;       // (kept for the write below: the element's key)
     }
     const unsigned long long bal = __ballot(a);
     if (lane == 0) wcnt[wave][c] = (uint32_t)__popcll(bal);
-    if (a) { if (c < 32) act_bits |= 1u << c; else act_bits_hi |= 1u << (c - 32); }
+    if (a) bits |= 1ull << c;
   }
+  if (live) actmask[p0 + t] = bits;
   __syncthreads();
-  if (!WRITE) {
-    if (t < K) blkcnt[(long long)t * nblk + blockIdx.x] = wcnt[0][t] + wcnt[1][t] + wcnt[2][t] + wcnt[3][t];
-    return;
-  }
-  const long long p = p0 + t;
+  if (t < K) blkcnt[(long long)t * nblk + blockIdx.x] = wcnt[0][t] + wcnt[1][t] + wcnt[2][t] + wcnt[3][t];
   for (int c = 0; c < K; ++c) {
-    const bool a = c < 32 ? (act_bits >> c) & 1u : (act_bits_hi >> (c - 32)) & 1u;
+    const bool a = (bits >> c) & 1ull;
     const unsigned long long bal = __ballot(a);
     if (a) {
-      uint32_t off = blkcnt[(long long)c * nblk + blockIdx.x];
+      uint32_t off = (uint32_t)__popcll(bal & lt_mask);
       for (int w2 = 0; w2 < wave; ++w2) off += wcnt[w2][c];
-      off += (uint32_t)__popcll(bal & lt_mask);
       const uint32_t fg = (lab == c) ? 1u : 0u;
-      const float err = fabsf((float)fg - row[c] / s);
-      keys[(long long)c * P + off] = 0x3F800000u - __float_as_uint(err);
-      vals[(long long)c * P + off] = (uint32_t)p | (fg << 31);
+      tmp[(long long)c * P + p0 + off] = (0x3F800000u - __float_as_uint(row[c])) | (fg << 31);
     }
+  }
+}
+
+// blkoff = the exclusive scan of blkcnt (lv_blkscan_kernel); a block's run of class c is [blkoff[c][b], blkoff[c][b + 1]) (the last one ends at
+// nact[c]).  val = the element's position in the class's compacted (pixel-ordered) sequence | fg << 31: d loss / d prob is stored in that
+// compact domain (lv_grad_kernel scatters to it, lv_backward_kernel finds a pixel's slot from actmask and blkoff) -- no K x P plane is zeroed
+// or read for the pruned elements.
+__global__ __launch_bounds__(PIX) void lv_gather_kernel(const uint32_t* __restrict__ tmp, long long P, int K, const uint32_t* __restrict__ counts,
+                                                        const uint32_t* __restrict__ blkoff, long long nblk, const uint32_t* __restrict__ nact,
+                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const long long p0 = (long long)blockIdx.x * PIX;
+  const uint32_t t = threadIdx.x;
+  const bool last = blockIdx.x + 1 == nblk;
+  for (int c0 = 0; c0 < K; c0 += 5) {          // five classes' loads in flight (a class per round trip made this pass latency-bound)
+    uint32_t off[5], n[5], v[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int c = c0 + u;
+      off[u] = 0; n[u] = 0;
+      if (c < K && counts[c] != 0) {
+        off[u] = blkoff[(long long)c * nblk + blockIdx.x];
+        n[u] = (last ? nact[c] : blkoff[(long long)c * nblk + blockIdx.x + 1]) - off[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) v[u] = t < n[u] ? tmp[(long long)(c0 + u) * P + p0 + t] : 0u;
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+      if (t < n[u]) {
+        keys[(long long)(c0 + u) * P + off[u] + t] = v[u] & 0x7FFFFFFFu;
+        vals[(long long)(c0 + u) * P + off[u] + t] = (off[u] + t) | (v[u] & 0x80000000u);
+      }
   }
 }
 
@@ -601,16 +631,35 @@ __global__ __launch_bounds__(256) void lv_finalize_kernel(const uint32_t* __rest
   }
 }
 
+// actmask != nullptr (active-set pruning): d loss / d prob lives in the compact domain of lv_gather_kernel -- the slot of (pixel, class) is
+// blkoff[c][block] + the number of active pixels of class c in front of this one inside the block (ballot ranks, as lv_compact1_kernel
+// counted them); a pruned element's gradient is exactly 0 and is never stored.  actmask == nullptr: dprob is [K][P] by pixel.
 __global__ __launch_bounds__(PIX) void lv_backward_kernel(const float* __restrict__ logits, long long P, int K, const uint32_t* __restrict__ counts,
                                                           const float* __restrict__ dprob, float weight, float* __restrict__ dlogits, int acc,
-                                                          const float* __restrict__ upstream = nullptr) {
+                                                          const float* __restrict__ upstream, const unsigned long long* __restrict__ actmask,
+                                                          const uint32_t* __restrict__ blkoff, long long nblk) {
   extern __shared__ float sh[];
+  __shared__ uint32_t wcnt[4][MAXK];
   const int KS = K | 1;
   const long long p0 = (long long)blockIdx.x * PIX;
   const int np = (int)min((long long)PIX, P - p0);
   stage_rows(logits, p0, np, K, KS, sh);
-  __syncthreads();
   const int t = threadIdx.x;
+  unsigned long long bits = 0;
+  if (actmask) {
+    const int lane = t & 63, wave = t >> 6;
+    if (t < np) bits = actmask[p0 + t];
+    for (int c = 0; c < K; ++c) {
+      const unsigned long long bal = __ballot((bits >> c) & 1ull);
+      if (lane == 0) wcnt[wave][c] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    if (t < K) {        // thread = class: wcnt[w][c] <- first compact slot of wave w's pixels of class c
+      const uint32_t b = blkoff[(long long)t * nblk + blockIdx.x], w0 = wcnt[0][t], w1 = wcnt[1][t], w2 = wcnt[2][t];
+      wcnt[0][t] = b; wcnt[1][t] = b + w0; wcnt[2][t] = b + w0 + w1; wcnt[3][t] = b + w0 + w1 + w2;
+    }
+  }
+  __syncthreads();
   if (t < np) {
     float* row = sh + t * KS;
     float m = row[0];
@@ -628,10 +677,27 @@ __global__ __launch_bounds__(PIX) void lv_backward_kernel(const float* __restric
     float dot = 0.f;
     for (int c0 = 0; c0 < K; c0 += 8) {   // eight independent class-plane loads in flight (absent classes: dprob is not written, g = 0)
       float gv[8];
+      if (actmask) {
+        const int lane = t & 63, wave = t >> 6;
+        const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int c = c0 + u;
-        gv[u] = (c < K && counts[c]) ? dprob[(long long)c * P + p] : 0.f;
+        for (int u = 0; u < 8; ++u) {
+          const int c = c0 + u;
+          gv[u] = 0.f;
+          if (c < K) {
+            // (every lane of the wave is here: np is a multiple of 64 except in the tensor's last block, whose idle lanes hold bits = 0 and
+            //  are not inside this branch -- their ballot bit is 0 either way)
+            const bool a = (bits >> c) & 1ull;
+            const unsigned long long bal = __ballot(a);
+            if (a) gv[u] = dprob[(long long)c * P + wcnt[wave][c] + (uint32_t)__popcll(bal & lt_mask)];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int c = c0 + u;
+          gv[u] = (c < K && counts[c]) ? dprob[(long long)c * P + p] : 0.f;
+        }
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -821,12 +887,12 @@ int lovasz_run(const float* logits, const int64_t* labels, long long P, int K, f
     // active-set pruning: min foreground error per class -> count -> scan -> ordered compaction (3 passes over the logits)
     if (hipMemsetAsync(w.minfg, 0x7F, MAXK * 4, st) != hipSuccess) { catseg_set_error("lovasz: memset failed"); return CATSEG_EHIP; }
     hipLaunchKernelGGL(lv_minfg_kernel, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, w.minfg);
-    hipLaunchKernelGGL(lv_compact_kernel<false>, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, (const uint32_t*)w.counts,
-                       (const uint32_t*)w.minfg, w.blkcnt, (long long)nb, w.keys[0], w.vals[0]);
+    hipLaunchKernelGGL(lv_compact1_kernel, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, (const uint32_t*)w.counts,
+                       (const uint32_t*)w.minfg, w.blkcnt, (long long)nb, w.keys[1], w.actmask);
     hipLaunchKernelGGL(lv_blkscan_kernel, dim3(K), dim3(1024), 0, st, (const uint32_t*)w.counts, w.blkcnt, (long long)nb, w.nact);
-    hipLaunchKernelGGL(lv_compact_kernel<true>, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, (const uint32_t*)w.counts,
-                       (const uint32_t*)w.minfg, w.blkcnt, (long long)nb, w.keys[0], w.vals[0]);
-    if (want_grad && hipMemsetAsync(w.dprob, 0, (size_t)K * P * 4, st) != hipSuccess) { catseg_set_error("lovasz: memset failed"); return CATSEG_EHIP; }
+    hipLaunchKernelGGL(lv_gather_kernel, dim3(nb), dim3(PIX), 0, st, (const uint32_t*)w.keys[1], P, K, (const uint32_t*)w.counts,
+                       (const uint32_t*)w.blkcnt, (long long)nb, (const uint32_t*)w.nact, w.keys[0], w.vals[0]);
+    // (d loss / d prob in the compact domain: every slot below nact[c] is written by lv_grad_kernel, nothing beyond it is read)
   } else {
     hipLaunchKernelGGL(lv_fill_nact_kernel, dim3(1), dim3(64), 0, st, w.nact, (uint32_t)P);
     hipLaunchKernelGGL(lv_prep_kernel, dim3(nb), dim3(PIX), shb, st, logits, labels, P, K, (const uint32_t*)w.counts, w.keys[0], w.vals[0]);
@@ -848,7 +914,8 @@ int lovasz_run(const float* logits, const int64_t* labels, long long P, int K, f
   hipLaunchKernelGGL(lv_finalize_kernel, dim3(1), dim3(256), 0, st, (const uint32_t*)w.counts, (const float*)w.lpart, ntiles, K, weight, loss_out, 0);
   if (dlogits)
     hipLaunchKernelGGL(lv_backward_kernel, dim3(nb), dim3(PIX), 2 * shb, st, logits, P, K, (const uint32_t*)w.counts, (const float*)w.dprob, weight, dlogits,
-                       accumulate_dlogits);
+                       accumulate_dlogits, (const float*)nullptr, g_prune ? (const unsigned long long*)w.actmask : nullptr, (const uint32_t*)w.blkcnt,
+                       (long long)nb);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
@@ -877,8 +944,9 @@ extern "C" int catseg_lovasz_softmax_bwd(const float* logits, long long P, int K
   lv_layout(P, K, (char*)workspace, &w);
   const int nb = (int)((P + PIX - 1) / PIX);
   const size_t shb = (size_t)PIX * (K | 1) * 4;
+  // (the workspace holds what THIS process' _fwd call left: catseg_debug_set_lovasz_prune must not change between the two calls)
   hipLaunchKernelGGL(lv_backward_kernel, dim3(nb), dim3(PIX), 2 * shb, (hipStream_t)stream, logits, P, K, (const uint32_t*)w.counts, (const float*)w.dprob, weight,
-                     dlogits, accumulate_dlogits, upstream);
+                     dlogits, accumulate_dlogits, upstream, g_prune ? (const unsigned long long*)w.actmask : nullptr, (const uint32_t*)w.blkcnt, (long long)nb);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

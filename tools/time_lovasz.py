@@ -24,4 +24,10 @@ for K in (25, 17):
     t = timeit(lambda: ops.lovasz_softmax(lg, lb, 1.0, dl))
     loss = float(ops.lovasz_softmax(lg, lb, 1.0, dl))
     out += "  K=%d: lovasz %7.1f us (loss %.7f, |dl| %.6e)" % (K, t, loss, float(dl.double().abs().sum()))
+    if K == 25:
+        # a randomly initialised network (the bench's regime): near-uniform predictions, the pruning keeps ~1/K of the elements
+        lg = 0.05 * torch.randn(P, K, device=dev, generator=g)
+        t = timeit(lambda: ops.lovasz_softmax(lg, lb, 1.0, dl))
+        loss = float(ops.lovasz_softmax(lg, lb, 1.0, dl))
+        out += "  K=25 random-init: %7.1f us (loss %.7f, |dl| %.6e)" % (t, loss, float(dl.double().abs().sum()))
 print(out, flush=True)
