@@ -164,6 +164,10 @@ int catseg_conv2d_bwd_data_f16x2_blocked(const catseg_conv_desc* d, const void* 
 size_t catseg_conv2d_bwd_weight_f16x2_workspace(const catseg_conv_desc* d);
 int catseg_conv2d_bwd_weight_f16x2(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* dy_planes,
                                    const void* dy_scale, float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
+/* the same from the BLOCKED planes of catseg_split2h (the operand layout of the forward / backward-data kernels): one plane set per tensor
+ * serves all three directions of a layer (the backward of F.conv2d at models/OCR.py:72-89, 326-333). */
+int catseg_conv2d_bwd_weight_f16x2_blocked(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* dy_planes,
+                                           const void* dy_scale, float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
 
 /* ---- direct 3x3 / stride 1 / pad 1 convolution in split precision (csrc/dconv3_b3.hip) for the HRNet trunk: the BasicBlock
  * convolutions conv3x3(planes, planes) at models/HRNetv2.py:22-25,41-44 (Cin = Cout = C in {48, 96}; catseg_dconv3_supported).

@@ -490,6 +490,8 @@ struct H2TArgs {
   int H, W, Ho, Wo, kw, stride, pad, dil;
   int step_b, step_qy, step_rx;                    // 16 pixels = step_b images + step_qy rows + step_rx pixels
   int tilesM, tilesN;
+  int blocked;                                     // planes in the BLOCKED layout [C/16][rows][16] (the forward / backward-data operand): see below
+  long long x_rows;                                // blocked: pixel rows of the x planes (B * H * W)
 };
 
 __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
@@ -537,7 +539,14 @@ __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
   bool bcv[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
+#ifdef H2T_STAGE2
     const int q = j * 256 + tid, krow = q >> 5, cl = (q & 31) ^ ((krow & 3) << 2);
+#else
+    // LDS image of a plane: [group of 4 pixel rows][half of the 256 columns][pixel row & 3][16 chunks] -- one LDS-DMA instruction (64 lanes,
+    // 1 KB of LDS) covers FOUR consecutive pixel rows x 16 chunks, so that with blocked planes a 16-channel chunk contributes 4 x 32 = 128
+    // contiguous bytes per instruction (two rows x 32 chunks, the round-3 image, made that 64: +4 % on the kernel)
+    const int q = j * 256 + tid, krow = ((q >> 7) << 2) | ((q >> 4) & 3), cl = ((((q >> 6) & 1) << 4) | (q & 15)) ^ ((krow & 3) << 2);
+#endif
     arow[j] = r_begin + krow;
     acol[j] = (m0 + cl * 8) < p.ldo ? m0 + cl * 8 : -1;
     brow[j] = r_begin + krow;
@@ -560,12 +569,25 @@ __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
   // s_waitcnt vmcnt(0) in front of the first fragment read behind the issue -- every K-step waited for its own fresh loads.)
   const unsigned apl_b = (unsigned)(p.dy_plane * 2), xpl_b = (unsigned)(p.x_plane * 2);
   constexpr unsigned OOB = 0xFFFFFFF0u;
+  // byte offset of a lane's 8-channel chunk = pixel row * mul + add.  Planar planes [row][ld]: mul = 2 ld, add = 2 channel.  BLOCKED planes
+  // [channel / 16][row][16] -- what igemm_h2w_kernel reads, so that ONE plane set per tensor serves all three directions (round 5: the planar
+  // set and its share of the split pass' write traffic are gone): mul = 32, add = (channel / 16) rows 32 + (channel & 8) 2.  A DMA instruction
+  // (2 pixel rows x 32 chunks) then touches 16 pieces of 64 contiguous bytes instead of 2 of 512; the neighbouring waves fetch the other halves
+  // of the same 128-byte lines in the same K-step.
+  const unsigned amul = p.blocked ? 32u : (unsigned)p.ldo * 2u, bmul = p.blocked ? 32u : (unsigned)p.ldx * 2u;
+  unsigned aadd[2], badd[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const unsigned ac = (unsigned)(acol[j] < 0 ? 0 : acol[j]), bc = (unsigned)bch[j];
+    aadd[j] = p.blocked ? (ac >> 4) * (unsigned)p.P * 32u + (ac & 8u) * 2u : ac * 2u;
+    badd[j] = p.blocked ? (bc >> 4) * (unsigned)p.x_rows * 32u + (bc & 8u) * 2u : bc * 2u;
+  }
   unsigned VA[2], VB[2];
   auto prepA = [&]() {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const bool ok = (int)(arow[j] < r_end) & (int)(acol[j] >= 0);
-      VA[j] = ok ? (unsigned)(arow[j] * p.ldo + acol[j]) * 2u : OOB;
+      VA[j] = ok ? (unsigned)arow[j] * amul + aadd[j] : OOB;
       arow[j] += 16;
     }
   };
@@ -573,7 +595,7 @@ __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
     const int iy = ty[j] * p.stride - p.pad + bky[j] * p.dil;
     const int ix = tx[j] * p.stride - p.pad + bkx[j] * p.dil;
     const bool ok = (int)(brow[j] < r_end) & (int)bcv[j] & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W);
-    VB[j] = ok ? (unsigned)(((tb[j] * p.H + iy) * p.W + ix) * p.ldx + bch[j]) * 2u : OOB;
+    VB[j] = ok ? (unsigned)((tb[j] * p.H + iy) * p.W + ix) * bmul + badd[j] : OOB;
     brow[j] += 16;                                   // advance this row by 16 pixels
     tx[j] += p.step_rx;
     ty[j] += p.step_qy;
@@ -618,11 +640,17 @@ __global__ __launch_bounds__(256, 1) void igemm_h2t_kernel(const H2TArgs p) {
   int ra[TM], rb[TN];
   {
     const int g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+#ifdef H2T_STAGE2
     const int rowb = (8 * h + q) * 512;               // pixel row 8h + q (+ 4 for the second read: + 2048 bytes)
+    const int hm = wm * 256, hn = wn * 256;
+#else
+    const int rowb = h * 4096 + q * 256;              // pixel row 8h + q: row group 2h (+ 1 for the second read: + 2048 bytes), row q inside it
+    const int hm = wm * 1024, hn = wn * 1024;         // the wave's half of the columns
+#endif
 #pragma unroll
-    for (int t = 0; t < TM; ++t) ra[t] = rowb + ((wm * 16 + ((t ^ q) << 2) + 2 * g1 + (pp >> 1)) << 4) + ((pp & 1) << 3);
+    for (int t = 0; t < TM; ++t) ra[t] = rowb + hm + ((((t ^ q) << 2) + 2 * g1 + (pp >> 1)) << 4) + ((pp & 1) << 3);
 #pragma unroll
-    for (int u = 0; u < TN; ++u) rb[u] = 2 * PLANE + rowb + ((wn * 16 + ((u ^ q) << 2) + 2 * g1 + (pp >> 1)) << 4) + ((pp & 1) << 3);
+    for (int u = 0; u < TN; ++u) rb[u] = 2 * PLANE + rowb + hn + ((((u ^ q) << 2) + 2 * g1 + (pp >> 1)) << 4) + ((pp & 1) << 3);
   }
   half8 Ah[TM], Bh[TN], Al[TM], Bl[TN];
 #define T_READ(dst, base, off)                                                                              \
@@ -942,23 +970,25 @@ extern "C" size_t catseg_conv2d_bwd_weight_f16x2_workspace(const catseg_conv_des
 
 // dw[o][ky][kx][c] = sum_p dy[p][o] x[pix(p,ky,kx)][c] from two-plane fp16 operands in the PLANAR layout of catseg_split2h:
 // dy_planes / dy_scale of dy (C = Cout), x_planes / x_scale of x (C = Cin, Cin % 8 == 0)
-extern "C" int catseg_conv2d_bwd_weight_f16x2(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* dy_planes,
-                                              const void* dy_scale, float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+namespace {
+int run_h2t(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* dy_planes, const void* dy_scale, float* dw,
+            void* workspace, size_t workspace_bytes, int blocked, hipStream_t st) {
   CS_REQUIRE(d && !d->stem4 && d->groups <= 1 && d->Cin % 8 == 0, "conv bwd_weight f16x2: dense, Cin % 8 == 0");
   CS_REQUIRE(cs_aligned16(x_planes) && cs_aligned16(dy_planes) && cs_aligned16(dw) && x_scale && dy_scale, "conv bwd_weight f16x2: alignment");
-  CS_REQUIRE((long long)d->B * d->H * d->W * d->Cin * 4 < (1ll << 32) - 64 && (long long)d->B * d->Ho * d->Wo * ((d->Cout + 7) & ~7) * 4 < (1ll << 32) - 64,
+  const int cpad_x = blocked ? (d->Cin + 15) & ~15 : d->Cin, cpad_o = blocked ? (d->Cout + 15) & ~15 : (d->Cout + 7) & ~7;
+  CS_REQUIRE((long long)d->B * d->H * d->W * cpad_x * 4 < (1ll << 32) - 64 && (long long)d->B * d->Ho * d->Wo * cpad_o * 4 < (1ll << 32) - 64,
              "conv bwd_weight f16x2: an operand's two planes must stay below 4 GB");
   const size_t need = catseg_conv2d_bwd_weight_f16x2_workspace(d);
   if (workspace_bytes < need || (need && !workspace)) {
     catseg_set_error("conv bwd_weight f16x2: workspace %zu < %zu", workspace_bytes, need);
     return CATSEG_EWORKSPACE;
   }
-  hipStream_t st = (hipStream_t)stream;
   H2TArgs a = {};
   a.P = d->B * d->Ho * d->Wo;
   a.M = d->Cout; a.Cin = d->Cin; a.taps = d->kh * d->kw; a.N = a.taps * d->Cin;
-  a.ldo = (d->Cout + 7) & ~7; a.dy = (const u16*)dy_planes; a.dy_plane = (long long)a.P * a.ldo;
-  a.ldx = d->Cin; a.x = (const u16*)x_planes; a.x_plane = (long long)d->B * d->H * d->W * d->Cin;
+  a.ldo = (d->Cout + 7) & ~7; a.dy = (const u16*)dy_planes; a.dy_plane = (long long)a.P * cpad_o;
+  a.ldx = d->Cin; a.x = (const u16*)x_planes; a.x_rows = (long long)d->B * d->H * d->W; a.x_plane = a.x_rows * cpad_x;
+  a.blocked = blocked;
   a.edy = (const int*)dy_scale + 1; a.ex = (const int*)x_scale + 1;
   a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
   const int img = d->Ho * d->Wo;
@@ -978,4 +1008,18 @@ extern "C" int catseg_conv2d_bwd_weight_f16x2(const catseg_conv_desc* d, const v
     CS_LAUNCH_CHECK();
   }
   return CATSEG_OK;
+}
+}  // namespace
+
+extern "C" int catseg_conv2d_bwd_weight_f16x2(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* dy_planes,
+                                              const void* dy_scale, float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+  return run_h2t(d, x_planes, x_scale, dy_planes, dy_scale, dw, workspace, workspace_bytes, 0, (hipStream_t)stream);
+}
+
+// the same from the BLOCKED planes of catseg_split2h ([2][ceil(C / 16)][rows][16], channel tails zero) -- the planes the forward and the
+// backward-data kernel read: one plane set per tensor serves all three directions
+extern "C" int catseg_conv2d_bwd_weight_f16x2_blocked(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* dy_planes,
+                                                      const void* dy_scale, float* dw, void* workspace, size_t workspace_bytes,
+                                                      catseg_stream_t stream) {
+  return run_h2t(d, x_planes, x_scale, dy_planes, dy_scale, dw, workspace, workspace_bytes, 1, (hipStream_t)stream);
 }

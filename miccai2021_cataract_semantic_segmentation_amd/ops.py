@@ -169,6 +169,11 @@ def _h2():
     return HEADS == "f16x2"
 
 
+# Backward-weight of the f16x2 layers from the BLOCKED planes its forward / backward-data read (csrc/igemm_f16x2.hip: igemm_h2t_kernel's
+# blocked mode): one plane set per tensor, the split passes write half as much.  CATSEG_H2T=planar: the separate planar set of round 3.
+H2T_BLOCKED = _os.environ.get("CATSEG_H2T", "blocked") != "planar"
+
+
 # A/B hooks (tools/ab_env_bench.sh): launch-shape knobs of the library's debug interface (include/catseg_debug.h) from the environment, so that
 # a whole bench process can run under another setting.  Unset = the library's defaults.
 for _var, _setter in (("CATSEG_WG_BLOCKS", "catseg_debug_set_dwgrad3_blocks"), ("CATSEG_DC_BLOCKS", "catseg_debug_set_dconv3_blocks"),
@@ -750,7 +755,7 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
         blk = _b3_blocked_ok(max(zero_to, Cout), Cin, B * H * W, Cout, kh * kw)
         if blk and _h2():
             with _Timed("split3", 0.0):
-                xp, xsc = _split3_cached(x, "h2", both=train, keep=train)
+                xp, xsc = _split3_cached(x, "h2", both=train and not H2T_BLOCKED, keep=train)
                 wp, wsc = split2h_weight_blocked(w_ptr_tensor)
             with _Timed("fwd_h2", flops):
                 check(lib.catseg_conv2d_fwd_f16x2_blocked(ctypes.byref(d), ptr(xp), ptr(xsc), ptr(wp), ptr(wsc), ptr(bias), ptr(out), zero_to,
@@ -898,7 +903,20 @@ def _wgrad_dgrad_blk(x, dy, kh, kw, stride):
 
 def _wgrad_h2_route(x, dy):
     Cout, Cin = dy.shape[-1], x.shape[-1]
-    return bool(_h2() and 4 * rows_of(x) * Cin < B3_PLANE_LIMIT and 4 * rows_of(dy) * ((Cout + 7) // 8 * 8) < B3_PLANE_LIMIT)
+    pad = 16 if H2T_BLOCKED else 8
+    return bool(_h2() and 4 * rows_of(x) * ((Cin + pad - 1) // pad * pad) < B3_PLANE_LIMIT
+                and 4 * rows_of(dy) * ((Cout + pad - 1) // pad * pad) < B3_PLANE_LIMIT)
+
+
+def _wgrad_h2_planes(x, dy, dgrad_blk):
+    """(x planes, x scale, dy planes, dy scale) of the f16x2 backward-weight kernel"""
+    if H2T_BLOCKED:
+        xp, xsc = _split3_cached(x, "h2")
+        dyp, dysc = _split3_cached_dy(dy, "h2")
+    else:
+        xp, xsc = _split3_cached(x, "h2p")
+        dyp, dysc = _split3_cached_dy(dy, "h2p", both=dgrad_blk)
+    return xp, xsc, dyp, dysc
 
 
 def wgrad_presplit(x, dy, kh, kw, stride=1, pad=0, dil=1, stem4=False, groups=1):
@@ -913,9 +931,7 @@ def wgrad_presplit(x, dy, kh, kw, stride=1, pad=0, dil=1, stem4=False, groups=1)
     dgrad_blk = _wgrad_dgrad_blk(x, dy, kh, kw, stride)
     with _Timed("split3", 0.0):
         if _wgrad_h2_route(x, dy):
-            xp, xsc = _split3_cached(x, "h2p")
-            dyp, dysc = _split3_cached_dy(dy, "h2p", both=dgrad_blk)
-            return [xp, xsc, dyp, dysc]
+            return list(_wgrad_h2_planes(x, dy, dgrad_blk))
         return [_split3_cached(x, "planar"), _split3_cached_dy(dy, "planar", both=dgrad_blk)]
 
 
@@ -962,11 +978,10 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
             # blocked planes for this layer's backward-data from the same pass
             wsb = workspace(lib.catseg_conv2d_bwd_weight_f16x2_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
             with _Timed("split3", 0.0):
-                xp, xsc = _split3_cached(x, "h2p")
-                dyp, dysc = _split3_cached_dy(dy, "h2p", both=dgrad_blk)
+                xp, xsc, dyp, dysc = _wgrad_h2_planes(x, dy, dgrad_blk)
             with _Timed("wgrad_h2", flops):
-                check(lib.catseg_conv2d_bwd_weight_f16x2(ctypes.byref(d), ptr(xp), ptr(xsc), ptr(dyp), ptr(dysc), ptr(dw), ptr(wsb), wsb.numel(),
-                                                         stream()))
+                fn = lib.catseg_conv2d_bwd_weight_f16x2_blocked if H2T_BLOCKED else lib.catseg_conv2d_bwd_weight_f16x2
+                check(fn(ctypes.byref(d), ptr(xp), ptr(xsc), ptr(dyp), ptr(dysc), ptr(dw), ptr(wsb), wsb.numel(), stream()))
             if dbias is not None:
                 check(lib.catseg_bias_grad(ptr(dy), ld_of(dy), rows_of(dy), Cout, ptr(dbias), ptr(wsb), wsb.numel(), stream()))
             return dw

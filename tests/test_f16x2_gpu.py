@@ -152,6 +152,13 @@ def test_forward_and_backward_data_vs_fp64(ops, case):
                                                  ops.ptr(ws), ws.numel(), ops.stream()))
     e3 = close(dw, w64.grad, 2e-5)
     print("f16x2 %s: backward-weight %.2g of the output scale" % (case, e3))
+    # ... and from the BLOCKED planes (the operand layout of the forward / backward-data kernels): the same values reach the same MFMAs in the
+    # same order -- bit-identical results
+    gb = ops.split2h_blocked(gyd)[0]
+    dwb = torch.full((Co, Ci, k, k), float("nan")).cuda().contiguous(memory_format=torch.channels_last)
+    ops.check(lib.catseg_conv2d_bwd_weight_f16x2_blocked(ctypes.byref(dsc), ops.ptr(xb), ops.ptr(xsc), ops.ptr(gb), ops.ptr(gsc), ops.ptr(dwb),
+                                                         ops.ptr(ws), ws.numel(), ops.stream()))
+    assert torch.equal(dwb, dw), "backward-weight from blocked planes differs from the planar-plane result"
 
 
 def test_dispatch_takes_the_f16x2_kernels_and_matches_bf16x3(ops):
