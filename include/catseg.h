@@ -278,6 +278,16 @@ int catseg_bn_backward_pre_planes(const float* g, int ldg, const float* q, int l
                                   int n_blocks, long long rows, int C, void* dq_planes, void* dq_record, const void* g_record,
                                   const void* y_record, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                   catseg_stream_t stream);
+/* catseg_bn_backward with dy written ONLY as the blocked fp16 x 2 planes of catseg_split2h (dy_planes: catseg_split2h_blocked_elems(rows, C)
+ * halves; dy_scale: its 8-byte record {bits of the bound, e}) -- for a layer whose backward-weight / backward-data run
+ * catseg_conv2d_bwd_weight_f16x2_blocked / catseg_conv2d_bwd_data_f16x2_blocked (the BatchNorm behind the head convolutions, models/OCR.py:72-89,
+ * 326-333).  dbias (may be null) = column sums of dy (gradient of a convolution bias in front of the BatchNorm).  No residual branch; C % 64 == 0.
+ * g_record / y_record / dy_record: three zeroed amax records; they receive max|masked gradient|, max|y| and the bound dy's exponent came from. */
+size_t catseg_bn_backward_h2_workspace(long long rows, int C);
+int catseg_bn_backward_h2(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* stats, const float* gamma,
+                          const float* beta, long long rows, int C, int relu, void* dy_planes, void* dy_scale, float* dgamma, float* dbeta,
+                          float* dbias, void* g_record, void* y_record, void* dy_record, void* workspace, size_t workspace_bytes,
+                          catseg_stream_t stream);
 
 /* catseg_dwgrad3_f16x2 on producer-written planes of BOTH operands (csrc/dwgrad3_pl.hip): dw[o][ky][kx][c] = sum_px dy[px][o] x[px + tap][c]
  * for the trunk widths 48 / 96 / 192 / 384 (autograd of F.conv2d, models/HRNetv2.py:22-65); workspace = catseg_dwgrad3_pl_workspace bytes

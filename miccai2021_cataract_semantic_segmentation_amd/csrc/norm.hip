@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              int ldz, const float* __restrict__ y, int ldy,
                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, long long rows, int C, int relu,
-                                                             RowSplit s, float* __restrict__ part, unsigned* __restrict__ gmax_rec = nullptr) {
+                                                             RowSplit s, float* __restrict__ part, unsigned* __restrict__ gmax_rec = nullptr,
+                                                             unsigned* __restrict__ ymax_rec = nullptr) {
   const int t = threadIdx.x;
   const int cg = blockIdx.y * s.tpr + t % s.tpr;
   const int rl = t / s.tpr;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   const long long r1 = min(r0 + s.rpb, rows);
   const bool act = (c < C) && (rl < s.rpp);
   f32x4 sg = {0, 0, 0, 0}, sgx = {0, 0, 0, 0};
-  unsigned gm = 0;
+  unsigned gm = 0, ym = 0;
   if (act) {
     const f32x4 mean = ld4(stats + c), inv = ld4(stats + C + c);
     f32x4 sc = {0, 0, 0, 0}, be = {0, 0, 0, 0};
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         sg += g[u];
         sgx += g[u] * xh;
         gm = max(gm, cs_abs_bits4(g[u]));
+        ym = max(ym, cs_abs_bits4(yy[u]));
       }
     }
     for (; r < r1; r += st) {
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
       sg += g;
       sgx += g * xh;
       gm = max(gm, cs_abs_bits4(g));
+      ym = max(ym, cs_abs_bits4(yy));
     }
   }
   __shared__ f32x4 sh1[256], sh2[256];
@@ -343,6 +346,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     *(f32x4*)(o + C + c) = sgx;
   }
   if (gmax_rec) cs_amax_commit(gm, gmax_rec);     // max |masked gradient|: the bound of the output's planes needs it (bn_bwd_finalize_kernel)
+  if (ymax_rec) {                                 // max |y|, for a layer whose forward left none (the head layers: bn_bwd_apply_h2_kernel)
+    __syncthreads();                              // (cs_amax_commit's LDS words are still being read by thread 0 for the first record)
+    cs_amax_commit(ym, ymax_rec);
+  }
 }
 
 // 4 channels x 256 row lanes per block (the geometry of bn_finalize_kernel): up to 2040 partial rows (one per pixel tile of the direct
@@ -457,6 +464,108 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const float* _
     CsPlaneTile::flush(sm, planes, rows, NG, row0, left < CsPlaneTile::ROWS ? (int)left : CsPlaneTile::ROWS, g0, ng);
     __syncthreads();
   }
+}
+
+// bn_bwd_apply_kernel writing dy ONLY as the BLOCKED fp16 x 2 planes of the head layers' kernels (csrc/igemm_f16x2.hip: [2][C / 16][rows][16],
+// what catseg_split2h produces from an fp32 dy) -- the fp32 tensor, the split pass that read it back and the bias gradient's pass over it
+// disappear (round 5; per 512-channel head layer at 8 x 136 x 240: 535 MB written + 2 x 535 MB read).  The exponent comes from the bound
+// bn_bwd_finalize_kernel left in dy_rec, as for the trunk's planes; scale = the 8-byte record {bits of the bound, e} the consuming kernels read.
+// Grid (row blocks, channel blocks of 64): a block walks the 128-row tiles bx, bx + gridDim.x, ... of ITS 64 channels, so that the column
+// sums of dy -- the gradient of a convolution bias in front of the BatchNorm (models/OCR.py:72-74; mathematically 0, rounding noise in any
+// implementation) -- accumulate in registers: colpart[bx][C], merged by colsum_rows_kernel in a fixed order.  Requires C % 64 == 0.
+__global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz,
+                                                              const float* __restrict__ y, int ldy, const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ coef, long long rows, int C, int relu,
+                                                              unsigned char* __restrict__ planes, long long plane_bytes,
+                                                              const unsigned* __restrict__ dy_rec, unsigned* __restrict__ scale,
+                                                              float* __restrict__ colpart) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[CsPlaneTile::BYTES];
+  const unsigned bound = dy_rec[CS_REC_BOUND];
+  const int e = cs_plane_exponent(bound);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    scale[0] = bound;
+    ((int*)scale)[1] = e;
+  }
+  const float sc = __builtin_ldexpf(1.f, e);
+  const int g0 = blockIdx.y * 8, g8 = threadIdx.x & 7, c = (g0 + g8) * 8;     // this thread's 8 channels, for every tile
+  const long long rblocks = (rows + CsPlaneTile::ROWS - 1) / CsPlaneTile::ROWS;
+  f32x4 ga[2], ia[2], me[2], be[2], c0[2], c1[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    ia[q] = ld4(stats + C + c + 4 * q); me[q] = ld4(stats + c + 4 * q);
+    ga[q] = ld4(gamma + c + 4 * q);
+    be[q] = beta ? ld4(beta + c + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    c0[q] = ld4(coef + c + 4 * q); c1[q] = ld4(coef + C + c + 4 * q);
+  }
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long rt = blockIdx.x; rt < rblocks; rt += gridDim.x) {
+    const long long row0 = rt * CsPlaneTile::ROWS;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = (threadIdx.x >> 3) + 32 * k;
+      if (row0 + row < rows) {
+        const long long r = row0 + row;
+        float xs[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          f32x4 g = ld4(dz + r * lddz + c + 4 * q);
+          const f32x4 yy = ld4(y + r * ldy + c + 4 * q);
+          if (relu) {
+            const f32x4 zz = z ? ld4(z + r * ldz + c + 4 * q) : bn_affine(yy, me[q], ga[q] * ia[q], be[q]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = zz[j] > 0.f ? g[j] : 0.f;
+          }
+          const f32x4 xh = (yy - me[q]) * ia[q];
+          const f32x4 o = ga[q] * ia[q] * (g - c0[q] - xh * c1[q]);     // = bn_bwd_apply_kernel's expression
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            xs[4 * q + j] = o[j] * sc;
+            cs[4 * q + j] += o[j];
+          }
+        }
+        CsPlaneTile::stage(sm, row, g8, xs);
+      }
+    }
+    __syncthreads();
+    // the tile leaves as 32-byte (row, 16-channel chunk) pieces, consecutive rows of a chunk back to back: 2 KB runs per wave instruction
+    const long long left = rows - row0;
+    const int nrows = left < CsPlaneTile::ROWS ? (int)left : CsPlaneTile::ROWS;
+    for (int i = threadIdx.x; i < 2 * CsPlaneTile::GROUPS * CsPlaneTile::ROWS; i += 256) {
+      const int half = i & 1, row = (i >> 1) & (CsPlaneTile::ROWS - 1), cp = (i >> 8) & 3, p = i >> 10;
+      if (row < nrows)
+        *(cs_h8*)(planes + p * plane_bytes + (((long long)((g0 >> 1) + cp) * rows + row0 + row) << 5) + half * 16) =
+            *(const cs_h8*)(sm + p * CsPlaneTile::PS + (2 * cp + half) * CsPlaneTile::GS + row * 16);
+    }
+    __syncthreads();
+  }
+  if (colpart) {
+    float* red = (float*)sm;          // [32 row lanes][64 channels + 1]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[(threadIdx.x >> 3) * 65 + g8 * 8 + j] = cs[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float t = 0.f;
+      for (int k = 0; k < 32; ++k) t += red[k * 65 + threadIdx.x];
+      colpart[(long long)blockIdx.x * C + g0 * 8 + threadIdx.x] = t;
+    }
+  }
+}
+
+// out[c] = sum over the partial rows part[0 .. nparts)[c], four independent chains combined in a fixed order (csrc/igemm.hip: colsum_final_kernel)
+__global__ void colsum_rows_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int i = 0;
+  for (; i + 3 < nparts; i += 4) {
+    s0 += part[(long long)i * C + c];
+    s1 += part[(long long)(i + 1) * C + c];
+    s2 += part[(long long)(i + 2) * C + c];
+    s3 += part[(long long)(i + 3) * C + c];
+  }
+  for (; i < nparts; ++i) s0 += part[(long long)i * C + c];
+  out[c] = (s0 + s1) + (s2 + s3);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z,
@@ -754,6 +863,50 @@ extern "C" int catseg_bn_backward_pre_planes(const float* g, int ldg, const floa
   hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3((int)(tiles > 8192 ? 8192 : tiles)), dim3(256), 0, st, g, ldg, (const float*)nullptr, 0, q, ldq,
                      stats, gamma, (const float*)nullptr, (const float*)coef, rows, C, 0, (unsigned char*)dq_planes, (unsigned*)dq_record,
                      (float*)nullptr, 0, 0);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// catseg_bn_backward with dy written ONLY as the blocked fp16 x 2 planes of catseg_split2h (dy_planes: catseg_split2h_blocked_elems(rows, C)
+// halves; dy_scale: its 8-byte record), for a layer whose backward-weight / backward-data run catseg_conv2d_bwd_weight_f16x2_blocked /
+// catseg_conv2d_bwd_data_f16x2_blocked; dbias (may be null) = the column sums of dy (the gradient of a bias in front of the BatchNorm).
+// No residual branch.  g_record / y_record / dy_record: three zeroed amax records (csrc/common.h) -- they receive max|g|, max|y|, the bound of dy.
+extern "C" size_t catseg_bn_backward_h2_workspace(long long rows, int C) {
+  return catseg_bn_workspace(rows, C) + cs_align_up((size_t)256 * ((C + 3) & ~3) * 4, 256);
+}
+extern "C" int catseg_bn_backward_h2(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* stats,
+                                     const float* gamma, const float* beta, long long rows, int C, int relu, void* dy_planes, void* dy_scale,
+                                     float* dgamma, float* dbeta, float* dbias, void* g_record, void* y_record, void* dy_record, void* workspace,
+                                     size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && C % 64 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && dy_planes && dy_scale && g_record && y_record && dy_record,
+             "bn bwd (h2 planes): C must be a multiple of 64, ld of 4; planes, scale and records required");
+  CS_REQUIRE(!relu || (z != nullptr && ldz % 4 == 0) || (z == nullptr && beta != nullptr),
+             "bn bwd (h2 planes): relu needs z, or beta to recompute the mask from y");
+  CS_REQUIRE(cs_aligned16(dz) && cs_aligned16(y) && cs_aligned16(dy_planes) && cs_aligned16(stats) && cs_aligned16(gamma) && cs_aligned16(z) &&
+                 cs_aligned16(beta) && (((uintptr_t)dy_scale) & 7) == 0, "bn bwd (h2 planes): alignment");
+  CS_REQUIRE(rows * C * 4 < (1ll << 32) - 64, "bn bwd (h2 planes): the two planes must stay below 4 GB");
+  if (workspace_bytes < catseg_bn_backward_h2_workspace(rows, C) || !workspace) {
+    catseg_set_error("bn bwd (h2 planes): workspace too small");
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const RowSplit s = plan_rows(rows, C);
+  float* part = (float*)workspace;
+  float* coef = part + (size_t)kMaxRowBlocks * 3 * ((C + 3) & ~3);
+  float* colpart = (float*)((char*)workspace + catseg_bn_workspace(rows, C));
+  unsigned* g_rec = (unsigned*)g_record;
+  unsigned* y_rec = (unsigned*)y_record;
+  unsigned* dy_rec = (unsigned*)dy_record;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma, beta, rows, C, relu, s, part,
+                     g_rec, y_rec);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef,
+                     (const unsigned*)g_rec, (const unsigned*)y_rec, stats, gamma, dy_rec);
+  const long long rblocks = (rows + 127) / 128;
+  const int gx = (int)(rblocks < 256 ? rblocks : 256);
+  hipLaunchKernelGGL(bn_bwd_apply_h2_kernel, dim3(gx, C / 64), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma, beta, (const float*)coef, rows,
+                     C, relu, (unsigned char*)dy_planes, (long long)rows * C * 2, (const unsigned*)dy_rec, (unsigned*)dy_scale,
+                     dbias ? colpart : (float*)nullptr);
+  if (dbias) hipLaunchKernelGGL(colsum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)colpart, gx, C, dbias);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

@@ -525,6 +525,18 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
                         cx.bn_pre[id(x)] = r[1]
                 cx.done(bn.weight, bn.bias, w, conv.bias)
                 return
+            if (pre is None and residual is None and not conv.stem and not pad3 and not (conv.async_wgrad and ASYNC_WGRAD)
+                    and ops.h2_dy_route(x_in, y, w.data, kh, kw, s, p, d, conv.groups, need_dx)):
+                # head layers on the f16x2 kernels: dy exists only as the blocked planes both of its consumers read (ops.bn_backward_h2)
+                dyp, dysc = ops.bn_backward_h2(dz, y, stats, bn.weight.data, relu, cx.pgrad(bn.weight), cx.pgrad(bn.bias), bn.bias.data,
+                                               cx.pgrad(conv.bias) if conv.bias is not None else None)
+                del dz
+                ops.conv_bwd_weight_h2(x_in, dyp, dysc, Cout, cx.pgrad(w), kh, kw, s, p, d)
+                if need_dx:
+                    dx, accx = cx.dest(x)
+                    ops.conv_bwd_data_h2(dyp, dysc, w.data, tuple(x.shape), Cout, kh, kw, p, d, dx, accx)
+                cx.done(bn.weight, bn.bias, w, conv.bias)
+                return
             if pre is not None:
                 # dz is already masked and its per-tile sums exist (the consumer's backward-data epilogue): merge + apply only
                 dy = ops.bn_backward_pre(dz, y, stats, bn.weight.data, pre, cx.pgrad(bn.weight), cx.pgrad(bn.bias))

@@ -1169,6 +1169,82 @@ def bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres=None, dres_acc
     return dy_out
 
 
+# The head layers (conv -> BatchNorm -> ReLU on the f16x2 kernels: models/OCR.py:72-89, 326-333): the BatchNorm backward writes dy straight
+# as the blocked fp16 x 2 planes that the layer's backward-weight AND backward-data read (csrc/norm.hip: bn_bwd_apply_h2_kernel) -- no fp32 dy,
+# no split pass over it, the bias gradient from the same pass.  CATSEG_HEAD_DY_PLANES=0: fp32 dy + catseg_split2h, as before.
+HEAD_DY_PLANES = _os.environ.get("CATSEG_HEAD_DY_PLANES", "1") != "0"
+
+
+def h2_dy_route(x, y, w, kh, kw, stride, pad, dil, groups, need_dx):
+    """True when conv_bwd_weight / conv_bwd_data would BOTH run this layer on the blocked f16x2 planes of dy (the conditions below repeat
+    their route selection in its order; tests/test_heads_dy_planes_gpu.py pins the two against each other)"""
+    if not (HEAD_DY_PLANES and H2T_BLOCKED and _h2() and x.is_cuda and x.dim() == 4 and y.dim() == 4 and w.dim() == 4 and groups == 1):
+        return False
+    Cout, Cin, taps = y.shape[-1], x.shape[-1], kh * kw
+    rows_o, rows_i = rows_of(y), rows_of(x)
+    if Cout % 64 != 0 or 4 * rows_o * Cout >= B3_PLANE_LIMIT:
+        return False
+    # backward-weight: direct trunk kernel, pointwise kernel (the gather kernel is excluded by _wgrad_split_route), then the split route
+    if _d3_ok(rows_o, Cin, Cout, kh, kw, stride, pad, dil, groups) and lib.catseg_dwgrad3_supported(Cin):
+        return False
+    if ("wgrad" in P1_OPS and min(Cout, Cin) >= P1_WGRAD_MIN_DIM and _p1_ok(rows_o, Cin, Cout, kh, kw, stride, pad, dil, groups)
+            and lib.catseg_pconv1_wgrad_supported(Cout, Cin)):
+        return False
+    if not (_wgrad_split_route(x, y, kh, kw, stride, False, groups) and _wgrad_h2_route(x, y)):
+        return False
+    if need_dx:
+        if _d3_ok(rows_i, Cin, Cout, kh, kw, stride, pad, dil, groups):
+            return False
+        if "dgrad" in P1_OPS and _p1_ok(rows_i, Cout, Cin, kh, kw, stride, pad, dil, groups) and lib.catseg_pconv1_supported(Cin, Cout):
+            return False
+        if not (stride == 1 and "dgrad" in B3_OPS and _b3_eligible(rows_i, Cin, taps, (Cout + 7) // 8 * 8, True)
+                and _b3_blocked_ok(Cin, (Cout + 15) // 16 * 16, rows_o, Cin, taps)):
+            return False
+    return True
+
+
+def bn_backward_h2(dz, y, stats, gamma, relu, dgamma, dbeta, beta, dbias=None):
+    """BatchNorm (+ ReLU, mask recomputed from y) backward without a residual branch: (blocked planes of dy, their scale record); dbias = the
+    column sums of dy"""
+    C, rows = y.shape[-1], rows_of(y)
+    blk = torch.empty((2, C // 16, rows, 16), dtype=torch.int16, device=y.device)
+    scale = torch.empty(2, dtype=torch.int32, device=y.device)
+    need = lib.catseg_bn_backward_h2_workspace(rows, C)
+    ws = workspace(need, y.device)
+    grec, yrec, dyrec = new_amax(y.device), new_amax(y.device), new_amax(y.device)
+    with _Timed("hbm:bn_backward", 4.0 * y.numel() * 5):
+        check(lib.catseg_bn_backward_h2(ptr(dz), ld_of(dz), None, 0, ptr(y), ld_of(y), ptr(stats), ptr(gamma), ptr(beta), rows, C, 1 if relu else 0,
+                                        ptr(blk), ptr(scale), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(grec), ptr(yrec), ptr(dyrec), ptr(ws),
+                                        ws.numel(), stream()))
+    return blk, scale
+
+
+def conv_bwd_weight_h2(x, dyp, dysc, Cout, dw, kh, kw, stride, pad, dil):
+    """backward-weight from the blocked planes of dy (bn_backward_h2) and of x (kept from the forward pass, or split now)"""
+    Cin = x.shape[-1]
+    d = make_desc(x.shape, Cin, Cout, (Cout + 7) // 8 * 8, kh, kw, stride, pad, dil)
+    wsb = workspace(lib.catseg_conv2d_bwd_weight_f16x2_workspace(ctypes.byref(d)) + 256 * Cout * 4, x.device)
+    with _Timed("split3", 0.0):
+        xp, xsc = _split3_cached(x, "h2")
+    with _Timed("wgrad_h2", 2.0 * d.B * d.Ho * d.Wo * Cout * Cin * kh * kw):
+        check(lib.catseg_conv2d_bwd_weight_f16x2_blocked(ctypes.byref(d), ptr(xp), ptr(xsc), ptr(dyp), ptr(dysc), ptr(dw), ptr(wsb), wsb.numel(),
+                                                         stream()))
+    return dw
+
+
+def conv_bwd_data_h2(dyp, dysc, w, xshape, Cout, kh, kw, pad, dil, out, accumulate):
+    """backward-data (stride 1) from the blocked planes of dy"""
+    B, H, W, Cin = xshape
+    drop_amax(out)
+    d = make_desc(xshape, ld_of(out), Cout, (Cout + 7) // 8 * 8, kh, kw, 1, pad, dil)
+    with _Timed("split3", 0.0):
+        wtp, wtsc = split2h_weight_t_blocked(w)
+    with _Timed("dgrad_h2", 2.0 * d.B * d.Ho * d.Wo * Cout * Cin * kh * kw):
+        check(lib.catseg_conv2d_bwd_data_f16x2_blocked(ctypes.byref(d), ptr(dyp), ptr(dysc), ptr(wtp), ptr(wtsc), ptr(out),
+                                                       1 if accumulate else 0, stream()))
+    return out
+
+
 def bn_backward_pre(g, q, stats, gamma, partials, dgamma, dbeta, dq_out=None):
     """backward of relu(bn(q)) from the masked gradient g and the per-tile sums (partials, n_tiles) that conv_bwd_data(bn_src=...)
     returned: merge + apply pass only"""
