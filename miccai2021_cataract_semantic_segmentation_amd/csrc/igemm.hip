@@ -776,9 +776,30 @@ __global__ void colsum_partial_kernel(const float* __restrict__ dy, int ld, long
   __syncthreads();
   if (rl == 0 && c < C) part[(long long)blockIdx.y * C + c] = sh[threadIdx.x] + sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192];
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
+// the K-class logits' gradient (rows of 32 floats, C <= 32 valid columns; models/OCR.py:82-85, 98): 16-byte loads, 8 column quads x 32 row lanes per
+// block (the generic kernel above keeps 25 of 64 lanes busy with 4-byte loads 128 bytes apart: 90 us for a 33 MB tensor)
+__global__ __launch_bounds__(256) void colsum_ld32_kernel(const float* __restrict__ dy, long long rows, float* __restrict__ part) {
+  const int q = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  long long r = (long long)blockIdx.x * 32 + rl;
+  const long long st = (long long)gridDim.x * 32;
+  for (; r + st < rows; r += 2 * st) {
+    s0 += *(const f32x4*)(dy + r * 32 + q * 4);
+    s1 += *(const f32x4*)(dy + (r + st) * 32 + q * 4);
+  }
+  if (r < rows) s0 += *(const f32x4*)(dy + r * 32 + q * 4);
+  __shared__ f32x4 sh[256];
+  sh[threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (rl == 0) {
+    f32x4 t = sh[q];
+    for (int k = 1; k < 32; ++k) t += sh[k * 8 + q];
+    *(f32x4*)(part + (long long)blockIdx.x * 32 + q * 4) = t;
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out, int n_out = -1) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  if (c >= (n_out < 0 ? C : n_out)) return;
   // four independent chains (up to 256 partial rows: one dependent chain of loads was 66 us on the step's serial path), combined in a fixed order
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int i = 0;
@@ -1296,8 +1317,14 @@ extern "C" int catseg_conv2d_bwd_weight(const catseg_conv_desc* d, const float* 
     float* part = (float*)((char*)workspace + (splits > 1 ? (size_t)splits * wel * 4 : 0));
     const long long rows = (long long)d->B * d->Ho * d->Wo;
     const int gy = (int)((rows + 1023) / 1024 < 256 ? (rows + 1023) / 1024 : 256);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((d->Cout + 63) / 64, gy), dim3(256), 0, st, dy, d->ldy, rows, d->Cout, part);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((d->Cout + 255) / 256), dim3(256), 0, st, (const float*)part, gy, d->Cout, dbias);
+    if (d->ldy == 32 && d->Cout <= 32 && cs_aligned16(dy)) {       // (the workspace holds 256 x Cout floats for the partials: 256 x 32 only then)
+      const int gn = d->Cout == 32 ? gy : (int)((long long)gy * d->Cout / 32 > 0 ? (long long)gy * d->Cout / 32 : 1);
+      hipLaunchKernelGGL(colsum_ld32_kernel, dim3(gn), dim3(256), 0, st, dy, rows, part);
+      hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, st, (const float*)part, gn, 32, dbias, d->Cout);
+    } else {
+      hipLaunchKernelGGL(colsum_partial_kernel, dim3((d->Cout + 63) / 64, gy), dim3(256), 0, st, dy, d->ldy, rows, d->Cout, part);
+      hipLaunchKernelGGL(colsum_final_kernel, dim3((d->Cout + 255) / 256), dim3(256), 0, st, (const float*)part, gy, d->Cout, dbias);
+    }
     CS_LAUNCH_CHECK();
   }
   return CATSEG_OK;
@@ -1310,6 +1337,12 @@ extern "C" int catseg_bias_grad(const float* dy, int ld, long long rows, int C, 
   CS_REQUIRE(workspace && workspace_bytes >= (size_t)256 * C * 4, "bias_grad: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int gy = (int)((rows + 1023) / 1024 < 256 ? (rows + 1023) / 1024 : 256);
+  if (ld == 32 && C <= 32 && cs_aligned16(dy) && workspace_bytes >= (size_t)256 * 32 * 4) {
+    hipLaunchKernelGGL(colsum_ld32_kernel, dim3(gy), dim3(256), 0, st, dy, rows, (float*)workspace);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, gy, 32, dbias, C);
+    CS_LAUNCH_CHECK();
+    return CATSEG_OK;
+  }
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, gy), dim3(256), 0, st, dy, ld, rows, C, (float*)workspace);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace, gy, C, dbias);
   CS_LAUNCH_CHECK();

@@ -76,14 +76,28 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ logits, lon
   if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
     const int n4 = n >> 2;
     const float4* s4 = reinterpret_cast<const float4*>(src);
-    for (int i4 = threadIdx.x; i4 < n4; i4 += blockDim.x) {
-      const float4 v = s4[i4];
-      const float e[4] = {v.x, v.y, v.z, v.w};
-      int r = (4 * i4) / K, c = 4 * i4 - r * K;
+    // Eight 16-byte loads per thread IN FLIGHT, then their LDS stores (a load -> LDS store loop waits for every load in turn -- the compiler
+    // cannot move a global load over an LDS store through a generic pointer: 256 x 25 floats were 7 dependent HBM round trips per block and
+    // the per-pixel kernels ran at ~2 TB/s)
+    for (int base = 0; base < n4; base += 8 * blockDim.x) {
+      float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        sh[r * KS + c] = e[u];
-        if (++c == K) { c = 0; ++r; }
+      for (int u = 0; u < 8; ++u) {
+        const int i4 = base + u * blockDim.x + threadIdx.x;
+        v[u] = i4 < n4 ? s4[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i4 = base + u * blockDim.x + threadIdx.x;
+        if (i4 < n4) {
+          const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+          int r = (4 * i4) / K, c = 4 * i4 - r * K;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            sh[r * KS + c] = e[q];
+            if (++c == K) { c = 0; ++r; }
+          }
+        }
       }
     }
     done = n4 << 2;
@@ -614,9 +628,16 @@ __global__ __launch_bounds__(256) void lv_finalize_kernel(const uint32_t* __rest
   double tot = 0;
   for (int c = 0; c < K; ++c) {
     if (counts[c] == 0) continue;
-    double s = 0;
-    for (long long i = threadIdx.x; i < ntiles; i += 256) s += lpart[(long long)c * ntiles + i];
-    tot += s;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;      // four independent load chains (one chain of ~100 dependent loads per class was 25 - 57 us)
+    long long i = threadIdx.x;
+    for (; i + 768 < ntiles; i += 1024) {
+      s0 += lpart[(long long)c * ntiles + i];
+      s1 += lpart[(long long)c * ntiles + i + 256];
+      s2 += lpart[(long long)c * ntiles + i + 512];
+      s3 += lpart[(long long)c * ntiles + i + 768];
+    }
+    for (; i < ntiles; i += 256) s0 += lpart[(long long)c * ntiles + i];
+    tot += (s0 + s1) + (s2 + s3);
   }
   sh[threadIdx.x] = tot;
   __syncthreads();
