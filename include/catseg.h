@@ -152,6 +152,11 @@ int catseg_split2h(const float* x, long long rows, int C, int ld, void* blocked_
 int catseg_split2h_bound(const float* x, long long rows, int C, int ld, void* blocked_planes, void* planar_planes, void* scale,
                          const void* rec0, const void* rec1, const void* rec2, const void* rec3, catseg_stream_t stream);
 int catseg_split2h_weight_blocked(const float* w, int O, int taps, int Cin, void* planes, void* scale, catseg_stream_t stream);
+/* blocked planes of the channel concatenation of up to four bilinearly resized tensors (F.interpolate(..., mode='bilinear', align_corners=False)
+ * + torch.cat: the HRNet head input, models/HRNetv2.py:505-508) WITHOUT the fp32 concatenation: xs[i] NHWC [B][Hs[i]][Ws[i]][Cs[i]] (row stride
+ * lds[i], Cs[i] % 16 == 0; a source of the output's size is copied), records[i] its amax record; planes [2][sum Cs / 16][B Ho Wo][16]. */
+int catseg_concat_bilinear_split2h(int nsrc, const float* const* xs, const int* lds, const int* Hs, const int* Ws, const int* Cs,
+                                   const void* const* records, int B, int Ho, int Wo, void* blocked_planes, void* scale, catseg_stream_t stream);
 int catseg_split2h_weight_t_blocked(const float* w, int O, int taps, int Cin, void* planes, void* scale, catseg_stream_t stream);
 int catseg_conv2d_fwd_f16x2_blocked(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* w_planes,
                                     const void* w_scale, const float* bias, float* y, int zero_to, float* bn_part, size_t bn_part_floats,

@@ -117,6 +117,7 @@ _SIGS = {
     "catseg_conv2d_bwd_weight_f16x2_workspace": (SZ, [P]),
     "catseg_conv2d_bwd_weight_f16x2": (I, [P, P, P, P, P, P, P, SZ, P]),
     "catseg_conv2d_bwd_weight_f16x2_blocked": (I, [P, P, P, P, P, P, P, SZ, P]),
+    "catseg_concat_bilinear_split2h": (I, [I, P, P, P, P, P, P, I, I, I, P, P, P]),
     "catseg_split2h_weight_blocked": (I, [P, I, I, I, P, P, P]),
     "catseg_split2h_weight_t_blocked": (I, [P, I, I, I, P, P, P]),
     "catseg_conv2d_fwd_f16x2_blocked": (I, [P, P, P, P, P, P, P, I, P, SZ, P, P, P]),

@@ -130,6 +130,79 @@ __global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ 
   }
 }
 
+// ---- the channel concatenation of up to four bilinearly resized NHWC tensors, written ONLY as blocked planes ------------------------------
+// HRNet's head input (models/HRNetv2.py:505-508 of the reference: F.interpolate(x_i, size of x_0, mode='bilinear', align_corners=False) of
+// branches 1..3, torch.cat with branch 0) feeds nothing but the f16x2 kernels of the two 3 x 3 head convolutions: the fp32 concatenation
+// (752 MB at 8 x 136 x 240 x 720), the copy of branch 0 into it and the split pass that read it back are replaced by ONE launch that
+// interpolates, splits and writes the planes.  Thread = (output pixel, 16-channel chunk): a wave writes 64 pixels x 32 bytes = 2 KB
+// contiguous per plane.  The interpolation is bilinear_fwd_kernel's expression (csrc/pointwise.hip; ATen's source index in fp32);
+// a source of the output's size is copied.  Exponent from amax_bits (the maximum over the sources' records: interpolation weights lie in
+// [0, 1] and sum to 1), as split2h_kernel.
+struct CatSrc { const float* x; int ld, H, W, chunk0; float sh, sw; };
+struct CatArgs { CatSrc s[4]; int nsrc, nchunks, B, Ho, Wo; long long rows; };
+
+__device__ __forceinline__ void cat_lerp(float scale, int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {
+  float sidx = scale * (dst + 0.5f) - 0.5f;        // area_pixel_compute_source_index, align_corners = False
+  sidx = sidx < 0.f ? 0.f : sidx;
+  i0 = (int)sidx;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = sidx - i0;
+  l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void concat_bilinear_split2h_kernel(const CatArgs a, const unsigned* __restrict__ amax_bits, u16* __restrict__ blk,
+                                                                      long long blk_plane, int* __restrict__ e_out) {
+  const int e = h2_exponent(*amax_bits);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *e_out = e;
+  const int chunk = blockIdx.y;
+  int si = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) si = (k < a.nsrc && chunk >= a.s[k].chunk0) ? k : si;
+  const CatSrc s = a.s[si];
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.rows) return;
+  const int c = (chunk - s.chunk0) * 16;
+  const int ox = (int)(p % a.Wo);
+  const long long t = p / a.Wo;
+  const int oy = (int)(t % a.Ho), b = (int)(t / a.Ho);
+  f32x4 v[4];
+  if (s.H == a.Ho && s.W == a.Wo) {
+    const float* r = s.x + (((long long)b * s.H + oy) * s.W + ox) * s.ld + c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *(const f32x4*)(r + 4 * q);
+  } else {
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    cat_lerp(s.sh, oy, s.H, y0, y1, ly0, ly1);
+    cat_lerp(s.sw, ox, s.W, x0, x1, lx0, lx1);
+    const float* r0 = s.x + ((long long)b * s.H + y0) * s.W * s.ld + c;
+    const float* r1 = s.x + ((long long)b * s.H + y1) * s.W * s.ld + c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 a0 = *(const f32x4*)(r0 + x0 * s.ld + 4 * q), a1 = *(const f32x4*)(r0 + x1 * s.ld + 4 * q);
+      const f32x4 b0 = *(const f32x4*)(r1 + x0 * s.ld + 4 * q), b1 = *(const f32x4*)(r1 + x1 * s.ld + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[q][j] = ly0 * (lx0 * a0[j] + lx1 * a1[j]) + ly1 * (lx0 * b0[j] + lx1 * b1[j]);
+    }
+  }
+  u16 h[16], l[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2h_one(v[q][j], e, h[4 * q + j], l[4 * q + j]);
+  typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+  u16* d = blk + ((long long)chunk * a.rows + p) * 16;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    u16x8 hv, lv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { hv[j] = h[8 * half + j]; lv[j] = l[8 * half + j]; }
+    *(u16x8*)(d + 8 * half) = hv;
+    *(u16x8*)(d + blk_plane + 8 * half) = lv;
+  }
+}
+
 // fp32 weights viewed as [N][K] -> blocked fp16 planes [K/16][N][16], prescaled; T = the transposed filter bank of backward-data
 // (row n = input channel c, k = tap * Opad + o, source w[(o * taps + tap) * Cin + c], zero for o >= O)
 template <bool T>
@@ -852,6 +925,36 @@ extern "C" int catseg_split2h_bound(const float* x, long long rows, int C, int l
   const int c16 = (C + 15) / 16, ldp = (C + 7) & ~7;
   hipLaunchKernelGGL(split2h_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((c16 * 16 + 127) / 128)), dim3(256), 0, st, x, ld, rows, C, ldp,
                      (const unsigned*)ab, (u16*)blocked_planes, (long long)c16 * rows * 16, (u16*)planar_planes, rows * ldp, (int*)(ab + 1));
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// blocked planes [2][sum C_i / 16][B Ho Wo][16] of cat_i(bilinear(x_i -> Ho x Wo, align_corners = False)) for up to four NHWC sources
+// x_i [B][H_i][W_i][C_i] (row stride ld_i, C_i % 16 == 0; a source of the output's size is copied), without the fp32 concatenation; scale as
+// catseg_split2h_bound: {bits of max over the sources' amax records, e}.
+extern "C" int catseg_concat_bilinear_split2h(int nsrc, const float* const* xs, const int* lds, const int* Hs, const int* Ws, const int* Cs,
+                                              const void* const* records, int B, int Ho, int Wo, void* blocked_planes, void* scale,
+                                              catseg_stream_t stream) {
+  CS_REQUIRE(nsrc >= 1 && nsrc <= 4 && xs && lds && Hs && Ws && Cs && records && B > 0 && Ho > 0 && Wo > 0 && blocked_planes && scale &&
+                 cs_aligned16(blocked_planes) && (((uintptr_t)scale) & 7) == 0, "concat_bilinear_split2h: bad args");
+  CatArgs a = {};
+  AmaxRecs recs = {{nullptr, nullptr, nullptr, nullptr}};
+  int chunk = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    CS_REQUIRE(xs[i] && records[i] && Cs[i] > 0 && Cs[i] % 16 == 0 && lds[i] >= Cs[i] && lds[i] % 4 == 0 && cs_aligned16(xs[i]) && Hs[i] > 0 && Ws[i] > 0,
+               "concat_bilinear_split2h: source %d (channels must be a multiple of 16, ld of 4, an amax record per source)", i);
+    a.s[i].x = xs[i]; a.s[i].ld = lds[i]; a.s[i].H = Hs[i]; a.s[i].W = Ws[i]; a.s[i].chunk0 = chunk;
+    a.s[i].sh = (float)Hs[i] / (float)Ho; a.s[i].sw = (float)Ws[i] / (float)Wo;
+    recs.r[i] = (const unsigned*)records[i];
+    chunk += Cs[i] / 16;
+  }
+  a.nsrc = nsrc; a.nchunks = chunk; a.B = B; a.Ho = Ho; a.Wo = Wo; a.rows = (long long)B * Ho * Wo;
+  CS_REQUIRE(a.rows * chunk * 64 < (1ll << 32) - 64, "concat_bilinear_split2h: the two planes must stay below 4 GB");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* ab = (unsigned*)scale;
+  hipLaunchKernelGGL(amax_merge_kernel, dim3(1), dim3(64), 0, st, recs, ab);
+  hipLaunchKernelGGL(concat_bilinear_split2h_kernel, dim3((unsigned)((a.rows + 255) / 256), (unsigned)chunk), dim3(256), 0, st, a, (const unsigned*)ab,
+                     (u16*)blocked_planes, (long long)chunk * a.rows * 16, (int*)(ab + 1));
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

@@ -724,8 +724,8 @@ def maxpool(cx, x):
     return y
 
 
-def bilinear(cx, x, Ho, Wo, align_corners, out=None):
-    y = ops.bilinear_fwd(x, Ho, Wo, align_corners, out=out)
+def bilinear_backward_of(cx, x, y, align_corners):
+    """tape entry of y = bilinear(x): the gradient of y, resized back, goes to x"""
     if cx.record:
         def bwd():
             dy = cx.take(y)
@@ -736,6 +736,11 @@ def bilinear(cx, x, Ho, Wo, align_corners, out=None):
             ops.bilinear_bwd(dy, tuple(x.shape), align_corners, out=dx, zero_to=(ops.ld_of(dx) if ops.ld_of(dx) != C else 0),
                              accumulate=acc)
         cx.push(bwd)
+
+
+def bilinear(cx, x, Ho, Wo, align_corners, out=None):
+    y = ops.bilinear_fwd(x, Ho, Wo, align_corners, out=out)
+    bilinear_backward_of(cx, x, y, align_corners)
     return y
 
 

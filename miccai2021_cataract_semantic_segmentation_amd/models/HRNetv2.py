@@ -7,6 +7,7 @@ BatchNorm momentum 0.01 (:19), bilinear resizes with align_corners=False (:253-2
 import torch
 from torch import nn
 
+from .. import engine
 from ..engine import BatchNorm2d, Conv2d, EngineNet, add_n, bilinear, image_hw, concat_views, conv_bias, conv_bn_act, tap
 from ..utils import num_classes
 
@@ -292,12 +293,34 @@ def run_hrnet_trunk(net, cx, x):
     return ys
 
 
-def concat_branches(cx, ys):
-    """upsample branches 1..3 to branch 0's size (bilinear, align_corners=False) and concatenate"""
+def concat_branches(cx, ys, h2_consumers=None):
+    """upsample branches 1..3 to branch 0's size (bilinear, align_corners=False) and concatenate.
+    h2_consumers: the caller states that the result feeds NOTHING but these Conv2d modules.  When all of them run on blocked f16x2 planes in
+    forward and backward-weight (ops.concat_planes_route), a recorded training pass writes the concatenation ONLY as those planes -- the returned
+    fp32 tensor is an unwritten placeholder (ops.register_h2_planes) that carries shape and gradient identity."""
     B, H, W, _ = ys[0].shape
     chans = [y.shape[-1] for y in ys]
     cat = torch.empty((B, H, W, sum(chans)), dtype=torch.float32, device=ys[0].device)
     parts, c0 = [], 0
+    if h2_consumers and cx.record and cx.train and engine.TAPS is None:
+        from .. import ops
+        if ops.concat_planes_route(ys, h2_consumers):
+            blk, sc = ops.concat_bilinear_h2(ys, H, W)
+            ops.register_h2_planes(cat, blk, sc)
+            for y, c in zip(ys, chans):
+                dst = cat[..., c0:c0 + c]           # (never written: the key under which concat_views hands this slice's gradient out)
+                if y.shape[1] == H and y.shape[2] == W:
+                    def bwd(src=y, d=dst):
+                        g = cx.take(d)
+                        if g is not None:
+                            cx.give(src, g)
+                    cx.push(bwd)
+                else:
+                    engine.bilinear_backward_of(cx, y, dst, False)
+                parts.append((dst, c0, c0 + c))
+                c0 += c
+            concat_views(cx, cat, parts)
+            return cat
     for y, c in zip(ys, chans):
         dst = cat[..., c0:c0 + c]
         if y is ys[0]:

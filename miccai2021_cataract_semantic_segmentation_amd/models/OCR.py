@@ -69,8 +69,8 @@ class HRNetFeatures(nn.Module):
         super().__init__()
         self.out_channels = int(sum(build_hrnet_trunk(self, width, stage1_width, tuple(modules))))
 
-    def run(self, cx, x):
-        return concat_branches(cx, run_hrnet_trunk(self, cx, x))
+    def run(self, cx, x, h2_consumers=None):
+        return concat_branches(cx, run_hrnet_trunk(self, cx, x), h2_consumers)
 
 
 class OCRNet(EngineNet):
@@ -126,7 +126,8 @@ class OCRNet(EngineNet):
         H, W = image_hw(x)
         K = self.num_classes
         if isinstance(self.backbone, HRNetFeatures):
-            low = high = self.backbone.run(cx, x)
+            # (the two 3 x 3 head convolutions below are the only readers of the trunk's output: models/HRNetv2.concat_branches)
+            low = high = self.backbone.run(cx, x, h2_consumers=[self.interm_prediction_head[0], self.conv_high_map[0]])
         else:
             f = self.backbone.run(cx, x)
             low, high = f["low"], f["high"]

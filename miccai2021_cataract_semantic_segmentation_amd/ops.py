@@ -198,6 +198,7 @@ def _cached(cache, x, key, want, both):
     if not hit:
         cache.update(key=key, x=x, planar=None, blk=None, h2=None, h2p=None)
     if cache.get(want) is None:
+        _refuse_h2_only(x, "a split pass (%s planes)" % want)
         if want in ("h2", "h2p"):
             blk, pl, sc = split2h(x, blocked=(want == "h2" or both), planar=(want == "h2p" or both))
             if blk is not None:
@@ -690,6 +691,13 @@ def _refuse_placeholder(t, what):
                            "(engine.conv_bn_act(sole_conv_out=True) requires the planes route on the consumer)" % what)
 
 
+def _refuse_h2_only(t, what):
+    """a tensor that exists ONLY as blocked f16x2 planes (concat_bilinear_h2: the HRNet head input) is an unwritten fp32 placeholder too: only
+    the f16x2 kernels, through the planes registered for it, may consume it"""
+    if getattr(t, "_h2_only", False):
+        raise RuntimeError("a tensor that exists only as blocked f16x2 planes reached %s, which reads fp32 (its fp32 tensor was never written)" % what)
+
+
 def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=None, zero_to=0, stem4=False, groups=1, bn_stats=False, train=False,
              exact=False):
     """train=True (the engine's recorded forward): a backward pass will follow -- the split planes of x are written in both layouts
@@ -728,6 +736,10 @@ def conv_fwd(x, w_ptr_tensor, bias, Cout, kh, kw, stride=1, pad=0, dil=1, out=No
             res = dconv3(x, wimg, bias, out=out, bn_stats=bn_stats, x_amax=rec)
         return res
     _refuse_placeholder(x, "a convolution forward outside the planes route")
+    if getattr(x, "_h2_only", False) and not (not exact and "fwd" in B3_OPS and not stem4 and groups == 1 and w_ptr_tensor.dim() == 4 and amax_of(x) is None
+                                               and _b3_eligible(rows, Cout, kh * kw, Cin) and _h2()
+                                               and _b3_blocked_ok(max(zero_to, Cout), Cin, B * H * W, Cout, kh * kw)):
+        _refuse_h2_only(x, "a convolution forward outside the blocked f16x2 route")
     if (not exact and not stem4 and zero_to == 0 and w_ptr_tensor.dim() == 4 and "fwd" in P1_OPS and amax_of(x) is not None
             and _p1_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups) and lib.catseg_pconv1_supported(Cout, Cin)
             and rows * ld_of(x) * 4 < B3_PLANE_LIMIT):
@@ -940,6 +952,10 @@ def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=Fals
     Cout, Cin = dy.shape[-1], x.shape[-1]
     _refuse_placeholder(x, "conv_bwd_weight (fp32 input)")
     _refuse_placeholder(dy, "conv_bwd_weight (fp32 output gradient)")
+    if getattr(x, "_h2_only", False) and not (H2T_BLOCKED and not stem4 and amax_of(x) is None and _wgrad_split_route(x, dy, kh, kw, stride, stem4, groups)
+                                               and _wgrad_h2_route(x, dy)
+                                               and not (_d3_ok(rows_of(dy), Cin, Cout, kh, kw, stride, pad, dil, groups) and lib.catseg_dwgrad3_supported(Cin))):
+        _refuse_h2_only(x, "conv_bwd_weight outside the blocked f16x2 route")
     flops = 2.0 * rows_of(dy) * Cout * (3 if stem4 else Cin // groups) * kh * kw
     if (not stem4 and x.dim() == 4 and _d3_ok(rows_of(dy), Cin, Cout, kh, kw, stride, pad, dil, groups)
             and lib.catseg_dwgrad3_supported(Cin)):
@@ -1167,6 +1183,66 @@ def bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres=None, dres_acc
     with _Timed("hbm:bn_backward", 4.0 * y.numel() * (5 + (1 if dres is not None else 0))):
         _bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres, dres_accumulate, dy_out, beta, rows, C, ws)
     return dy_out
+
+
+# The HRNet head input -- torch.cat of branch 0 and the bilinearly upsampled branches 1..3 (models/HRNetv2.py:505-508) -- feeds nothing but the two
+# 3 x 3 head convolutions on the f16x2 kernels: ONE launch interpolates, splits and writes the blocked planes (csrc/igemm_f16x2.hip:
+# concat_bilinear_split2h_kernel); the fp32 concatenation, the copy of branch 0 into it and the split pass over it are gone.
+# CATSEG_CONCAT_PLANES=0: fp32 concatenation + catseg_split2h, as before.
+CONCAT_PLANES = _os.environ.get("CATSEG_CONCAT_PLANES", "1") != "0"
+
+
+def concat_planes_route(ys, consumers):
+    """True when every consumer (the Conv2d modules that read the concatenation of `ys` at ys[0]'s size) runs forward AND backward-weight on
+    blocked f16x2 planes of its input: the concatenation then never needs to exist in fp32"""
+    import types
+    if not (CONCAT_PLANES and H2T_BLOCKED and _h2() and PRECISION == "bf16x3" and consumers and 1 <= len(ys) <= 4):
+        return False
+    if not all(y.is_cuda and y.dim() == 4 and y.shape[-1] % 16 == 0 and ld_of(y) % 4 == 0 and amax_of(y) is not None and y.shape[0] == ys[0].shape[0]
+               for y in ys):
+        return False
+    B, H, W, _ = ys[0].shape
+    Cin, rows = sum(y.shape[-1] for y in ys), B * H * W
+    if 4 * rows * Cin >= B3_PLANE_LIMIT:
+        return False
+    x = types.SimpleNamespace(shape=(B, H, W, Cin))
+    for conv in consumers:
+        kh, kw = conv.kernel_size
+        st, pd, dl, Cout = conv.stride[0], conv.padding[0], conv.dilation[0], conv.out_channels
+        if (conv.in_channels != Cin or getattr(conv, "exact_operands", False) or getattr(conv, "stem", False) or conv.groups != 1
+                or conv_out_size(H, kh, st, pd, dl) != H or conv_out_size(W, kw, st, pd, dl) != W):
+            return False
+        if _d3_ok(rows, Cin, Cout, kh, kw, st, pd, dl, 1):
+            return False
+        if not ("fwd" in B3_OPS and _b3_eligible(rows, Cout, kh * kw, Cin) and _b3_blocked_ok(Cout, Cin, rows, Cout, kh * kw)):
+            return False
+        dy = types.SimpleNamespace(shape=(B, H, W, Cout))
+        if not (_wgrad_split_route(x, dy, kh, kw, st, False, 1) and _wgrad_h2_route(x, dy)):
+            return False
+    return True
+
+
+def concat_bilinear_h2(ys, Ho, Wo):
+    """(blocked planes [2, sum C / 16, B Ho Wo, 16], scale record) of cat_i(bilinear(y_i -> Ho x Wo, align_corners=False))"""
+    n, B, dev = len(ys), ys[0].shape[0], ys[0].device
+    C, rows = sum(y.shape[-1] for y in ys), B * Ho * Wo
+    blk = torch.empty((2, C // 16, rows, 16), dtype=torch.int16, device=dev)
+    scale = torch.empty(2, dtype=torch.int32, device=dev)
+    PA, IA = ctypes.c_void_p * 4, ctypes.c_int * 4
+    pad = lambda v: list(v) + [0] * (4 - n)
+    xs, recs = PA(*pad([ptr(y) for y in ys])), PA(*pad([ptr(amax_of(y)) for y in ys]))
+    lds, Hs, Ws, Cs = IA(*pad([ld_of(y) for y in ys])), IA(*pad([y.shape[1] for y in ys])), IA(*pad([y.shape[2] for y in ys])), IA(*pad([y.shape[-1] for y in ys]))
+    with _Timed("hbm:bilinear_fwd", 4.0 * (sum(y.numel() for y in ys) + rows * C)):
+        check(lib.catseg_concat_bilinear_split2h(n, xs, lds, Hs, Ws, Cs, recs, B, Ho, Wo, ptr(blk), ptr(scale), stream()))
+    return blk, scale
+
+
+def register_h2_planes(x, blk, scale):
+    """x: an UNWRITTEN fp32 placeholder whose contents exist as the blocked planes (blk, scale): the f16x2 kernels find them where a split pass
+    of x would have left them (kept until release_b3_cache(), i.e. through the backward pass); every fp32 route refuses x"""
+    x._h2_only = True
+    key = (x.data_ptr(), x._version, tuple(x.shape), ld_of(x), torch.cuda.current_stream(x.device).cuda_stream)
+    _b3_kept[key] = {"key": key, "x": x, "planar": None, "blk": None, "h2": (blk, scale), "h2p": None}
 
 
 # The head layers (conv -> BatchNorm -> ReLU on the f16x2 kernels: models/OCR.py:72-89, 326-333): the BatchNorm backward writes dy straight

@@ -128,3 +128,92 @@ def test_route_predicate_on_the_bench_shapes(ops):
         x, y = torch.empty(8, 136, 240, Cin, device=dev), torch.empty(8, 136, 240, Cout, device=dev)
         w = torch.empty(Cout, Cin, k, k, device=dev)
         assert ops.h2_dy_route(x, y, w, k, k, 1, k // 2, 1, 1, True) == want, (Cin, Cout, k)
+
+
+def test_concat_bilinear_planes_vs_fp32_concat_and_split(ops):
+    """ops.concat_bilinear_h2 (one launch: interpolate, split, write blocked planes) against bilinear_fwd into channel slices + catseg_split2h"""
+    g = torch.Generator().manual_seed(9)
+    dev = torch.device("cuda")
+    B, H, W = 2, 24, 40
+    ys = []
+    for C, sdiv, mag in ((48, 1, 1.0), (96, 2, 3.0), (192, 4, 0.2), (384, 8, 40.0)):
+        y = (torch.randn(B, H // sdiv, W // sdiv, C, generator=g) * mag).to(dev)
+        rec = ops.new_amax(dev)
+        rec[0] = int(np.frombuffer(np.float32(float(y.abs().max())).tobytes(), dtype=np.int32)[0])
+        y._amax = rec
+        ys.append(y)
+    cat = torch.empty(B, H, W, 720, device=dev)
+    c0 = 0
+    for y in ys:
+        C = y.shape[-1]
+        if y.shape[1] == H:
+            cat[..., c0:c0 + C].copy_(y)
+        else:
+            ops.bilinear_fwd(y, H, W, False, out=cat[..., c0:c0 + C])
+        c0 += C
+    blk, sc = ops.concat_bilinear_h2(ys, H, W)
+    torch.cuda.synchronize()
+    amax = max(float(y.abs().max()) for y in ys)
+    assert np.frombuffer(np.int32(int(sc.cpu()[0])).tobytes(), dtype=np.float32)[0] == np.float32(amax)
+    v, e = _planes_to_f64(blk, sc, 720)
+    ref = cat.cpu().double().reshape(-1, 720)
+    err = (v - ref).abs()
+    # 22-bit planes of the interpolated value; the interpolation may contract its multiply-adds differently in the two kernels: an ulp of its
+    # largest TERM (a result that cancels to ~0 between neighbours carries that absolute error)
+    tol = torch.maximum(ref.abs() * 2.0 ** -22, torch.full_like(ref, 2.0 ** -25 * 2.0 ** -e))
+    c0 = 0
+    for y in ys:
+        C = y.shape[-1]
+        tol[:, c0:c0 + C] += 2.0 ** -23 * float(y.abs().max())
+        c0 += C
+    assert bool((err <= tol).all()), float((err / tol).max())
+    # branch 0 is a copy: its planes are exactly the split of its values
+    b0, s0 = ops.split2h_blocked(cat[..., :48].contiguous())
+    if int(s0.cpu()[1]) == e:
+        assert torch.equal(blk[:, :3], b0)
+
+
+def test_ocrnet_hrnet_step_with_and_without_the_concat_planes(ops):
+    """a small OCRNet-HRNet training step (thresholds lowered so that the head layers take the f16x2 kernels) with the trunk output as planes
+    only (A) against the fp32 concatenation + split pass (B): logits to 2e-5; gradients against the step's own numerical sensitivity --
+    B re-run on an image perturbed by 1e-7 relative (C): at 2 x 24 x 40 head pixels the BatchNorm / attention backward passes amplify such
+    a perturbation to 1e-2 of some head gradients, so |A - B| is held to a small multiple of |B - C|, tensor by tensor"""
+    from miccai2021_cataract_semantic_segmentation_amd.models import OCRNet
+    saved = (ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES, ops.B3_MIN_WGRAD_ROWS, ops.CONCAT_PLANES)
+    try:
+        ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES, ops.B3_MIN_WGRAD_ROWS = "bf16x3", 1, 64, 32, 1, 1
+        torch.manual_seed(5)
+        net = OCRNet({"backbone": "hrnet48", "pretrained": False}, 3).cuda().train()
+        x = torch.randn(2, 3, 96, 160, device="cuda")
+        x2 = x * (1 + 1e-7 * torch.randn_like(x))
+        r1, r2 = torch.randn(2, 25, 96, 160, device="cuda"), torch.randn(2, 25, 96, 160, device="cuda")
+        res = {}
+        for tag, mode, inp in (("A", True, x), ("B", False, x), ("C", False, x2)):
+            ops.CONCAT_PLANES = mode
+            net.zero_grad()
+            ops.PROFILE = []
+            interm, final = net(inp)
+            (final * r1).mean().add(0.4 * (interm * r2).mean()).backward()
+            torch.cuda.synchronize()
+            kinds = [p[0] for p in ops.PROFILE]
+            ops.PROFILE = None
+            assert kinds.count("fwd_h2") >= 2 and kinds.count("wgrad_h2") >= 2, kinds
+            assert ("split3" in kinds), kinds
+            res[tag] = (final.detach().clone(), interm.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
+        for k in (0, 1):
+            assert float((res["A"][k] - res["B"][k]).abs().max()) <= 2e-5 * float(res["B"][k].abs().max())
+        # (the biases of the two head convolutions sit in front of a BatchNorm: their gradient is rounding noise around 0 in any implementation)
+        noise = ("interm_prediction_head.0.bias", "conv_high_map.0.bias")
+        bad = []
+        for n in res["A"][2]:
+            if n in noise:
+                continue
+            a, b, c = (res[t][2][n].double() for t in "ABC")
+            scale = float(b.abs().max()) + 1e-30
+            dab, dbc = float((a - b).abs().max()) / scale, float((b - c).abs().max()) / scale
+            if dab > 4.0 * dbc + 1e-5:
+                bad.append((n, dab, dbc))
+        assert not bad, bad[:8]
+    finally:
+        (ops.PRECISION, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES, ops.B3_MIN_WGRAD_ROWS, ops.CONCAT_PLANES) = saved
+        ops.PROFILE = None
