@@ -174,6 +174,20 @@ int catseg_conv2d_bwd_weight_f16x2(const catseg_conv_desc* d, const void* x_plan
 int catseg_conv2d_bwd_weight_f16x2_blocked(const catseg_conv_desc* d, const void* x_planes, const void* x_scale, const void* dy_planes,
                                            const void* dy_scale, float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
 
+/* ---- the first stem convolution of HRNet: nn.Conv2d(3, 64, 3, stride 2, padding 1) on the image (models/HRNetv2.py:281-283), exact fp32, HBM-bound
+ * direct kernels (csrc/stem3.hip).  x is addressed through element strides (sb, sc, sy, sx) for (batch, channel, row, column): NCHW or NHWC-4,
+ * no repack pass.  w / dw: OHWI [64][3][3][3].  y / dy: NHWC rows of ldy floats.
+ *   catseg_stem3_fwd: y = F.conv2d(x, w, bias, 2, 1); bn_part != NULL: catseg_stem3_partial_rows(B, H, W) rows [row][3][64] of BatchNorm
+ *                     partials (K, sum(v - K), sum((v - K)^2)) with pixel counts in bn_counts, for catseg_bn_finalize_counts.
+ *   catseg_stem3_bwd_weight: dw = the weight gradient of the same call (autograd of F.conv2d); workspace catseg_stem3_wgrad_workspace(). */
+int catseg_stem3_supported(int H, int W, int Cout);
+int catseg_stem3_partial_rows(int B, int H, int W);
+size_t catseg_stem3_wgrad_workspace(void);
+int catseg_stem3_fwd(const float* x, long long sb, long long sc, long long sy, long long sx, int B, int H, int W, const float* w, const float* bias,
+                     float* y, int ldy, float* bn_part, int* bn_counts, catseg_stream_t stream);
+int catseg_stem3_bwd_weight(const float* x, long long sb, long long sc, long long sy, long long sx, int B, int H, int W, const float* dy, int lddy,
+                            float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
+
 /* ---- direct 3x3 / stride 1 / pad 1 convolution in split precision (csrc/dconv3_b3.hip) for the HRNet trunk: the BasicBlock
  * convolutions conv3x3(planes, planes) at models/HRNetv2.py:22-25,41-44 (Cin = Cout = C in {48, 96}; catseg_dconv3_supported).
  * Same F.conv2d call sites and same arithmetic as catseg_conv2d_fwd_bf16x3 (three exact bf16 planes per fp32 operand, six bf16

@@ -448,9 +448,14 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
     kh, kw = conv.kernel_size
     s, p, d = conv.stride[0], conv.padding[0], conv.dilation[0]
     pad3 = (not conv.stem) and w.shape[1] == 3       # 3-channel image into a generic conv (HRNet 3x3/2 stem)
+    stem3 = False
     if conv.stem:
         x_in = x if is_nhwc4(x) else ops.nchw3_to_nhwc4(x)
         wk = ops.stem_pack_weight(w.data, Cout)
+    elif pad3 and cx.train and conv.bias is None and not need_dx and out is None and ops.stem3_ok(x, w.data, kh, kw, s, p, d, conv.groups):
+        # the HRNet stem's first convolution: HBM-bound direct kernels on the image as it is (NCHW or NHWC-4), no repack, no channel padding
+        stem3 = True
+        x_in, wk = x, w.data
     elif pad3:
         x_in = x if is_nhwc4(x) else ops.nchw3_to_nhwc4(x)
         wk = ops.weight_pad_cin(w.data, Cout, kh * kw, 3, 4)
@@ -467,8 +472,11 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
         return ops.conv_fwd_fused(x_in, wf, bf, residual, relu, Cout, kh, kw, s, p, d, out=out, stem4=conv.stem, groups=conv.groups)
     if cx.train:
         # batch statistics: per-tile partial sums come out of the convolution's epilogue (no separate pass over y)
-        y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups, bn_stats=FUSE_BN_STATS, train=cx.record,
-                         exact=conv.exact_operands)
+        if stem3:
+            y = ops.stem3_fwd(x_in, wk, None, bn_stats=FUSE_BN_STATS)
+        else:
+            y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups, bn_stats=FUSE_BN_STATS, train=cx.record,
+                             exact=conv.exact_operands)
         y, partials = y if FUSE_BN_STATS else (y, None)
         # planes route: the convolution streamed planes and left max|y|; then the BatchNorm's output gets planes too (exponent from a bound)
         yrec = getattr(y, "_yrec", None)
@@ -551,6 +559,8 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
                 dpk = torch.empty_like(wk)
                 ops.conv_bwd_weight(x_in, dy, dpk, dbias, kh, kw, s, p, d, stem4=True)
                 ops.stem_unpack_grad(dpk, cx.pgrad(w), Cout)
+            elif stem3:
+                ops.stem3_bwd_weight(x_in, dy, cx.pgrad(w))
             elif pad3:
                 dpk = torch.empty_like(wk)
                 ops.conv_bwd_weight(x_in, dy, dpk, dbias, kh, kw, s, p, d)

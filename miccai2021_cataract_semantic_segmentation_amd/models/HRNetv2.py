@@ -302,7 +302,8 @@ def concat_branches(cx, ys, h2_consumers=None):
     chans = [y.shape[-1] for y in ys]
     cat = torch.empty((B, H, W, sum(chans)), dtype=torch.float32, device=ys[0].device)
     parts, c0 = [], 0
-    if h2_consumers and cx.record and cx.train and engine.TAPS is None:
+    # (not with engine.ASYNC_WGRAD: the extra stream's backward-weight looks its operand planes up under ITS stream and would split the tensor again)
+    if h2_consumers and cx.record and cx.train and engine.TAPS is None and not engine.ASYNC_WGRAD:
         from .. import ops
         if ops.concat_planes_route(ys, h2_consumers):
             blk, sc = ops.concat_bilinear_h2(ys, H, W)

@@ -224,6 +224,11 @@ def _split3_cached(x, want="planar", both=False, keep=False):
     bf16x3 layers of a step: 5.5 GB for OCRNet-HRNet-W48 at bs 8, of 288 GB)"""
     # (per stream: since round 5 a branch output may be read by fuse chains on SEVERAL branch streams -- each splits for itself; planes made
     #  on one stream are never read on another without an ordering event)
+    hp = getattr(x, "_h2_planes", None)
+    if hp is not None:          # a tensor that exists only as blocked f16x2 planes (register_h2_planes): they travel with it
+        if want == "h2":
+            return hp
+        _refuse_h2_only(x, "a split pass (%s planes)" % want)
     key = (x.data_ptr(), x._version, tuple(x.shape), ld_of(x), torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0)
     ent = _b3_kept.get(key)
     if ent is not None and ent["x"] is x:
@@ -689,6 +694,54 @@ def _refuse_placeholder(t, what):
     if getattr(t, "_planes_only", False):
         raise RuntimeError("a planes-only activation reached %s, which reads fp32: its fp32 tensor was never written "
                            "(engine.conv_bn_act(sole_conv_out=True) requires the planes route on the consumer)" % what)
+
+
+# The first stem convolution of HRNet (3 -> 64, 3 x 3 / stride 2 / pad 1 on the image) as HBM-bound direct fp32 kernels (csrc/stem3.hip) instead of
+# the implicit GEMM over 9 taps x 4 padded channels.  CATSEG_STEM3=0: the implicit-GEMM route.
+STEM3 = _os.environ.get("CATSEG_STEM3", "1") != "0"
+
+
+def _image_strides(x):
+    """(B, H, W, sb, sc, sy, sx) of a 3-channel image given as NCHW [B, 3, H, W] or NHWC-4 [B, H, W, 4]"""
+    if x.dim() == 4 and x.shape[-1] == 4 and x.shape[1] != 3:
+        B, H, W, _ = x.shape
+        return B, H, W, x.stride(0), 1, x.stride(1), x.stride(2)
+    B, _, H, W = x.shape
+    return B, H, W, x.stride(0), x.stride(1), x.stride(2), x.stride(3)
+
+
+def stem3_ok(x, w, kh, kw, stride, pad, dil, groups):
+    if not (STEM3 and x.is_cuda and x.dtype == torch.float32 and w.dim() == 4 and w.shape[1] == 3 and (kh, kw, stride, pad, dil, groups) == (3, 3, 2, 1, 1, 1)):
+        return False
+    B, H, W = _image_strides(x)[:3]
+    return bool(lib.catseg_stem3_supported(H, W, w.shape[0]))
+
+
+def stem3_fwd(x, w, bias, bn_stats=False):
+    """x: the image (NCHW or NHWC-4, any strides); w: [64, 3, 3, 3] in channels_last memory (physical OHWI).  Returns y NHWC [B, Ho, Wo, 64]
+    (+ the BatchNorm partials (part, rows, 0, counts) for bn_finalize)"""
+    B, H, W, sb, sc, sy, sx = _image_strides(x)
+    Cout = w.shape[0]
+    Ho, Wo = conv_out_size(H, 3, 2, 1, 1), conv_out_size(W, 3, 2, 1, 1)
+    out = new_act(B, Ho, Wo, Cout, x.device)
+    part = cnt = None
+    nt = 0
+    if bn_stats:
+        nt = lib.catseg_stem3_partial_rows(B, H, W)
+        part = _bn_part_buffer(3 * nt * Cout + nt, x.device)
+        cnt = part[3 * nt * Cout:3 * nt * Cout + nt].view(torch.int32)
+    with _Timed("hbm:stem3", 4.0 * (B * 3 * H * W + out.numel())):
+        check(lib.catseg_stem3_fwd(ptr(x), sb, sc, sy, sx, B, H, W, ptr(w), ptr(bias), ptr(out), ld_of(out), ptr(part), ptr(cnt), stream()))
+    return (out, (part, nt, 0, cnt)) if bn_stats else out
+
+
+def stem3_bwd_weight(x, dy, dw):
+    B, H, W, sb, sc, sy, sx = _image_strides(x)
+    need = lib.catseg_stem3_wgrad_workspace()
+    ws = workspace(need, x.device)
+    with _Timed("hbm:stem3", 4.0 * (B * 3 * H * W + dy.numel())):
+        check(lib.catseg_stem3_bwd_weight(ptr(x), sb, sc, sy, sx, B, H, W, ptr(dy), ld_of(dy), ptr(dw), ptr(ws), need, stream()))
+    return dw
 
 
 def _refuse_h2_only(t, what):
@@ -1238,11 +1291,11 @@ def concat_bilinear_h2(ys, Ho, Wo):
 
 
 def register_h2_planes(x, blk, scale):
-    """x: an UNWRITTEN fp32 placeholder whose contents exist as the blocked planes (blk, scale): the f16x2 kernels find them where a split pass
-    of x would have left them (kept until release_b3_cache(), i.e. through the backward pass); every fp32 route refuses x"""
+    """x: an UNWRITTEN fp32 placeholder whose contents exist as the blocked planes (blk, scale).  The planes travel with the tensor (they live
+    as long as the tape holds it: a second forward pass before this one's backward does not release them); _split3_cached hands them to the
+    f16x2 kernels where a split pass of x would have run; every fp32 route refuses x"""
     x._h2_only = True
-    key = (x.data_ptr(), x._version, tuple(x.shape), ld_of(x), torch.cuda.current_stream(x.device).cuda_stream)
-    _b3_kept[key] = {"key": key, "x": x, "planar": None, "blk": None, "h2": (blk, scale), "h2p": None}
+    x._h2_planes = (blk, scale)
 
 
 # The head layers (conv -> BatchNorm -> ReLU on the f16x2 kernels: models/OCR.py:72-89, 326-333): the BatchNorm backward writes dy straight
