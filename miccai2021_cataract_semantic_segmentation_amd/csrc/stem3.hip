@@ -4,10 +4,10 @@
 // K = 27: the implicit-GEMM kernels gathered it as 9 taps x 4 padded channels and ran the layer at 0.5 TB/s (642 us forward + 89 us for the
 // NCHW -> NHWC-4 repack of the image, 351 us backward-weight at 8 x 3 x 544 x 960).  The layer's floor is its output: 267 MB written (forward),
 // 267 MB of dy read (backward-weight); the image is 50 MB.  Here a block owns ONE output row (segments of 480 pixels for wider images): the three input rows it needs are staged
-// once in LDS as [ky][column][c0 c1 c2 0] (from NCHW or NHWC-4 memory: the strides are arguments, no repack pass), and thread = (pixel lane 0..15,
-// channel quad 0..15): 16-byte stores / loads of y / dy (a wave covers four pixels x 256 bytes), one LDS read of an input column serves four
-// channels.  Arithmetic: one fp32 FMA chain over k = (ky, kx, c) ascending from 0 per output, the order of the
-// OHWI weight tensor (the fp32 MFMA chain of csrc/igemm.hip walks the same order).
+// once in LDS as [ky][column][c0 c1 c2 0] (from NCHW or NHWC-4 memory: the strides are arguments, no repack pass), and thread = (pixel lane, channel
+// pair / quad): 8- / 16-byte stores / loads of y / dy (a wave covers two / four pixels x 256 bytes), one LDS read of an input column serves
+// two / four channels.  Arithmetic of the forward pass: the 27 products of an output accumulated in fp64 and rounded once
+// (see stem3_pixel); backward-weight: fp32 FMA chains over the pixels, fixed-order merges.
 // BatchNorm statistics: (K, sum(v - K), sum((v - K)^2)) per channel with K = the block's first pixel: one partial row per block with its pixel
 // count, merged by catseg_bn_finalize_counts in fp64.
 #include "common.h"
@@ -41,70 +41,78 @@ __device__ __forceinline__ void stem3_stage(const Stem3Args& a, int b, int oy, i
   }
 }
 
-// one output pixel's four channels 4 q .. 4 q + 3: an fp32 FMA chain over k = (ky, kx, c) ascending per channel
-__device__ __forceinline__ f32x4 stem3_pixel(const f32x4* sh, int px, const f32x4 (&w)[27]) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+// one output pixel's two channels 2 q, 2 q + 1: the 27 products accumulated in FP64 and rounded ONCE.  The rounding error of this layer is what
+// the rest of the network amplifies most (x 250 from the stem to the logits, tools/error_growth.py): a single fp32 FMA chain here -- the CPU
+// path's arithmetic -- raised the full-resolution logits' RMS distance to fp64 from 6.7e-5 to 7.2e-5 and the label disagreements from 65 to 89
+// (tests/test_fullres_gpu.py), the implicit GEMM's two-level fp32 chains sat in between.  fp32 x fp32 products are exact in fp64 and 27 of
+// them lose nothing that survives the final rounding: the layer's output is the correctly rounded convolution.  The kernel stays HBM-bound
+// (27 conversions + 54 fp64 FMAs per thread and pixel).
+__device__ __forceinline__ void stem3_pixel(const f32x4* sh, int px, const double (&w)[27][2], double& a0, double& a1) {
+  a0 = 0.0; a1 = 0.0;
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const f32x4 v = sh[ky * ST_WP + 2 * px + kx];
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(v[c], w[(ky * 3 + kx) * 3 + c][j], acc[j]);
+      for (int c = 0; c < 3; ++c) {
+        const double x = (double)v[c];
+        a0 = __builtin_fma(x, w[(ky * 3 + kx) * 3 + c][0], a0);
+        a1 = __builtin_fma(x, w[(ky * 3 + kx) * 3 + c][1], a1);
+      }
     }
-  return acc;
 }
 
-// thread = (pixel lane 0..15, channel quad 0..15): 16-byte stores, one LDS read of an input column serves four channels.  BatchNorm partials:
-// K = the block's FIRST pixel (every thread computes it for its channels), sums of (v - K) and (v - K)^2 over the thread's pixels, merged over the
-// 16 pixel lanes by lane shuffles and through LDS in a fixed order: one partial row + pixel count per block.
+// thread = (pixel lane 0..7, channel pair 0..31): 8-byte stores (a wave covers two pixels x 256 bytes), one LDS read of an input column serves two
+// channels.  BatchNorm partials: K = the block's FIRST pixel (every thread computes it for its channels), sums of (v - K) and (v - K)^2 over the
+// thread's pixels, merged over the 8 pixel lanes by a lane shuffle and through LDS in a fixed order: one partial row + pixel count per block.
 __global__ __launch_bounds__(256) void stem3_fwd_kernel(const Stem3Args a, const float* __restrict__ bias, float* __restrict__ y, int ldy,
                                                         float* __restrict__ part, int* __restrict__ counts) {
   __shared__ f32x4 sh[3 * ST_WP];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int b = blockIdx.x / a.Ho, oy = blockIdx.x - b * a.Ho;
   const int ox0 = blockIdx.y * ST_SEG, npx = min(ST_SEG, a.Wo - ox0);
-  const int q = threadIdx.x & 15, pl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
-  f32x4 w[27];
+  const int q = threadIdx.x & 31, pl = threadIdx.x >> 5, wave = threadIdx.x >> 6;
+  double w[27][2];
 #pragma unroll
-  for (int k = 0; k < 27; ++k)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[k][j] = a.w[(4 * q + j) * 27 + k];
-  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-  if (bias) bv = *(const f32x4*)(bias + 4 * q);
+  for (int k = 0; k < 27; ++k) {
+    w[k][0] = (double)a.w[(2 * q) * 27 + k];
+    w[k][1] = (double)a.w[(2 * q + 1) * 27 + k];
+  }
+  const double b0 = bias ? (double)bias[2 * q] : 0.0, b1 = bias ? (double)bias[2 * q + 1] : 0.0;
   stem3_stage(a, b, oy, ox0, npx, sh);
   __syncthreads();
-  float* yrow = y + ((long long)blockIdx.x * a.Wo + ox0) * ldy + 4 * q;
-  const f32x4 K = stem3_pixel(sh, 0, w) + bv;
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  float* yrow = y + ((long long)blockIdx.x * a.Wo + ox0) * ldy + 2 * q;
+  double a0, a1;
+  stem3_pixel(sh, 0, w, a0, a1);
+  const f32x2 K = {(float)(a0 + b0), (float)(a1 + b1)};
+  f32x2 s1 = {0.f, 0.f}, s2 = s1;
 #pragma unroll 2
-  for (int px = pl; px < npx; px += 16) {
-    const f32x4 v = stem3_pixel(sh, px, w) + bv;
-    *(f32x4*)(yrow + (long long)px * ldy) = v;
-    const f32x4 d = v - K;
+  for (int px = pl; px < npx; px += 8) {
+    stem3_pixel(sh, px, w, a0, a1);
+    const f32x2 v = {(float)(a0 + b0), (float)(a1 + b1)};
+    *(f32x2*)(yrow + (long long)px * ldy) = v;
+    const f32x2 d = v - K;
     s1 += d;
     s2 += d * d;
   }
   if (part == nullptr) return;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
-    s2[j] += __shfl_xor(s2[j], 16, 64); s2[j] += __shfl_xor(s2[j], 32, 64);
+  for (int j = 0; j < 2; ++j) {
+    s1[j] += __shfl_xor(s1[j], 32, 64);
+    s2[j] += __shfl_xor(s2[j], 32, 64);
   }
   __syncthreads();
-  f32x4* red = sh;                   // [3 waves][16 quads][2]
-  if (wave > 0 && (threadIdx.x & 63) < 16) {
-    red[((wave - 1) * 16 + q) * 2] = s1;
-    red[((wave - 1) * 16 + q) * 2 + 1] = s2;
-  }
+  f32x4* red = sh;                   // [3 waves][32 pairs]: (s1.x, s1.y, s2.x, s2.y)
+  if (wave > 0 && (threadIdx.x & 63) < 32) red[(wave - 1) * 32 + q] = f32x4{s1[0], s1[1], s2[0], s2[1]};
   __syncthreads();
-  if (threadIdx.x < 16) {
+  if (threadIdx.x < 32) {
     const long long prow = (long long)blockIdx.x * a.nseg + blockIdx.y;
-    float* p = part + prow * 3 * ST_CO + 4 * q;
-    *(f32x4*)p = K;
-    *(f32x4*)(p + ST_CO) = ((s1 + red[(0 * 16 + q) * 2]) + red[(1 * 16 + q) * 2]) + red[(2 * 16 + q) * 2];
-    *(f32x4*)(p + 2 * ST_CO) = ((s2 + red[(0 * 16 + q) * 2 + 1]) + red[(1 * 16 + q) * 2 + 1]) + red[(2 * 16 + q) * 2 + 1];
+    float* p = part + prow * 3 * ST_CO + 2 * q;
+    const f32x4 t = ((f32x4{s1[0], s1[1], s2[0], s2[1]} + red[q]) + red[32 + q]) + red[64 + q];
+    *(f32x2*)p = K;
+    *(f32x2*)(p + ST_CO) = f32x2{t[0], t[1]};
+    *(f32x2*)(p + 2 * ST_CO) = f32x2{t[2], t[3]};
     if (q == 0) counts[prow] = npx;
   }
 }
@@ -228,8 +236,8 @@ extern "C" size_t catseg_stem3_wgrad_workspace(void) { return (size_t)kWgradBloc
 // [row][3][64] = (K, sum(v - K), sum((v - K)^2)) with their pixel counts in bn_counts, for catseg_bn_finalize_counts.
 extern "C" int catseg_stem3_fwd(const float* x, long long sb, long long sc, long long sy, long long sx, int B, int H, int W, const float* w,
                                 const float* bias, float* y, int ldy, float* bn_part, int* bn_counts, catseg_stream_t stream) {
-  CS_REQUIRE(x && w && y && B > 0 && H >= 2 && W >= 2 && ldy >= ST_CO && ldy % 4 == 0 && cs_aligned16(y) && cs_aligned16(bias) && cs_aligned16(bn_part),
-             "stem3 fwd: bad args (y rows, bias, partials: 16-byte aligned)");
+  CS_REQUIRE(x && w && y && B > 0 && H >= 2 && W >= 2 && ldy >= ST_CO && ldy % 2 == 0 && (((uintptr_t)y) & 7) == 0 && (((uintptr_t)bn_part) & 7) == 0,
+             "stem3 fwd: bad args (y rows, partials: 8-byte aligned)");
   CS_REQUIRE((bn_part == nullptr) == (bn_counts == nullptr), "stem3 fwd: partials and counts come together");
   Stem3Args a;
   stem3_args(a, x, sb, sc, sy, sx, B, H, W, w);

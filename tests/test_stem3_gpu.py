@@ -40,7 +40,9 @@ def test_forward_stats_and_backward_weight_vs_fp64(ops, shape, layout):
     assert tuple(y.shape) == (B, Ho, Wo, 64)
     yh = y.cpu().double().permute(0, 3, 1, 2)
     scale = float(y64.abs().max())
-    assert float((yh - y64.detach()).abs().max()) <= 2e-6 * scale      # 27-term fp32 FMA chain
+    # the products accumulated in fp64, rounded once: the correctly rounded convolution (half an ulp of every element)
+    ref = y64.detach()
+    assert bool(((yh - ref).abs() <= ref.abs() * 2.0 ** -24 * 1.0001 + 1e-37).all()), float(((yh - ref).abs() / (ref.abs() + 1e-30)).max())
     # BatchNorm statistics from the kernel's partial rows
     gamma, rm, rv = torch.ones(64, device=dev), torch.zeros(64, device=dev), torch.ones(64, device=dev)
     stats, _ = ops.bn_finalize(partials, B * Ho * Wo, 64, gamma, 0.0, 0.1, rm, rv)
