@@ -88,7 +88,7 @@ MODELS = {
     "deeplabv3plus_r50": ({"backbone": "resnet50", "out_stride": 8, "pretrained": False}, "DeepLabv3+-ResNet50-OS8"),
 }
 IS_DEEPLAB = lambda name: name.startswith("deeplab")   # noqa: E731
-PROFILE_ROUND, PREVIOUS_PROFILE_ROUND = "r05", "r04"   # profiles/<round>_pmc_traffic_<model>.json feeds roofline.traffic
+PROFILE_ROUND, PREVIOUS_PROFILE_ROUND = "r05_s2", "r05"   # profiles/<round>_pmc_traffic_<model>.json feeds roofline.traffic
 
 
 def host_cpu_info():

@@ -17,7 +17,7 @@ for m in ocrnet_hrnet48 ocrnet_r50 deeplabv3plus_r50; do
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch_$m" -- python3 "$R/bench.py" --model $m --eager --steps 1 --warmup 1 --no-roofline --no-cpu-baseline --no-side-figures > "$O/pmc_fetch_$m.log" 2>&1
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write_$m" -- python3 "$R/bench.py" --model $m --eager --steps 1 --warmup 1 --no-roofline --no-cpu-baseline --no-side-figures > "$O/pmc_write_$m.log" 2>&1
     python3 "$R/tools/pmc_traffic.py" "$O/pmc_fetch_$m" "$O/pmc_write_$m" $m > "$O/pmc_traffic_$m.json"
-    mkdir -p "$R/profiles" && cp "$O/pmc_traffic_$m.json" "$R/profiles/r05_pmc_traffic_$m.json"     # bench.py reads it for roofline.traffic
+    mkdir -p "$R/profiles" && cp "$O/pmc_traffic_$m.json" "$R/profiles/r05_s2_pmc_traffic_$m.json"     # bench.py reads it for roofline.traffic
     rm -rf "$O"/pmc_fetch_$m "$O"/pmc_write_$m
   fi
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$m" -o p -- python3 "$R/bench.py" --model $m --eager --steps 3 --warmup 1 --no-cpu-baseline --no-side-figures > "$O/bench_prof_$m.json" 2> "$O/bench_prof_$m.err"
