@@ -200,7 +200,8 @@ __device__ __forceinline__ f32x4 bn_affine(f32x4 y, f32x4 mean, f32x4 scale, f32
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ mean,
                                                        const float* __restrict__ scale, const float* __restrict__ beta,
                                                        const float* __restrict__ res, int ldr, float* __restrict__ z,
-                                                       int ldz, long long rows, int C, int relu, unsigned* __restrict__ amax) {
+                                                       int ldz, long long rows, int C, int relu, unsigned* __restrict__ amax,
+                                                       unsigned long long* __restrict__ mask = nullptr) {
   const int cpt = C >> 2;
   unsigned m = 0;
   CS_QUAD_LOOP(rows, cpt, r, c) {
@@ -211,6 +212,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
     *(f32x4*)(z + r * ldz + c) = v;
     m = max(m, cs_abs_bits4(v));
+    if (mask) {
+      // the ReLU mask as BITS (C % 256 == 0: the 64 lanes of a wave hold 64 consecutive quads of one row, flat quad index i = 64 w + lane):
+      // mask[4 w + k] bit lane = (element k of quad 64 w + lane is positive).  The backward passes read 1 bit per element instead of z.
+      const long long i = r * cpt + (c >> 2);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned long long bal = __ballot(v[k] > 0.f);
+        if ((threadIdx.x & 63) == 0) mask[(i >> 6) * 4 + k] = bal;
+      }
+    }
   }
   if (amax) cs_amax_commit(m, amax);       // (uniform per launch: the shuffles run with every lane)
 }
@@ -277,7 +288,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, long long rows, int C, int relu,
                                                              RowSplit s, float* __restrict__ part, unsigned* __restrict__ gmax_rec = nullptr,
-                                                             unsigned* __restrict__ ymax_rec = nullptr) {
+                                                             unsigned* __restrict__ ymax_rec = nullptr,
+                                                             const unsigned long long* __restrict__ mask = nullptr) {
   const int t = threadIdx.x;
   const int cg = blockIdx.y * s.tpr + t % s.tpr;
   const int rl = t / s.tpr;
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   if (act) {
     const f32x4 mean = ld4(stats + c), inv = ld4(stats + C + c);
     f32x4 sc = {0, 0, 0, 0}, be = {0, 0, 0, 0};
-    if (relu && !z) { sc = ld4(gamma + c) * inv; be = ld4(beta + c); }   // scale exactly as bn_finalize stored it
+    if (relu && !z && !mask) { sc = ld4(gamma + c) * inv; be = ld4(beta + c); }   // scale exactly as bn_finalize stored it
     const long long st = s.rpp;
     long long r = r0 + rl;
     for (; r + 3 * st < r1; r += 4 * st) {   // four independent rows in flight (8 - 12 loads)
@@ -300,7 +312,14 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         g[u] = ld4(dz + (r + u * st) * lddz + c);
         yy[u] = ld4(y + (r + u * st) * ldy + c);
       }
-      if (relu) {
+      if (relu && mask) {        // (C % 256 == 0: this wave's 64 lanes are the 64 consecutive quads of mask words 4 w .. 4 w + 3)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long w4 = (((r + u * st) * (long long)(C >> 2) + cg) >> 6) * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) g[u][i] = ((mask[w4 + i] >> (t & 63)) & 1ull) ? g[u][i] : 0.f;
+        }
+      } else if (relu) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) zz[u] = z ? ld4(z + (r + u * st) * ldz + c) : bn_affine(yy[u], mean, sc, be);
 #pragma unroll
@@ -320,7 +339,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     for (; r < r1; r += st) {
       f32x4 g = ld4(dz + r * lddz + c);
       const f32x4 yy = ld4(y + r * ldy + c);
-      if (relu) {
+      if (relu && mask) {
+        const long long w4 = ((r * (long long)(C >> 2) + cg) >> 6) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = ((mask[w4 + i] >> (t & 63)) & 1ull) ? g[i] : 0.f;
+      } else if (relu) {
         const f32x4 zz = z ? ld4(z + r * ldz + c) : bn_affine(yy, mean, sc, be);
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[i] = zz[i] > 0.f ? g[i] : 0.f;
@@ -573,14 +596,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ coef, long long rows, int C,
                                                            int relu, float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres,
-                                                           int dres_acc, unsigned* __restrict__ amax) {
+                                                           int dres_acc, unsigned* __restrict__ amax,
+                                                           const unsigned long long* __restrict__ mask = nullptr) {
   const int cpt = C >> 2;
   unsigned m = 0;
   CS_QUAD_LOOP(rows, cpt, r, c) {
     f32x4 g = ld4(dz + r * lddz + c);
     const f32x4 inv = ld4(stats + C + c), mean = ld4(stats + c);
     const f32x4 yy = ld4(y + r * ldy + c);
-    if (relu) {
+    if (relu && mask) {          // (the walk of bn_apply_kernel, which wrote the bits: flat quad index i, lane = i & 63)
+      const long long w4 = ((r * cpt + (c >> 2)) >> 6) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = ((mask[w4 + k] >> (threadIdx.x & 63)) & 1ull) ? g[k] : 0.f;
+    } else if (relu) {
       const f32x4 zz = z ? ld4(z + r * ldz + c) : bn_affine(yy, mean, ld4(gamma + c) * inv, ld4(beta + c));
 #pragma unroll
       for (int k = 0; k < 4; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
@@ -907,6 +935,49 @@ extern "C" int catseg_bn_backward_h2(const float* dz, int lddz, const float* z, 
                      C, relu, (unsigned char*)dy_planes, (long long)rows * C * 2, (const unsigned*)dy_rec, (unsigned*)dy_scale,
                      dbias ? colpart : (float*)nullptr);
   if (dbias) hipLaunchKernelGGL(colsum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)colpart, gx, C, dbias);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// ---- the ReLU mask as bits (round 5): a residual block's output z = relu(bn(y) + residual) is read by its BatchNorm backward only for its
+// sign.  catseg_bn_apply_mask = catseg_bn_apply_amax that also writes mask (catseg_bn_mask_words(rows, C) 64-bit words: 1 bit per element);
+// catseg_bn_backward_mask = catseg_bn_backward_amax reading the bits instead of z (both passes: 4 bytes per element less each).  C % 256 == 0
+// (the residual BatchNorms of the stage-1 bottlenecks, models/HRNetv2.py:68-106, and of torchvision's Bottleneck).
+extern "C" size_t catseg_bn_mask_words(long long rows, int C) { return (size_t)((rows * (C >> 2) + 63) / 64) * 4; }
+
+extern "C" int catseg_bn_apply_mask(const float* y, int ldy, const float* mean, const float* scale, const float* beta, const float* residual,
+                                    int ldr, float* z, int ldz, long long rows, int C, void* amax_record, void* mask, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && C % 256 == 0 && ldy % 4 == 0 && ldz % 4 == 0 && (residual == nullptr || ldr % 4 == 0) && mask,
+             "bn apply (mask): C must be a multiple of 256, ld of 4");
+  CS_REQUIRE(cs_aligned16(y) && cs_aligned16(z) && cs_aligned16(mean) && cs_aligned16(scale) && cs_aligned16(beta) && cs_aligned16(residual) &&
+                 (((uintptr_t)mask) & 7) == 0, "bn apply (mask): alignment");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, mean, scale, beta, residual, ldr, z,
+                     ldz, rows, C, 1, (unsigned*)amax_record, (unsigned long long*)mask);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+extern "C" int catseg_bn_backward_mask(const float* dz, int lddz, const void* mask, const float* y, int ldy, const float* stats, const float* gamma,
+                                       long long rows, int C, float* dy, int lddy, float* dgamma, float* dbeta, float* dres, int lddres,
+                                       int dres_accumulate, void* workspace, size_t workspace_bytes, void* amax_record, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && C % 256 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && mask, "bn bwd (mask): C must be a multiple of 256, ld of 4");
+  CS_REQUIRE(cs_aligned16(dz) && cs_aligned16(y) && cs_aligned16(dy) && cs_aligned16(stats) && cs_aligned16(gamma) && cs_aligned16(dres) &&
+                 (((uintptr_t)mask) & 7) == 0, "bn bwd (mask): alignment");
+  if (workspace_bytes < catseg_bn_workspace(rows, C) || !workspace) {
+    catseg_set_error("bn bwd (mask): workspace too small");
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const RowSplit s = plan_rows(rows, C);
+  CS_REQUIRE(s.tpr == 64, "bn bwd (mask): row split");
+  float* part = (float*)workspace;
+  float* coef = part + (size_t)kMaxRowBlocks * 3 * ((C + 3) & ~3);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, dz, lddz, (const float*)nullptr, 0, y, ldy, stats, gamma,
+                     (const float*)nullptr, rows, C, 1, s, part, (unsigned*)nullptr, (unsigned*)nullptr, (const unsigned long long*)mask);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, st, dz, lddz, (const float*)nullptr, 0, y, ldy, stats, gamma,
+                     (const float*)nullptr, (const float*)coef, rows, C, 1, dy, lddy, dres, lddres, dres_accumulate, (unsigned*)amax_record,
+                     (const unsigned long long*)mask);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

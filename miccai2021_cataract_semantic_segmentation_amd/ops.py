@@ -1141,7 +1141,17 @@ def bn_eval_scale(gamma, running_var, eps):
     return scale
 
 
-def bn_apply(y, mean, scale, beta, residual, relu, out=None, planes_rec=None, planes_only=False):
+# The ReLU mask of a residual block's output as bits (csrc/norm.hip: catseg_bn_apply_mask / catseg_bn_backward_mask): the BatchNorm backward of
+# z = relu(bn(y) + residual) reads 1 bit per element instead of z in both of its passes.  CATSEG_RELU_BITS=0: z is read, as before.
+RELU_BITS = _os.environ.get("CATSEG_RELU_BITS", "1") != "0"
+
+
+def relu_bits_ok(y, residual, relu, out):
+    return bool(RELU_BITS and relu and residual is not None and y.is_cuda and y.shape[-1] % 256 == 0 and ld_of(y) % 4 == 0
+                and (out is None or ld_of(out) % 4 == 0))
+
+
+def bn_apply(y, mean, scale, beta, residual, relu, out=None, planes_rec=None, planes_only=False, want_mask=False):
     """the output carries an amax record (out._amax: max|out| accumulated by the kernel) when the trunk runs the f16x2 kernels.
     planes_rec (the record bn_finalize(bound=...) left the bound in): the kernel also writes the fp16 x 2 planes of the output (out._planes);
     planes_only: and NOT the fp32 output -- `out` is then an unwritten placeholder that only plane-streaming kernels may consume"""
@@ -1158,6 +1168,17 @@ def bn_apply(y, mean, scale, beta, residual, relu, out=None, planes_rec=None, pl
         out._amax = planes_rec
         out._planes = Planes(buf, planes_rec, y.shape)
         out._planes_only = bool(planes_only)
+        return out
+    if want_mask and relu_bits_ok(y, residual, relu, out):
+        rows, C = rows_of(y), y.shape[-1]
+        mask = torch.empty(lib.catseg_bn_mask_words(rows, C), dtype=torch.int64, device=y.device)
+        rec = new_amax(y.device) if _trunk_h2() else None
+        with _Timed("hbm:bn_apply", 4.0 * y.numel() * 3):
+            check(lib.catseg_bn_apply_mask(ptr(y), ld_of(y), ptr(mean), ptr(scale), ptr(beta), ptr(residual), ld_of(residual), ptr(out), ld_of(out),
+                                           rows, C, ptr(rec), ptr(mask), stream()))
+        if rec is not None:
+            out._amax = rec
+        out._relu_mask = mask
         return out
     with _Timed("hbm:bn_apply", 4.0 * y.numel() * (3 if residual is not None else 2)):
         _bn_apply(y, mean, scale, beta, residual, relu, out)
@@ -1226,12 +1247,24 @@ def _bn_apply(y, mean, scale, beta, residual, relu, out):
 
 
 def bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres=None, dres_accumulate=False, dy_out=None, beta=None):
-    """z=None (only without a residual branch): the ReLU mask is recomputed from y and beta instead of being read"""
+    """z=None (only without a residual branch): the ReLU mask is recomputed from y and beta instead of being read; a z that carries its mask as
+    bits (bn_apply(want_mask=True)) is not read either"""
     C = y.shape[-1]
     rows = rows_of(y)
     if dy_out is None:
         dy_out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
     ws = workspace(lib.catseg_bn_workspace(rows, C), y.device)
+    mask = getattr(z, "_relu_mask", None) if (z is not None and relu) else None
+    if mask is not None:
+        rec = new_amax(y.device) if _trunk_h2() else None
+        # algorithmic bytes: two passes over (dz, y) + dy written (+ the residual gradient)
+        with _Timed("hbm:bn_backward", 4.0 * y.numel() * (5 + (1 if dres is not None else 0))):
+            check(lib.catseg_bn_backward_mask(ptr(dz), ld_of(dz), ptr(mask), ptr(y), ld_of(y), ptr(stats), ptr(gamma), rows, C, ptr(dy_out),
+                                              ld_of(dy_out), ptr(dgamma), ptr(dbeta), ptr(dres), ld_of(dres) if dres is not None else 0,
+                                              1 if dres_accumulate else 0, ptr(ws), ws.numel(), ptr(rec), stream()))
+        if rec is not None:
+            dy_out._amax = rec
+        return dy_out
     # algorithmic bytes: two passes over (dz, y [or z]) + dy written (+ the residual gradient)
     with _Timed("hbm:bn_backward", 4.0 * y.numel() * (5 + (1 if dres is not None else 0))):
         _bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres, dres_accumulate, dy_out, beta, rows, C, ws)
