@@ -362,15 +362,24 @@ int catseg_bn_backward_amax(const float* dz, int lddz, const float* z, int ldz, 
                             const float* gamma, const float* beta, long long rows, int C, int relu, float* dy, int lddy, float* dgamma,
                             float* dbeta, float* dres, int lddres, int dres_accumulate, void* workspace, size_t workspace_bytes,
                             void* amax_record, catseg_stream_t stream);
-/* The ReLU mask of a residual block's output z = relu(bn(y) + residual) as BITS: catseg_bn_apply_mask = catseg_bn_apply_amax (relu on) that also
- * writes mask (catseg_bn_mask_words(rows, C) 64-bit words); catseg_bn_backward_mask = catseg_bn_backward_amax reading the bits instead of z in both
- * passes.  C % 256 == 0 (nn.BatchNorm2d + residual + ReLU of the stage-1 bottlenecks, models/HRNetv2.py:68-106, and torchvision's Bottleneck). */
-size_t catseg_bn_mask_words(long long rows, int C);
+/* The ReLU mask of a residual block's output z = relu(bn(y) + residual) as BITS (catseg_bn_mask_bytes(rows, C) = rows C / 8 bytes: bit (e & 7) of byte
+ * e >> 3 for the flat element index e = r C + c; C % 8 == 0): catseg_bn_apply_mask / catseg_bn_apply_planes_mask = catseg_bn_apply_amax /
+ * catseg_bn_apply_planes (relu on) that also write the mask; catseg_bn_backward_mask / catseg_bn_backward_planes_mask = catseg_bn_backward_amax /
+ * catseg_bn_backward_planes reading the bits instead of z in both passes (nn.BatchNorm2d + residual + ReLU of the blocks of models/HRNetv2.py:36-106
+ * and of torchvision's BasicBlock / Bottleneck). */
+size_t catseg_bn_mask_bytes(long long rows, int C);
 int catseg_bn_apply_mask(const float* y, int ldy, const float* mean, const float* scale, const float* beta, const float* residual, int ldr, float* z,
                          int ldz, long long rows, int C, void* amax_record, void* mask, catseg_stream_t stream);
 int catseg_bn_backward_mask(const float* dz, int lddz, const void* mask, const float* y, int ldy, const float* stats, const float* gamma,
                             long long rows, int C, float* dy, int lddy, float* dgamma, float* dbeta, float* dres, int lddres, int dres_accumulate,
                             void* workspace, size_t workspace_bytes, void* amax_record, catseg_stream_t stream);
+int catseg_bn_apply_planes_mask(const float* y, int ldy, const float* mean, const float* scale, const float* beta, const float* residual, int ldr,
+                                const void* residual_record, float* z, int ldz, void* z_planes, long long rows, int C, void* z_record, void* mask,
+                                catseg_stream_t stream);
+int catseg_bn_backward_planes_mask(const float* dz, int lddz, const void* mask, const float* y, int ldy, const float* stats, const float* gamma,
+                                   long long rows, int C, void* dy_planes, void* dy_record, void* g_record, const void* y_record, float* dgamma,
+                                   float* dbeta, float* dres, int lddres, int dres_accumulate, void* workspace, size_t workspace_bytes,
+                                   catseg_stream_t stream);
 int catseg_bn_backward_pre_amax(const float* g, int ldg, const float* q, int ldq, const float* stats, const float* gamma,
                                 const float* partials, int n_blocks, long long rows, int C, float* dq, int lddq, float* dgamma,
                                 float* dbeta, void* workspace, size_t workspace_bytes, void* amax_record, catseg_stream_t stream);

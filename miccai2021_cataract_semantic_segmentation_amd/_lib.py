@@ -73,9 +73,11 @@ _SIGS = {
     "catseg_bias_rows": (I, [P, P, I, L, I, P]),
     "catseg_bn_apply_amax": (I, [P, I, P, P, P, P, I, P, I, L, I, I, P, P]),
     "catseg_bn_backward_amax": (I, [P, I, P, I, P, I, P, P, P, L, I, I, P, I, P, P, P, I, I, P, SZ, P, P]),
-    "catseg_bn_mask_words": (SZ, [L, I]),
+    "catseg_bn_mask_bytes": (SZ, [L, I]),
     "catseg_bn_apply_mask": (I, [P, I, P, P, P, P, I, P, I, L, I, P, P, P]),
     "catseg_bn_backward_mask": (I, [P, I, P, P, I, P, P, L, I, P, I, P, P, P, I, I, P, SZ, P, P]),
+    "catseg_bn_apply_planes_mask": (I, [P, I, P, P, P, P, I, P, P, I, P, L, I, P, P, P]),
+    "catseg_bn_backward_planes_mask": (I, [P, I, P, P, I, P, P, L, I, P, P, P, P, P, P, P, I, I, P, SZ, P]),
     "catseg_bn_backward_pre_amax": (I, [P, I, P, I, P, P, P, I, L, I, P, I, P, P, P, SZ, P, P]),
     "catseg_add_n_act_amax": (I, [P, P, I, P, I, L, I, I, P, P]),
     "catseg_conv2d_fwd_fused": (I, [P, P, P, P, P, I, I, P, P]),

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ scale, const float* __restrict__ beta,
                                                        const float* __restrict__ res, int ldr, float* __restrict__ z,
                                                        int ldz, long long rows, int C, int relu, unsigned* __restrict__ amax,
-                                                       unsigned long long* __restrict__ mask = nullptr) {
+                                                       unsigned char* __restrict__ mask = nullptr) {
   const int cpt = C >> 2;
   unsigned m = 0;
   CS_QUAD_LOOP(rows, cpt, r, c) {
@@ -213,14 +213,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     *(f32x4*)(z + r * ldz + c) = v;
     m = max(m, cs_abs_bits4(v));
     if (mask) {
-      // the ReLU mask as BITS (C % 256 == 0: the 64 lanes of a wave hold 64 consecutive quads of one row, flat quad index i = 64 w + lane):
-      // mask[4 w + k] bit lane = (element k of quad 64 w + lane is positive).  The backward passes read 1 bit per element instead of z.
-      const long long i = r * cpt + (c >> 2);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const unsigned long long bal = __ballot(v[k] > 0.f);
-        if ((threadIdx.x & 63) == 0) mask[(i >> 6) * 4 + k] = bal;
-      }
+      // the ReLU mask as BITS: bit (e & 7) of byte e >> 3, e = r C + c the flat element index (C % 8 == 0).  This thread holds a nibble; its
+      // neighbour lane ^ 1 holds the other half of the byte (consecutive lanes walk consecutive quads, an even number per row and per stride:
+      // both lanes of a pair are in the loop together).  The backward passes read 1 bit per element instead of z.
+      const unsigned nib = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+      const unsigned other = (unsigned)__shfl_xor((int)nib, 1, 64);
+      if ((c & 4) == 0) mask[(r * C + c) >> 3] = (unsigned char)(nib | (other << 4));
     }
   }
   if (amax) cs_amax_commit(m, amax);       // (uniform per launch: the shuffles run with every lane)
@@ -234,7 +232,8 @@ __global__ __launch_bounds__(256) void bn_apply_planes_kernel(const float* __res
                                                               const float* __restrict__ scale, const float* __restrict__ beta,
                                                               const float* __restrict__ res, int ldr, const unsigned* __restrict__ res_rec,
                                                               float* __restrict__ zf, int ldz, unsigned char* __restrict__ planes,
-                                                              long long rows, int C, int relu, unsigned* __restrict__ rec) {
+                                                              long long rows, int C, int relu, unsigned* __restrict__ rec,
+                                                              unsigned char* __restrict__ mask = nullptr) {
   __shared__ __attribute__((aligned(16))) unsigned char sm[CsPlaneTile::BYTES];
   float bound = __uint_as_float(rec[CS_REC_BOUND]);
   if (res) bound += __uint_as_float(cs_amax_read(res_rec));
@@ -269,6 +268,12 @@ __global__ __launch_bounds__(256) void bn_apply_planes_kernel(const float* __res
           *(f32x4*)(zf + r * ldz + c) = v0;
           *(f32x4*)(zf + r * ldz + c + 4) = v1;
         }
+        if (mask) {       // the ReLU mask as bits (bn_apply_kernel): this thread's 8 channels are one byte
+          unsigned b = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) b |= (v0[k] > 0.f ? 1u << k : 0u) | (v1[k] > 0.f ? 16u << k : 0u);
+          mask[(r * C + c) >> 3] = (unsigned char)b;
+        }
         m = max(m, max(cs_abs_bits4(v0), cs_abs_bits4(v1)));
         const float xs[8] = {v0[0] * sc, v0[1] * sc, v0[2] * sc, v0[3] * sc, v1[0] * sc, v1[1] * sc, v1[2] * sc, v1[3] * sc};
         CsPlaneTile::stage(sm, row, g, xs);
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ beta, long long rows, int C, int relu,
                                                              RowSplit s, float* __restrict__ part, unsigned* __restrict__ gmax_rec = nullptr,
                                                              unsigned* __restrict__ ymax_rec = nullptr,
-                                                             const unsigned long long* __restrict__ mask = nullptr) {
+                                                             const unsigned char* __restrict__ mask = nullptr) {
   const int t = threadIdx.x;
   const int cg = blockIdx.y * s.tpr + t % s.tpr;
   const int rl = t / s.tpr;
@@ -312,12 +317,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         g[u] = ld4(dz + (r + u * st) * lddz + c);
         yy[u] = ld4(y + (r + u * st) * ldy + c);
       }
-      if (relu && mask) {        // (C % 256 == 0: this wave's 64 lanes are the 64 consecutive quads of mask words 4 w .. 4 w + 3)
+      if (relu && mask) {        // (this quad's nibble of the mask byte (r C + c) >> 3)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const long long w4 = (((r + u * st) * (long long)(C >> 2) + cg) >> 6) * 4;
+          const unsigned nib = (unsigned)mask[((r + u * st) * C + c) >> 3] >> (c & 4);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) g[u][i] = ((mask[w4 + i] >> (t & 63)) & 1ull) ? g[u][i] : 0.f;
+          for (int i = 0; i < 4; ++i) g[u][i] = ((nib >> i) & 1u) ? g[u][i] : 0.f;
         }
       } else if (relu) {
 #pragma unroll
@@ -340,9 +345,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
       f32x4 g = ld4(dz + r * lddz + c);
       const f32x4 yy = ld4(y + r * ldy + c);
       if (relu && mask) {
-        const long long w4 = ((r * (long long)(C >> 2) + cg) >> 6) * 4;
+        const unsigned nib = (unsigned)mask[(r * C + c) >> 3] >> (c & 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = ((mask[w4 + i] >> (t & 63)) & 1ull) ? g[i] : 0.f;
+        for (int i = 0; i < 4; ++i) g[i] = ((nib >> i) & 1u) ? g[i] : 0.f;
       } else if (relu) {
         const f32x4 zz = z ? ld4(z + r * ldz + c) : bn_affine(yy, mean, sc, be);
 #pragma unroll
@@ -441,7 +446,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const float* _
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   const float* __restrict__ coef, long long rows, int C, int relu,
                                                                   unsigned char* __restrict__ planes, unsigned* __restrict__ rec,
-                                                                  float* __restrict__ dres, int lddres, int dres_acc) {
+                                                                  float* __restrict__ dres, int lddres, int dres_acc,
+                                                                  const unsigned char* __restrict__ mask = nullptr) {
   __shared__ __attribute__((aligned(16))) unsigned char sm[CsPlaneTile::BYTES];
   const int e = cs_plane_exponent(rec[CS_REC_BOUND]);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -465,7 +471,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const float* _
           f32x4 g = ld4(dz + r * lddz + c);
           const f32x4 inv = ld4(stats + C + c), mean = ld4(stats + c);
           const f32x4 yy = ld4(y + r * ldy + c);
-          if (relu) {
+          if (relu && mask) {
+            const unsigned nib = (unsigned)mask[(r * C + c) >> 3] >> (c & 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = ((nib >> k) & 1u) ? g[k] : 0.f;
+          } else if (relu) {
             const f32x4 zz = z ? ld4(z + r * ldz + c) : bn_affine(yy, mean, ld4(gamma + c) * inv, ld4(beta + c));
 #pragma unroll
             for (int k = 0; k < 4; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
@@ -597,17 +607,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta, const float* __restrict__ coef, long long rows, int C,
                                                            int relu, float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres,
                                                            int dres_acc, unsigned* __restrict__ amax,
-                                                           const unsigned long long* __restrict__ mask = nullptr) {
+                                                           const unsigned char* __restrict__ mask = nullptr) {
   const int cpt = C >> 2;
   unsigned m = 0;
   CS_QUAD_LOOP(rows, cpt, r, c) {
     f32x4 g = ld4(dz + r * lddz + c);
     const f32x4 inv = ld4(stats + C + c), mean = ld4(stats + c);
     const f32x4 yy = ld4(y + r * ldy + c);
-    if (relu && mask) {          // (the walk of bn_apply_kernel, which wrote the bits: flat quad index i, lane = i & 63)
-      const long long w4 = ((r * cpt + (c >> 2)) >> 6) * 4;
+    if (relu && mask) {
+      const unsigned nib = (unsigned)mask[(r * C + c) >> 3] >> (c & 4);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) g[k] = ((mask[w4 + k] >> (threadIdx.x & 63)) & 1ull) ? g[k] : 0.f;
+      for (int k = 0; k < 4; ++k) g[k] = ((nib >> k) & 1u) ? g[k] : 0.f;
     } else if (relu) {
       const f32x4 zz = z ? ld4(z + r * ldz + c) : bn_affine(yy, mean, ld4(gamma + c) * inv, ld4(beta + c));
 #pragma unroll
@@ -940,19 +950,20 @@ extern "C" int catseg_bn_backward_h2(const float* dz, int lddz, const float* z, 
 }
 
 // ---- the ReLU mask as bits (round 5): a residual block's output z = relu(bn(y) + residual) is read by its BatchNorm backward only for its
-// sign.  catseg_bn_apply_mask = catseg_bn_apply_amax that also writes mask (catseg_bn_mask_words(rows, C) 64-bit words: 1 bit per element);
-// catseg_bn_backward_mask = catseg_bn_backward_amax reading the bits instead of z (both passes: 4 bytes per element less each).  C % 256 == 0
-// (the residual BatchNorms of the stage-1 bottlenecks, models/HRNetv2.py:68-106, and of torchvision's Bottleneck).
-extern "C" size_t catseg_bn_mask_words(long long rows, int C) { return (size_t)((rows * (C >> 2) + 63) / 64) * 4; }
+// sign.  Mask = rows x C / 8 bytes: bit (e & 7) of byte e >> 3 for the flat element index e = r C + c (C % 8 == 0).  catseg_bn_apply_mask /
+// catseg_bn_apply_planes_mask = catseg_bn_apply_amax / catseg_bn_apply_planes (relu on) that also write it; catseg_bn_backward_mask /
+// catseg_bn_backward_planes_mask = catseg_bn_backward_amax / catseg_bn_backward_planes reading the bits instead of z in both passes (4 bytes per
+// element less each).  The residual BatchNorms of the trunk (models/HRNetv2.py:36-106) and of torchvision's blocks.
+extern "C" size_t catseg_bn_mask_bytes(long long rows, int C) { return (size_t)(rows * C / 8); }
 
 extern "C" int catseg_bn_apply_mask(const float* y, int ldy, const float* mean, const float* scale, const float* beta, const float* residual,
                                     int ldr, float* z, int ldz, long long rows, int C, void* amax_record, void* mask, catseg_stream_t stream) {
-  CS_REQUIRE(rows > 0 && C > 0 && C % 256 == 0 && ldy % 4 == 0 && ldz % 4 == 0 && (residual == nullptr || ldr % 4 == 0) && mask,
-             "bn apply (mask): C must be a multiple of 256, ld of 4");
-  CS_REQUIRE(cs_aligned16(y) && cs_aligned16(z) && cs_aligned16(mean) && cs_aligned16(scale) && cs_aligned16(beta) && cs_aligned16(residual) &&
-                 (((uintptr_t)mask) & 7) == 0, "bn apply (mask): alignment");
+  CS_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && ldy % 4 == 0 && ldz % 4 == 0 && (residual == nullptr || ldr % 4 == 0) && mask,
+             "bn apply (mask): C must be a multiple of 8, ld of 4");
+  CS_REQUIRE(cs_aligned16(y) && cs_aligned16(z) && cs_aligned16(mean) && cs_aligned16(scale) && cs_aligned16(beta) && cs_aligned16(residual),
+             "bn apply (mask): alignment");
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, mean, scale, beta, residual, ldr, z,
-                     ldz, rows, C, 1, (unsigned*)amax_record, (unsigned long long*)mask);
+                     ldz, rows, C, 1, (unsigned*)amax_record, (unsigned char*)mask);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
@@ -960,24 +971,68 @@ extern "C" int catseg_bn_apply_mask(const float* y, int ldy, const float* mean, 
 extern "C" int catseg_bn_backward_mask(const float* dz, int lddz, const void* mask, const float* y, int ldy, const float* stats, const float* gamma,
                                        long long rows, int C, float* dy, int lddy, float* dgamma, float* dbeta, float* dres, int lddres,
                                        int dres_accumulate, void* workspace, size_t workspace_bytes, void* amax_record, catseg_stream_t stream) {
-  CS_REQUIRE(rows > 0 && C > 0 && C % 256 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && mask, "bn bwd (mask): C must be a multiple of 256, ld of 4");
-  CS_REQUIRE(cs_aligned16(dz) && cs_aligned16(y) && cs_aligned16(dy) && cs_aligned16(stats) && cs_aligned16(gamma) && cs_aligned16(dres) &&
-                 (((uintptr_t)mask) & 7) == 0, "bn bwd (mask): alignment");
+  CS_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && mask, "bn bwd (mask): C must be a multiple of 8, ld of 4");
+  CS_REQUIRE(cs_aligned16(dz) && cs_aligned16(y) && cs_aligned16(dy) && cs_aligned16(stats) && cs_aligned16(gamma) && cs_aligned16(dres),
+             "bn bwd (mask): alignment");
   if (workspace_bytes < catseg_bn_workspace(rows, C) || !workspace) {
     catseg_set_error("bn bwd (mask): workspace too small");
     return CATSEG_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
   const RowSplit s = plan_rows(rows, C);
-  CS_REQUIRE(s.tpr == 64, "bn bwd (mask): row split");
   float* part = (float*)workspace;
   float* coef = part + (size_t)kMaxRowBlocks * 3 * ((C + 3) & ~3);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, dz, lddz, (const float*)nullptr, 0, y, ldy, stats, gamma,
-                     (const float*)nullptr, rows, C, 1, s, part, (unsigned*)nullptr, (unsigned*)nullptr, (const unsigned long long*)mask);
+                     (const float*)nullptr, rows, C, 1, s, part, (unsigned*)nullptr, (unsigned*)nullptr, (const unsigned char*)mask);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, st, dz, lddz, (const float*)nullptr, 0, y, ldy, stats, gamma,
                      (const float*)nullptr, (const float*)coef, rows, C, 1, dy, lddy, dres, lddres, dres_accumulate, (unsigned*)amax_record,
-                     (const unsigned long long*)mask);
+                     (const unsigned char*)mask);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// catseg_bn_apply_planes (relu on) that also writes the mask
+extern "C" int catseg_bn_apply_planes_mask(const float* y, int ldy, const float* mean, const float* scale, const float* beta, const float* residual,
+                                           int ldr, const void* residual_record, float* z, int ldz, void* z_planes, long long rows, int C,
+                                           void* z_record, void* mask, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && ldy % 4 == 0 && (z == nullptr || ldz % 4 == 0) && (residual == nullptr || (ldr % 4 == 0 && residual_record)) && mask,
+             "bn apply (planes, mask): C must be a multiple of 8, ld of 4; a residual needs its amax record");
+  CS_REQUIRE(cs_aligned16(y) && cs_aligned16(z) && cs_aligned16(mean) && cs_aligned16(scale) && cs_aligned16(beta) && cs_aligned16(residual) &&
+                 cs_aligned16(z_planes) && z_planes && z_record, "bn apply (planes, mask): alignment");
+  const long long tiles = ((rows + 127) / 128) * ((C / 8 + 7) / 8);
+  hipLaunchKernelGGL(bn_apply_planes_kernel, dim3((int)(tiles > 8192 ? 8192 : tiles)), dim3(256), 0, (hipStream_t)stream, y, ldy, mean, scale, beta,
+                     residual, ldr, (const unsigned*)residual_record, z, ldz, (unsigned char*)z_planes, rows, C, 1, (unsigned*)z_record,
+                     (unsigned char*)mask);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// catseg_bn_backward_planes (relu on) reading the mask instead of z
+extern "C" int catseg_bn_backward_planes_mask(const float* dz, int lddz, const void* mask, const float* y, int ldy, const float* stats,
+                                              const float* gamma, long long rows, int C, void* dy_planes, void* dy_record, void* g_record,
+                                              const void* y_record, float* dgamma, float* dbeta, float* dres, int lddres, int dres_accumulate,
+                                              void* workspace, size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && dy_planes && dy_record && g_record && y_record && mask,
+             "bn bwd (planes, mask): C must be a multiple of 8, ld of 4; records required");
+  CS_REQUIRE(cs_aligned16(dz) && cs_aligned16(y) && cs_aligned16(dy_planes) && cs_aligned16(stats) && cs_aligned16(gamma) && cs_aligned16(dres),
+             "bn bwd (planes, mask): alignment");
+  if (workspace_bytes < catseg_bn_workspace(rows, C) || !workspace) {
+    catseg_set_error("bn bwd (planes, mask): workspace too small");
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const RowSplit s = plan_rows(rows, C);
+  float* part = (float*)workspace;
+  float* coef = part + (size_t)kMaxRowBlocks * 3 * ((C + 3) & ~3);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(s.nrb, s.gy), dim3(256), 0, st, dz, lddz, (const float*)nullptr, 0, y, ldy, stats, gamma,
+                     (const float*)nullptr, rows, C, 1, s, part, (unsigned*)g_record, (unsigned*)nullptr, (const unsigned char*)mask);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, st, (const float*)part, s.nrb, rows, C, dgamma, dbeta, coef,
+                     (const unsigned*)g_record, (const unsigned*)y_record, stats, gamma, (unsigned*)dy_record);
+  const long long tiles = ((rows + 127) / 128) * ((C / 8 + 7) / 8);
+  hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3((int)(tiles > 8192 ? 8192 : tiles)), dim3(256), 0, st, dz, lddz, (const float*)nullptr, 0, y, ldy,
+                     stats, gamma, (const float*)nullptr, (const float*)coef, rows, C, 1, (unsigned char*)dy_planes, (unsigned*)dy_record, dres, lddres,
+                     dres_accumulate, (const unsigned char*)mask);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

@@ -499,7 +499,7 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
         scale = ops.bn_eval_scale(bn.weight.data, bn.running_var, bn.eps)
     z = ops.bn_apply(y, mean, scale, bn.bias.data, residual, relu, out=out, planes_rec=zrec,
                      planes_only=zrec is not None and sole_conv_out and relu and residual is None,
-                     want_mask=cx.record and cx.train and zrec is None)       # (a residual block's output: its ReLU mask as bits for the backward pass)
+                     want_mask=cx.record and cx.train)       # (a residual block's output: its ReLU mask as bits for the backward pass)
     if cx.record:
         if not cx.train:
             raise NotImplementedError("backward through eval-mode BatchNorm is not on the training path")

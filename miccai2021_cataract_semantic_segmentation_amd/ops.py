@@ -1147,7 +1147,7 @@ RELU_BITS = _os.environ.get("CATSEG_RELU_BITS", "1") != "0"
 
 
 def relu_bits_ok(y, residual, relu, out):
-    return bool(RELU_BITS and relu and residual is not None and y.is_cuda and y.shape[-1] % 256 == 0 and ld_of(y) % 4 == 0
+    return bool(RELU_BITS and relu and residual is not None and y.is_cuda and y.shape[-1] % 8 == 0 and ld_of(y) % 4 == 0
                 and (out is None or ld_of(out) % 4 == 0))
 
 
@@ -1159,19 +1159,28 @@ def bn_apply(y, mean, scale, beta, residual, relu, out=None, planes_rec=None, pl
         out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
     if planes_rec is not None:
         buf = torch.empty(lib.catseg_planes_bytes(rows_of(y), y.shape[-1]), dtype=torch.uint8, device=y.device)
+        mask = None
+        if want_mask and not planes_only and relu_bits_ok(y, residual, relu, out):
+            mask = torch.empty(lib.catseg_bn_mask_bytes(rows_of(y), y.shape[-1]), dtype=torch.uint8, device=y.device)
         # algorithmic bytes: y (+ residual) read, planes written (4 B / element, like fp32), z written unless planes only
         with _Timed("hbm:bn_apply", 4.0 * y.numel() * ((3 if residual is not None else 2) + (0 if planes_only else 1))):
-            check(lib.catseg_bn_apply_planes(ptr(y), ld_of(y), ptr(mean), ptr(scale), ptr(beta), ptr(residual),
-                                             ld_of(residual) if residual is not None else 0, ptr(amax_of(residual)) if residual is not None else None,
-                                             None if planes_only else ptr(out), ld_of(out), ptr(buf), rows_of(y), y.shape[-1], 1 if relu else 0,
-                                             ptr(planes_rec), stream()))
+            if mask is not None:
+                check(lib.catseg_bn_apply_planes_mask(ptr(y), ld_of(y), ptr(mean), ptr(scale), ptr(beta), ptr(residual), ld_of(residual),
+                                                      ptr(amax_of(residual)), ptr(out), ld_of(out), ptr(buf), rows_of(y), y.shape[-1], ptr(planes_rec),
+                                                      ptr(mask), stream()))
+                out._relu_mask = mask
+            else:
+                check(lib.catseg_bn_apply_planes(ptr(y), ld_of(y), ptr(mean), ptr(scale), ptr(beta), ptr(residual),
+                                                 ld_of(residual) if residual is not None else 0, ptr(amax_of(residual)) if residual is not None else None,
+                                                 None if planes_only else ptr(out), ld_of(out), ptr(buf), rows_of(y), y.shape[-1], 1 if relu else 0,
+                                                 ptr(planes_rec), stream()))
         out._amax = planes_rec
         out._planes = Planes(buf, planes_rec, y.shape)
         out._planes_only = bool(planes_only)
         return out
     if want_mask and relu_bits_ok(y, residual, relu, out):
         rows, C = rows_of(y), y.shape[-1]
-        mask = torch.empty(lib.catseg_bn_mask_words(rows, C), dtype=torch.int64, device=y.device)
+        mask = torch.empty(lib.catseg_bn_mask_bytes(rows, C), dtype=torch.uint8, device=y.device)
         rec = new_amax(y.device) if _trunk_h2() else None
         with _Timed("hbm:bn_apply", 4.0 * y.numel() * 3):
             check(lib.catseg_bn_apply_mask(ptr(y), ld_of(y), ptr(mean), ptr(scale), ptr(beta), ptr(residual), ld_of(residual), ptr(out), ld_of(out),
@@ -1192,6 +1201,13 @@ def bn_backward_planes(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres, dres_a
     ws = workspace(lib.catseg_bn_workspace(rows, C), y.device)
     buf = torch.empty(lib.catseg_planes_bytes(rows, C), dtype=torch.uint8, device=y.device)
     rec, grec = new_amax(y.device), new_amax(y.device)
+    mask = getattr(z, "_relu_mask", None) if (z is not None and relu) else None
+    if mask is not None:
+        with _Timed("hbm:bn_backward", 4.0 * y.numel() * (5 + (1 if dres is not None else 0))):
+            check(lib.catseg_bn_backward_planes_mask(ptr(dz), ld_of(dz), ptr(mask), ptr(y), ld_of(y), ptr(stats), ptr(gamma), rows, C, ptr(buf), ptr(rec),
+                                                     ptr(grec), ptr(y_rec), ptr(dgamma), ptr(dbeta), ptr(dres), ld_of(dres) if dres is not None else 0,
+                                                     1 if dres_accumulate else 0, ptr(ws), ws.numel(), stream()))
+        return Planes(buf, rec, y.shape)
     with _Timed("hbm:bn_backward", 4.0 * y.numel() * (5 + (1 if dres is not None else 0))):
         check(lib.catseg_bn_backward_planes(ptr(dz), ld_of(dz), ptr(z), ld_of(z) if z is not None else 0, ptr(y), ld_of(y), ptr(stats), ptr(gamma),
                                             ptr(beta), rows, C, 1 if relu else 0, ptr(buf), ptr(rec), ptr(grec), ptr(y_rec), ptr(dgamma), ptr(dbeta),
