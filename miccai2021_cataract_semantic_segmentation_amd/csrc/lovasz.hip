@@ -292,28 +292,28 @@ __global__ __launch_bounds__(PIX) void lv_compact1_kernel(const float* __restric
 __global__ __launch_bounds__(PIX) void lv_gather_kernel(const uint32_t* __restrict__ tmp, long long P, int K, const uint32_t* __restrict__ counts,
                                                         const uint32_t* __restrict__ blkoff, long long nblk, const uint32_t* __restrict__ nact,
                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  // every class's (offset, count) of this block in ONE round trip (thread = class), then wave w moves classes w, w + 4, ...: no load depends on
+  // the previous class (a loop over the classes with its offsets fetched class by class took 167 us for 8 MB)
+  __shared__ uint32_t soff[MAXK], scnt[MAXK];
   const long long p0 = (long long)blockIdx.x * PIX;
-  const uint32_t t = threadIdx.x;
-  const bool last = blockIdx.x + 1 == nblk;
-  for (int c0 = 0; c0 < K; c0 += 5) {          // five classes' loads in flight (a class per round trip made this pass latency-bound)
-    uint32_t off[5], n[5], v[5];
-#pragma unroll
-    for (int u = 0; u < 5; ++u) {
-      const int c = c0 + u;
-      off[u] = 0; n[u] = 0;
-      if (c < K && counts[c] != 0) {
-        off[u] = blkoff[(long long)c * nblk + blockIdx.x];
-        n[u] = (last ? nact[c] : blkoff[(long long)c * nblk + blockIdx.x + 1]) - off[u];
-      }
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < K) {
+    uint32_t off = 0, n = 0;
+    if (counts[t] != 0) {
+      off = blkoff[(long long)t * nblk + blockIdx.x];
+      n = (blockIdx.x + 1 == nblk ? nact[t] : blkoff[(long long)t * nblk + blockIdx.x + 1]) - off;
     }
-#pragma unroll
-    for (int u = 0; u < 5; ++u) v[u] = t < n[u] ? tmp[(long long)(c0 + u) * P + p0 + t] : 0u;
-#pragma unroll
-    for (int u = 0; u < 5; ++u)
-      if (t < n[u]) {
-        keys[(long long)(c0 + u) * P + off[u] + t] = v[u] & 0x7FFFFFFFu;
-        vals[(long long)(c0 + u) * P + off[u] + t] = (off[u] + t) | (v[u] & 0x80000000u);
-      }
+    soff[t] = off;
+    scnt[t] = n;
+  }
+  __syncthreads();
+  for (int c = wave; c < K; c += 4) {
+    const uint32_t off = soff[c], n = scnt[c];
+    for (uint32_t j = lane; j < n; j += 64) {
+      const uint32_t v = tmp[(long long)c * P + p0 + j];
+      keys[(long long)c * P + off + j] = v & 0x7FFFFFFFu;
+      vals[(long long)c * P + off + j] = (off + j) | (v & 0x80000000u);
+    }
   }
 }
 
