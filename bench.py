@@ -442,6 +442,7 @@ def main():
 
     def drop_graph():
         if graphed["step"] is not None:
+            graphed["overlap"] = graphed["step"].overlap_report()
             graphed["step"].release()
             graphed["step"], graphed["key"] = None, None
 
@@ -641,10 +642,14 @@ def main():
     comm = None
     if world > 1:
         drop_graph()                             # (hands the reducer back to the model)
-        comm = model._grad_sync.stats()
-        comm["overlap"] = ("none: the exchange runs behind the replayed graph of zero_grad .. backward (graph.GraphedTrainStep); exposed_wait_ms is "
-                           "the whole all-reduce" if (not args.eager and not args.with_h2d) else
-                           "buckets are launched from the backward tape as their last gradient is written")          # every rank (it synchronises its device); rank 0 prints
+        overlap = graphed.get("overlap") if (not args.eager and not args.with_h2d and "error" not in graphed) else None
+        comm = model._grad_sync.stats()          # every rank (it synchronises its device); rank 0 prints
+        # how the exchange sits against the backward pass in the mode the timed region ran in: the replayed step is cut into a chain of
+        # hipGraphs at bucket boundaries and each all_reduce is launched between two of them (graph.GraphedTrainStep), or --eager: the
+        # buckets are launched from the backward tape as their last gradient is written.  exposed_wait_ms = what the launch stream still
+        # waited for after its last backward kernel
+        comm["overlap"] = overlap if overlap is not None else {
+            "mode": "eager launch loop: buckets are launched from the backward tape as their last gradient is written"}
         comm["payload_MB_per_step"] = round(comm["bytes_reduced_per_step"] / 1e6, 1)
         if comm["backend"] != "nccl":
             comm["note"] = "FUNCTIONAL ARTEFACT: backend %s asked for through CATSEG_DIST_BACKEND -- not an RCCL / xGMI measurement, not a scaling figure" % comm["backend"]
@@ -780,8 +785,9 @@ def main():
         out["config"]["execution"] = (("the step recorded once by stream capture and replayed as one hipGraph per step (graph.GraphedTrainStep: same "
                                        "launches, same streams, bit-identical results; %d capture(s), %.1f s, outside the timed region)%s"
                                        % (graphed["captures"], graphed["capture_s"],
-                                          "; data parallel: graph = zero_grad .. backward, then bucketed RCCL all-reduce, Adam, confusion matrix as "
-                                          "ordinary launches" if world > 1 else ""))
+                                          "; data parallel: the capture is cut into a chain of hipGraphs at gradient-bucket boundaries, each bucket's "
+                                          "RCCL all_reduce is launched between two replays and overlaps the rest of the backward pass; Adam + "
+                                          "confusion matrix are the chain's last graph (comm.overlap)" if world > 1 else ""))
                                       if (not args.eager and not args.with_h2d and "error" not in graphed) else
                                       ("eager: one ctypes launch per kernel" + (" (hipGraph capture failed: %s)" % graphed["error"] if "error" in graphed else " (--eager)")))
         _emit(json.dumps(out))

@@ -25,6 +25,10 @@ def init_group(backend, rank, world, local=0):
     SIMDs); the hardware scheduler serves a high-priority queue first whenever a workgroup slot frees, so a bucket's few-CU ring kernel
     starts beside them instead of behind the queue of the compute streams."""
     if backend == "nccl":
+        # the host driver of the target pool only supports dmabuf IPC: without this RCCL's peer mappings fail with
+        # `hipIpcGetMemHandle: invalid argument`.  Set here, in front of this process's first GPU call of the group, so that a rank
+        # started by an external torchrun or through managers.* gets it as bench.self_launch's children do.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         opts = None
         if COMM_HIGH_PRIORITY:
@@ -87,6 +91,8 @@ class GradSync:
         self.handles = []
         self.launched = []
         self.bytes_reduced = 0
+        self.bytes_early = 0    # ... of which launched while the backward pass still had kernels to enqueue (from the tape / between graphs)
+        self.launches_early = 0
         self.steps = 0
         self.exposed_ms = 0.0   # GPU time the launch stream spent waiting for the exchange after its last backward kernel
         self.host_wait_ms = 0.0
@@ -127,7 +133,7 @@ class GradSync:
         self.launched = [False] * len(self.buckets)
         self.handles = []
 
-    def _launch(self, b):
+    def _launch(self, b, early=True):
         if self.launched[b]:
             return
         self.launched[b] = True
@@ -135,6 +141,9 @@ class GradSync:
         if self.world > 1 or (self.force and dist.is_initialized()):
             self.handles.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.bytes_reduced += (e - s) * 4
+            if early:
+                self.bytes_early += (e - s) * 4
+                self.launches_early += 1
 
     def param_ready(self, p):
         b = self.bucket_of.get(id(p))
@@ -147,7 +156,7 @@ class GradSync:
     def finish(self):
         import time
         for b in range(len(self.buckets)):   # parameters that received no gradient this step
-            self._launch(b)
+            self._launch(b, early=False)
         cuda = self.grad.is_cuda and bool(self.handles)
         if cuda:
             if self._ev is not None:         # (read last step's pair here: no synchronisation on the hot path)
@@ -179,6 +188,8 @@ class GradSync:
                 "tail_bucket_MB": self.tail_bytes / (1 << 20),
                 "bucket_sizes_MB": [round((e - s) * 4 / (1 << 20), 2) for (s, e, _) in self.buckets],
                 "bytes_reduced_per_step": self.bytes_reduced // n, "exposed_wait_ms": self.exposed_ms / n,
+                "bytes_launched_under_backward_per_step": self.bytes_early // n,
+                "buckets_launched_under_backward_per_step": self.launches_early / n,
                 "host_wait_ms": self.host_wait_ms / n, "steps": self.steps,
                 "comm_stream_priority": "high" if (COMM_HIGH_PRIORITY and dist.is_initialized() and dist.get_backend(self.group) == "nccl")
                 else "default", "forced_in_world_of_one": bool(self.force and self.world == 1)}

@@ -161,6 +161,7 @@ class Ctx:
         self.grads = {}
         self.shared = set()
         self.on_param_grad = on_param_grad
+        self.on_quiet = None           # backward: called on the launch stream between two tape entries outside every parallel region
         self.claimed = set()
         self.branch_stream = None      # stream of the branch being recorded (None: the main stream)
         self.region = None
@@ -378,9 +379,13 @@ class Ctx:
                         ready, self._deferred = self._deferred, []
                         for p in ready:         # (on the main stream, which now follows every branch of the region)
                             self.on_param_grad(p)
+                    if self._region_depth == 0 and self.on_quiet is not None and tape:
+                        self.on_quiet()
                 continue
             if tag is None:
                 fn()
+                if self._region_depth == 0 and self.on_quiet is not None and tape:
+                    self.on_quiet()             # (graph.GraphedTrainStep cuts its capture here when enough buckets are complete)
             else:
                 with torch.cuda.stream(tag):
                     fn()
@@ -883,23 +888,15 @@ class NetFunction(torch.autograd.Function):
         ctx.cx = cx
         ctx.net = net
         ctx.outs_nhwc = outs
+        if net._keep_pass:
+            net._last_pass = (cx, outs)
         res = tuple(o.permute(0, 3, 1, 2) for o in outs)
         ctx.mark_non_differentiable()
         return res if len(res) > 1 else res[0]
 
     @staticmethod
     def backward(ctx, *gouts):
-        cx = ctx.cx
-        for o, g in zip(ctx.outs_nhwc, gouts):
-            if g is None:
-                continue
-            gn = g.permute(0, 2, 3, 1)
-            if not gn.is_contiguous():
-                gn = gn.contiguous()
-            cx.give(o, gn)
-        ctx.net._begin_backward(cx)
-        cx.backward()
-        ctx.net._end_backward(cx)
+        ctx.net._tape_backward(ctx.cx, ctx.outs_nhwc, gouts)
         return None, None, None
 
 
@@ -912,6 +909,8 @@ class EngineNet(nn.Module):
         self._flatp = None
         self._grad_sync = None  # optional data-parallel gradient reducer
         self._grads_pending = False
+        self._keep_pass = False  # graph.GraphedTrainStep (segmented capture): keep the recorded pass for backward_from()
+        self._last_pass = self._last_outputs = None
 
     def flat(self):
         if self._flatp is None:
@@ -1039,7 +1038,31 @@ class EngineNet(nn.Module):
             ops.set_amax_scope(cx.amax_scope)           # (another forward pass may have run since this one)
         if self._grad_sync is not None:
             cx.on_param_grad = self._grad_sync.param_ready
+            cx.on_quiet = getattr(self._grad_sync, "quiet_point", None)
             self._grad_sync.begin(fp)
+
+    def _tape_backward(self, cx, outs_nhwc, gouts):
+        """the backward pass of a recorded forward: hands the output gradients (NCHW, as autograd carries them) to the tape and pops it"""
+        for o, g in zip(outs_nhwc, gouts):
+            if g is None:
+                continue
+            gn = g.permute(0, 2, 3, 1)
+            if not gn.is_contiguous():
+                gn = gn.contiguous()
+            cx.give(o, gn)
+        self._begin_backward(cx)
+        cx.backward()
+        self._end_backward(cx)
+
+    def backward_from(self, gouts):
+        """runs the tape of the last recorded forward pass ON THE CALLING THREAD from the gradients of its outputs (one per output of
+        forward(), None allowed) -- what NetFunction.backward does inside autograd's device thread.  graph.GraphedTrainStep drives the
+        backward pass this way when it cuts the captured step into segments: a stream capture has to end on the thread that began it.
+        Needs `_keep_pass` set before the forward."""
+        if self._last_pass is None:
+            raise RuntimeError("backward_from(): no recorded forward pass is kept (set model._keep_pass = True before the forward)")
+        (cx, outs), self._last_pass, self._last_outputs = self._last_pass, None, None
+        self._tape_backward(cx, outs, gouts)
 
     def _end_backward(self, cx):
         if getattr(cx, "amax_scope", None) is not None:
@@ -1055,7 +1078,10 @@ class EngineNet(nn.Module):
         fp = self.flat()
         x = x.contiguous().float()
         if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in fp.params):
-            return NetFunction.apply(self, x, fp.params[0])
+            res = NetFunction.apply(self, x, fp.params[0])
+            if self._keep_pass:
+                self._last_outputs = res if isinstance(res, tuple) else (res,)
+            return res
         _, outs = self._run(x, record=False)
         res = tuple(o.permute(0, 3, 1, 2) for o in outs)
         return res if len(res) > 1 else res[0]

@@ -63,24 +63,32 @@ def main():
     dst = torch.zeros_like(src)
     dist.all_gather_into_tensor(dst, src)
     torch.cuda.synchronize()
-    # the step as a hipGraph with the RCCL group alive (its watchdog thread included): the graph ends with the backward pass, the forced
-    # bucketed exchange, Adam and nothing else follow as ordinary launches -- what every rank of `bench.py --gpus N` does
+    # the step in the DEFAULT execution mode of `bench.py --gpus N` with the RCCL group alive (its watchdog thread included): the
+    # captured step cut into a chain of hipGraphs at bucket boundaries, every bucket's forced ncclAllReduce launched between two replays
+    # on RCCL's high-priority stream, the launch stream waiting for them in front of the tail graph (Adam)
     from miccai2021_cataract_semantic_segmentation_amd.graph import GraphedTrainStep
     from miccai2021_cataract_semantic_segmentation_amd.optim import FusedAdam
     opt = FusedAdam(model, lr=0.0, grad_scale=scale)
-    step = GraphedTrainStep(model, lambda o, l: crit(*o, l), opt, x, lbl)
+    step = GraphedTrainStep(model, lambda o, l: crit(*o, l), opt, x, lbl, segment_bytes=32 << 20)
     assert step.split and model._grad_sync is None
     g_graph = []
+    early0, bytes0 = sync.launches_early, sync.bytes_reduced
     for _ in range(2):
         lg = float(step(x, lbl))
         torch.cuda.synchronize()
         g_graph.append((model.flat().grad.clone(), lg))
+    graph_overlap = step.overlap_report()
+    graph_log = list(step.launch_log)
+    n_graphs = len(step.graphs)
     step.release()
     assert model._grad_sync is sync
     st2 = sync.stats()
     out = {"deterministic": bool(torch.equal(g_plain, g_plain2)),
            "graph_bit_identical": all(bool(torch.equal(g, g_plain)) and l == l_plain for g, l in g_graph),
-           "graph_steps_reduced": st2["steps"] - st["steps"],
+           "graph_steps_reduced": st2["steps"] - st["steps"], "graph_overlap": graph_overlap, "graph_launch_log": graph_log,
+           "graph_backward_graphs": n_graphs, "graph_early_launches_per_step": (sync.launches_early - early0) / 2,
+           "graph_bytes_per_step": (sync.bytes_reduced - bytes0) / 2,
+           "graph_exposed_wait_ms": st2["exposed_wait_ms"],
            "bit_identical": all(bool(torch.equal(g, g_plain)) for g, _ in res),
            "loss_equal": all(l == l_plain for _, l in res), "scale": scale, "stats": st,
            "flat_bytes": int(model.flat().grad.numel() * 4), "gather_ok": bool(torch.equal(dst, src)),

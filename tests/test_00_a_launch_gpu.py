@@ -79,4 +79,14 @@ def test_rccl_world1_forced_gradient_exchange(tmp_path):
     assert r["grad_norm"] > 0 and r["scale"] == 1.0
     # the graph replay with the RCCL group (and its watchdog thread) alive: same gradients, one forced exchange per replayed step
     assert r["graph_bit_identical"] and r["graph_steps_reduced"] == 2
+    # ... in the segmented form: >= 4 buckets went to RCCL before the LAST backward graph was replayed (they overlap the rest of the
+    # backward pass), every bucket exactly once per step, the whole flat gradient per step
+    ov, log = r["graph_overlap"], r["graph_launch_log"]
+    last = r["graph_backward_graphs"] - 1
+    assert r["graph_backward_graphs"] >= 4 and ov["graphs_per_step"] == r["graph_backward_graphs"] + 1
+    assert sum(1 for i, _ in log if i < last) >= 4 and ov["buckets_launched_before_the_last_backward_graph"] >= 4
+    assert sorted(b for _, b in log) == list(range(st["buckets"]))
+    assert r["graph_early_launches_per_step"] >= 4 and r["graph_bytes_per_step"] >= 0.99 * r["flat_bytes"]
+    assert r["graph_exposed_wait_ms"] >= 0.0
+    print("segmented graph replay over RCCL:", json.dumps(ov))
     print("RCCL world-1 forced exchange:", json.dumps(st))

@@ -90,6 +90,80 @@ def test_graphed_step_is_bit_identical_to_the_eager_step(name, shape):
     assert torch.isfinite(loss)
 
 
+def test_segmented_replay_cuts_at_bucket_boundaries_and_is_bit_identical():
+    """data parallel, default execution mode: with a reducer attached the captured step is CUT where the backward tape has released whole
+    gradient buckets (graph.GraphedTrainStep, segmented replay) so that each bucket's all_reduce can be launched between two hipGraph
+    replays, under the rest of the backward pass.  Here: no process group (a world of one: GradSync launches nothing), so this pins the
+    chain itself -- several graphs from one private pool, the backward tape driven on the calling thread (EngineNet.backward_from) --
+    against the eager loop: losses, parameters, Adam moments, BatchNorm statistics, confusion matrix bit for bit over changing batches
+    and learning rates; every bucket is released exactly once, most of them before the last backward graph."""
+    _need_gpu()
+    from miccai2021_cataract_semantic_segmentation_amd import dist as D
+    from miccai2021_cataract_semantic_segmentation_amd.graph import GraphedTrainStep
+    from miccai2021_cataract_semantic_segmentation_amd.utils.metrics import t_get_confusion_matrix
+    model, crit, opt, batches = _setup("ocrnet_hrnet48", 2, 128, 192)
+    fp = model.flat()
+    w0 = fp.flat.clone()
+    bufs0 = [b.clone() for b in model.buffers()]
+    lrs = [1e-3, 5e-4, 2.5e-4]
+    cm_e = torch.zeros((25, 25), dtype=torch.int32, device="cuda")
+    losses_e = []
+    for i, lr in enumerate(lrs):
+        opt.param_groups[0]["lr"] = lr
+        x, y = batches[i % 4]
+        opt.zero_grad()
+        out = model(x)
+        loss = crit(*out, y)
+        loss.backward()
+        opt.step()
+        t_get_confusion_matrix(out[1].detach(), y, cm_e)
+        losses_e.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    w_e, m_e, v_e = fp.flat.clone(), opt._m.clone(), opt._v.clone()
+    bufs_e = [b.clone() for b in model.buffers()]
+    g_e = fp.grad.clone()
+    with torch.no_grad():
+        fp.flat.copy_(w0)
+        opt._m.zero_()
+        opt._v.zero_()
+        for b, s in zip(model.buffers(), bufs0):
+            b.copy_(s)
+    opt._steps = 0
+    assert D.attach(model, bucket_bytes=16 << 20) == 1.0
+    sync = model._grad_sync
+    cm_g = torch.zeros((25, 25), dtype=torch.int32, device="cuda")
+    step = GraphedTrainStep(model, lambda o, l: crit(*o, l), opt, *batches[0], confusion=cm_g, segment_bytes=32 << 20)
+    assert step.split and model._grad_sync is None and step.graph is None
+    nb = len(sync.buckets)
+    assert nb >= 10 and len(step.graphs) >= 4 and step.tail_graph is not None
+    assert sorted(b for r in step.releases for b in r) == list(range(nb))
+    rep = step.overlap_report()
+    assert rep["graphs_per_step"] == len(step.graphs) + 1 and rep["buckets_launched_before_the_last_backward_graph"] >= nb // 2
+    assert 0 in step.releases[-1]                       # the tail bucket (stem: lowest offsets) is ready last
+    losses_g = []
+    for i, lr in enumerate(lrs):
+        opt.param_groups[0]["lr"] = lr
+        losses_g.append(float(step(*batches[i % 4])))
+    torch.cuda.synchronize()
+    assert [b for _, b in step.launch_log] == [b for r in step.releases for b in r]
+    assert [i for i, _ in step.launch_log] == sorted(i for i, _ in step.launch_log)
+    assert losses_g == losses_e
+    assert torch.equal(fp.grad, g_e)
+    assert torch.equal(fp.flat, w_e) and torch.equal(opt._m, m_e) and torch.equal(opt._v, v_e)
+    for b, s in zip(model.buffers(), bufs_e):
+        assert torch.equal(b, s)
+    assert torch.equal(cm_g, cm_e) and int(cm_e.sum()) > 0
+    assert opt._steps == len(lrs) and sync.steps == len(lrs)
+    step.release()
+    assert model._grad_sync is sync and not model._keep_pass
+    opt.zero_grad()                                     # the eager loop goes on (reducer back on the tape)
+    loss = crit(*model(batches[1][0]), batches[1][1])
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and sync.steps == len(lrs) + 1
+
+
 def test_manager_epochs_through_the_graph_equal_the_eager_loop(tmp_path):
     """config['train']['hip_graph'] = True: the manager records its step once per epoch and replays it -- two epochs (the second at the
     scheduler's next learning rate) give the history, the weights and the BatchNorm statistics of the eager loop, bit for bit"""
