@@ -331,8 +331,12 @@ def infer_bench(args):
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = infer_cpu_baseline(H, W, args.cpu_threads)
+    # the one exchange of a frame-sharded inference run (reference managers/BaseManager.py:640-688 scores one confusion matrix over the whole
+    # set): every rank's matrix summed once, after the timed region
+    torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.all_reduce(cm)
+    cm_pixels, cm_local = int(cm.sum()), int((lbl != 25).sum())
     if rank == 0:
         _emit(json.dumps({"metric": "inference frames/sec @1080x1920 UPerNet-ResNeXt101", "value": world * B * args.steps / dt,
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -340,7 +344,9 @@ def infer_bench(args):
                           "dtype": DTYPE_STRING(), "data": "synthetic",
                           "config": {"workload": "EncDec(ResNeXt101_32x8d + UPerNet), 25-class, bs=%d/GPU @3x%dx%d, eval-mode forward + "
                                                  "argmax + confusion matrix (BASELINE config 5)" % (B, H, W),
-                                     "global_batch": world * B, "parallelism": "dp%d (frame sharded)" % world},
+                                     "global_batch": world * B, "parallelism": "dp%d (frame sharded)" % world,
+                                     "confusion_matrix": {"pixels_scored_all_ranks": cm_pixels, "labelled_pixels_per_step_rank0": cm_local,
+                                                          "summed_over_ranks": world > 1}},
                           "roofline": roof, "cpu_baseline": cpu}))
     if world > 1:
         dist.destroy_process_group()

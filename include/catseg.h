@@ -188,6 +188,15 @@ int catseg_stem3_fwd(const float* x, long long sb, long long sc, long long sy, l
 int catseg_stem3_bwd_weight(const float* x, long long sb, long long sc, long long sy, long long sx, int B, int H, int W, const float* dy, int lddy,
                             float* dw, void* workspace, size_t workspace_bytes, catseg_stream_t stream);
 
+/* ---- the first convolution of the torchvision ResNet stem: nn.Conv2d(3, 64, 7, stride 2, padding 3, bias=False) on the image (the resnet50 / resnet101
+ * backbones built at models/OCR.py:58-61 and models/DeepLabv3Plus.py:32-38 of the reference; torchvision's `conv1`), training forward as a direct
+ * kernel whose 147 products per output are accumulated in fp64 and rounded once (csrc/stem7.hip).  Arguments as catseg_stem3_fwd; w: OHWI [64][7][7][3].
+ *   catseg_stem7_fwd: y = F.conv2d(x, w, bias, 2, 3); bn_part != NULL: catseg_stem7_partial_rows(B, H, W) rows of BatchNorm partials + pixel counts. */
+int catseg_stem7_supported(int H, int W, int Cout);
+int catseg_stem7_partial_rows(int B, int H, int W);
+int catseg_stem7_fwd(const float* x, long long sb, long long sc, long long sy, long long sx, int B, int H, int W, const float* w, const float* bias,
+                     float* y, int ldy, float* bn_part, int* bn_counts, catseg_stream_t stream);
+
 /* ---- direct 3x3 / stride 1 / pad 1 convolution in split precision (csrc/dconv3_b3.hip) for the HRNet trunk: the BasicBlock
  * convolutions conv3x3(planes, planes) at models/HRNetv2.py:22-25,41-44 (Cin = Cout = C in {48, 96}; catseg_dconv3_supported).
  * Same F.conv2d call sites and same arithmetic as catseg_conv2d_fwd_bf16x3 (three exact bf16 planes per fp32 operand, six bf16

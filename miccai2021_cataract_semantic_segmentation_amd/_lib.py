@@ -128,6 +128,9 @@ _SIGS = {
     "catseg_stem3_wgrad_workspace": (SZ, []),
     "catseg_stem3_fwd": (I, [P, L, L, L, L, I, I, I, P, P, P, I, P, P, P]),
     "catseg_stem3_bwd_weight": (I, [P, L, L, L, L, I, I, I, P, I, P, P, SZ, P]),
+    "catseg_stem7_supported": (I, [I, I, I]),
+    "catseg_stem7_partial_rows": (I, [I, I, I]),
+    "catseg_stem7_fwd": (I, [P, L, L, L, L, I, I, I, P, P, P, I, P, P, P]),
     "catseg_split2h_weight_blocked": (I, [P, I, I, I, P, P, P]),
     "catseg_split2h_weight_t_blocked": (I, [P, I, I, I, P, P, P]),
     "catseg_conv2d_fwd_f16x2_blocked": (I, [P, P, P, P, P, P, P, I, P, SZ, P, P, P]),

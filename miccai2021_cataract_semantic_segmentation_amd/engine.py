@@ -453,8 +453,14 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
     kh, kw = conv.kernel_size
     s, p, d = conv.stride[0], conv.padding[0], conv.dilation[0]
     pad3 = (not conv.stem) and w.shape[1] == 3       # 3-channel image into a generic conv (HRNet 3x3/2 stem)
-    stem3 = False
-    if conv.stem:
+    stem3 = stem7 = False
+    if (conv.stem and cx.train and conv.bias is None and not need_dx and out is None and w.data.is_contiguous(memory_format=torch.channels_last)
+            and ops.stem7_ok(x, w.data, kh, kw, s, p, d, conv.groups)):
+        # the ResNet stem's first convolution, training forward: the direct fp64-accumulating kernel on the image as it is (csrc/stem7.hip);
+        # the backward-weight pass packs its operands for the implicit GEMM itself
+        stem7 = True
+        x_in, wk = x, w.data
+    elif conv.stem:
         x_in = x if is_nhwc4(x) else ops.nchw3_to_nhwc4(x)
         wk = ops.stem_pack_weight(w.data, Cout)
     elif pad3 and cx.train and conv.bias is None and not need_dx and out is None and ops.stem3_ok(x, w.data, kh, kw, s, p, d, conv.groups):
@@ -479,6 +485,8 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
         # batch statistics: per-tile partial sums come out of the convolution's epilogue (no separate pass over y)
         if stem3:
             y = ops.stem3_fwd(x_in, wk, None, bn_stats=FUSE_BN_STATS)
+        elif stem7:
+            y = ops.stem7_fwd(x_in, wk, None, bn_stats=FUSE_BN_STATS)
         else:
             y = ops.conv_fwd(x_in, wk, bias, Cout, kh, kw, s, p, d, stem4=conv.stem, groups=conv.groups, bn_stats=FUSE_BN_STATS, train=cx.record,
                              exact=conv.exact_operands)
@@ -562,8 +570,9 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
             del dz
             dbias = cx.pgrad(conv.bias) if conv.bias is not None else None
             if conv.stem:
-                dpk = torch.empty_like(wk)
-                ops.conv_bwd_weight(x_in, dy, dpk, dbias, kh, kw, s, p, d, stem4=True)
+                x4 = x_in if is_nhwc4(x_in) else ops.nchw3_to_nhwc4(x_in)      # (stem7: the forward read the image as it was)
+                dpk = torch.empty((Cout, 7, 8, 4), dtype=torch.float32, device=dy.device)     # the packed layout of ops.stem_pack_weight
+                ops.conv_bwd_weight(x4, dy, dpk, dbias, kh, kw, s, p, d, stem4=True)
                 ops.stem_unpack_grad(dpk, cx.pgrad(w), Cout)
             elif stem3:
                 ops.stem3_bwd_weight(x_in, dy, cx.pgrad(w))

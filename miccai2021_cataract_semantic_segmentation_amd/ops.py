@@ -744,6 +744,37 @@ def stem3_bwd_weight(x, dy, dw):
     return dw
 
 
+# The first convolution of the torchvision ResNet stem (3 -> 64, 7 x 7 / stride 2 / pad 3 on the image), training forward accumulated in fp64 and
+# rounded once (csrc/stem7.hip): what csrc/stem3.hip did for the HRNet models' literal-1e-3 distance to the CPU path, for OCRNet-R50 / DeepLabv3+.
+# The layer's backward-weight stays on the implicit GEMM (stem4 layout).  CATSEG_STEM7=0: the implicit-GEMM forward.
+STEM7 = _os.environ.get("CATSEG_STEM7", "1") != "0"
+
+
+def stem7_ok(x, w, kh, kw, stride, pad, dil, groups):
+    if not (STEM7 and x.is_cuda and x.dtype == torch.float32 and w.dim() == 4 and w.shape[1] == 3 and (kh, kw, stride, pad, dil, groups) == (7, 7, 2, 3, 1, 1)):
+        return False
+    B, H, W = _image_strides(x)[:3]
+    return bool(lib.catseg_stem7_supported(H, W, w.shape[0]))
+
+
+def stem7_fwd(x, w, bias, bn_stats=False):
+    """x: the image (NCHW or NHWC-4, any strides); w: [64, 3, 7, 7] in channels_last memory (physical OHWI).  Returns y NHWC [B, Ho, Wo, 64]
+    (+ the BatchNorm partials (part, rows, 0, counts) for bn_finalize)"""
+    B, H, W, sb, sc, sy, sx = _image_strides(x)
+    Cout = w.shape[0]
+    Ho, Wo = conv_out_size(H, 7, 2, 3, 1), conv_out_size(W, 7, 2, 3, 1)
+    out = new_act(B, Ho, Wo, Cout, x.device)
+    part = cnt = None
+    nt = 0
+    if bn_stats:
+        nt = lib.catseg_stem7_partial_rows(B, H, W)
+        part = _bn_part_buffer(3 * nt * Cout + nt, x.device)
+        cnt = part[3 * nt * Cout:3 * nt * Cout + nt].view(torch.int32)
+    with _Timed("hbm:stem7", 4.0 * (B * 3 * H * W + out.numel())):
+        check(lib.catseg_stem7_fwd(ptr(x), sb, sc, sy, sx, B, H, W, ptr(w), ptr(bias), ptr(out), ld_of(out), ptr(part), ptr(cnt), stream()))
+    return (out, (part, nt, 0, cnt)) if bn_stats else out
+
+
 def _refuse_h2_only(t, what):
     """a tensor that exists ONLY as blocked f16x2 planes (concat_bilinear_h2: the HRNet head input) is an unwritten fp32 placeholder too: only
     the f16x2 kernels, through the planes registered for it, may consume it"""

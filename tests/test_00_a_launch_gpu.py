@@ -45,6 +45,29 @@ def test_bench_gpus2_launches_its_own_ranks():
     assert r["roofline"] is not None and r["cpu_baseline"] is None        # (the CPU baseline is an N = 1 figure)
 
 
+def test_bench_infer_gpus2_shards_frames_and_sums_the_confusion_matrices():
+    """BASELINE config 5's launch path: `bench.py --infer --gpus 2` starts its two ranks itself, each rank scores its own frames
+    (frame-sharded, no exchange in the timed region), the confusion matrices are summed once at the end (the reference scores ONE
+    matrix over the whole set, managers/BaseManager.py:640-688).  Two ranks on the one GPU over gloo = the labelled functional artefact."""
+    if torch.cuda.device_count() == 0:
+        pytest.skip("needs a GPU")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--infer", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--height", "256", "--width", "384", "--no-cpu-baseline"], env=_env(CATSEG_DIST_BACKEND="gloo"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+    assert p.returncode == 0, err[-4000:]
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, out[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["unit"] == "frames/s" and r["scaling"] == "weak" and r["steps"] == 2
+    assert r["config"]["global_batch"] == 4 and r["config"]["parallelism"] == "dp2 (frame sharded)"
+    cmx = r["config"]["confusion_matrix"]
+    # warm-up + timed + (rank 0 only) three instrumented steps all score into the matrix: at least (1 + 2) steps x 2 ranks of labelled pixels
+    assert cmx["summed_over_ranks"] and cmx["pixels_scored_all_ranks"] >= 2 * 3 * cmx["labelled_pixels_per_step_rank0"] * 0.8
+    assert cmx["pixels_scored_all_ranks"] > 3 * cmx["labelled_pixels_per_step_rank0"] * 1.5      # ... more than one rank's share
+    assert r["value"] > 0 and abs(r["value"] - 4 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+
+
 def test_bench_refuses_a_group_that_is_not_rccl():
     """a multi-GPU line must be an RCCL line: without the explicit CATSEG_DIST_BACKEND=gloo the two-ranks-on-one-GPU job must fail
     (RCCL refuses two ranks on one device) instead of printing a number, and the launcher must pass the failure on"""

@@ -166,8 +166,9 @@ def test_deeplabv3plus_r50_fullres_train_step_vs_oracle():
 
 
 def test_resnext101_upernet_fullres_inference_vs_oracle():
-    """BASELINE config 5 at its resolution (one frame of 3 x 1088 x 1920, reference models/UPerNet.py:108-145): the fused inference path
-    (folded BatchNorm, bf16x3 blocked kernels on conv_last / FPN) against the CPU restatement"""
+    """BASELINE config 5 at its resolution and at its per-GPU batch (4 frames of 3 x 1088 x 1920 = bs 32 over 8 GPUs, reference
+    models/UPerNet.py:108-145, managers/BaseManager.py:640-688): the fused inference path (folded BatchNorm, bf16x3 blocked kernels on
+    conv_last / FPN) -- every frame of the four-frame call bit-identical to its single-frame run, frame 0 against the CPU restatement"""
     _need_gpu()
     import os
     import sys
@@ -184,7 +185,22 @@ def test_resnext101_upernet_fullres_inference_vs_oracle():
     model.cuda().eval()
     g = torch.Generator().manual_seed(13)
     x = torch.rand(1, 3, 1088, 1920, generator=g)
+    # configuration 5 as stated: bs 32 sharded by frame over 8 GPUs = FOUR frames of 3 x 1088 x 1920 per GPU in one call.  Eval-mode
+    # BatchNorm makes a frame's logits independent of its batch mates: the four-frame call must reproduce each frame's single-frame run
+    # (frame 0 is the frame the oracle evaluates below)
+    x4 = torch.cat([x, torch.rand(3, 3, 1088, 1920, generator=g)]).cuda()
     with torch.no_grad():
+        out4 = model(x4)
+        out4 = (out4[0] if isinstance(out4, (tuple, list)) else out4).detach()
+        assert out4.shape[0] == 4
+        for i in range(4):
+            oi = model(x4[i:i + 1])
+            oi = (oi[0] if isinstance(oi, (tuple, list)) else oi).detach()
+            d = float((out4[i:i + 1] - oi).abs().max())
+            FR.record("resnext101_upernet_4x1088x1920_inference", "frame%d_vs_single_frame_run" % i,
+                      {"max_abs_diff": d, "bit_identical": bool(torch.equal(out4[i:i + 1], oi)), "labels_equal": bool(torch.equal(out4[i:i + 1].argmax(1), oi.argmax(1)))})
+            assert torch.equal(out4[i:i + 1], oi), (i, d)
+        del out4, oi, x4
         out = model(x.cuda())
         out = out[0] if isinstance(out, (tuple, list)) else out
         ref = upernet_forward(S, _resnext_oracle(S, x), False)
