@@ -186,8 +186,10 @@ def test_resnext101_upernet_fullres_inference_vs_oracle():
     g = torch.Generator().manual_seed(13)
     x = torch.rand(1, 3, 1088, 1920, generator=g)
     # configuration 5 as stated: bs 32 sharded by frame over 8 GPUs = FOUR frames of 3 x 1088 x 1920 per GPU in one call.  Eval-mode
-    # BatchNorm makes a frame's logits independent of its batch mates: the four-frame call must reproduce each frame's single-frame run
-    # (frame 0 is the frame the oracle evaluates below)
+    # BatchNorm makes a frame's logits mathematically independent of its batch mates; the kernels' tile / split plans are chosen from the
+    # row count of a call (4 frames: other tile forms and batch pieces than 1 frame), so the two calls round differently: each frame of
+    # the four-frame call must agree with its single-frame run to 2e-5 of the logit scale (measured 4.5e-6) with label maps that differ
+    # only where the top-2 margin is inside that distance, and frame 0 of the four-frame call is held to the oracle bars below as well
     x4 = torch.cat([x, torch.rand(3, 3, 1088, 1920, generator=g)]).cuda()
     with torch.no_grad():
         out4 = model(x4)
@@ -196,11 +198,17 @@ def test_resnext101_upernet_fullres_inference_vs_oracle():
         for i in range(4):
             oi = model(x4[i:i + 1])
             oi = (oi[0] if isinstance(oi, (tuple, list)) else oi).detach()
-            d = float((out4[i:i + 1] - oi).abs().max())
+            o4 = out4[i:i + 1]
+            d, sc = float((o4 - oi).abs().max()), float(oi.abs().max())
+            top2 = oi.topk(2, dim=1).values
+            differ = o4.argmax(1) != oi.argmax(1)
+            outside = int((differ & ((top2[:, 0] - top2[:, 1]) > 2.2 * d)).sum())
             FR.record("resnext101_upernet_4x1088x1920_inference", "frame%d_vs_single_frame_run" % i,
-                      {"max_abs_diff": d, "bit_identical": bool(torch.equal(out4[i:i + 1], oi)), "labels_equal": bool(torch.equal(out4[i:i + 1].argmax(1), oi.argmax(1)))})
-            assert torch.equal(out4[i:i + 1], oi), (i, d)
-        del out4, oi, x4
+                      {"max_abs_diff": d, "logit_scale": sc, "bit_identical": bool(torch.equal(o4, oi)), "labels_differ": int(differ.sum()),
+                       "labels_differ_outside_error_band": outside, "pixels": int(differ.numel())})
+            assert d <= 2e-5 * sc and outside == 0, (i, d, sc, outside)
+        out4_0 = out4[0:1].cpu()
+        del out4, oi, o4, x4
         out = model(x.cuda())
         out = out[0] if isinstance(out, (tuple, list)) else out
         ref = upernet_forward(S, _resnext_oracle(S, x), False)
@@ -212,6 +220,7 @@ def test_resnext101_upernet_fullres_inference_vs_oracle():
     # (b) with factor 4: the fused inference path folds BatchNorm into the weights (one more rounding of every weight) and runs the wide
     # layers on three bf16 planes; measured 3.5e-6 of the logit scale against the fp32 CPU oracle's 1.1e-6, label maps identical
     _logit_bar("resnext101_upernet_1x1088x1920_inference", "production", out_h, ref, f64, True, noise_factor=4.0)
+    _logit_bar("resnext101_upernet_4x1088x1920_inference", "frame0_of_four_vs_oracle", out4_0, ref, f64, True, noise_factor=4.0)
 
 
 def test_config3_batch8_production_vs_exact_fp32_cross_plan():

@@ -150,7 +150,9 @@ class _ModeFrames:
         return rng.randint(0, 256, (self.h, self.w, 3)).astype(np.uint8), rng.randint(0, 36, (self.h, self.w)).astype(np.uint8)
 
 
-@pytest.mark.parametrize("mode", [dict(workers=0), dict(workers=1), dict(worker_processes=2), dict(worker_processes=3, prefetch=1)])
+# (each forked-worker parametrisation costs ~40 s on the GPU box -- forking a GPU-initialised process; the three-worker one stays in the default run)
+@pytest.mark.parametrize("mode", [dict(workers=0), dict(workers=1), pytest.param(dict(worker_processes=2), marks=pytest.mark.slow),
+                                  dict(worker_processes=3, prefetch=1)])
 def test_pinned_frame_loader_modes_agree_and_survive_an_abandoned_epoch(mode):
     """the three ways the staging slots get filled -- inline on the consumer's thread (workers=0, the default), a fill thread, FORKED worker
     PROCESSES writing shared pinned slots -- deliver identical batches; an iteration abandoned after two batches (break) is followed by a
