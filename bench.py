@@ -788,6 +788,10 @@ def main():
         if side:
             out["side_figures"] = side
         out["config"]["step"] = "zero_grad, forward, loss, backward, Adam, confusion matrix of the batch (the reference's per-step training metric)"
+        # the execution plan the timed region ran under: every route / threshold switch of the host layer with its live value
+        # (miccai2021_cataract_semantic_segmentation_amd/plan.py documents the fields); `non_default` is empty for the shipped plan
+        from miccai2021_cataract_semantic_segmentation_amd import plan as P
+        out["config"]["plan"] = {"non_default": P.non_default(), "fields": ops.plan()}
         out["config"]["execution"] = (("the step recorded once by stream capture and replayed as one hipGraph per step (graph.GraphedTrainStep: same "
                                        "launches, same streams, bit-identical results; %d capture(s), %.1f s, outside the timed region)%s"
                                        % (graphed["captures"], graphed["capture_s"],

@@ -15,7 +15,15 @@ import torch.distributed as dist
 import torch.utils.data
 
 
-COMM_HIGH_PRIORITY = os.environ.get("CATSEG_COMM_PRIORITY", "high") != "normal"
+try:
+    from . import plan as _plan
+except ImportError:          # this file loaded on its own (tests/test_dist_cpu.py: gloo workers without the HIP library): plan.py by path
+    import importlib.util as _ilu
+    _spec = _ilu.spec_from_file_location("catseg_plan", os.path.join(os.path.dirname(os.path.abspath(__file__)), "plan.py"))
+    _plan = _ilu.module_from_spec(_spec)
+    _spec.loader.exec_module(_plan)
+
+COMM_HIGH_PRIORITY = _plan.get("comm_priority") != "normal"
 
 
 def init_group(backend, rank, world, local=0):
@@ -68,7 +76,7 @@ def default_bucket_bytes():
     """CATSEG_BUCKET_MB (default 32): size of the gradient buckets.  xGMI is point to point (7 links x ~153 GB/s per GPU): a ring
     all-reduce of a 32 MB bucket over 8 GPUs moves 2 * 7/8 * 32 MB per link ~ 0.4 ms -- long enough to run at link rate, short
     enough that several buckets are in flight under the backward pass"""
-    return int(float(os.environ.get("CATSEG_BUCKET_MB", "32")) * (1 << 20))
+    return int(_plan.get("bucket_mb") * (1 << 20))
 
 
 class GradSync:
@@ -81,7 +89,7 @@ class GradSync:
         # RCCL path -- communicator, its stream, the event hand-over from and to the launch stream -- with nothing to add
         self.force = (os.environ.get("CATSEG_FORCE_ALLREDUCE") == "1") if force is None else bool(force)
         self.bucket_bytes = int(bucket_bytes) if bucket_bytes else default_bucket_bytes()
-        self.tail_bytes = int(tail_bytes) if tail_bytes else min(self.bucket_bytes, int(float(os.environ.get("CATSEG_TAIL_BUCKET_MB", "4")) * (1 << 20)))
+        self.tail_bytes = int(tail_bytes) if tail_bytes else min(self.bucket_bytes, int(_plan.get("tail_bucket_mb") * (1 << 20)))
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._key = None

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from . import ops
+from . import plan as _plan
 
 
 # --------------------------------------------------------------------------- parameter containers
@@ -17,7 +18,6 @@ class Conv2d(nn.Conv2d):
     """Parameter container with nn.Conv2d's init / state-dict behaviour; runs on the HIP engine."""
     stem = False
     exact_operands = False      # forward on the fp32 MFMA kernel whatever the split-precision kernels could take: ops.conv_fwd(exact=)
-    async_wgrad = False         # backward-weight on the side stream of Ctx.async_wgrad (the large head layers: nobody waits for dW until Adam)
 
     def forward(self, x):  # pragma: no cover
         raise RuntimeError("engine Conv2d is executed by the owning network, not called directly")
@@ -95,42 +95,18 @@ class FlatParams:
 
 # --------------------------------------------------------------------------- tape
 _side_streams = {}
-_skew_streams = []
-STREAM_SKEW = int(__import__("os").environ.get("CATSEG_STREAM_SKEW", "0"))
-
-
-BRANCH_PRIORITY = int(__import__("os").environ.get("CATSEG_BRANCH_PRIORITY", "0"))   # A/B: -1 = the first branch's stream at high priority
 
 
 def side_streams(device, n):
     """a small pool of HIP streams per device for the parallel-branch regions (HRNet's branches are independent)"""
     key = (device.type, device.index)
     pool = _side_streams.setdefault(key, [])
-    if not pool and STREAM_SKEW > 0:            # A/B (CATSEG_STREAM_SKEW): shift the pool's position in the runtime's round-robin over hardware queues
-        _skew_streams.extend(torch.cuda.Stream(device=device) for _ in range(STREAM_SKEW))
     while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=device, priority=BRANCH_PRIORITY if len(pool) == 0 else 0))
+        pool.append(torch.cuda.Stream(device=device))
     return pool[:n]
 
 
-# Backward-weight of the layers marked Conv2d.async_wgrad (the three head convolutions of OCRNet: 9.3 ms of matrix work per HRNet-W48 step
-# whose result nothing reads before the optimiser / the gradient exchange) on ONE extra stream: the launch stream goes straight on to the
-# layer's backward-data and to the HBM-bound kernels behind it.  Measured (tools/ab_modes.sh, two alternating rounds on one box, graph replay):
-# 113.39 / 112.42 ms with it against 113.19 / 112.93 ms in line; eager 115.5 / 119.7 against 116.2 / 117.8 -- NO gain: igemm_h2t_kernel runs one
-# wave per SIMD with all 512 registers, so a CU that holds one of its blocks holds nothing else, and beside the layer's backward-data (the
-# same matrix pipes at the power ceiling) it only time-slices.  Off by default (CATSEG_ASYNC_WGRAD=1 enables it); kept with its test.
-ASYNC_WGRAD = __import__("os").environ.get("CATSEG_ASYNC_WGRAD", "0") == "1"
-_wgrad_streams = {}
-
-
-def wgrad_stream(device):
-    key = (device.type, device.index)
-    if key not in _wgrad_streams:
-        _wgrad_streams[key] = torch.cuda.Stream(device=device)
-    return _wgrad_streams[key]
-
-
-PREP_ASYNC = __import__("os").environ.get("CATSEG_PREP_ASYNC", "1") != "0"
+PREP_ASYNC = _plan.get("prep_async")
 _prep_streams = {}
 
 
@@ -143,8 +119,8 @@ def prep_stream(device):
 
 PARALLEL_BRANCHES = True   # run independent branches (HRNet stages) on separate HIP streams, forward and backward
 # streams a parallel region spreads its branches over (branch i runs on stream i % BRANCH_STREAMS): A/B knob, CATSEG_BRANCH_STREAMS
-BRANCH_STREAMS = int(__import__("os").environ.get("CATSEG_BRANCH_STREAMS", "4"))
-LAST_BRANCH_ON_MAIN = __import__("os").environ.get("CATSEG_LAST_BRANCH_ON_MAIN", "1") != "0"
+BRANCH_STREAMS = _plan.get("branch_streams")
+LAST_BRANCH_ON_MAIN = _plan.get("last_branch_on_main")
 
 
 class _Region:
@@ -167,7 +143,6 @@ class Ctx:
         self.region = None
         self._region_depth = 0         # backward: parallel regions entered and not yet joined
         self._deferred = []            # backward: parameters whose 'gradient ready' signal waits for the join
-        self._async = None             # backward: (side stream, [parameters whose gradient it writes]) of async_wgrad launches not yet joined
         self.bn_src = {}               # id(z) -> (y, stats, gamma, beta) of a conv_bn_act output z = relu(bn(y))
         self.bn_pre = {}               # backward: id(z) -> per-tile sums of the already masked gradient of z (conv_bn_act private_in)
 
@@ -319,35 +294,6 @@ class Ctx:
                     else:
                         self.on_param_grad(p)
 
-    def async_wgrad(self, fn, tensors, params, presplit):
-        """runs fn() -- a backward-weight launch -- on the extra stream behind everything the current stream has enqueued; `presplit()` runs
-        first, on the CURRENT stream, and returns the operand planes the launch will read (the same split pass serves the layer's
-        backward-data on this stream).  The 'gradient ready' signals of `params` are held back until join_async() (end of backward)."""
-        dev = tensors[0].device
-        cur = torch.cuda.current_stream(dev)
-        side = wgrad_stream(dev)
-        planes = presplit() or []
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        side.wait_event(ev)
-        with torch.cuda.stream(side):
-            fn()
-        for t in list(tensors) + list(planes):
-            if t is not None:
-                t.record_stream(side)      # (allocated on the launch stream, read by the side stream: no reuse before its launch is done)
-        if self._async is None:
-            self._async = (side, [])
-        self._async[1].extend(p for p in params if p is not None)
-
-    def join_async(self):
-        if self._async is not None:
-            side, params = self._async
-            self._async = None
-            torch.cuda.current_stream(side.device).wait_stream(side)
-            if self.on_param_grad is not None:
-                for p in params:
-                    self.on_param_grad(p)
-
     def backward(self):
         tape = self.tape
         main = None
@@ -389,7 +335,6 @@ class Ctx:
             else:
                 with torch.cuda.stream(tag):
                     fn()
-        self.join_async()
         self.grads.clear()
         self.shared.clear()
         self.bn_src.clear()
@@ -547,7 +492,7 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
                         cx.bn_pre[id(x)] = r[1]
                 cx.done(bn.weight, bn.bias, w, conv.bias)
                 return
-            if (pre is None and residual is None and not conv.stem and not pad3 and not (conv.async_wgrad and ASYNC_WGRAD)
+            if (pre is None and residual is None and not conv.stem and not pad3
                     and ops.h2_dy_route(x_in, y, w.data, kh, kw, s, p, d, conv.groups, need_dx)):
                 # head layers on the f16x2 kernels: dy exists only as the blocked planes both of its consumers read (ops.bn_backward_h2)
                 dyp, dysc = ops.bn_backward_h2(dz, y, stats, bn.weight.data, relu, cx.pgrad(bn.weight), cx.pgrad(bn.bias), bn.bias.data,
@@ -581,24 +526,13 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
                 ops.conv_bwd_weight(x_in, dy, dpk, dbias, kh, kw, s, p, d)
                 ops.weight_unpad_cin(dpk, cx.pgrad(w), Cout, kh * kw, 3, 4)
             else:
-                deferred = False
-                if (conv.async_wgrad and ASYNC_WGRAD and dy.is_cuda and ops.PROFILE is None and cx._region_depth == 0
-                        and cx.branch_stream is None):
-                    dw = cx.pgrad(w)
-                    cx.async_wgrad(lambda: ops.conv_bwd_weight(x_in, dy, dw, dbias, kh, kw, s, p, d, groups=conv.groups), (x_in, dy), (w, conv.bias),
-                                   lambda: ops.wgrad_presplit(x_in, dy, kh, kw, s, p, d, groups=conv.groups))
-                    deferred = True
-                else:
-                    ops.conv_bwd_weight(x_in, dy, cx.pgrad(w), dbias, kh, kw, s, p, d, groups=conv.groups)
+                ops.conv_bwd_weight(x_in, dy, cx.pgrad(w), dbias, kh, kw, s, p, d, groups=conv.groups)
                 if need_dx:
                     dx, accx = cx.dest(x)
                     src = cx.bn_src.get(id(x)) if (private_in and not accx) else None
                     r = ops.conv_bwd_data(dy, w.data, tuple(x.shape), kh, kw, s, p, d, out=dx, accumulate=accx, groups=conv.groups, bn_src=src)
                     if isinstance(r, tuple):
                         cx.bn_pre[id(x)] = r[1]
-                if deferred:
-                    cx.done(bn.weight, bn.bias)
-                    return
             cx.done(bn.weight, bn.bias, w, conv.bias)
         cx.push(bwd)
     return z

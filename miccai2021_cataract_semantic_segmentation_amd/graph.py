@@ -35,11 +35,10 @@ capture order, so an activation written by segment i is read by segment j > i ex
 network is driven on the CALLING thread (EngineNet.backward_from: the gradients of the logits come from torch.autograd.grad over the loss,
 the tape is popped here), because a stream capture must end on the thread that began it and autograd runs a device's nodes on its own.
 """
-import os
-
 import torch
 
 from . import engine
+from . import plan as _plan
 from .optim import FusedAdam
 
 
@@ -47,7 +46,7 @@ def default_segment_bytes():
     """CATSEG_SEGMENT_MB (default 48): gradient bytes the backward tape must have released since the last cut before the captured step is
     cut again.  A cut costs one more hipGraphLaunch per step (~0.1 ms of host time, and the GPU-side hand-over between two graphs); a
     segment that is too long delays the start of its buckets' all-reduce.  HRNet-W48 (292.7 MB of gradients): 5 graphs + the tail graph."""
-    return int(float(os.environ.get("CATSEG_SEGMENT_MB", "48")) * (1 << 20))
+    return int(_plan.get("segment_mb") * (1 << 20))
 
 
 class _CutRecorder:

@@ -260,7 +260,8 @@ def build_hrnet_trunk(net, width, stage1_width, modules):
     # take their FORWARD pass (tools/error_growth.py at 2 x 3 x 544 x 960: relative RMS error at the stem 2.2e-7 -> 3.7e-7 and 1.4 x at every later tap,
     # 113 instead of 63 label disagreements with fp64 at the logits): they stay on the fp32 kernel forward (backward takes the gather route).
     # CATSEG_EXACT_EARLY = "layer1" / "stem" / "all" (default) selects how far the rule reaches.
-    early = __import__("os").environ.get("CATSEG_EXACT_EARLY", "all")
+    from .. import plan as _plan
+    early = _plan.get("exact_early")
     parts = [net.layer1]
     if early in ("stem", "all"):
         parts.append(net.conv2)
@@ -302,8 +303,7 @@ def concat_branches(cx, ys, h2_consumers=None):
     chans = [y.shape[-1] for y in ys]
     cat = torch.empty((B, H, W, sum(chans)), dtype=torch.float32, device=ys[0].device)
     parts, c0 = [], 0
-    # (not with engine.ASYNC_WGRAD: the extra stream's backward-weight looks its operand planes up under ITS stream and would split the tensor again)
-    if h2_consumers and cx.record and cx.train and engine.TAPS is None and not engine.ASYNC_WGRAD:
+    if h2_consumers and cx.record and cx.train and engine.TAPS is None:
         from .. import ops
         if ops.concat_planes_route(ys, h2_consumers):
             blk, sc = ops.concat_bilinear_h2(ys, H, W)

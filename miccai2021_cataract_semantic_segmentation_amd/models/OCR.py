@@ -112,11 +112,6 @@ class OCRNet(EngineNet):
             Conv2d(512, self.num_classes, 1, 1, 0, bias=True))
         self.spatial_gather = SpatialGatherModule(self.num_classes)
         self.spatial_ocr_head = SpatialOCR_Module(512, 256, 512, 1, self.dropout)
-        # the three large head convolutions: their backward-weight launches (igemm_h2t_kernel: 9.3 ms of matrix work per HRNet-W48 step) feed
-        # nothing but the optimiser -- engine.Ctx.async_wgrad runs them beside the rest of the backward pass
-        self.conv_high_map[0].async_wgrad = True
-        self.interm_prediction_head[0].async_wgrad = True
-        self.spatial_ocr_head.conv_bn_dropout[0].async_wgrad = True
         self.conv_out = Conv2d(512, self.num_classes, 1, 1, bias=True)
         if "projector" in config:
             raise NotImplementedError("the contrastive projector is outside the accelerated path")

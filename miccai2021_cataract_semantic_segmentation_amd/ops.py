@@ -10,6 +10,7 @@ import ctypes
 import torch
 
 from . import _lib
+from . import plan as _plan
 from ._lib import ConvDesc, check, lib, ptr, stream
 
 _ws = {}
@@ -72,7 +73,7 @@ PROFILE = None  # bench.py sets this to a list: every implicit-GEMM launch is br
 # roctx ranges: CATSEG_ROCTX=1 brackets every timed C-ABI call with roctxRangePush(kind) / roctxRangePop(), so that a
 # `rocprofv3 --marker-trace --kernel-trace` timeline shows which layer operation a kernel belongs to.  Off by default (two ctypes calls per launch).
 _roctx = None
-if __import__("os").environ.get("CATSEG_ROCTX", "0") == "1":
+if __import__("os").environ.get("CATSEG_ROCTX", "0") == "1":      # (a profiling aid, not a route: roctx ranges around every C-ABI call)
     for _name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
         try:
             _roctx = ctypes.CDLL(_name)
@@ -110,7 +111,7 @@ class _Timed:
 # backward-data of dense 3x3-class convolutions with a long reduction and >= 192 output columns qualify; everything else runs
 # the fp32 kernels.  CATSEG_PRECISION=fp32 selects the exact fp32 path everywhere.
 import os as _os
-PRECISION = _os.environ.get("CATSEG_PRECISION", "bf16x3")
+PRECISION = _plan.get("precision")
 _b3_cache = {"key": None, "x": None, "planar": None, "blk": None}
 # thresholds of the layer selection (tests lower them to push small layers through the split-precision kernels)
 B3_MIN_TAPS, B3_MIN_K, B3_MIN_N, B3_MIN_TILES = 2, 2048, 192, 192
@@ -162,7 +163,7 @@ def _b3_blocked_ok(ncols, cred, a_rows, w_rows, taps):
 # Arithmetic of the layers on the blocked 256 x 256 path (forward / backward-data of the head convolutions): "f16x2" = two fp16 planes
 # per operand after a per-tensor power-of-two prescale, three MFMA products (csrc/igemm_f16x2.hip: 22 significant bits per operand,
 # half the matrix work of bf16x3); "bf16x3" = three exact bf16 planes, six products.  CATSEG_HEADS selects.
-HEADS = _os.environ.get("CATSEG_HEADS", "f16x2")
+HEADS = _plan.get("heads")
 
 
 def _h2():
@@ -171,16 +172,20 @@ def _h2():
 
 # Backward-weight of the f16x2 layers from the BLOCKED planes its forward / backward-data read (csrc/igemm_f16x2.hip: igemm_h2t_kernel's
 # blocked mode): one plane set per tensor, the split passes write half as much.  CATSEG_H2T=planar: the separate planar set of round 3.
-H2T_BLOCKED = _os.environ.get("CATSEG_H2T", "blocked") != "planar"
+H2T_BLOCKED = _plan.get("h2t") != "planar"
 
 
-# A/B hooks (tools/ab_env_bench.sh): launch-shape knobs of the library's debug interface (include/catseg_debug.h) from the environment, so that
-# a whole bench process can run under another setting.  Unset = the library's defaults.
-for _var, _setter in (("CATSEG_WG_BLOCKS", "catseg_debug_set_dwgrad3_blocks"), ("CATSEG_DC_BLOCKS", "catseg_debug_set_dconv3_blocks"),
-                      ("CATSEG_PL_SLOTS", "catseg_debug_set_dconv3_pl_slots"), ("CATSEG_PL_PAIR", "catseg_debug_set_dconv3_pl_pair"),
-                      ("CATSEG_WP96_BLOCKS", "catseg_debug_set_dwgrad3_pl_blocks"), ("CATSEG_IGEMM_SPLITS", "catseg_debug_set_splits")):
-    if _os.environ.get(_var):
-        getattr(lib, _setter)(int(_os.environ[_var]))
+# launch-shape knobs of the library's debug interface (include/catseg_debug.h) as plan fields, so that a whole bench process can run under
+# another setting (tools/ab_env_bench.sh).  0 = the library's default.
+for _field, _setter in _plan.LIBRARY_KNOBS.items():
+    if _plan.get(_field):
+        getattr(lib, _setter)(int(_plan.get(_field)))
+
+
+def plan():
+    """the active execution plan: every route / threshold switch of the host layer with its live value (plan.FIELDS documents them);
+    bench.py prints it as `config.plan`"""
+    return _plan.active()
 
 
 def _split3_any(x, want, both):
@@ -270,7 +275,7 @@ def _d3_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
 # Arithmetic of the direct trunk kernels' forward / backward-data: "f16x2" = two fp16 planes, three products (csrc/dconv3_f16x2.hip) for
 # every launch whose input carries an amax record (left by its producer: bn_apply, add_n_act, bn_backward), "bf16x3" = three bf16 planes,
 # six products.  CATSEG_TRUNK selects; inputs without a record always take the bf16x3 kernel.
-TRUNK = _os.environ.get("CATSEG_TRUNK", "f16x2")
+TRUNK = _plan.get("trunk")
 
 
 def _trunk_h2():
@@ -280,7 +285,7 @@ def _trunk_h2():
 # The trunk on PRODUCER-WRITTEN planes (round 4; csrc/planes.h, dconv3_pl.hip, dwgrad3_pl.hip): BatchNorm apply / the HRNet fuse sum / BatchNorm
 # backward write the fp16 x 2 operand planes of what they produce, the direct kernels stream them by LDS-DMA.  CATSEG_TRUNK_PLANES=0: the
 # round-3 route (fp32 tensors + amax records, split inside the convolution kernels).
-PLANES = _os.environ.get("CATSEG_TRUNK_PLANES", "1") != "0"
+PLANES = _plan.get("trunk_planes")
 
 
 def _trunk_planes():
@@ -292,7 +297,7 @@ def _trunk_planes():
 # only 120.8 / 121.0.  The 48-channel layers stay on the round-3 kernel: standalone the planes kernel is 5 us faster there too (47.8 against
 # 52.7 us), but it owns its CUs (eight waves of 128 registers per block, two blocks: every register of the SIMDs), whereas the uniform
 # four-wave kernel leaves room for the BatchNorm / reduction kernels of the other branch streams to run beside it.
-PLANES_WIDTHS = tuple(int(v) for v in _os.environ.get("CATSEG_PLANES_WIDTHS", "96,192,384").split(",") if v)
+PLANES_WIDTHS = _plan.get("planes_widths")
 
 
 def planes_ok(C, rows):
@@ -357,7 +362,7 @@ def amax_of(t):
     return getattr(t, "_amax", None)
 
 
-SPLIT_BOUND = _os.environ.get("CATSEG_SPLIT_BOUND", "1") != "0"    # f16x2 split passes take max|x| from the producers' records when they exist
+SPLIT_BOUND = _plan.get("split_bound")    # f16x2 split passes take max|x| from the producers' records when they exist
 
 
 def amax_records_of(t):
@@ -468,10 +473,10 @@ class Dconv3Bank:
 # (p1t_kernel: LDS-bound, both operands pass through the transposing reads) pays for the 256 / 512-channel layers only (619 -> 492, 343 -> 276 us;
 # 64-channel layers 0.82 - 0.89 x): P1_WGRAD_MIN_DIM.  HRNet-W48 step (tools/ab_p1.sh, graph replay, two alternating rounds): 109.06 / 109.97 ms
 # without, 108.24 / 108.09 with all three operations on every layer, 107.72 / 107.65 with forward + backward-data only.
-P1 = _os.environ.get("CATSEG_P1", "1") != "0"
+P1 = _plan.get("p1")
 P1_MIN_ROWS = 100000
 P1_WGRAD_MIN_DIM = 256
-P1_OPS = tuple(v for v in _os.environ.get("CATSEG_P1_OPS", "fwd,dgrad,wgrad").split(",") if v)
+P1_OPS = _plan.get("p1_ops")
 _p1_wimg = {}
 
 
@@ -550,11 +555,11 @@ def p1_weight_image(w, transposed=False):
 # 72 -> 46 forward, 107 -> 73 backward-weight -- but its backward-data (four parity-class launches with N = 48 columns) 88 -> 95 and 48 -> 48: 59 -> 76:
 # backward-data takes the route from G1_DGRAD_MIN_CIN input channels on.  HRNet-W48 step (graph replay, three alternating rounds): 108.1 - 108.8 ms
 # without, 107.9 - 108.2 with.
-G1 = _os.environ.get("CATSEG_G1", "1") != "0"
-G1_MIN_ROWS = int(_os.environ.get("CATSEG_G1_MIN_ROWS", "16384"))
-G1_DGRAD_MIN_CIN = int(_os.environ.get("CATSEG_G1_DGRAD_MIN_CIN", "128"))
-G1_MIN_CIN = int(_os.environ.get("CATSEG_G1_MIN_CIN", "0"))
-G1_OPS = tuple(v for v in _os.environ.get("CATSEG_G1_OPS", "fwd,dgrad,wgrad").split(",") if v)
+G1 = _plan.get("g1")
+G1_MIN_ROWS = _plan.get("g1_min_rows")
+G1_DGRAD_MIN_CIN = _plan.get("g1_dgrad_min_cin")
+G1_MIN_CIN = _plan.get("g1_min_cin")
+G1_OPS = _plan.get("g1_ops")
 
 
 def _g1_ok(rows, Cin, Cout, kh, kw, stride, pad, dil, groups):
@@ -698,7 +703,7 @@ def _refuse_placeholder(t, what):
 
 # The first stem convolution of HRNet (3 -> 64, 3 x 3 / stride 2 / pad 1 on the image) as HBM-bound direct fp32 kernels (csrc/stem3.hip) instead of
 # the implicit GEMM over 9 taps x 4 padded channels.  CATSEG_STEM3=0: the implicit-GEMM route.
-STEM3 = _os.environ.get("CATSEG_STEM3", "1") != "0"
+STEM3 = _plan.get("stem3")
 
 
 def _image_strides(x):
@@ -747,7 +752,7 @@ def stem3_bwd_weight(x, dy, dw):
 # The first convolution of the torchvision ResNet stem (3 -> 64, 7 x 7 / stride 2 / pad 3 on the image), training forward accumulated in fp64 and
 # rounded once (csrc/stem7.hip): what csrc/stem3.hip did for the HRNet models' literal-1e-3 distance to the CPU path, for OCRNet-R50 / DeepLabv3+.
 # The layer's backward-weight stays on the implicit GEMM (stem4 layout).  CATSEG_STEM7=0: the implicit-GEMM forward.
-STEM7 = _os.environ.get("CATSEG_STEM7", "1") != "0"
+STEM7 = _plan.get("stem7")
 
 
 def stem7_ok(x, w, kh, kw, stride, pad, dil, groups):
@@ -1015,22 +1020,6 @@ def _wgrad_h2_planes(x, dy, dgrad_blk):
     return xp, xsc, dyp, dysc
 
 
-def wgrad_presplit(x, dy, kh, kw, stride=1, pad=0, dil=1, stem4=False, groups=1):
-    """engine.Ctx.async_wgrad: the split passes conv_bwd_weight would run, issued on the CURRENT stream ahead of it -- the backward-weight
-    kernel itself then runs on another stream while this stream goes on to the layer's backward-data, which reads the blocked planes of dy
-    that the same pass wrote.  Returns the plane tensors the other stream will read (for record_stream), or None: no split route."""
-    if (not stem4 and x.dim() == 4 and _d3_ok(rows_of(dy), x.shape[-1], dy.shape[-1], kh, kw, stride, pad, dil, groups)
-            and lib.catseg_dwgrad3_supported(x.shape[-1])):
-        return None
-    if not _wgrad_split_route(x, dy, kh, kw, stride, stem4, groups):
-        return None
-    dgrad_blk = _wgrad_dgrad_blk(x, dy, kh, kw, stride)
-    with _Timed("split3", 0.0):
-        if _wgrad_h2_route(x, dy):
-            return list(_wgrad_h2_planes(x, dy, dgrad_blk))
-        return [_split3_cached(x, "planar"), _split3_cached_dy(dy, "planar", both=dgrad_blk)]
-
-
 def conv_bwd_weight(x, dy, dw, dbias, kh, kw, stride=1, pad=0, dil=1, stem4=False, groups=1):
     """dw: destination tensor (physical OHWI, or packed [O][7][8][4] for the stem)."""
     Cout, Cin = dy.shape[-1], x.shape[-1]
@@ -1127,7 +1116,7 @@ def gemm(layout, batch, M, N, K, A, lda, sA, Bm, ldb, sB, Cm, ldc, sC, zero_to=0
     return Cm
 
 
-GEMM_TN_SPLIT = _os.environ.get("CATSEG_GEMM_TN_SPLIT", "1") != "0"
+GEMM_TN_SPLIT = _plan.get("gemm_tn_split")
 
 
 def tn_splits(M, N, K):
@@ -1174,7 +1163,7 @@ def bn_eval_scale(gamma, running_var, eps):
 
 # The ReLU mask of a residual block's output as bits (csrc/norm.hip: catseg_bn_apply_mask / catseg_bn_backward_mask): the BatchNorm backward of
 # z = relu(bn(y) + residual) reads 1 bit per element instead of z in both of its passes.  CATSEG_RELU_BITS=0: z is read, as before.
-RELU_BITS = _os.environ.get("CATSEG_RELU_BITS", "1") != "0"
+RELU_BITS = _plan.get("relu_bits")
 
 
 def relu_bits_ok(y, residual, relu, out):
@@ -1322,7 +1311,7 @@ def bn_backward(dz, z, y, stats, gamma, relu, dgamma, dbeta, dres=None, dres_acc
 # 3 x 3 head convolutions on the f16x2 kernels: ONE launch interpolates, splits and writes the blocked planes (csrc/igemm_f16x2.hip:
 # concat_bilinear_split2h_kernel); the fp32 concatenation, the copy of branch 0 into it and the split pass over it are gone.
 # CATSEG_CONCAT_PLANES=0: fp32 concatenation + catseg_split2h, as before.
-CONCAT_PLANES = _os.environ.get("CATSEG_CONCAT_PLANES", "1") != "0"
+CONCAT_PLANES = _plan.get("concat_planes")
 
 
 def concat_planes_route(ys, consumers):
@@ -1381,7 +1370,7 @@ def register_h2_planes(x, blk, scale):
 # The head layers (conv -> BatchNorm -> ReLU on the f16x2 kernels: models/OCR.py:72-89, 326-333): the BatchNorm backward writes dy straight
 # as the blocked fp16 x 2 planes that the layer's backward-weight AND backward-data read (csrc/norm.hip: bn_bwd_apply_h2_kernel) -- no fp32 dy,
 # no split pass over it, the bias gradient from the same pass.  CATSEG_HEAD_DY_PLANES=0: fp32 dy + catseg_split2h, as before.
-HEAD_DY_PLANES = _os.environ.get("CATSEG_HEAD_DY_PLANES", "1") != "0"
+HEAD_DY_PLANES = _plan.get("head_dy_planes")
 
 
 def h2_dy_route(x, y, w, kh, kw, stride, pad, dil, groups, need_dx):

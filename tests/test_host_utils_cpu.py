@@ -261,3 +261,37 @@ def test_loader_worker_errors_reach_the_consumer_with_their_traceback():
     finally:
         pool.close()
     assert pool.pending == {} and pool.conns == []
+
+
+def test_plan_registry_parses_one_variable_and_reads_live_values_back(monkeypatch):
+    """plan.py: every route switch is a field with a default, a parser and an owner; CATSEG_PLAN overrides the field's own variable, an
+    unknown field is refused, and active() reports the LIVE module attributes (what bench.py prints as config.plan)"""
+    import importlib
+    from miccai2021_cataract_semantic_segmentation_amd import plan
+    monkeypatch.setenv("CATSEG_PLAN", "heads=bf16x3, planes_widths=96+192,segment_mb=16")
+    monkeypatch.setenv("CATSEG_HEADS", "f16x2")
+    monkeypatch.setenv("CATSEG_G1_MIN_ROWS", "4096")
+    monkeypatch.setattr(plan, "_plan_env", None)
+    assert plan.get("heads") == "bf16x3" and plan.get("planes_widths") == (96, 192) and plan.get("segment_mb") == 16.0
+    assert plan.get("g1_min_rows") == 4096 and plan.get("trunk") == "f16x2" and plan.get("stem7") is True
+    monkeypatch.setenv("CATSEG_PLAN", "no_such_field=1")
+    monkeypatch.setattr(plan, "_plan_env", None)
+    try:
+        plan.get("heads")
+        raise AssertionError("an unknown CATSEG_PLAN field must be refused")
+    except ValueError as e:
+        assert "no_such_field" in str(e)
+    monkeypatch.delenv("CATSEG_PLAN")
+    monkeypatch.setattr(plan, "_plan_env", None)
+    ops = importlib.import_module("miccai2021_cataract_semantic_segmentation_amd.ops")
+    act = ops.plan()
+    assert set(act) == set(plan.FIELDS) and act["precision"] == ops.PRECISION
+    saved = ops.TRUNK
+    try:
+        ops.TRUNK = "bf16x3"
+        assert ops.plan()["trunk"] == "bf16x3" and plan.non_default().get("trunk") == "bf16x3"
+    finally:
+        ops.TRUNK = saved
+    for name, (default, parse, owner, doc) in plan.FIELDS.items():
+        assert doc and (owner is None or ":" in owner), name
+        assert parse(default) == default, name            # a default survives its own parser

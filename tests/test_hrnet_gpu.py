@@ -170,74 +170,3 @@ def test_gradient_ready_signals_follow_region_joins():
     params = [id(p) for p in model.parameters()]
     assert sorted(rec.seen) == sorted(params)
     assert rec.streams == {rec.main.cuda_stream}
-
-
-def test_async_head_backward_weight_is_bit_identical_and_signals_after_the_join():
-    """engine.Ctx.async_wgrad: the backward-weight launches of the three large head convolutions run on an extra stream (the split pass of
-    dy stays on the launch stream and serves the layer's backward-data).  Gradients are bit-identical to the in-line schedule, on the
-    split-precision route (thresholds lowered so that the small test layers take igemm_h2t_kernel) and on the fp32 route; their
-    'gradient ready' signals come from the MAIN stream, after the join at the end of the backward pass, exactly once per parameter."""
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
-    from oracle.state import fill_state, spec_of
-    from miccai2021_cataract_semantic_segmentation_amd import engine, ops
-    from miccai2021_cataract_semantic_segmentation_amd.models import OCRNet
-    from miccai2021_cataract_semantic_segmentation_amd.losses import TwoScaleLoss
-    cfg = {"backbone": "hrnet18", "pretrained": False, "hrnet": {"width": 16, "stage1_width": 32, "modules": (1, 1, 1)}}
-    gen = torch.Generator().manual_seed(4)
-    x = torch.rand(2, 3, 96, 160, generator=gen).cuda()
-    lbl = torch.randint(0, 26, (2, 12, 20), generator=gen).repeat_interleave(8, 1).repeat_interleave(8, 2).cuda()
-    crit = TwoScaleLoss({"experiment": 3, "interm": {"name": "LovaszSoftmax", "args": []}, "final": {"name": "LovaszSoftmax", "args": []}})
-
-    class Recorder:
-        world = 1
-
-        def __init__(self):
-            self.seen, self.streams, self.order = [], set(), []
-
-        def begin(self, fp):
-            self.main = torch.cuda.current_stream()
-
-        def param_ready(self, p):
-            self.seen.append(id(p))
-            self.streams.add(torch.cuda.current_stream().cuda_stream)
-
-        def finish(self):
-            pass
-
-    saved = (engine.ASYNC_WGRAD, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES, ops.B3_MIN_WGRAD_ROWS)
-    saved_dy, saved_cat = ops.HEAD_DY_PLANES, ops.CONCAT_PLANES
-    try:
-        # (the in-line schedule compared here is the one the extra stream runs: fp32 dy + split pass.  The default in-line route since round 5 --
-        #  dy written as planes by the BatchNorm backward, ops.bn_backward_h2 -- derives the planes' exponent from a bound instead of the exact
-        #  maximum: same values to 2^-22, not the same bits; tests/test_heads_dy_planes_gpu.py covers it)
-        ops.HEAD_DY_PLANES = False
-        ops.CONCAT_PLANES = False       # (the planes-only head input is not offered to the extra stream: models/HRNetv2.concat_branches)
-        for forced in (False, True):
-            if forced:
-                ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES, ops.B3_MIN_WGRAD_ROWS = 1, 64, 32, 1, 1
-            res = []
-            for on in (False, True):
-                engine.ASYNC_WGRAD = on
-                model = OCRNet(dict(cfg), 3)
-                model.load_state_dict(fill_state(spec_of(model.state_dict()), 3))
-                model.cuda().train()
-                assert model.conv_high_map[0].async_wgrad and model.interm_prediction_head[0].async_wgrad
-                rec = Recorder()
-                model._grad_sync = rec
-                interm, final = model(x)
-                crit(interm, final, lbl).backward()
-                torch.cuda.synchronize()
-                res.append({k: p.grad.clone() for k, p in model.named_parameters()})
-                assert sorted(rec.seen) == sorted(id(p) for p in model.parameters())
-                assert rec.streams == {rec.main.cuda_stream}
-                if on:      # the deferred signals are the LAST ones: after the join
-                    late = {id(model.conv_high_map[0].weight), id(model.conv_high_map[0].bias), id(model.interm_prediction_head[0].weight),
-                            id(model.interm_prediction_head[0].bias), id(model.spatial_ocr_head.conv_bn_dropout[0].weight)}
-                    assert set(rec.seen[-len(late):]) == late
-            for k in res[0]:
-                assert torch.equal(res[0][k], res[1][k]), (forced, k)
-            ops.release_b3_cache()
-    finally:
-        ops.HEAD_DY_PLANES, ops.CONCAT_PLANES = saved_dy, saved_cat
-        (engine.ASYNC_WGRAD, ops.B3_MIN_TAPS, ops.B3_MIN_K, ops.B3_MIN_N, ops.B3_MIN_TILES, ops.B3_MIN_WGRAD_ROWS) = saved

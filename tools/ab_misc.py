@@ -1,4 +1,5 @@
-"""within-run A/B of scheduling knobs on the HRNet-W48 train step (lr = 0): branch-stream priority, persistent-block count of the planes kernel"""
+"""within-run A/B of the persistent-block count of the planes kernel on the HRNet-W48 train step (lr = 0).  (Round 5 also tried the first branch
+stream at high priority here: no gain, the knob left the product in round 6.)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,12 +24,11 @@ def timeit(n=8):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 def setup(prio, slots):
     torch.cuda.synchronize()
-    engine.BRANCH_PRIORITY = prio
     engine._side_streams.clear()
     ops.release_workspaces()
     ops._bn_part.clear()
     ops.lib.catseg_debug_set_dconv3_pl_slots(slots)
-CONFIGS = [("baseline", 0, 512), ("branch 0 high priority", -1, 512), ("pl slots 384", 0, 384), ("pl slots 448", 0, 448), ("pl slots 640", 0, 640)]
+CONFIGS = [("baseline", 0, 512), ("pl slots 384", 0, 384), ("pl slots 448", 0, 448), ("pl slots 640", 0, 640)]
 res = {n: [] for n, *_ in CONFIGS}
 for rnd in range(rounds):
     for name, prio, slots in CONFIGS:

@@ -1,14 +1,13 @@
 #!/bin/bash
-# step-level A/B of the execution modes on one box: graph / eager x async head backward-weight on / off, alternating rounds
+# step-level A/B of the execution modes on one box: hipGraph replay against the eager launch loop, alternating rounds
+# (round 5 also ran the asynchronous head backward-weight here: measured, no gain, removed in round 6 -- docs/DESIGN_history.md)
 # usage (on the GPU box): bash tools/ab_modes.sh <tag> [rounds]
 TAG=${1:-modes}; N=${2:-2}
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/$TAG; mkdir -p "$O"
 A="--steps 15 --warmup 4 --no-cpu-baseline --no-side-figures --no-roofline"
 for r in $(seq 1 $N); do
-  python3 "$R/bench.py" $A > "$O/graph_async_$r.json" 2> "$O/graph_async_$r.err"
-  CATSEG_ASYNC_WGRAD=0 python3 "$R/bench.py" $A > "$O/graph_inline_$r.json" 2> /dev/null
-  python3 "$R/bench.py" $A --eager > "$O/eager_async_$r.json" 2> /dev/null
-  CATSEG_ASYNC_WGRAD=0 python3 "$R/bench.py" $A --eager > "$O/eager_inline_$r.json" 2> /dev/null
+  python3 "$R/bench.py" $A > "$O/graph_$r.json" 2> "$O/graph_$r.err"
+  python3 "$R/bench.py" $A --eager > "$O/eager_$r.json" 2> /dev/null
 done
 python3 - "$O" <<'PY'
 import glob, json, os, sys
