@@ -57,6 +57,9 @@ int catseg_debug_set_b3_tile(int t);
  *     in N / M; 3 / 4 = 16 / 32 wide), splits, direct (1 = the direct backward-weight kernel handles it). */
 int catseg_debug_plan_conv(const catseg_conv_desc* d, int op, int* out);
 
+/* A/B hook: 1 (default) = catseg_bilinear_bwd as one launch with the intermediate row in LDS where the layout allows 16-byte loads
+ * (csrc/pointwise.hip: bilinear_bwd_fused_kernel), 0 = the two separable passes through the workspace.  Bit-identical results. */
+int catseg_debug_set_bilinear_bwd_fused(int on);
 /* A/B hook: waves per block of the f16x2 forward / backward-data kernel of the head layers (csrc/igemm_f16x2.hip): 8 (default) =
  * igemm_h2w8_kernel, two waves per SIMD; 4 = igemm_h2w_kernel, one 512-register wave per SIMD.  Bit-identical results. */
 int catseg_debug_set_h2w_waves(int waves);

@@ -3,6 +3,13 @@
 // deterministic (backward passes are written as gathers, never atomics).
 #include "planes.h"
 
+// 1 (default): catseg_bilinear_bwd runs as one launch with its intermediate row in LDS where the layout allows; 0: the two separable passes
+int catseg_g_bilinear_bwd_fused = 1;
+extern "C" int catseg_debug_set_bilinear_bwd_fused(int on) {
+  catseg_g_bilinear_bwd_fused = on ? 1 : 0;
+  return CATSEG_OK;
+}
+
 namespace {
 
 int grid_for(long long total, int per_block = 256) {
@@ -406,6 +413,160 @@ __global__ void bilinear_bwd_cols_kernel(const float* __restrict__ tmp, float* _
   }
 }
 
+// backward in ONE launch (round 6): the two separable passes above with the intermediate row `tmp[b, iy, ox, :]` kept in LDS instead of HBM.
+// Block = (image b, input row iy, a segment of input columns, a channel chunk): phase 1 computes t[ox][c] = sum_oy wy(oy -> iy) dy[b, oy, ox, c] for
+// the output columns the segment's input columns can gather from (16-byte loads along the contiguous (ox, c) index, exactly
+// bilinear_bwd_rows_kernel's expression and order), phase 2 dx[b, iy, ix, c] = sum_ox wx(ox -> ix) t[ox][c] (bilinear_bwd_cols_kernel's): the
+// results are BIT-IDENTICAL to the two-pass route, the 4 B per (input row x output column x channel) of tmp are neither written nor re-read
+// (the K-class logits at 544 x 960 from 136 x 240: 104 MB each way per call), and one launch replaces two.
+// Input rows are dealt to the blocks so that the rows iy, iy + 1, ... of one image go to ONE XCD (blocks b, b + 8, ... share an XCD's L2):
+// every dy row feeds two input rows, the second read is an L2 hit instead of a second trip over the fabric.
+// MODE 1: lddy == C, (Wo C) % 4 == 0 (contiguous output rows: the logits); MODE 2: C % 4 == 0, channel chunks of CC (feature maps, channel
+// slices of a concatenation buffer).
+struct BilinearBwdFused {
+  const float* dy; int lddy;
+  float* dx; int lddx;
+  int B, H, W, C, Ho, Wo, align;
+  float sh, sw;
+  int zero_to, acc;
+  int seg, nseg, CC, nchunk;      // input columns per block, segments per row, channels per chunk, chunks
+};
+
+__device__ __forceinline__ void bil_cand(float scale, int i, int align, int out_size, int& lo, int& hi) {
+  if (scale > 0.f) {
+    lo = align ? (int)floorf((i - 1) / scale) - 1 : (int)floorf((i - 0.5f) / scale) - 2;
+    hi = align ? (int)ceilf((i + 1) / scale) + 1 : (int)ceilf((i + 1.5f) / scale) + 1;
+  } else {
+    lo = 0; hi = out_size - 1;
+  }
+  if (lo < 0) lo = 0;
+  if (hi > out_size - 1) hi = out_size - 1;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bilinear_bwd_fused_kernel(const BilinearBwdFused a) {
+  extern __shared__ __attribute__((aligned(16))) float t[];
+  // XCD-aware row order: logical row = the (bid / 8)-th row of XCD (bid % 8)'s contiguous share
+  const int nrow = gridDim.x, bid = blockIdx.x;
+  const int q8 = nrow >> 3, r8 = nrow & 7, xcd = bid & 7;
+  const int row = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int b = row / a.H, iy = row - b * a.H;
+  const int sg = blockIdx.y / a.nchunk, ch = blockIdx.y - sg * a.nchunk;
+  const int ix0 = sg * a.seg, nix = min(a.seg, a.W - ix0);
+  const int c0 = ch * a.CC, cc = min(a.CC, a.C - c0);
+  int ylo, yhi, oxa, oxb, tmp_;
+  bil_cand(a.sh, iy, a.align, a.Ho, ylo, yhi);
+  bil_cand(a.sw, ix0, a.align, a.Wo, oxa, tmp_);
+  bil_cand(a.sw, ix0 + nix - 1, a.align, a.Wo, tmp_, oxb);
+  auto wy = [&](int oy) {
+    int y0, y1;
+    float l0, l1;
+    lerp_setup(a.sh, oy, a.align, a.H, y0, y1, l0, l1);
+    float w = 0.f;
+    if (y0 == iy) w += l0;
+    if (y1 == iy) w += l1;
+    return w;
+  };
+  const float* drow0 = a.dy + ((long long)b * a.Ho) * a.Wo * a.lddy;
+  int f0 = 0;                       // MODE 1: first float of the (ox, c) run held in LDS
+  if (MODE == 1) {
+    f0 = (oxa * a.C) & ~3;
+    int f1 = ((oxb + 1) * a.C + 3) & ~3;
+    if (f1 > a.Wo * a.C) f1 = a.Wo * a.C;
+    const int n4 = (f1 - f0) >> 2;
+    for (int u = threadIdx.x; u < n4; u += 256) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        const float w = wy(oy);
+        if (w != 0.f) {
+          const f32x4 v = ld4(drow0 + (long long)oy * a.Wo * a.lddy + f0 + 4 * u);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[e] += w * v[e];
+        }
+      }
+      *(f32x4*)(t + 4 * u) = s;
+    }
+  } else {
+    const int q4 = cc >> 2, n4 = (oxb - oxa + 1) * q4;
+    for (int u = threadIdx.x; u < n4; u += 256) {
+      const int oxi = u / q4, q = u - oxi * q4;
+      const long long off = (long long)(oxa + oxi) * a.lddy + c0 + 4 * q;
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        const float w = wy(oy);
+        if (w != 0.f) {
+          const f32x4 v = ld4(drow0 + (long long)oy * a.Wo * a.lddy + off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[e] += w * v[e];
+        }
+      }
+      *(f32x4*)(t + oxi * a.CC + 4 * q) = s;
+    }
+  }
+  __syncthreads();
+  // phase 2: this block's input columns x (its channels + the zero padding behind the last chunk)
+  const bool last = ch == a.nchunk - 1;
+  const int cw = (last && a.zero_to > a.C) ? cc + (a.zero_to - a.C) : cc;
+  float* orow = a.dx + ((long long)row * a.W + ix0) * a.lddx + c0;
+  for (int i = threadIdx.x; i < nix * cw; i += 256) {
+    const int ixl = i / cw, c = i - ixl * cw;
+    float* d = orow + (long long)ixl * a.lddx + c;
+    if (c >= cc) {
+      *d = 0.f;
+      continue;
+    }
+    const int ix = ix0 + ixl;
+    int lo, hi;
+    bil_cand(a.sw, ix, a.align, a.Wo, lo, hi);
+    float s = 0.f;
+    for (int ox = lo; ox <= hi; ++ox) {
+      int x0, x1;
+      float l0, l1;
+      lerp_setup(a.sw, ox, a.align, a.W, x0, x1, l0, l1);
+      float w = 0.f;
+      if (x0 == ix) w += l0;
+      if (x1 == ix) w += l1;
+      if (w != 0.f) s += w * (MODE == 1 ? t[ox * a.C + c - f0] : t[(ox - oxa) * a.CC + c]);
+    }
+    *d = a.acc ? (*d + s) : s;
+  }
+}
+
+// host side of the fused launch: the candidate ranges exactly as the kernel computes them (same float expressions)
+static void bil_cand_host(float scale, int i, int align, int out_size, int& lo, int& hi) {
+  if (scale > 0.f) {
+    lo = align ? (int)floorf((i - 1) / scale) - 1 : (int)floorf((i - 0.5f) / scale) - 2;
+    hi = align ? (int)ceilf((i + 1) / scale) + 1 : (int)ceilf((i + 1.5f) / scale) + 1;
+  } else {
+    lo = 0; hi = out_size - 1;
+  }
+  if (lo < 0) lo = 0;
+  if (hi > out_size - 1) hi = out_size - 1;
+}
+
+// LDS floats a block of `seg` input columns needs at most (0: does not fit `cap`)
+static int bil_fused_lds_floats(int W, int Wo, int C, int CC, int mode, int align, float sw, int seg, int cap) {
+  int need = 0;
+  for (int ix0 = 0; ix0 < W; ix0 += seg) {
+    const int nix = seg < W - ix0 ? seg : W - ix0;
+    int oxa, oxb, t_;
+    bil_cand_host(sw, ix0, align, Wo, oxa, t_);
+    bil_cand_host(sw, ix0 + nix - 1, align, Wo, t_, oxb);
+    int n;
+    if (mode == 1) {
+      const int f0 = (oxa * C) & ~3;
+      int f1 = ((oxb + 1) * C + 3) & ~3;
+      if (f1 > Wo * C) f1 = Wo * C;
+      n = f1 - f0;
+    } else {
+      n = (oxb - oxa + 1) * CC;
+    }
+    if (n > cap) return 0;
+    need = n > need ? n : need;
+  }
+  return need;
+}
+
 // ------------------------------------------------------------------ global average pool
 __global__ void gap_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int HW, int C) {
   // grid (C/64 ceil, B); block 256 = 64 channels x 4 row lanes
@@ -723,6 +884,38 @@ extern "C" int catseg_bilinear_bwd(const float* dy, int lddy, float* dx, int ldd
     return CATSEG_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  // ONE launch with the intermediate row in LDS where the layout allows 16-byte loads (bilinear_bwd_fused_kernel; bit-identical to the two passes)
+  if (catseg_g_bilinear_bwd_fused) {
+    const int mode = (lddy == C && (Wo * C) % 4 == 0 && cs_aligned16(dy)) ? 1 : ((C % 4 == 0 && lddy % 4 == 0 && cs_aligned16(dy)) ? 2 : 0);
+    if (mode != 0) {
+      BilinearBwdFused a;
+      a.dy = dy; a.lddy = lddy; a.dx = dx; a.lddx = lddx;
+      a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = Ho; a.Wo = Wo; a.align = align_corners;
+      a.sh = resize_scale(H, Ho, align_corners); a.sw = resize_scale(W, Wo, align_corners);
+      a.zero_to = zero_to; a.acc = accumulate;
+      a.CC = mode == 1 ? C : (C < 96 ? C : 96);
+      a.nchunk = mode == 1 ? 1 : (C + a.CC - 1) / a.CC;
+      constexpr int CAP = 10240;                      // 40 KB of LDS per block: three blocks per CU
+      // the longest segment that fits, halved while the grid is shorter than ~4 blocks per CU
+      int seg = W, need = 0;
+      while (seg >= 1 && (need = bil_fused_lds_floats(W, Wo, C, a.CC, mode, align_corners, a.sw, seg, CAP)) == 0) seg = seg > 1 ? (seg + 1) / 2 : 0;
+      while (seg > 8 && (long long)B * H * ((W + seg - 1) / seg) * a.nchunk < 1024) {
+        seg = (seg + 1) / 2;
+        need = bil_fused_lds_floats(W, Wo, C, a.CC, mode, align_corners, a.sw, seg, CAP);
+      }
+      if (seg >= 1 && need > 0) {
+        a.seg = seg; a.nseg = (W + seg - 1) / seg;
+        const dim3 grid(B * H, a.nseg * a.nchunk);
+        const size_t lds = (size_t)need * 4;
+        if (mode == 1)
+          hipLaunchKernelGGL(bilinear_bwd_fused_kernel<1>, grid, dim3(256), lds, st, a);
+        else
+          hipLaunchKernelGGL(bilinear_bwd_fused_kernel<2>, grid, dim3(256), lds, st, a);
+        CS_LAUNCH_CHECK();
+        return CATSEG_OK;
+      }
+    }
+  }
   // few, long input rows at low resolution: split each row's sweep so that the grid still fills the chip
   const int ysplit_r = (int)((2048 + (long long)B * H - 1) / ((long long)B * H)) < (Wo * C + 255) / 256
                            ? (int)((2048 + (long long)B * H - 1) / ((long long)B * H)) : (Wo * C + 255) / 256;

@@ -274,6 +274,47 @@ def test_bilinear(ops, align, sizes):
     assert float(full[..., C:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("case", [
+    # (B, H, W, C, Ho, Wo, ld of dy, align, zero_to, accumulate): contiguous logits rows (mode 1), feature maps / channel slices of a wider
+    # buffer (mode 2, several channel chunks, several column segments), the scalar fallback (C % 4 != 0 with a padded row stride)
+    (2, 34, 60, 25, 136, 240, 25, False, 32, False), (2, 34, 60, 25, 136, 240, 25, True, 32, True), (1, 136, 240, 25, 544, 960, 25, False, 32, False),
+    (2, 17, 30, 384, 136, 240, 720, False, 0, False), (2, 34, 60, 192, 136, 240, 192, False, 0, True), (2, 68, 120, 96, 136, 240, 720, False, 0, False),
+    (3, 5, 7, 48, 5, 7, 48, False, 0, False), (2, 9, 9, 8, 20, 31, 8, True, 0, False), (1, 1, 1, 4, 7, 9, 4, False, 0, False),
+    (2, 6, 10, 25, 48, 80, 32, False, 32, False), (2, 20, 31, 12, 9, 9, 12, False, 0, False)])
+def test_bilinear_backward_in_one_launch_is_bit_identical_to_the_two_passes(ops, case):
+    """catseg_bilinear_bwd as ONE launch with the intermediate row in LDS (bilinear_bwd_fused_kernel) against the two separable passes it
+    replaces (catseg_debug_set_bilinear_bwd_fused(0)): the same sums in the same order -> bit-identical gradients, padding columns and
+    accumulation included; and against autograd of F.interpolate (reference call sites: models/OCR.py:128-131, models/HRNetv2.py:505-508)"""
+    B, H, W, C, Ho, Wo, ld, align, zero_to, acc = case
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(H * W + C)
+    gy = torch.randn(B, Ho, Wo, C, generator=g)
+    buf = torch.randn(B, Ho, Wo, ld, generator=g).to(dev)          # dy as a channel slice of a wider buffer
+    buf[..., :C] = gy.to(dev)
+    dy = buf[..., :C] if ld != C else buf
+    base = torch.randn(B, H, W, max(zero_to, (C + 3) // 4 * 4), generator=g).to(dev)
+    res = []
+    for fused in (1, 0):
+        ops.lib.catseg_debug_set_bilinear_bwd_fused(fused)
+        out = base.clone()[..., :C] if acc else None
+        if acc:
+            o = base.clone()
+            out = torch.as_strided(o, (B, H, W, C), o.stride())
+        dx = ops.bilinear_bwd(dy, (B, H, W, C), align, out=out, zero_to=zero_to, accumulate=acc)
+        torch.cuda.synchronize()
+        full = torch.as_strided(dx, dx.shape[:3] + (ops.ld_of(dx),), dx.stride())
+        res.append(full.clone())
+    ops.lib.catseg_debug_set_bilinear_bwd_fused(1)
+    assert torch.equal(res[0], res[1])
+    x = torch.zeros(B, C, H, W, requires_grad=True)
+    F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=align).backward(gy.permute(0, 3, 1, 2))
+    ref = x.grad.permute(0, 2, 3, 1)
+    got = res[0][..., :C].cpu() - (base[..., :C].cpu() if acc else 0)
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    if zero_to > C and not acc:
+        assert float(res[0][..., C:zero_to].abs().max()) == 0
+
+
 def test_global_avgpool(ops):
     g = torch.Generator().manual_seed(8)
     x = torch.randn(2, 72, 9, 13, generator=g)
