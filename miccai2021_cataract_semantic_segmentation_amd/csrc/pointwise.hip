@@ -346,7 +346,7 @@ __global__ void bilinear_bwd_rows_kernel(const float* __restrict__ dy, int lddy,
       float s = 0.f;
       for (int oy = lo; oy <= hi; ++oy) {
         const float w = weight(oy);
-        if (w != 0.f) s += w * dy[(((long long)b * Ho + oy) * Wo + ox) * lddy + c];
+        if (w != 0.f) s = __builtin_fmaf(w, dy[(((long long)b * Ho + oy) * Wo + ox) * lddy + c], s);
       }
       trow[i] = s;
     }
@@ -368,7 +368,7 @@ __global__ void bilinear_bwd_rows_kernel(const float* __restrict__ dy, int lddy,
         if (w != 0.f) {
           const f32x4 v = ld4(dy + ((long long)b * Ho + oy) * Wo * lddy + off);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) s[e] += w * v[e];
+          for (int e = 0; e < 4; ++e) s[e] = __builtin_fmaf(w, v[e], s[e]);
         }
       }
       *(f32x4*)(trow + (long long)u * 4) = s;
@@ -407,7 +407,7 @@ __global__ void bilinear_bwd_cols_kernel(const float* __restrict__ tmp, float* _
       float w = 0.f;
       if (x0 == ix) w += l0;
       if (x1 == ix) w += l1;
-      if (w != 0.f) s += w * t[ox * C + c];
+      if (w != 0.f) s = __builtin_fmaf(w, t[ox * C + c], s);
     }
     *d = acc ? (*d + s) : s;
   }
@@ -423,6 +423,7 @@ __global__ void bilinear_bwd_cols_kernel(const float* __restrict__ tmp, float* _
 // every dy row feeds two input rows, the second read is an L2 hit instead of a second trip over the fabric.
 // MODE 1: lddy == C, (Wo C) % 4 == 0 (contiguous output rows: the logits); MODE 2: C % 4 == 0, channel chunks of CC (feature maps, channel
 // slices of a concatenation buffer).
+constexpr int BIL_MAXROWS = 64;   // output rows that can weigh into one input row (the host falls back to two passes beyond)
 struct BilinearBwdFused {
   const float* dy; int lddy;
   float* dx; int lddx;
@@ -467,40 +468,63 @@ __global__ __launch_bounds__(256) void bilinear_bwd_fused_kernel(const BilinearB
     if (y1 == iy) w += l1;
     return w;
   };
+  // the output rows with a non-zero weight for this input row, in ascending order (what the two-pass kernel's `if (w != 0.f)` visits): found
+  // once per block, so that the sweep below has no branch between its loads -- four rows' 16-byte loads are in flight per thread instead of
+  // one load -> FMA round trip per row (the first version of this kernel was latency-bound at 2.5 TB/s)
+  __shared__ float wl[BIL_MAXROWS];
+  __shared__ int yl[BIL_MAXROWS];
+  __shared__ int nw_s;
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float w = wy(oy);
+      if (w != 0.f && n < BIL_MAXROWS) {
+        wl[n] = w;
+        yl[n] = oy;
+        ++n;
+      }
+    }
+    nw_s = n;
+  }
+  __syncthreads();
+  const int nw = nw_s;
   const float* drow0 = a.dy + ((long long)b * a.Ho) * a.Wo * a.lddy;
+  const long long rstride = (long long)a.Wo * a.lddy;
+  auto sweep = [&](const long long off) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 4 <= nw; k += 4) {
+      const f32x4 v0 = ld4(drow0 + yl[k] * rstride + off), v1 = ld4(drow0 + yl[k + 1] * rstride + off);
+      const f32x4 v2 = ld4(drow0 + yl[k + 2] * rstride + off), v3 = ld4(drow0 + yl[k + 3] * rstride + off);
+      const float w0 = wl[k], w1 = wl[k + 1], w2 = wl[k + 2], w3 = wl[k + 3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s[e] = __builtin_fmaf(w0, v0[e], s[e]);      // (explicit FMAs here and in the two-pass kernels: the same roundings by construction)
+        s[e] = __builtin_fmaf(w1, v1[e], s[e]);
+        s[e] = __builtin_fmaf(w2, v2[e], s[e]);
+        s[e] = __builtin_fmaf(w3, v3[e], s[e]);
+      }
+    }
+    for (; k < nw; ++k) {
+      const f32x4 v = ld4(drow0 + yl[k] * rstride + off);
+      const float w = wl[k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = __builtin_fmaf(w, v[e], s[e]);
+    }
+    return s;
+  };
   int f0 = 0;                       // MODE 1: first float of the (ox, c) run held in LDS
   if (MODE == 1) {
     f0 = (oxa * a.C) & ~3;
     int f1 = ((oxb + 1) * a.C + 3) & ~3;
     if (f1 > a.Wo * a.C) f1 = a.Wo * a.C;
     const int n4 = (f1 - f0) >> 2;
-    for (int u = threadIdx.x; u < n4; u += 256) {
-      f32x4 s = {0.f, 0.f, 0.f, 0.f};
-      for (int oy = ylo; oy <= yhi; ++oy) {
-        const float w = wy(oy);
-        if (w != 0.f) {
-          const f32x4 v = ld4(drow0 + (long long)oy * a.Wo * a.lddy + f0 + 4 * u);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) s[e] += w * v[e];
-        }
-      }
-      *(f32x4*)(t + 4 * u) = s;
-    }
+    for (int u = threadIdx.x; u < n4; u += 256) *(f32x4*)(t + 4 * u) = sweep(f0 + 4 * u);
   } else {
     const int q4 = cc >> 2, n4 = (oxb - oxa + 1) * q4;
     for (int u = threadIdx.x; u < n4; u += 256) {
       const int oxi = u / q4, q = u - oxi * q4;
-      const long long off = (long long)(oxa + oxi) * a.lddy + c0 + 4 * q;
-      f32x4 s = {0.f, 0.f, 0.f, 0.f};
-      for (int oy = ylo; oy <= yhi; ++oy) {
-        const float w = wy(oy);
-        if (w != 0.f) {
-          const f32x4 v = ld4(drow0 + (long long)oy * a.Wo * a.lddy + off);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) s[e] += w * v[e];
-        }
-      }
-      *(f32x4*)(t + oxi * a.CC + 4 * q) = s;
+      *(f32x4*)(t + oxi * a.CC + 4 * q) = sweep((long long)(oxa + oxi) * a.lddy + c0 + 4 * q);
     }
   }
   __syncthreads();
@@ -526,7 +550,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_fused_kernel(const BilinearB
       float w = 0.f;
       if (x0 == ix) w += l0;
       if (x1 == ix) w += l1;
-      if (w != 0.f) s += w * (MODE == 1 ? t[ox * a.C + c - f0] : t[(ox - oxa) * a.CC + c]);
+      if (w != 0.f) s = __builtin_fmaf(w, MODE == 1 ? t[ox * a.C + c - f0] : t[(ox - oxa) * a.CC + c], s);
     }
     *d = a.acc ? (*d + s) : s;
   }
@@ -887,7 +911,10 @@ extern "C" int catseg_bilinear_bwd(const float* dy, int lddy, float* dx, int ldd
   // ONE launch with the intermediate row in LDS where the layout allows 16-byte loads (bilinear_bwd_fused_kernel; bit-identical to the two passes)
   if (catseg_g_bilinear_bwd_fused) {
     const int mode = (lddy == C && (Wo * C) % 4 == 0 && cs_aligned16(dy)) ? 1 : ((C % 4 == 0 && lddy % 4 == 0 && cs_aligned16(dy)) ? 2 : 0);
-    if (mode != 0) {
+    const float shf = resize_scale(H, Ho, align_corners);
+    // (candidate rows of an input row: ~2 / sh + 6; the kernel lists at most BIL_MAXROWS of them)
+    const bool rows_fit = shf > 0.f ? (2.0f / shf + 8.0f <= (float)BIL_MAXROWS) : (Ho <= BIL_MAXROWS);
+    if (mode != 0 && rows_fit) {
       BilinearBwdFused a;
       a.dy = dy; a.lddy = lddy; a.dx = dx; a.lddx = lddx;
       a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = Ho; a.Wo = Wo; a.align = align_corners;
