@@ -88,7 +88,7 @@ MODELS = {
     "deeplabv3plus_r50": ({"backbone": "resnet50", "out_stride": 8, "pretrained": False}, "DeepLabv3+-ResNet50-OS8"),
 }
 IS_DEEPLAB = lambda name: name.startswith("deeplab")   # noqa: E731
-PROFILE_ROUND, PREVIOUS_PROFILE_ROUND = "r05_s2", "r05"   # profiles/<round>_pmc_traffic_<model>.json feeds roofline.traffic
+PROFILE_ROUND, PREVIOUS_PROFILE_ROUND = "r06", "r05_s2"   # profiles/<round>_pmc_traffic_<model>.json feeds roofline.traffic
 
 
 def host_cpu_info():
@@ -320,7 +320,7 @@ def infer_bench(args):
             peak = {"fwd_b3": 2500.0 / 6.0, "fwd_h2": 2500.0 / 3.0}.get(dom, 157.3)
             roof = {"bound": "mfma", "kernel": {"fwd": "igemm_f32_kernel<NT> (conv2d forward + folded BatchNorm / residual / ReLU epilogue, fp32 MFMA)",
                                                 "fwd_b3": "igemm_b3w_kernel (conv2d forward, bf16x3 split precision)",
-                                                "fwd_h2": "igemm_h2w_kernel (conv2d forward + fused epilogue, f16x2 split precision: 3 fp16 MFMA products)"}[dom],
+                                                "fwd_h2": "igemm_h2w8_kernel (conv2d forward + fused epilogue, f16x2 split precision: 3 fp16 MFMA products)"}[dom],
                     "achieved": fl / sec / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak,
                     "traffic": infer_traffic(dom, n // 2, (B, H, W))[0], "traffic_source": infer_traffic(dom, n // 2, (B, H, W))[1],
                     "launches_per_step": n // 2, "avg_launch_ms": sec / n * 1e3, "algorithmic_gflop_per_launch": fl / n / 1e9,
@@ -595,8 +595,8 @@ def main():
                        "global memory, weight image through LDS, three MFMA products; csrc/pconv1.hip)",
                  "wgrad_p1": "p1t_kernel (pointwise 1x1 conv2d backward-weight, in-register split, transposed LDS reads, incl. slab reduction)",
                  "b3w": "igemm_b3w_kernel (conv2d forward and backward-data of the large layers, bf16x3 split precision)",
-                 "h2w": "igemm_h2w_kernel (conv2d forward and backward-data of the large layers, f16x2 split precision: two fp16 planes "
-                        "per operand, three MFMA products)",
+                 "h2w": "igemm_h2w8_kernel (conv2d forward and backward-data of the large layers, f16x2 split precision: two fp16 planes "
+                        "per operand, three MFMA products; 256 x 256 block tile, two waves per SIMD)",
                  "wgrad_b3": "igemm_b3t_kernel (conv2d backward-weight, bf16x3 split precision, incl. slab reduction)",
                  "wgrad_h2": "igemm_h2t_kernel (conv2d backward-weight of the large layers, f16x2 split precision, incl. slab reduction)",
                  "wgrad_d3h": "dwgrad3_h2_kernel (direct 3x3 conv2d backward-weight of the HRNet trunk, f16x2 split precision, incl. slab reduction)",

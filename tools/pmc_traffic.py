@@ -38,8 +38,8 @@ def group(name):
         return "d3_prep"
     if "igemm_h2t_kernel" in name or "h2_reduce_slabs" in name:
         return "wgrad_h2"
-    if "igemm_h2w_kernel" in name:
-        return "h2w"            # f16x2 forward AND backward-data
+    if "igemm_h2w_kernel" in name or "igemm_h2w8_kernel" in name:
+        return "h2w"            # f16x2 forward AND backward-data (round 6: igemm_h2w8_kernel, two waves per SIMD)
     if "split2h" in name or "amax_kernel" in name:
         return "split3"
     if "igemm_b3w_kernel" in name or "igemm_b3_kernel" in name:
