@@ -15,16 +15,23 @@ crit = TwoScaleLoss({"experiment": 3, "interm": {"name": "LovaszSoftmax", "args"
 opt = FusedAdam(model, lr=1e-4)
 img, lbl = bench.synth_batch(8, 544, 960, 25, 1, dev)
 
-# wrap the three conv entry points to remember shapes
-shapes = []
-_f, _d, _w = ops.conv_fwd, ops.conv_bwd_data, ops.conv_bwd_weight
-def cf(x, w, b, Cout, kh, kw, *a, **k):
-    shapes.append(("fwd", tuple(x.shape), Cout, kh, a[:3])); return _f(x, w, b, Cout, kh, kw, *a, **k)
-def cd(dy, w, xs, kh, kw, *a, **k):
-    shapes.append(("dgrad", tuple(xs), dy.shape[-1], kh, a[:3])); return _d(dy, w, xs, kh, kw, *a, **k)
-def cw(x, dy, dw, db, kh, kw, *a, **k):
-    shapes.append(("wgrad", tuple(x.shape), dy.shape[-1], kh, a[:3])); return _w(x, dy, dw, db, kh, kw, *a, **k)
+# wrap the three conv entry points: the PROFILE entries a call appends belong to its shape (routes that bypass the wrapped entry points --
+# the planes / blocked-planes backward -- stay labelled by their kind only)
 import miccai2021_cataract_semantic_segmentation_amd.engine as E
+owner = {}
+_f, _d, _w = ops.conv_fwd, ops.conv_bwd_data, ops.conv_bwd_weight
+def _wrap(fn, label):
+    def g(*a, **k):
+        n0 = len(ops.PROFILE) if ops.PROFILE is not None else 0
+        r = fn(*a, **k)
+        if ops.PROFILE is not None:
+            for i in range(n0, len(ops.PROFILE)):
+                owner[i] = label(*a, **k)
+        return r
+    return g
+cf = _wrap(_f, lambda x, w, b, Cout, kh, kw, *a, **k: (tuple(x.shape), Cout, kh, a[:3], "exact" if k.get("exact") else ""))
+cd = _wrap(_d, lambda dy, w, xs, kh, kw, *a, **k: (tuple(xs), dy.shape[-1], kh, a[:3], ""))
+cw = _wrap(_w, lambda x, dy, dw, db, kh, kw, *a, **k: (tuple(x.shape), dy.shape[-1], kh, a[:3], ""))
 def step():
     opt.zero_grad(); i, f = model(img); l = crit(i, f, lbl); l.backward(); opt.step()
 for _ in range(2): step()
@@ -33,14 +40,16 @@ E.PARALLEL_BRANCHES = False   # sequential branches: the events around one launc
 step(); torch.cuda.synchronize()
 ops.PROFILE = []
 step(); torch.cuda.synchronize()
-prof = [q for q in ops.PROFILE if q[0].split('_')[0] in ('fwd', 'dgrad', 'wgrad') and q[0] not in ('dgrad_d3p', 'wgrad_d3p')]   # (the planes route's backward does not pass the wrapped entry points); ops.PROFILE = None
+prof = ops.PROFILE; ops.PROFILE = None
 agg = collections.OrderedDict()
-for (kind, fl, e0, e1), sh in zip(prof, shapes):
-    assert kind.split('_')[0] == sh[0], (kind, sh)
-    k = (kind,) + sh[1:]
+for i, (kind, fl, e0, e1) in enumerate(prof):
+    k = (kind,) + owner.get(i, ("-", 0, 0, (), ""))
     a = agg.setdefault(k, [0, 0.0, 0.0]); a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1)
+only = sys.argv[2] if len(sys.argv) > 2 else None      # e.g. "f32": kinds fwd / dgrad / wgrad (the fp32 family) only
 rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
-tot = sum(v[2] for v in agg.values())
-print("total igemm ms %.1f" % tot)
-for k, (n, fl, ms) in rows[:120]:
-    print("%-8s x%-3d in%-22s Cout %-5d k%d %-10s %8.2f ms %6.1f TF %5.1f%%" % (k[0], n, k[1], k[2], k[3], k[4], ms, fl / ms / 1e9, 100 * ms / tot))
+if only == "f32":
+    rows = [r for r in rows if r[0][0] in ("fwd", "dgrad", "wgrad")]
+tot = sum(v[2] for _, v in rows)
+print("total ms %.1f" % tot)
+for k, (n, fl, ms) in rows[:150]:
+    print("%-10s x%-3d in%-22s Cout %-5d k%d %-10s %-5s %8.3f ms %6.1f TF %5.1f%%" % (k[0], n, k[1], k[2], k[3], k[4], k[5], ms, fl / ms / 1e9 if ms else 0, 100 * ms / tot))
