@@ -474,8 +474,8 @@ class Dconv3Bank:
 # 64-channel layers 0.82 - 0.89 x): P1_WGRAD_MIN_DIM.  HRNet-W48 step (tools/ab_p1.sh, graph replay, two alternating rounds): 109.06 / 109.97 ms
 # without, 108.24 / 108.09 with all three operations on every layer, 107.72 / 107.65 with forward + backward-data only.
 P1 = _plan.get("p1")
-P1_MIN_ROWS = 100000
-P1_WGRAD_MIN_DIM = 256
+P1_MIN_ROWS = _plan.get("p1_min_rows")
+P1_WGRAD_MIN_DIM = _plan.get("p1_wgrad_min_dim")
 P1_OPS = _plan.get("p1_ops")
 _p1_wimg = {}
 

@@ -270,10 +270,10 @@ def test_plan_registry_parses_one_variable_and_reads_live_values_back(monkeypatc
     from miccai2021_cataract_semantic_segmentation_amd import plan
     monkeypatch.setenv("CATSEG_PLAN", "heads=bf16x3, planes_widths=96+192,segment_mb=16")
     monkeypatch.setenv("CATSEG_HEADS", "f16x2")
-    monkeypatch.setenv("CATSEG_G1_MIN_ROWS", "4096")
+    monkeypatch.setenv("CATSEG_G1_MIN_ROWS", "2048")
     monkeypatch.setattr(plan, "_plan_env", None)
     assert plan.get("heads") == "bf16x3" and plan.get("planes_widths") == (96, 192) and plan.get("segment_mb") == 16.0
-    assert plan.get("g1_min_rows") == 4096 and plan.get("trunk") == "f16x2" and plan.get("stem7") is True
+    assert plan.get("g1_min_rows") == 2048 and plan.get("trunk") == "f16x2" and plan.get("stem7") is True
     monkeypatch.setenv("CATSEG_PLAN", "no_such_field=1")
     monkeypatch.setattr(plan, "_plan_env", None)
     try:

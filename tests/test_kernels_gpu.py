@@ -326,6 +326,20 @@ def test_global_avgpool(ops):
     close(nchw(dx), 1 + gy[:, :, None, None].expand(2, 72, 9, 13) / (9 * 13), atol=1e-6)
 
 
+def test_global_avgpool_vector_kernel(ops):
+    """gap_fwd4_kernel (C % 4 == 0, HW >= 256: 16-byte loads, 64 row lanes, four load chains): ragged HW (tail loops), a channel count that
+    leaves the last block partly empty, a channel SLICE of a wider tensor (ld > C), against the fp64 mean; run twice: deterministic"""
+    g = torch.Generator().manual_seed(18)
+    for (B, C, H, W, wide) in ((2, 136, 20, 33, 0), (1, 64, 16, 16, 0), (2, 72, 31, 17, 24), (1, 2048, 17, 30, 0)):
+        full = torch.randn(B, H, W, C + wide, generator=g).cuda()
+        x = full[..., :C]
+        y1 = ops.global_avgpool_fwd(x)
+        y2 = ops.global_avgpool_fwd(x)
+        ref = x.double().mean((1, 2))
+        assert torch.equal(y1, y2)
+        assert float((y1.reshape(B, C).double() - ref).abs().max()) < 2e-7 * max(1.0, float(ref.abs().max())) + 3e-7, (B, C, H, W)
+
+
 def test_softmaxes(ops):
     g = torch.Generator().manual_seed(6)
     B, N, K, ld = 2, 300, 25, 32
