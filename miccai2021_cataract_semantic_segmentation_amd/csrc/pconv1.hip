@@ -587,7 +587,7 @@ int g_p1t_blocks = 256;
 }  // namespace
 
 extern "C" int catseg_pconv1_supported(int N, int K) {
-  return (N >= 32 && K >= 32 && K % 8 == 0 && N <= 512 && K <= 8160) ? 1 : 0;       // (K < 8192: the 32-bit reciprocal of the tap decode)
+  return (N >= 32 && K >= 32 && K % 8 == 0 && N <= 2048 && K <= 8160) ? 1 : 0;       // (K < 8192: the 32-bit reciprocal of the tap decode)
 }
 
 extern "C" size_t catseg_pconv1_wimg_bytes(int N, int K) {

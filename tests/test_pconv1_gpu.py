@@ -35,7 +35,8 @@ def _act(rows, C, ld, gen, scale=1.0, spread=3.0):
 
 SHAPES = [  # (rows, K = Cin, N = Cout)
     (4096 + 37, 64, 256), (2049, 256, 64), (3000, 64, 64), (2500, 512, 256), (2304, 256, 256), (2200, 256, 512),
-    (2100, 96, 48), (2050, 192, 96), (2060, 384, 48), (2070, 384, 192), (2111, 192, 48), (5000, 48, 96), (2300, 1024, 512)]
+    (2100, 96, 48), (2050, 192, 96), (2060, 384, 48), (2070, 384, 192), (2111, 192, 48), (5000, 48, 96), (2300, 1024, 512),
+    (2150, 256, 1024), (2090, 1024, 256), (2077, 512, 2048), (2310, 2048, 512), (2081, 128, 520)]     # (wide layers: ResNet bottlenecks, > 2 column tiles)
 
 
 @pytest.mark.parametrize("rows,K,N", SHAPES)
