@@ -125,7 +125,8 @@ _b3_cache_dy = {"key": None, "x": None, "planar": None, "blk": None}
 # 2.38 -> 1.54 + 0.57 ms, backward-data 2.42 -> 1.80 + 0.30 ms at 8 x 136 x 240); smaller 1x1 layers stay on the fp32 kernels
 # Round 3, with two fp16 planes and three products: the 1x1 layers of a ResNet50's layer 4 at stride 8 (2048 <-> 512 on 8 x 68 x 120 = 65 280
 # pixels) pay as well -- OCRNet-R50 step 98.8 -> 87.5 ms (tools/ab_1x1_rows.py); smaller extents (256) still do not (87.6 -> 88.5 ms)
-B3_1X1_MIN_DIM, B3_1X1_MIN_PROD, B3_1X1_MIN_ROWS = 512, 512 * 1024, 60000
+B3_1X1_MIN_DIM = _plan.get("wide_1x1_min_dim")
+B3_1X1_MIN_PROD, B3_1X1_MIN_ROWS = B3_1X1_MIN_DIM * 1024, _plan.get("wide_1x1_min_rows")
 
 
 def _b3_wide_1x1(rows, ncols, taps, cred):
