@@ -120,9 +120,74 @@ struct P1Args {
   P1Geo geo;                          // (GEO launches)
 };
 
+// cs_tile_bn_partials (common.h) for a FULL 256-row tile of p1_kernel -- 8 waves stacked along M, 16 accumulator rows per lane, lanes l and
+// l ^ 32 hold the other rows of the same columns -- with the same operations in the same order (bit-identical partials) and a scheduling fence
+// behind every column tile: in straight-line code the scheduler otherwise interleaves the eight column tiles' sums, keeps their temporaries alive
+// together and spills ~300 registers per thread in the 256-column form.
+template <int NS>
+__device__ __forceinline__ void p1_full_tile_bn_partials(float* lds, int tile_cols, int l31, bool writer_lane, int wave_m, const f32x16 (&acc)[NS],
+                                                         float* part, int C, int gcol0) {
+  constexpr int WM = 8;
+  float mean[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a += acc[j][i];
+    a += __shfl_xor(a, 32, 64);
+    if (writer_lane) lds[wave_m * tile_cols + 32 * j + l31] = a;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  const float inv = 1.f / 256.f;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) t += lds[w * tile_cols + 32 * j + l31];
+    mean[j] = t * inv;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float d = acc[j][i] - mean[j];
+      a += d;
+      b += d * d;
+    }
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 32, 64);
+    if (writer_lane) {
+      lds[wave_m * tile_cols + 32 * j + l31] = a;
+      lds[(WM + wave_m) * tile_cols + 32 * j + l31] = b;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  if (writer_lane && wave_m == 0) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int gc = gcol0 + 32 * j + l31;
+      if (gc < C) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          a += lds[w * tile_cols + 32 * j + l31];
+          b += lds[(WM + w) * tile_cols + 32 * j + l31];
+        }
+        part[gc] = mean[j];
+        part[C + gc] = a;
+        part[2 * C + gc] = b;
+      }
+    }
+  }
+}
+
 constexpr int p1_waitcnt(int vm) { return (vm & 15) | (7 << 4) | (15 << 8) | ((vm >> 4) << 14); }     // vmcnt only (expcnt / lgkmcnt: no wait)
 
-template <int NT, bool GEO>
+template <int NT, bool GEO, bool FULL>
 __global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
   constexpr int BN = 32 * NT;
   constexpr int GB = 4 * BN * 32;                   // bytes of one k-group of B: k-tile (2) x plane (2) x BN rows x 32 bytes
@@ -281,6 +346,64 @@ __global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
   __builtin_amdgcn_s_waitcnt(p1_waitcnt(0));
   __syncthreads();
 
+  // ---- epilogue, FAST PATH (round 6): a tile that lies wholly inside M x N, no accumulation, linear output rows -- every tile of the layers
+  // that matter (M = 261 120 = 1020 x 256, N a multiple of the column tile).  The general path below spends ~3000 instructions per tile on
+  // per-element predication (a scalar branch around each of the 128 stores, 256 row-validity selects in the BatchNorm partials), two ldexps per
+  // element and the bias added three times -- as many as the K loop of a 512-deep layer (3900) and more than that of a 256-deep one (1950), with
+  // the matrix pipe idle (SQ counters: MFMA busy 27 - 39 % of the CU-busy cycles).  Here: one ldexp by -(e_x + e_w) (exact; the
+  // two-step ldexp stays for exponent sums outside +-120), the bias added once, partial sums without selects, 128 unconditional stores.
+  // The arithmetic of every output and of the BatchNorm partials is the general path's (same operations in the same order).
+  // FULL is a property of the LAUNCH (p1_launch: M a multiple of 256, N of the column tile, no accumulation, linear output rows), hence a
+  // template parameter: with both epilogues in one kernel the register allocator kept copies of the 128 accumulator registers for either
+  // arm and spilled 300 - 500 registers per thread in the 256-column form.
+  if constexpr (FULL) {
+    // (wave-uniform by construction; readfirstlane SAYS so: a branch the compiler takes for divergent keeps both arms' 128 accumulator
+    //  registers alive)
+    const int ew_u = __builtin_amdgcn_readfirstlane(p.wrec[1]), ex_u = __builtin_amdgcn_readfirstlane(ex);
+    const int es = -(ex_u + ew_u);
+    if (es >= -120 && es <= 120) {
+      // (ONE ldexp, not a multiplication by 2^es: the compiler folds a multiplication into the fused multiply-adds of the BatchNorm partials
+      //  below, keeps scaled AND unscaled accumulators alive and spills 256 registers per thread)
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = __builtin_ldexpf(acc[u][r], es);
+    } else {
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = __builtin_ldexpf(__builtin_ldexpf(acc[u][r], -ex_u), -ew_u);
+    }
+    if (p.bias != nullptr) {
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const float b = p.bias[n0 + 32 * u + l31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] += b;
+      }
+    }
+    if (p.bn_part != nullptr)
+      p1_full_tile_bn_partials<NT>((float*)smem, BN, l31, hh == 0, wave, acc, p.bn_part + (long long)tile_m * 3 * p.N, p.N, n0);
+    // stores through a buffer resource over this tile's 256 output rows: ONE per-lane offset register, the row of accumulator element r in the
+    // scalar offset, the column tile in the instruction's immediate (pointers per row cost 32 registers: the 256-column form spilled)
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)m0 * p.ldy + n0), (short)0,
+                                                                        (int)(256u * (unsigned)p.ldy * 4u), 0x00020000);
+    const int ld4 = p.ldy * 4;
+    const int voff = (wave * 32 + 4 * hh) * ld4 + l31 * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int soff = ((r & 3) + 8 * (r >> 2)) * ld4;
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const float v = acc[u][r];        // (a copy: __builtin_bit_cast applied to the vector ELEMENT itself reads element 0 for every r -- hipcc 7.2)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, voff + 128 * u, soff, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
+
+  // ---- general path: ragged tiles, accumulation, gathered output rows
   // back to the operands' scale: 2^-(e_x + e_w) in two exact steps
   {
     const int ea = -ex, ew = -p.wrec[1];
@@ -339,8 +462,14 @@ template <int NT>
 void p1_launch(const P1Args& a, bool geo, hipStream_t st) {
   const int per = 8 * a.ntn;
   const int blocks = a.ntn > 1 ? (a.tilesM + 7) / 8 * per : a.tilesM;
-  if (geo) hipLaunchKernelGGL((p1_kernel<NT, true>), dim3(blocks), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((p1_kernel<NT, false>), dim3(blocks), dim3(512), 0, st, a);
+  const bool full = a.M % 256 == 0 && a.N % (32 * NT) == 0 && !a.accumulate && (!geo || a.geo.linear_out);
+  if (geo) {
+    if (full) hipLaunchKernelGGL((p1_kernel<NT, true, true>), dim3(blocks), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((p1_kernel<NT, true, false>), dim3(blocks), dim3(512), 0, st, a);
+  } else {
+    if (full) hipLaunchKernelGGL((p1_kernel<NT, false, true>), dim3(blocks), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((p1_kernel<NT, false, false>), dim3(blocks), dim3(512), 0, st, a);
+  }
 }
 
 void p1_dispatch(const P1Args& a, bool geo, hipStream_t st) {
