@@ -928,7 +928,7 @@ inline double cu_quant(double tiles) {
   return c / (double)(long long)(c + 0.999999);
 }
 
-TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, long long red_rows, bool allow_narrow = true) {
+TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, long long red_rows, bool allow_narrow = true, long long kdepth = 0) {
   TilePlan best = {2, 2, 1, 0};
   double best_t = 1e300;
   const double R = 115e12;
@@ -944,7 +944,13 @@ TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, l
     if ((t.narrow == 1 || t.narrow >= 3) && tn > 1 && g_force_mi == 0) continue;  // in-network the 48/96-wide forms only win when one tile spans N
     const double padded = 2.0 * (double)(tm * tile_m) * (double)(tn * tile_n) * (double)extra * (double)red_rows;
     if (layout != L_TN) {
-      const double tt = padded / (R * (t.eff > 0.f ? t.eff : 1.f) * cu_quant((double)(tm * tn * extra)));
+      double eff = t.eff > 0.f ? t.eff : 1.f;
+      // forward layers with a SHORT reduction (1 x 1, <= 128 input channels: the stage-1 pointwise layers) are bound by their epilogue and
+      // their stores, not by the matrix pipe: the 128 x 128 tile has no full-tile epilogue (register budget) and the 64 x 128 tile writes the
+      // longest row segments -- measured at 8 x 136 x 240, 64 -> 256 (tools/sweep_f32_tiles.py): (2, 2) 175 us, (2, 1) 159, (1, 1) 164, (1, 2) 141
+      if (layout == L_NT && kdepth > 0 && kdepth <= 128 && t.narrow == 0 && g_force_mi == 0)
+        eff = (t.mi == 1 && t.ni == 2) ? 1.0 : ((t.mi * t.ni >= 4) ? 0.75 * eff : eff);
+      const double tt = padded / (R * eff * cu_quant((double)(tm * tn * extra)));
       if (tt < best_t) {
         best_t = tt;
         best = {t.mi, t.ni, 1, 0, t.narrow};
@@ -980,7 +986,7 @@ TilePlan plan_tiles(int layout, long long M, long long ncols, long long extra, l
 template <int LAYOUT>
 int launch_igemm(const IgemmArgs& a, int nbatch, int grid_y, hipStream_t st, const TilePlan* given = nullptr) {
   const int ncols = a.zero_to > a.N ? a.zero_to : a.N;  // pad columns to be zero-filled are visited too
-  const TilePlan pl = given ? *given : plan_tiles(LAYOUT, a.M, ncols, (long long)grid_y * nbatch, a.g.rows);
+  const TilePlan pl = given ? *given : plan_tiles(LAYOUT, a.M, ncols, (long long)grid_y * nbatch, a.g.rows, true, (long long)a.taps * a.Cred);
   const int mi = pl.mi, ni = pl.ni;
   bool ok = false;
 #define CS_FORM(F_, M_, N_)                                                          \
@@ -1143,7 +1149,7 @@ extern "C" int catseg_conv2d_fwd_bnstats(const catseg_conv_desc* d, const float*
   a.Cred_b = a.Cred; a.zero_to = zero_to; a.accumulate = 0;
   if (!d->stem4) fill_taps(a, d->kh, d->kw, d->dil, +1, d->stride, -d->pad);
   const int ncols = zero_to > a.N ? zero_to : a.N;
-  const TilePlan pl = plan_tiles(L_NT, a.M, ncols, 1, a.g.rows);
+  const TilePlan pl = plan_tiles(L_NT, a.M, ncols, 1, a.g.rows, true, (long long)a.taps * a.Cred);
   if (pl.narrow == 0 || pl.narrow == 1) {
     const int tm = 64 * pl.mi, nt = (a.M + tm - 1) / tm;
     if (bn_part != nullptr && (size_t)nt * 3 * d->Cout <= bn_part_floats) {
@@ -1279,7 +1285,7 @@ extern "C" int catseg_debug_plan_conv(const catseg_conv_desc* d, int op, int* ou
   int direct = 0;
   if (op == 0) {
     const int g = d->groups > 1 ? d->groups : 1;
-    pl = plan_tiles(L_NT, (long long)d->B * d->Ho * d->Wo, d->Cout / g, g, (long long)d->B * d->Ho * d->Wo);
+    pl = plan_tiles(L_NT, (long long)d->B * d->Ho * d->Wo, d->Cout / g, g, (long long)d->B * d->Ho * d->Wo, true, (long long)d->kh * d->kw * (d->Cin / g));
   } else if (op == 1) {
     const int s = d->stride;
     const long long rows = (long long)d->B * ((d->H + s - 1) / s) * ((d->W + s - 1) / s);
