@@ -49,6 +49,9 @@ int catseg_debug_set_dconv3_pl_pair(int mask);
 int catseg_debug_dconv3_pl_occupancy(int C, int pair);
 int catseg_debug_dwgrad3_pl_occupancy(int C);
 
+/* test hook: 1 = igemm_h2w8_kernel always runs its general (predicated) epilogue; 0 (default) = the full-row-tile epilogue where the launch allows */
+int catseg_debug_set_h2w_slow_epilogue(int on);
+
 /* tuning hook: bf16x3 block tile: 0 = heuristic, 1 = 256x256, 2 = 256x128, 3 = 128x256, 4 = 256x192, 5 = 256x96, 6 = 256x64 */
 int catseg_debug_set_b3_tile(int t);
 /* planner query: which tile / split count would the library pick for this convolution?

@@ -189,6 +189,7 @@ _SIGS = {
     "catseg_pconv1_wgrad": (I, [L, I, I, P, I, P, P, I, P, P, P, SZ, P]),
     "catseg_debug_set_pconv1_wgrad_blocks": (I, [I]),
     "catseg_debug_set_h2w_waves": (I, [I]),
+    "catseg_debug_set_h2w_slow_epilogue": (I, [I]),
     "catseg_debug_set_bilinear_bwd_fused": (I, [I]),
     "catseg_gconv_supported": (I, [P]),
     "catseg_gconv_class_bytes": (SZ, [P]),

@@ -21,6 +21,11 @@
 // waves per block of the forward / backward-data kernel: 8 = igemm_h2w8_kernel (two waves per SIMD, the default since round 6),
 // 4 = igemm_h2w_kernel (one 512-register wave per SIMD); bit-identical results
 int catseg_g_h2w_waves = 8;
+int catseg_g_h2w_slow_epilogue = 0;     // (tests: 1 = the general epilogue for every launch of igemm_h2w8_kernel -- bit-identity of the fast one)
+extern "C" int catseg_debug_set_h2w_slow_epilogue(int on) {
+  catseg_g_h2w_slow_epilogue = on ? 1 : 0;
+  return CATSEG_OK;
+}
 extern "C" int catseg_debug_set_h2w_waves(int waves) {
   catseg_g_h2w_waves = waves == 4 ? 4 : 8;
   return CATSEG_OK;
@@ -565,6 +570,7 @@ __global__ __launch_bounds__(256, 1) void igemm_h2w_kernel(const H2Args p) {
 // pieces or waits for its fragment reads, its partner's MFMAs keep the pipe busy -- the hardware interleaves, no hand-placed schedule.
 // Per wave and K-step: 24 MFMAs, 12 ds_read_b128, 4 LDS-DMA pieces, one barrier.  Every output element accumulates the products of a K-step
 // in the order lh, hh, hl and the K-steps in the order of igemm_h2w_kernel: results (and BatchNorm partials) are BIT-IDENTICAL to it.
+template <bool FAST>
 __global__ __launch_bounds__(512, 2) void igemm_h2w8_kernel(const H2Args p) {
   constexpr int TM = 4, TN = 2;
   constexpr int BM = 256, BN = 256;
@@ -696,6 +702,84 @@ __global__ __launch_bounds__(512, 2) void igemm_h2w8_kernel(const H2Args p) {
       cur = (cur + 1) & 3;
       fill = (fill + 1) & 3;
     }
+  }
+
+  // ---- FAST epilogue (round 6; a property of the LAUNCH: M a multiple of 256, no residual, no zero-filled pad columns -- run_h2 decides).  The
+  // general epilogue below predicates each of a lane's 128 stores with scalar branches, computes a 64-bit address per element, scales with two
+  // ldexps per element and selects the valid rows of the BatchNorm partials: ~3500 instructions per wave and tile with the matrix pipe idle --
+  // 40 % of a tile's time at K = 1024 (32 K-steps of 24 MFMAs: the 1 x 1 layers of the ResNet trunks and the OCR bottleneck), 10 % at K = 6480.
+  // Here: one ldexp, column validity once per column tile (N = 720 of the HRNet head's backward-data leaves the third column tile ragged),
+  // buffer loads / stores with one per-lane offset, the accumulator row in the scalar offset and the column tile in the immediate.  Same
+  // operations on every element in the same order ((acc + bias) + previous contents, then ReLU): bit-identical outputs and partials.
+  if constexpr (FAST) {
+    const int ea_u = __builtin_amdgcn_readfirstlane(*p.ea), ew_u = __builtin_amdgcn_readfirstlane(*p.ew);
+    const int es = -(ea_u + ew_u);
+    if (es >= -120 && es <= 120) {
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][u][r] = __builtin_ldexpf(acc[t][u][r], es);
+    } else {
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][u][r] = __builtin_ldexpf(__builtin_ldexpf(acc[t][u][r], -ea_u), -ew_u);
+    }
+    bool cok[TN];
+    float bv[TN];
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      const int col = n0 + wn * 64 + u * 32 + l31;
+      cok[u] = col < p.N;
+      bv[u] = (p.bias != nullptr && cok[u]) ? p.bias[col] : 0.f;
+    }
+    if (p.bn_part != nullptr) {
+      __builtin_amdgcn_s_waitcnt(h2_waitcnt(0, 0));      // (the zero pieces issued past the end of the reduction still target the slots)
+      __syncthreads();
+      int colv[TN];
+#pragma unroll
+      for (int u = 0; u < TN; ++u) colv[u] = wn * 64 + u * 32 + l31;
+      cs_tile_bn_partials<TN, TM * 16, 2, false>(
+          (float*)smem, BN, colv, h == 0, wm, BM, [&](int j, int i) { return acc[i >> 4][j][i & 15] + bv[j]; }, [&](int) { return true; },
+          p.bn_part + (long long)tile_m * 3 * p.N, p.N, n0);
+    }
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (long long)m0 * p.ldc + n0), (short)0,
+                                                                        (int)(256u * (unsigned)p.ldc * 4u), 0x00020000);
+    const int ld4 = p.ldc * 4;
+    const int voff = (wm * 128 + 4 * h) * ld4 + (wn * 64 + l31) * 4;
+    const bool accum = p.accumulate != 0, relu = p.relu != 0;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+#pragma unroll
+      for (int u = 0; u < TN; ++u) {
+        if (cok[u]) {
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = acc[t][u][r] + bv[u];
+          if (accum) {
+            float o[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              o[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, voff + 128 * u, (t * 32 + (r & 3) + 8 * (r >> 2)) * ld4, 0));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += o[r];
+          }
+          if (relu) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rsC, voff + 128 * u, (t * 32 + (r & 3) + 8 * (r >> 2)) * ld4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    return;
   }
 
   // back to the operands' scale: 2^-(e_a + e_w) in two exact steps (each exponent is within [-100, 100])
@@ -1071,8 +1155,13 @@ int run_h2(H2Args a, hipStream_t st) {
   CS_REQUIRE(a.ea && a.ew, "f16x2: prescale exponents missing");
   a.tilesM = (a.M + 255) / 256;
   a.tilesN = ((a.zero_to > a.N ? a.zero_to : a.N) + 255) / 256;
-  if (catseg_g_h2w_waves == 8)
-    hipLaunchKernelGGL(igemm_h2w8_kernel, dim3(a.tilesM * a.tilesN), dim3(512), 0, st, a);
+  if (catseg_g_h2w_waves == 8) {
+    // FAST epilogue: every row tile full, nothing but the previous contents added, no pad columns to zero (a ragged last column tile is fine)
+    if (a.M % 256 == 0 && a.residual == nullptr && a.zero_to <= a.N && !catseg_g_h2w_slow_epilogue)
+      hipLaunchKernelGGL(igemm_h2w8_kernel<true>, dim3(a.tilesM * a.tilesN), dim3(512), 0, st, a);
+    else
+      hipLaunchKernelGGL(igemm_h2w8_kernel<false>, dim3(a.tilesM * a.tilesN), dim3(512), 0, st, a);
+  }
   else
     hipLaunchKernelGGL(igemm_h2w_kernel, dim3(a.tilesM * a.tilesN), dim3(256), 0, st, a);
   CS_LAUNCH_CHECK();

@@ -64,6 +64,7 @@ FIELDS = {
     "pl_pair": (0, int, None, "bit mask of channel counts whose planes kernel runs two tiles per block"),
     "wp96_blocks": (0, int, None, "blocks of the 96+ channel backward-weight kernel on planes"),
     "igemm_splits": (0, int, None, "forced split count of the fp32 implicit-GEMM backward-weight"),
+    "h2w_slow_epilogue": (0, int, None, "1: igemm_h2w8_kernel always runs its general (element-predicated) epilogue (A/B of the full-row-tile epilogue)"),
     "h2w_waves": (0, int, None, "waves per block of the head layers' forward / backward-data kernel: 8 (default) or 4"),
     # ---- execution
     "branch_streams": (4, int, "engine:BRANCH_STREAMS", "HIP streams a parallel region spreads its branches over"),
@@ -80,7 +81,7 @@ _ENV_NAME = {"trunk_planes": "CATSEG_TRUNK_PLANES"}     # (every other field: CA
 LIBRARY_KNOBS = {"wg_blocks": "catseg_debug_set_dwgrad3_blocks", "dc_blocks": "catseg_debug_set_dconv3_blocks",
                  "pl_slots": "catseg_debug_set_dconv3_pl_slots", "pl_pair": "catseg_debug_set_dconv3_pl_pair",
                  "wp96_blocks": "catseg_debug_set_dwgrad3_pl_blocks", "igemm_splits": "catseg_debug_set_splits",
-                 "h2w_waves": "catseg_debug_set_h2w_waves"}
+                 "h2w_waves": "catseg_debug_set_h2w_waves", "h2w_slow_epilogue": "catseg_debug_set_h2w_slow_epilogue"}
 _plan_env = None
 
 

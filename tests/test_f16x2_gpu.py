@@ -161,6 +161,54 @@ def test_forward_and_backward_data_vs_fp64(ops, case):
     assert torch.equal(dwb, dw), "backward-weight from blocked planes differs from the planar-plane result"
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 400, 512, 1), (1, 32, 48, 176, 256, 3), (1, 16, 16, 720, 512, 1)])
+def test_fast_epilogue_bit_identical_to_the_general_one(ops, case):
+    """igemm_h2w8_kernel<FAST> (launches whose row tiles are all full: M % 256 == 0, no residual, no pad columns) against the general,
+    element-predicated epilogue of the same kernel (catseg_debug_set_h2w_slow_epilogue): forward with bias + BatchNorm partials, backward-data
+    into a RAGGED column count (N = Cin not a multiple of 256: the HRNet head's 720) with and without accumulation -- bit for bit; and the
+    forward against fp64."""
+    import ctypes
+    from miccai2021_cataract_semantic_segmentation_amd._lib import lib
+    B, H, W, Ci, Co, k = case
+    assert (B * H * W) % 256 == 0
+    g = torch.Generator().manual_seed(B + H + W + Ci + Co + k)
+    x = torch.randn(B, Ci, H, W, generator=g) * torch.exp(1.0 * torch.randn(1, Ci, 1, 1, generator=g))
+    w = torch.randn(Co, Ci, k, k, generator=g) * (2.0 / (Ci * k * k)) ** 0.5
+    b = torch.randn(Co, generator=g)
+    gy = torch.randn(B, Co, H, W, generator=g) * 1e-6
+    xd, wd, gyd = nhwc(x), ohwi(w), nhwc(gy)
+    xp, xs = ops.split2h_blocked(xd)
+    wp, ws = ops.split2h_weight_blocked(wd)
+    gp, gs = ops.split2h_blocked(gyd)
+    wtp, wts = ops.split2h_weight_t_blocked(wd)
+    base = torch.randn(B, H, W, Ci, generator=g).cuda() * 1e-6
+    res = []
+    try:
+        for slow in (0, 1):
+            lib.catseg_debug_set_h2w_slow_epilogue(slow)
+            y = torch.full((B, H, W, Co), float("nan")).cuda()
+            dsc = ops.make_desc(xd.shape, Ci, Co, Co, k, k, 1, k // 2, 1)
+            part = torch.full((3 * (B * H * W // 256) * Co,), float("nan")).cuda()
+            tr, nt = ctypes.c_int(0), ctypes.c_int(0)
+            ops.check(lib.catseg_conv2d_fwd_f16x2_blocked(ctypes.byref(dsc), ops.ptr(xp), ops.ptr(xs), ops.ptr(wp), ops.ptr(ws), ops.ptr(b.cuda()),
+                                                          ops.ptr(y), 0, ops.ptr(part), part.numel(), ctypes.byref(tr), ctypes.byref(nt), ops.stream()))
+            dx0 = torch.full((B, H, W, Ci), float("nan")).cuda()
+            dsc = ops.make_desc(xd.shape, Ci, Co, (Co + 7) // 8 * 8, k, k, 1, k // 2, 1)
+            ops.check(lib.catseg_conv2d_bwd_data_f16x2_blocked(ctypes.byref(dsc), ops.ptr(gp), ops.ptr(gs), ops.ptr(wtp), ops.ptr(wts), ops.ptr(dx0), 0,
+                                                               ops.stream()))
+            dx1 = base.clone()
+            ops.check(lib.catseg_conv2d_bwd_data_f16x2_blocked(ctypes.byref(dsc), ops.ptr(gp), ops.ptr(gs), ops.ptr(wtp), ops.ptr(wts), ops.ptr(dx1), 1,
+                                                               ops.stream()))
+            torch.cuda.synchronize()
+            res.append((y, part, dx0, dx1))
+    finally:
+        lib.catseg_debug_set_h2w_slow_epilogue(0)
+    for a, bb in zip(res[0], res[1]):
+        assert torch.equal(a, bb)
+    y64 = F.conv2d(x.double(), w.double(), b.double(), 1, k // 2)
+    close(nchw(res[0][0]), y64, 2e-5)
+
+
 def test_dispatch_takes_the_f16x2_kernels_and_matches_bf16x3(ops):
     """ops.conv_fwd / conv_bwd_data on a head-shaped layer: the f16x2 kernels run by default (CATSEG_HEADS), and agree with the
     six-product bf16x3 path to fp32 rounding"""
