@@ -592,7 +592,7 @@ __device__ __forceinline__ void igemm_f32_body(const IgemmArgs& p) {
   // ---- epilogue -------------------------------------------------------------------------
   float* cout = cbase;
   if (LAYOUT == L_TN) cout += split * p.c_split_stride + (long long)blockIdx.y * p.c_tap_stride;
-  // ---- FAST PATH (round 6): a tile wholly inside M x N with nothing added to it and no row remap -- every tile of most layers this kernel
+  // ---- FAST PATH (round 6): a tile wholly inside M x N, no residual operand and no row remap -- every tile of most layers this kernel
   // still takes (M a multiple of the tile height, N of its width).  The general path below predicates every one of the tile's stores with
   // scalar branches, computes a 64-bit address per element and selects the valid rows of the BatchNorm partials: ~2500 instructions per block
   // for the (128 x 64) tile of <NT, 2, 1> against ~500 in its whole K loop when K = 64 (the stage-1 pointwise layers): the kernels were
@@ -601,8 +601,8 @@ __device__ __forceinline__ void igemm_f32_body(const IgemmArgs& p) {
   // column tile in the immediate -- and partial sums without selects.  Only where the accumulators leave room for a second epilogue in the
   // register budget (MI * NI <= 2; backward-data / backward-weight, which carry no second accumulator set, up to 4).
   if constexpr (NARROW == 0 && (MI * NI <= 2 || (LAYOUT != L_NT && MI * NI <= 4))) {
-    const bool adds_any = p.accumulate || (LAYOUT == L_NT && p.residual != nullptr);
-    if (m0 + TILE_M <= p.M && n0 + TILE_N <= p.N && !adds_any && !(LAYOUT != L_TN && p.remap)) {
+    const bool has_res = LAYOUT == L_NT && p.residual != nullptr;
+    if (m0 + TILE_M <= p.M && n0 + TILE_N <= p.N && !has_res && !(LAYOUT != L_TN && p.remap)) {
       float bvv[NI];
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) bvv[ni] = p.bias != nullptr ? p.bias[zb * p.bias_bs + n0 + wn * 32 * NI + ni * 32 + l31] : 0.f;
@@ -623,17 +623,26 @@ __device__ __forceinline__ void igemm_f32_body(const IgemmArgs& p) {
                                                                           (int)((unsigned)TILE_M * (unsigned)p.ldc * 4u), 0x00020000);
       const int ld4 = p.ldc * 4;
       const int voff = (wm * 32 * MI + 4 * h) * ld4 + (wn * 32 * NI + l31) * 4;
-      const bool relu = LAYOUT == L_NT && p.relu;
+      const bool relu = LAYOUT == L_NT && p.relu, accum = p.accumulate != 0;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int soff = (mi * 32 + (r & 3) + 8 * (r >> 2)) * ld4;
+          float v[NI];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) v[ni] = acc[mi][ni][r] + bvv[ni];
+          if (accum) {                  // ((acc + bias) + previous contents, as the general path; a row is read before it is stored)
+            float o[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) o[ni] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, voff + 128 * ni, soff, 0));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) v[ni] += o[ni];
+          }
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
-            float v = acc[mi][ni][r] + bvv[ni];
-            if (relu) v = fmaxf(v, 0.f);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, voff + 128 * ni, soff, 0);
+            if (relu) v[ni] = fmaxf(v[ni], 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[ni]), rsC, voff + 128 * ni, soff, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -346,14 +346,14 @@ __global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
   __builtin_amdgcn_s_waitcnt(p1_waitcnt(0));
   __syncthreads();
 
-  // ---- epilogue, FAST PATH (round 6): a tile that lies wholly inside M x N, no accumulation, linear output rows -- every tile of the layers
+  // ---- epilogue, FAST PATH (round 6): a tile that lies wholly inside M x N, linear output rows -- every tile of the layers
   // that matter (M = 261 120 = 1020 x 256, N a multiple of the column tile).  The general path below spends ~3000 instructions per tile on
   // per-element predication (a scalar branch around each of the 128 stores, 256 row-validity selects in the BatchNorm partials), two ldexps per
   // element and the bias added three times -- as many as the K loop of a 512-deep layer (3900) and more than that of a 256-deep one (1950), with
   // the matrix pipe idle (SQ counters: MFMA busy 27 - 39 % of the CU-busy cycles).  Here: one ldexp by -(e_x + e_w) (exact; the
   // two-step ldexp stays for exponent sums outside +-120), the bias added once, partial sums without selects, 128 unconditional stores.
   // The arithmetic of every output and of the BatchNorm partials is the general path's (same operations in the same order).
-  // FULL is a property of the LAUNCH (p1_launch: M a multiple of 256, N of the column tile, no accumulation, linear output rows), hence a
+  // FULL is a property of the LAUNCH (p1_launch: M a multiple of 256, N of the column tile, linear output rows), hence a
   // template parameter: with both epilogues in one kernel the register allocator kept copies of the 128 accumulator registers for either
   // arm and spilled 300 - 500 registers per thread in the 256-column form.
   if constexpr (FULL) {
@@ -390,14 +390,22 @@ __global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
                                                                         (int)(256u * (unsigned)p.ldy * 4u), 0x00020000);
     const int ld4 = p.ldy * 4;
     const int voff = (wave * 32 + 4 * hh) * ld4 + l31 * 4;
+    const bool accum = p.accumulate != 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int soff = ((r & 3) + 8 * (r >> 2)) * ld4;
+      float v[NT];
 #pragma unroll
-      for (int u = 0; u < NT; ++u) {
-        const float v = acc[u][r];        // (a copy: __builtin_bit_cast applied to the vector ELEMENT itself reads element 0 for every r -- hipcc 7.2)
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, voff + 128 * u, soff, 0);
+      for (int u = 0; u < NT; ++u) v[u] = acc[u][r];        // (copies: __builtin_bit_cast applied to a vector ELEMENT itself reads element 0 for every r -- hipcc 7.2)
+      if (accum) {                                            // (the previous contents of the row, read before its stores: (acc + bias) + old, as the general path)
+        float o[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) o[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsY, voff + 128 * u, soff, 0));
+#pragma unroll
+        for (int u = 0; u < NT; ++u) v[u] += o[u];
       }
+#pragma unroll
+      for (int u = 0; u < NT; ++u) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[u]), rsY, voff + 128 * u, soff, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     return;
@@ -462,7 +470,7 @@ template <int NT>
 void p1_launch(const P1Args& a, bool geo, hipStream_t st) {
   const int per = 8 * a.ntn;
   const int blocks = a.ntn > 1 ? (a.tilesM + 7) / 8 * per : a.tilesM;
-  const bool full = a.M % 256 == 0 && a.N % (32 * NT) == 0 && !a.accumulate && (!geo || a.geo.linear_out);
+  const bool full = a.M % 256 == 0 && a.N % (32 * NT) == 0 && (!geo || a.geo.linear_out);
   if (geo) {
     if (full) hipLaunchKernelGGL((p1_kernel<NT, true, true>), dim3(blocks), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((p1_kernel<NT, true, false>), dim3(blocks), dim3(512), 0, st, a);
