@@ -572,7 +572,50 @@ __global__ __launch_bounds__(512) void p1t_kernel(const P1TArgs p) {
     q += (int)((q + 1) * d <= n);
     return q;
   };
+  // plain (not gathered) operands: an item's byte offset advances by a CONSTANT per 32-pixel step -- computed once (round 6: the 64-bit
+  // address arithmetic of every item of every step was most of the kernel's 7 VALU instructions per MFMA; profiles/r06_pmc_sq_p1t_fpixel.json:
+  // matrix pipes busy 18 % of the CU-busy cycles at 2.3 GHz, 62 % of the wave cycles waiting).  When the dy / x boundary of a pixel row falls on
+  // a wave boundary (QM a multiple of 64: the 256-row tiles) an item's operand is wave-uniform: ONE load per item instead of a dy load and an x
+  // load of which one is out of range.
+  constexpr bool UNI = (QM % 64 == 0) && (QT % 64 == 0);
+  unsigned off0[ITEMS], stepb[ITEMS];
+  int pxv[ITEMS];
+  if (!GEO) {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int q = i * 512 + tid;
+      const int px = q / QT, c4 = q - px * QT;
+      const bool isx = c4 >= QM;
+      const bool ok = q < 32 * QT && (isx ? (no + (c4 - QM) * 4 < p.N) : (mo + c4 * 4 < p.M));
+      const long long pix0 = step0 * 32 + px;
+      off0[i] = !ok ? OOB : (isx ? (unsigned)((pix0 * p.ldx + no + (c4 - QM) * 4) * 4) : (unsigned)((pix0 * p.lddy + mo + c4 * 4) * 4));
+      stepb[i] = (unsigned)(32 * (isx ? p.ldx : p.lddy) * 4);
+      pxv[i] = ok ? px : (1 << 30);
+    }
+  }
+  auto load_plain = [&](int srel) {          // step step0 + srel
+    const long long left = p.P - (step0 + srel) * 32;          // pixels of this step that exist
+    const int lim = left > 32 ? 32 : (int)left;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const unsigned off = pxv[i] < lim ? off0[i] + (unsigned)srel * stepb[i] : OOB;
+      if constexpr (UNI) {
+        const bool isx_w = __builtin_amdgcn_readfirstlane((int)(((i * 512 + tid) % QT) >= QM)) != 0;
+        raw[i] = isx_w ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0))
+                       : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, off, 0, 0));
+      } else {
+        const bool isx = ((i * 512 + tid) % QT) >= QM;
+        const f32x4 vd = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, isx ? OOB : off, 0, 0));
+        const f32x4 vx = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, isx ? off : OOB, 0, 0));
+        raw[i] = isx ? vx : vd;
+      }
+    }
+  };
   auto load = [&](long long s) {
+    if (!GEO) {
+      load_plain((int)(s - step0));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       const int q = i * 512 + tid;
