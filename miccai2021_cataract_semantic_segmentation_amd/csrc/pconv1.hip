@@ -611,9 +611,62 @@ __global__ __launch_bounds__(512) void p1t_kernel(const P1TArgs p) {
       }
     }
   };
+  // gather form, INCREMENTAL (round 6): the pixel (image, yo, xo) of an x item advances by 32 pixels per step -- two conditional wraps of xo
+  // (valid for Wo >= 16: xo + 32 < 3 Wo) and one of yo instead of two divisions per item and step; the tap's offsets (ky dil - pad,
+  // kx dil - pad) and channel are per-item constants; 32-bit offsets (the operands are below 4 GB).  dy items advance by a constant.  load()
+  // is called for consecutive steps in order, which is what the running state relies on.  Small maps keep the per-step decode.
+  const bool geo_inc = GEO && p.Wo >= 16 && p.Ho >= 2;
+  int gb[GEO ? ITEMS : 1], gy[GEO ? ITEMS : 1], gx[GEO ? ITEMS : 1], gcy[GEO ? ITEMS : 1], gcx[GEO ? ITEMS : 1], gcc[GEO ? ITEMS : 1];
+  if (geo_inc) {
+    const int hw = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int q = i * 512 + tid;
+      const int px = q / QT, c4 = q - px * QT;
+      const bool isx = c4 >= QM;
+      const long long pix0 = step0 * 32 + px;
+      // dy items: plain offsets (off0 / stepb / pxv as in the plain form); x items: running pixel
+      const bool okd = q < 32 * QT && !isx && mo + c4 * 4 < p.M;
+      off0[i] = okd ? (unsigned)((pix0 * p.lddy + mo + c4 * 4) * 4) : OOB;
+      stepb[i] = (unsigned)(32 * p.lddy * 4);
+      pxv[i] = okd ? px : (1 << 30);
+      const int b = (int)(pix0 / hw), rem = (int)(pix0 - (long long)b * hw);
+      gb[i] = b; gy[i] = rem / p.Wo; gx[i] = rem - gy[i] * p.Wo;
+      gcy[i] = (itap[i] & 255) * p.dil - p.pad; gcx[i] = ((itap[i] >> 8) & 255) * p.dil - p.pad; gcc[i] = itap[i] >> 16;
+    }
+  }
+  const int n_img = GEO ? (int)(p.P / ((long long)p.Ho * p.Wo)) : 0;
+  auto load_geo_inc = [&](int srel) {
+    const long long left = p.P - (step0 + srel) * 32;
+    const int lim = left > 32 ? 32 : (int)left;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const bool isx = ((i * 512 + tid) % QT) >= QM;
+      const unsigned offd = pxv[i] < lim ? off0[i] + (unsigned)srel * stepb[i] : OOB;
+      unsigned offx = OOB;
+      if (GEO) {
+        const int yi = gy[i] * p.stride + gcy[i], xi = gx[i] * p.stride + gcx[i];
+        const bool ok = itap[i] >= 0 && gb[i] < n_img && (unsigned)yi < (unsigned)p.Hi && (unsigned)xi < (unsigned)p.Wi;
+        offx = ok ? ((unsigned)((gb[i] * p.Hi + yi) * p.Wi + xi) * (unsigned)p.ldx + (unsigned)gcc[i]) * 4u : OOB;
+        // next step: 32 pixels on
+        int x2 = gx[i] + 32, y2 = gy[i];
+        bool c = x2 >= p.Wo; x2 -= c ? p.Wo : 0; y2 += c;
+        c = x2 >= p.Wo; x2 -= c ? p.Wo : 0; y2 += c;
+        c = y2 >= p.Ho; y2 -= c ? p.Ho : 0;
+        gx[i] = x2; gy[i] = y2; gb[i] += c;
+      }
+      const f32x4 vd = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, isx ? OOB : offd, 0, 0));
+      const f32x4 vx = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, isx ? offx : OOB, 0, 0));
+      raw[i] = isx ? vx : vd;
+    }
+  };
   auto load = [&](long long s) {
     if (!GEO) {
       load_plain((int)(s - step0));
+      return;
+    }
+    if (geo_inc) {
+      load_geo_inc((int)(s - step0));
       return;
     }
 #pragma unroll
