@@ -543,23 +543,35 @@ __global__ __launch_bounds__(512) void p1t_kernel(const P1TArgs p) {
   const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, (short)0, (int)(unsigned)p.dy_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)(unsigned)p.x_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  // staging: a step's 32 pixels x (MP + NP) channels in 4-float items, item q = (pixel, quad): consecutive lanes take consecutive quads
-  // of one pixel row (coalesced)
-  constexpr int QM = MP / 4, QT = (MP + NP) / 4;
-  constexpr int ITEMS = (32 * QT + 511) / 512;
+  // staging: a step's 32 pixels x (MP + NP) channels in 4-float items.  Round 6: the dy quads and the x quads of a step are TWO item lists --
+  // items 0 .. ITD - 1 walk the 32 x QM dy quads, items ITD .. ITEMS - 1 the 32 x QX x quads, consecutive lanes taking consecutive quads of
+  // one pixel row (coalesced) -- so that an item's operand is known at compile time: ONE load per item (one list over the MP + NP columns
+  // needed a dy load AND an x load per item, one of them out of range, and a select), no per-lane operand selects in the split either.
+  constexpr int QM = MP / 4, QT = (MP + NP) / 4, QX = QT - QM;
+  constexpr int ITD = (32 * QM + 511) / 512, ITX = (32 * QX + 511) / 512, ITEMS = ITD + ITX;
   const long long step0 = (long long)blockIdx.x * p.steps_per_block;
   f32x4 raw[ITEMS];
+  // (pixel, column quad of the LDS row, live) of item i; returns whether it is an x item
+  auto item = [&](const int i, int& px, int& c4, bool& live) -> bool {
+    const bool isx = i >= ITD;
+    const int q = (isx ? i - ITD : i) * 512 + tid, Q = isx ? QX : QM;
+    px = q / Q;
+    c4 = (isx ? QM : 0) + (q - px * Q);
+    live = q < 32 * Q;
+    return isx;
+  };
   // gather form: what does not change from step to step is decoded ONCE per item -- the tap and channel of its column quad, packed
-  // ky | kx << 8 | c << 16 (-1: a dy item, or a column past N) -- the pixel of a step by two multiplications with float reciprocals
+  // ky | kx << 8 | c << 16 (-1: a dy item, or a column past N)
   int itap[ITEMS];
   const float r_hw = GEO ? 1.f / (float)(p.Ho * p.Wo) : 0.f, r_wo = GEO ? 1.f / (float)p.Wo : 0.f;
   if (GEO) {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-      const int q = i * 512 + tid;
-      const int px = q / QT, c4 = q - px * QT;
+      int px, c4;
+      bool live;
+      const bool isx = item(i, px, c4, live);
       itap[i] = -1;
-      if (q < 32 * QT && c4 >= QM && no + (c4 - QM) * 4 < p.N) {
+      if (live && isx && no + (c4 - QM) * 4 < p.N) {
         const int v = no + (c4 - QM) * 4, tap = v / p.Cin, c = v - tap * p.Cin;
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
         itap[i] = ky | (kx << 8) | (c << 16);
@@ -574,19 +586,16 @@ __global__ __launch_bounds__(512) void p1t_kernel(const P1TArgs p) {
   };
   // plain (not gathered) operands: an item's byte offset advances by a CONSTANT per 32-pixel step -- computed once (round 6: the 64-bit
   // address arithmetic of every item of every step was most of the kernel's 7 VALU instructions per MFMA; profiles/r06_pmc_sq_p1t_fpixel.json:
-  // matrix pipes busy 18 % of the CU-busy cycles at 2.3 GHz, 62 % of the wave cycles waiting).  When the dy / x boundary of a pixel row falls on
-  // a wave boundary (QM a multiple of 64: the 256-row tiles) an item's operand is wave-uniform: ONE load per item instead of a dy load and an x
-  // load of which one is out of range.
-  constexpr bool UNI = (QM % 64 == 0) && (QT % 64 == 0);
+  // matrix pipes busy 18 % of the CU-busy cycles at 2.3 GHz, 62 % of the wave cycles waiting).
   unsigned off0[ITEMS], stepb[ITEMS];
   int pxv[ITEMS];
   if (!GEO) {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-      const int q = i * 512 + tid;
-      const int px = q / QT, c4 = q - px * QT;
-      const bool isx = c4 >= QM;
-      const bool ok = q < 32 * QT && (isx ? (no + (c4 - QM) * 4 < p.N) : (mo + c4 * 4 < p.M));
+      int px, c4;
+      bool live;
+      const bool isx = item(i, px, c4, live);
+      const bool ok = live && (isx ? (no + (c4 - QM) * 4 < p.N) : (mo + c4 * 4 < p.M));
       const long long pix0 = step0 * 32 + px;
       off0[i] = !ok ? OOB : (isx ? (unsigned)((pix0 * p.ldx + no + (c4 - QM) * 4) * 4) : (unsigned)((pix0 * p.lddy + mo + c4 * 4) * 4));
       stepb[i] = (unsigned)(32 * (isx ? p.ldx : p.lddy) * 4);
@@ -599,16 +608,8 @@ __global__ __launch_bounds__(512) void p1t_kernel(const P1TArgs p) {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       const unsigned off = pxv[i] < lim ? off0[i] + (unsigned)srel * stepb[i] : OOB;
-      if constexpr (UNI) {
-        const bool isx_w = __builtin_amdgcn_readfirstlane((int)(((i * 512 + tid) % QT) >= QM)) != 0;
-        raw[i] = isx_w ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0))
-                       : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, off, 0, 0));
-      } else {
-        const bool isx = ((i * 512 + tid) % QT) >= QM;
-        const f32x4 vd = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, isx ? OOB : off, 0, 0));
-        const f32x4 vx = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, isx ? off : OOB, 0, 0));
-        raw[i] = isx ? vx : vd;
-      }
+      raw[i] = i >= ITD ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0))
+                        : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, off, 0, 0));
     }
   };
   // gather form, INCREMENTAL (round 6): the pixel (image, yo, xo) of an x item advances by 32 pixels per step -- two conditional wraps of xo
@@ -621,12 +622,12 @@ __global__ __launch_bounds__(512) void p1t_kernel(const P1TArgs p) {
     const int hw = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-      const int q = i * 512 + tid;
-      const int px = q / QT, c4 = q - px * QT;
-      const bool isx = c4 >= QM;
+      int px, c4;
+      bool live;
+      const bool isx = item(i, px, c4, live);
       const long long pix0 = step0 * 32 + px;
       // dy items: plain offsets (off0 / stepb / pxv as in the plain form); x items: running pixel
-      const bool okd = q < 32 * QT && !isx && mo + c4 * 4 < p.M;
+      const bool okd = live && !isx && mo + c4 * 4 < p.M;
       off0[i] = okd ? (unsigned)((pix0 * p.lddy + mo + c4 * 4) * 4) : OOB;
       stepb[i] = (unsigned)(32 * p.lddy * 4);
       pxv[i] = okd ? px : (1 << 30);
@@ -641,23 +642,21 @@ __global__ __launch_bounds__(512) void p1t_kernel(const P1TArgs p) {
     const int lim = left > 32 ? 32 : (int)left;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-      const bool isx = ((i * 512 + tid) % QT) >= QM;
-      const unsigned offd = pxv[i] < lim ? off0[i] + (unsigned)srel * stepb[i] : OOB;
-      unsigned offx = OOB;
-      if (GEO) {
+      if (i < ITD) {
+        const unsigned offd = pxv[i] < lim ? off0[i] + (unsigned)srel * stepb[i] : OOB;
+        raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, offd, 0, 0));
+      } else if (GEO) {
         const int yi = gy[i] * p.stride + gcy[i], xi = gx[i] * p.stride + gcx[i];
         const bool ok = itap[i] >= 0 && gb[i] < n_img && (unsigned)yi < (unsigned)p.Hi && (unsigned)xi < (unsigned)p.Wi;
-        offx = ok ? ((unsigned)((gb[i] * p.Hi + yi) * p.Wi + xi) * (unsigned)p.ldx + (unsigned)gcc[i]) * 4u : OOB;
+        const unsigned offx = ok ? ((unsigned)((gb[i] * p.Hi + yi) * p.Wi + xi) * (unsigned)p.ldx + (unsigned)gcc[i]) * 4u : OOB;
         // next step: 32 pixels on
         int x2 = gx[i] + 32, y2 = gy[i];
         bool c = x2 >= p.Wo; x2 -= c ? p.Wo : 0; y2 += c;
         c = x2 >= p.Wo; x2 -= c ? p.Wo : 0; y2 += c;
         c = y2 >= p.Ho; y2 -= c ? p.Ho : 0;
         gx[i] = x2; gy[i] = y2; gb[i] += c;
+        raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, offx, 0, 0));
       }
-      const f32x4 vd = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, isx ? OOB : offd, 0, 0));
-      const f32x4 vx = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, isx ? offx : OOB, 0, 0));
-      raw[i] = isx ? vx : vd;
     }
   };
   auto load = [&](long long s) {
@@ -671,39 +670,35 @@ __global__ __launch_bounds__(512) void p1t_kernel(const P1TArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-      const int q = i * 512 + tid;
-      const int px = q / QT, c4 = q - px * QT;
+      int px, c4;
+      bool live;
+      const bool isx = item(i, px, c4, live);
       const long long pix = s * 32 + px;
-      const bool isx = c4 >= QM;
       unsigned off = OOB;
-      if (q < 32 * QT && pix < p.P) {
+      if (live && pix < p.P) {
         if (!isx) {
           if (mo + c4 * 4 < p.M) off = (unsigned)(pix * p.lddy + mo + c4 * 4) * 4u;
-        } else if (GEO) {
-          if (itap[i] >= 0) {
-            const int hw = p.Ho * p.Wo, b = fdiv((int)pix, hw, r_hw), rem = (int)pix - b * hw;
-            const int yo = fdiv(rem, p.Wo, r_wo), xo = rem - yo * p.Wo;
-            const int yi = yo * p.stride - p.pad + (itap[i] & 255) * p.dil, xi = xo * p.stride - p.pad + ((itap[i] >> 8) & 255) * p.dil;
-            if ((unsigned)yi < (unsigned)p.Hi && (unsigned)xi < (unsigned)p.Wi)
-              off = (unsigned)(((long long)(b * p.Hi + yi) * p.Wi + xi) * p.ldx + (itap[i] >> 16)) * 4u;
-          }
-        } else if (no + (c4 - QM) * 4 < p.N) {
-          off = (unsigned)(pix * p.ldx + no + (c4 - QM) * 4) * 4u;
+        } else if (itap[i] >= 0) {
+          const int hw = p.Ho * p.Wo, b = fdiv((int)pix, hw, r_hw), rem = (int)pix - b * hw;
+          const int yo = fdiv(rem, p.Wo, r_wo), xo = rem - yo * p.Wo;
+          const int yi = yo * p.stride - p.pad + (itap[i] & 255) * p.dil, xi = xo * p.stride - p.pad + ((itap[i] >> 8) & 255) * p.dil;
+          if ((unsigned)yi < (unsigned)p.Hi && (unsigned)xi < (unsigned)p.Wi)
+            off = (unsigned)(((long long)(b * p.Hi + yi) * p.Wi + xi) * p.ldx + (itap[i] >> 16)) * 4u;
         }
       }
-      const f32x4 vd = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, isx ? OOB : off, 0, 0));
-      const f32x4 vx = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, isx ? off : OOB, 0, 0));
-      raw[i] = isx ? vx : vd;
+      raw[i] = isx ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0))
+                   : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, off, 0, 0));
     }
   };
   auto stash = [&](int buf) {
     char* base = smem + buf * 2 * PL;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-      const int q = i * 512 + tid;
-      if (q < 32 * QT) {
-        const int px = q / QT, c4 = q - px * QT;
-        const int e = c4 >= QM ? ex : edy;
+      int px, c4;
+      bool live;
+      const bool isx = item(i, px, c4, live);
+      if (live) {
+        const int e = isx ? ex : edy;
         const f32x4 v = raw[i];
         u16 h[4], l[4];
 #pragma unroll
