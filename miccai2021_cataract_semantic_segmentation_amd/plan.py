@@ -44,7 +44,7 @@ FIELDS = {
     "wide_1x1_min_rows": (60000, int, "ops:B3_1X1_MIN_ROWS", "1 x 1 layers with both extents >= 512 take the blocked-plane kernels (split pass + igemm_f16x2) from this many pixels; below: the pointwise route"),
     "wide_1x1_min_dim": (512, int, "ops:B3_1X1_MIN_DIM", "... and both extents >= this (their product >= 1024 x this)"),
     "p1_min_rows": (60000, int, "ops:P1_MIN_ROWS", "pointwise route: minimum output pixels"),
-    "p1_wgrad_min_dim": (256, int, "ops:P1_WGRAD_MIN_DIM", "pointwise route, backward-weight: minimum of (Cin, Cout)"),
+    "p1_wgrad_min_dim": (64, int, "ops:P1_WGRAD_MIN_DIM", "pointwise route, backward-weight: minimum of (Cin, Cout)"),
     "g1": (True, _bool, "ops:G1", "strided / non-square 3 x 3 layers as gather launches of csrc/pconv1.hip"),
     "g1_min_rows": (4096, int, "ops:G1_MIN_ROWS", "gather route: minimum output pixels"),
     "g1_dgrad_min_cin": (96, int, "ops:G1_DGRAD_MIN_CIN", "gather route, backward-data: minimum input channels"),
