@@ -117,6 +117,7 @@ struct P1Args {
   int accumulate;
   float* bn_part;                     // [tilesM][3][N] or null
   unsigned long long x_bytes, img_bytes;
+  unsigned long long y_bytes;         // gather launches with gathered OUTPUT rows: bytes of the whole output (0: unknown -> general epilogue)
   P1Geo geo;                          // (GEO launches)
 };
 
@@ -353,7 +354,8 @@ __global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
   // the matrix pipe idle (SQ counters: MFMA busy 27 - 39 % of the CU-busy cycles).  Here: one ldexp by -(e_x + e_w) (exact; the
   // two-step ldexp stays for exponent sums outside +-120), the bias added once, partial sums without selects, 128 unconditional stores.
   // The arithmetic of every output and of the BatchNorm partials is the general path's (same operations in the same order).
-  // FULL is a property of the LAUNCH (p1_launch: M a multiple of 256, N of the column tile, linear output rows), hence a
+  // FULL is a property of the LAUNCH (p1_launch: M a multiple of 256 when BatchNorm partials are asked for; any column count; linear or
+  // gathered output rows), hence a
   // template parameter: with both epilogues in one kernel the register allocator kept copies of the 128 accumulator registers for either
   // arm and spilled 300 - 500 registers per thread in the 256-column form.
   if constexpr (FULL) {
@@ -377,20 +379,56 @@ __global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
     if (p.bias != nullptr) {
 #pragma unroll
       for (int u = 0; u < NT; ++u) {
-        const float b = p.bias[n0 + 32 * u + l31];
+        const int col = n0 + 32 * u + l31;
+        const float b = col < p.N ? p.bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[u][r] += b;
       }
     }
     if (p.bn_part != nullptr)
       p1_full_tile_bn_partials<NT>((float*)smem, BN, l31, hh == 0, wave, acc, p.bn_part + (long long)tile_m * 3 * p.N, p.N, n0);
-    // stores through a buffer resource over this tile's 256 output rows: ONE per-lane offset register, the row of accumulator element r in the
-    // scalar offset, the column tile in the instruction's immediate (pointers per row cost 32 registers: the 256-column form spilled)
+    constexpr unsigned OOBS = 0xFFFFFFF0u;      // a store / load at this offset is past the buffer's range: dropped / zero (columns past N)
+    const bool accum = p.accumulate != 0;
+    if (GEO && !p.geo.linear_out) {
+      // gathered output rows (the parity classes of a strided backward-data pass): the byte offset of each accumulator row in a register,
+      // the column added per store; one buffer resource over the whole output (below 4 GB: p1_launch)
+      const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, (short)0, (int)(unsigned)p.y_bytes, 0x00020000);
+      unsigned cb[NT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) cb[u] = n0 + 32 * u + l31 < p.N ? (unsigned)(n0 + 32 * u + l31) * 4u : OOBS;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rw = m0 + wave * 32 + 4 * hh + (r & 3) + 8 * (r >> 2);
+        const int gb = rw / p.geo.HWg, rem = rw - gb * p.geo.HWg;
+        const int gi = rem / p.geo.Wg, gj = rem - gi * p.geo.Wg;
+        const unsigned ro = rw < p.M ? (unsigned)((gb * p.geo.Ho + gi * p.geo.so + p.geo.oy) * p.geo.Wo + gj * p.geo.so + p.geo.ox) * (unsigned)p.ldy * 4u : OOBS;
+        float v[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) v[u] = acc[u][r];
+        if (accum) {
+          float o[NT];
+#pragma unroll
+          for (int u = 0; u < NT; ++u) o[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsY, (cb[u] == OOBS || ro == OOBS) ? OOBS : ro + cb[u], 0, 0));
+#pragma unroll
+          for (int u = 0; u < NT; ++u) v[u] += o[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[u]), rsY, (cb[u] == OOBS || ro == OOBS) ? OOBS : ro + cb[u], 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
+    // linear output rows: stores through a buffer resource over this tile's 256 rows -- one per-lane offset register per column tile (out of
+    // range for columns past N), the row of accumulator element r in the scalar offset
+    // (rows past M -- a ragged last row tile of a launch without BatchNorm partials -- lie past the resource's range: dropped)
+    const unsigned rows_here = (unsigned)(p.M - m0 < 256 ? p.M - m0 : 256);
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)m0 * p.ldy + n0), (short)0,
-                                                                        (int)(256u * (unsigned)p.ldy * 4u), 0x00020000);
+                                                                        (int)(rows_here * (unsigned)p.ldy * 4u - (unsigned)n0 * 4u), 0x00020000);
     const int ld4 = p.ldy * 4;
     const int voff = (wave * 32 + 4 * hh) * ld4 + l31 * 4;
-    const bool accum = p.accumulate != 0;
+    int vo[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) vo[u] = n0 + 32 * u + l31 < p.N ? voff + 128 * u : (int)OOBS;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int soff = ((r & 3) + 8 * (r >> 2)) * ld4;
@@ -400,12 +438,12 @@ __global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
       if (accum) {                                            // (the previous contents of the row, read before its stores: (acc + bias) + old, as the general path)
         float o[NT];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) o[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsY, voff + 128 * u, soff, 0));
+        for (int u = 0; u < NT; ++u) o[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsY, vo[u], soff, 0));
 #pragma unroll
         for (int u = 0; u < NT; ++u) v[u] += o[u];
       }
 #pragma unroll
-      for (int u = 0; u < NT; ++u) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[u]), rsY, voff + 128 * u, soff, 0);
+      for (int u = 0; u < NT; ++u) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[u]), rsY, vo[u], soff, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     return;
@@ -470,7 +508,9 @@ template <int NT>
 void p1_launch(const P1Args& a, bool geo, hipStream_t st) {
   const int per = 8 * a.ntn;
   const int blocks = a.ntn > 1 ? (a.tilesM + 7) / 8 * per : a.tilesM;
-  const bool full = a.M % 256 == 0 && a.N % (32 * NT) == 0 && (!geo || a.geo.linear_out);
+  // (ragged column counts ride on out-of-range store offsets; gathered output rows need 32-bit offsets over the whole output)
+  const bool gathered = geo && !a.geo.linear_out;
+  const bool full = gathered ? (a.y_bytes > 0 && a.y_bytes < 0xFFFFFFF0ull) : (a.M % 256 == 0 || a.bn_part == nullptr);
   if (geo) {
     if (full) hipLaunchKernelGGL((p1_kernel<NT, true, true>), dim3(blocks), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((p1_kernel<NT, true, false>), dim3(blocks), dim3(512), 0, st, a);
@@ -1049,6 +1089,7 @@ extern "C" int catseg_gconv_bwd_data(const catseg_conv_desc* d, const float* dy,
       a.y = dx; a.ldy = d->ldx; a.bias = nullptr; a.M = d->B * Hg * Wg; a.N = d->Cin; a.K = nky * nkx * d->Cout;
       a.tilesM = (a.M + 255) / 256; a.ntn = p1_ntn(a.N); a.accumulate = accumulate;
       a.x_bytes = (unsigned long long)rows_dy * d->ldy * 4ull; a.img_bytes = catseg_pconv1_wimg_bytes(a.N, a.K);
+      a.y_bytes = (unsigned long long)d->B * d->H * d->W * (unsigned long long)d->ldx * 4ull;
       P1Geo& g = a.geo;
       g.Wg = Wg; g.HWg = Hg * Wg; g.si = 1; g.y0 = y0; g.x0 = x0;
       g.ya = s == 1 ? -d->dil : -1; g.xa = g.ya; g.nb = nkx;

@@ -147,7 +147,10 @@ def test_conv_wrappers_take_the_pointwise_route_and_match_the_fp32_kernels():
 CONVS = [  # (B, H, W, Cin, Cout, k, stride, pad, dil)
     (2, 34, 50, 48, 96, 3, 2, 1, 1), (2, 33, 47, 48, 48, 3, 2, 1, 1), (1, 40, 64, 256, 48, 3, 1, 1, 1), (2, 36, 36, 64, 64, 3, 2, 1, 1),
     (2, 20, 30, 96, 192, 3, 2, 1, 1), (1, 24, 24, 192, 384, 3, 2, 1, 1), (1, 30, 30, 64, 128, 3, 1, 2, 2), (1, 26, 38, 96, 96, 3, 2, 1, 1),
-    (1, 21, 35, 256, 96, 3, 2, 1, 1), (2, 16, 16, 48, 384, 3, 2, 1, 1)]
+    (1, 21, 35, 256, 96, 3, 2, 1, 1), (2, 16, 16, 48, 384, 3, 2, 1, 1),
+    # row counts that are multiples of 256 in forward AND in every backward-data parity class: the full-tile epilogue with ragged column
+    # counts (48 of a 64-wide tile), gathered output rows and accumulation
+    (2, 32, 64, 48, 96, 3, 2, 1, 1), (1, 32, 32, 48, 48, 3, 2, 1, 1), (1, 32, 32, 64, 128, 3, 1, 2, 2), (4, 32, 32, 96, 192, 3, 2, 1, 1)]
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad,dil", CONVS)
