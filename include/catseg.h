@@ -546,7 +546,9 @@ int catseg_adam_step_dev(float* p, const float* g, float* m, float* v, long long
 /* ---- pointwise (1 x 1, stride 1) convolutions in split precision with the split in registers (csrc/pconv1.hip) ----
    Replaces the ATen 1 x 1 conv2d calls (forward, and their autograd backward) of the stage-1 bottlenecks (models/HRNetv2.py:68-106), of the
    object-attention block (models/OCR.py:186-235: f_pixel / f_up) and of the HRNet fuse layers (models/HRNetv2.py:237-261) -- layers too
-   small for the blocked-plane kernels above, HBM-bound GEMMs with K = 64 ... 512.  The activation operand is the fp32 NHWC tensor itself
+   small for the blocked-plane kernels above, HBM-bound GEMMs with K = 64 ... 512 -- and, since round 6, of the 1 x 1 layers of torchvision's
+   ResNet bottlenecks up to 2048 output columns (models/OCR.py:58-61: 64 <-> 256, 128 <-> 512, 256 <-> 1024 at stride 8; catseg_pconv1_supported:
+   32 <= N <= 2048, 32 <= K <= 8160, K % 8 == 0).  The activation operand is the fp32 NHWC tensor itself
    plus the amax record its producer left (CATSEG_AMAX_RECORD_BYTES); the weight operand is a pre-split image.
    catseg_pconv1_prep_batch: entries = DEVICE array of n 64-byte records {int64 weight offset (floats, relative to flat), int64 image offset
    (bytes, relative to wimg_base), int32 O, I, kh, kw, transposed, ky0, kys, nky, kx0, kxs, nkx, pad} (a 1 x 1 layer: kh = kw = nky = nkx =
