@@ -532,7 +532,10 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void dconv3_pl_kernel(const PlArg
         for (int ct = 0; ct < G::CB; ++ct)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float K = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[ct][0][r]), 0x150, 0xF, 0xF, true));
+            // (through a scalar copy: __builtin_bit_cast applied to the vector ELEMENT acc[ct][0][r] itself reads element 0 for every r -- hipcc 7.2;
+            //  until round 6 the shift of channels r = 1 .. 3 of a quad was therefore channel r = 0's first pixel: a valid shift, but not this channel's)
+            const float a0 = acc[ct][0][r];
+            const float K = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0x150, 0xF, 0xF, true));
             float d1 = 0.f, d2 = 0.f;
 #pragma unroll
             for (int pt = 0; pt < G::PB; ++pt) {
