@@ -189,7 +189,7 @@ __device__ __forceinline__ void p1_full_tile_bn_partials(float* lds, int tile_co
 constexpr int p1_waitcnt(int vm) { return (vm & 15) | (7 << 4) | (15 << 8) | ((vm >> 4) << 14); }     // vmcnt only (expcnt / lgkmcnt: no wait)
 
 template <int NT, bool GEO, bool FULL>
-__global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
+__device__ __forceinline__ void p1_body(const P1Args& p) {
   constexpr int BN = 32 * NT;
   constexpr int GB = 4 * BN * 32;                   // bytes of one k-group of B: k-tile (2) x plane (2) x BN rows x 32 bytes
   constexpr int PIECES = GB / 16;                   // = 256 NT: a multiple of 64
@@ -501,6 +501,45 @@ __global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
       const int rw = rbase + (r & 3) + 8 * (r >> 2);
       if (rw < p.M && col < p.N) p.y[orow[r] + col] = (acc[u][r] + bv[u]) + add[r];
     }
+  }
+}
+
+template <int NT, bool GEO, bool FULL>
+__global__ __launch_bounds__(512) void p1_kernel(const P1Args p) {
+  p1_body<NT, GEO, FULL>(p);
+}
+// the parity classes of a strided backward-data pass (catseg_gconv_bwd_data) as ONE launch: blockIdx.y = class.  A class of a 3 x 3 / 2 layer at
+// 8 x 34 x 60 is 64 blocks on 256 CUs: four launches of a quarter of the chip each, one behind the other (round 6)
+struct P1Multi { P1Args a[4]; };
+template <int NT, bool FULL>
+__global__ __launch_bounds__(512) void p1_multi_kernel(const P1Multi q) {
+  p1_body<NT, true, FULL>(q.a[blockIdx.y]);
+}
+
+template <int NT>
+void p1_launch_multi(const P1Multi& q, int n, hipStream_t st) {
+  int blocks = 0;
+  bool full = true;
+  for (int i = 0; i < n; ++i) {
+    const P1Args& a = q.a[i];
+    const int b = a.ntn > 1 ? (a.tilesM + 7) / 8 * 8 * a.ntn : a.tilesM;
+    blocks = b > blocks ? b : blocks;
+    const bool gathered = !a.geo.linear_out;
+    full = full && (gathered ? (a.y_bytes > 0 && a.y_bytes < 0xFFFFFFF0ull) : (a.M % 256 == 0 || a.bn_part == nullptr));
+  }
+  if (full) hipLaunchKernelGGL((p1_multi_kernel<NT, true>), dim3(blocks, n), dim3(512), 0, st, q);
+  else hipLaunchKernelGGL((p1_multi_kernel<NT, false>), dim3(blocks, n), dim3(512), 0, st, q);
+}
+void p1_dispatch_multi(const P1Multi& q, int n, hipStream_t st) {
+  switch (p1_bn(q.a[0].N) / 32) {
+    case 1: p1_launch_multi<1>(q, n, st); break;
+    case 2: p1_launch_multi<2>(q, n, st); break;
+    case 3: p1_launch_multi<3>(q, n, st); break;
+    case 4: p1_launch_multi<4>(q, n, st); break;
+    case 5: p1_launch_multi<5>(q, n, st); break;
+    case 6: p1_launch_multi<6>(q, n, st); break;
+    case 7: p1_launch_multi<7>(q, n, st); break;
+    default: p1_launch_multi<8>(q, n, st); break;
   }
 }
 
@@ -1075,6 +1114,8 @@ extern "C" int catseg_gconv_bwd_data(const catseg_conv_desc* d, const float* dy,
   CS_REQUIRE((unsigned long long)rows_dy * d->ldy * 4ull < 0xFFFFFFF0ull && (long long)d->B * d->H * d->W < (1ll << 31) - 256, "gconv bwd_data: operand beyond 4 GB");
   const int s = d->stride;
   const size_t cb = catseg_gconv_class_bytes(d);
+  P1Multi multi;
+  int nmulti = 0;
   for (int py = 0; py < s; ++py)
     for (int px = 0; px < s; ++px) {
       int ky0, kys, nky, y0, kx0, kxs, nkx, x0;
@@ -1095,8 +1136,11 @@ extern "C" int catseg_gconv_bwd_data(const catseg_conv_desc* d, const float* dy,
       g.ya = s == 1 ? -d->dil : -1; g.xa = g.ya; g.nb = nkx;
       g.Hi = d->Ho; g.Wi = d->Wo; g.C = d->Cout; g.mC = p1_magic(d->Cout); g.mnb = p1_magic(nkx);
       g.so = s; g.oy = py; g.ox = px; g.Ho = d->H; g.Wo = d->W; g.linear_out = (s == 1) ? 1 : 0;
-      p1_dispatch(a, true, (hipStream_t)stream);
+      if (s == 2) multi.a[nmulti++] = a;      // (the four classes of a stride-2 layer: one launch below; every class has the same column count)
+      else p1_dispatch(a, true, (hipStream_t)stream);
     }
+  if (nmulti == 1) p1_dispatch(multi.a[0], true, (hipStream_t)stream);
+  else if (nmulti > 1) p1_dispatch_multi(multi, nmulti, (hipStream_t)stream);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
