@@ -47,7 +47,7 @@ FIELDS = {
     "p1_wgrad_min_dim": (64, int, "ops:P1_WGRAD_MIN_DIM", "pointwise route, backward-weight: minimum of (Cin, Cout)"),
     "g1": (True, _bool, "ops:G1", "strided / non-square 3 x 3 layers as gather launches of csrc/pconv1.hip"),
     "g1_min_rows": (4096, int, "ops:G1_MIN_ROWS", "gather route: minimum output pixels"),
-    "g1_dgrad_min_cin": (96, int, "ops:G1_DGRAD_MIN_CIN", "gather route, backward-data: minimum input channels"),
+    "g1_dgrad_min_cin": (48, int, "ops:G1_DGRAD_MIN_CIN", "gather route, backward-data: minimum input channels"),
     "g1_min_cin": (0, int, "ops:G1_MIN_CIN", "gather route: minimum input channels"),
     "g1_ops": (("fwd", "dgrad", "wgrad"), _csv_str, "ops:G1_OPS", "directions of the gather route"),
     "stem3": (True, _bool, "ops:STEM3", "HRNet stem conv1 on the direct fp64-accumulating kernels (csrc/stem3.hip)"),
