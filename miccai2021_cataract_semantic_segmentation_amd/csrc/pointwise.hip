@@ -313,6 +313,51 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ldx, float*
   }
 }
 
+// MODE 1 with the two source rows of an output row staged in LDS (round 6): every output element gathers four source values, 16 scalar loads per
+// 16-byte store -- at the K-class logits (C = 25, 8 x 136 x 240 -> 8 x 544 x 960: 418 MB written) the texture path, not HBM, set the pace
+// (228 us = 1.8 TB/s).  The rows are W x ldx floats each, contiguous and 16-byte aligned; the arithmetic is bilinear_fwd_kernel's expression on
+// the same operands: bit-identical output.  Requires 2 W ldx floats of LDS (<= 64 KB: two blocks per CU), ldx % 4 == 0, x 16-byte aligned.
+__global__ __launch_bounds__(256) void bilinear_fwd_lds_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int B, int H, int W, int C,
+                                                               int Ho, int Wo, int align, float sh, float sw, int acc) {
+  extern __shared__ __attribute__((aligned(16))) float bl_rows[];
+  const int b = blockIdx.x / Ho, oy = blockIdx.x - b * Ho;
+  int y0, y1;
+  float ly0, ly1;
+  lerp_setup(sh, oy, align, H, y0, y1, ly0, ly1);
+  const int rowf = W * ldx;
+  const f32x4* g0 = (const f32x4*)(x + ((long long)b * H + y0) * rowf);
+  const f32x4* g1 = (const f32x4*)(x + ((long long)b * H + y1) * rowf);
+  f32x4* s0 = (f32x4*)bl_rows;
+  f32x4* s1 = (f32x4*)(bl_rows + rowf);
+  for (int i = threadIdx.x; i < (rowf >> 2); i += 256) {
+    s0[i] = g0[i];
+    s1[i] = g1[i];
+  }
+  __syncthreads();
+  const float* r0 = bl_rows;
+  const float* r1 = bl_rows + rowf;
+  float* o = y + ((long long)b * Ho + oy) * Wo * C;
+  const int n4 = (Wo * C) >> 2;
+  for (int u = threadIdx.x; u < n4; u += 256) {
+    int ox = (u * 4) / C, c = u * 4 - ox * C;
+    int x0, x1;
+    float lx0, lx1;
+    lerp_setup(sw, ox, align, W, x0, x1, lx0, lx1);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = ly0 * (lx0 * r0[x0 * ldx + c] + lx1 * r0[x1 * ldx + c]) + ly1 * (lx0 * r1[x0 * ldx + c] + lx1 * r1[x1 * ldx + c]);
+      if (++c == C) {
+        c = 0;
+        ++ox;
+        if (e < 3) lerp_setup(sw, ox < Wo ? ox : Wo - 1, align, W, x0, x1, lx0, lx1);
+      }
+    }
+    f32x4* d = (f32x4*)(o + u * 4);
+    *d = acc ? (*d + v) : v;
+  }
+}
+
 // backward pass 1: tmp[b, iy, ox, c] = sum_{oy} wy(oy -> iy) * dy[b, oy, ox, c]
 // The weights of the candidate output rows depend only on (iy, oy): computed once per block.  MODE as above (1: lddy == C).
 template <int MODE>
@@ -924,8 +969,13 @@ extern "C" int catseg_bilinear_fwd(const float* x, int ldx, float* y, int ldy, i
   hipStream_t st = (hipStream_t)stream;
   if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && cs_aligned16(x) && cs_aligned16(y))
     hipLaunchKernelGGL(bilinear_fwd_kernel<2>, dim3(B * Ho), dim3(256), 0, st, x, ldx, y, ldy, B, H, W, C, Ho, Wo, align_corners, sh, sw, accumulate);
-  else if (ldy == C && (Wo * C) % 4 == 0 && cs_aligned16(y))
-    hipLaunchKernelGGL(bilinear_fwd_kernel<1>, dim3(B * Ho), dim3(256), 0, st, x, ldx, y, ldy, B, H, W, C, Ho, Wo, align_corners, sh, sw, accumulate);
+  else if (ldy == C && (Wo * C) % 4 == 0 && cs_aligned16(y)) {
+    const size_t lds = (size_t)2 * W * ldx * 4;
+    if (ldx % 4 == 0 && cs_aligned16(x) && lds <= 64 * 1024 && Ho >= 2 * H)      // (an upsample: every source row serves several output rows)
+      hipLaunchKernelGGL(bilinear_fwd_lds_kernel, dim3(B * Ho), dim3(256), lds, st, x, ldx, y, B, H, W, C, Ho, Wo, align_corners, sh, sw, accumulate);
+    else
+      hipLaunchKernelGGL(bilinear_fwd_kernel<1>, dim3(B * Ho), dim3(256), 0, st, x, ldx, y, ldy, B, H, W, C, Ho, Wo, align_corners, sh, sw, accumulate);
+  }
   else
     hipLaunchKernelGGL(bilinear_fwd_kernel<0>, dim3(B * Ho), dim3(256), 0, st, x, ldx, y, ldy, B, H, W, C, Ho, Wo, align_corners, sh, sw, accumulate);
   CS_LAUNCH_CHECK();

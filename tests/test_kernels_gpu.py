@@ -274,6 +274,30 @@ def test_bilinear(ops, align, sizes):
     assert float(full[..., C:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("sizes", [((17, 30), (68, 120)), ((34, 60), (136, 240)), ((6, 10), (48, 80))])
+def test_bilinear_forward_with_staged_rows_is_bit_identical(ops, align, sizes):
+    """bilinear_fwd_lds_kernel (contiguous K-class output rows, source rows with a 16-byte-granular stride staged in LDS: the logits upsample of
+    models/OCR.py:128-131) against bilinear_fwd_kernel<1> on the same values from a densely packed source (row stride 25: not 16-byte
+    granular, so the launcher keeps the gather kernel): the same expression on the same operands -- bit for bit, also accumulating."""
+    (H, W), (Ho, Wo) = sizes
+    g = torch.Generator().manual_seed(H + W + Ho)
+    C = 25
+    x = torch.randn(2, H, W, C, generator=g).cuda()
+    xp = ops.new_act(2, H, W, C, torch.device("cuda"), ld=32, zero=True)
+    xp.copy_(x)
+    ya = ops.bilinear_fwd(xp, Ho, Wo, align)            # padded rows: the LDS kernel
+    yb = ops.bilinear_fwd(x.contiguous(), Ho, Wo, align)   # dense rows: the gather kernel
+    assert ya.shape == yb.shape and torch.equal(ya, yb)
+    base = torch.randn(ya.shape, generator=g).cuda()
+    oa, ob = base.clone(), base.clone()
+    ops.bilinear_fwd(xp, Ho, Wo, align, out=oa, accumulate=True)
+    ops.bilinear_fwd(x.contiguous(), Ho, Wo, align, out=ob, accumulate=True)
+    assert torch.equal(oa, ob)
+    ref = F.interpolate(x.permute(0, 3, 1, 2).cpu(), size=(Ho, Wo), mode="bilinear", align_corners=align)
+    close(nchw(ya), ref, atol=1e-5)
+
+
 @pytest.mark.parametrize("case", [
     # (B, H, W, C, Ho, Wo, ld of dy, align, zero_to, accumulate): contiguous logits rows (mode 1), feature maps / channel slices of a wider
     # buffer (mode 2, several channel chunks, several column segments), the scalar fallback (C % 4 != 0 with a padded row stride)
