@@ -317,6 +317,23 @@ int catseg_bn_backward_h2(const float* dz, int lddz, const float* z, int ldz, co
                           float* dbias, void* g_record, void* y_record, void* dy_record, void* workspace, size_t workspace_bytes,
                           catseg_stream_t stream);
 
+/* The K-class classifier of a segmentation head fused with the BatchNorm + ReLU in front of it (csrc/headfuse.h; replaces nn.BatchNorm2d + ReLU +
+ * the 1 x 1 nn.Conv2d of models/OCR.py:72-74 (interm_prediction_head[1..4]) and :97 with conv_bn_dropout[1..2], and their autograd): the
+ * normalised activation z and its gradient exist in registers only.
+ *   catseg_head_fwd       logits[rows][ldl] = relu((y - mean) * scale + beta) Wh^T + bh, columns [K, zero_to) zeroed; Wh [K][C], K <= 32,
+ *                         C % 32 == 0, C <= 512; mean / scale as catseg_bn_finalize left them
+ *   catseg_head_backward  from dl [rows][lddl] (lddl >= 32): dy as the blocked planes + scale record of catseg_bn_backward_h2 (same three zeroed
+ *                         amax records), dgamma / dbeta of the BatchNorm, dbias (may be null) = column sums of dy, dwh [K][C] and dbh [K]
+ *                         (may be null) of the classifier -- all WRITTEN; C % 64 == 0; workspace = catseg_head_backward_workspace bytes;
+ *                         every reduction in a fixed order (deterministic) */
+int catseg_head_fwd(const float* y, int ldy, const float* mean, const float* scale, const float* beta, const float* wh, const float* bh, int K,
+                    long long rows, int C, float* logits, int ldl, int zero_to, catseg_stream_t stream);
+size_t catseg_head_backward_workspace(long long rows, int C);
+int catseg_head_backward(const float* dl, int lddl, const float* y, int ldy, const float* stats, const float* gamma, const float* beta,
+                         const float* wh, int K, long long rows, int C, void* dy_planes, void* dy_scale, float* dgamma, float* dbeta, float* dbias,
+                         float* dwh, float* dbh, void* g_record, void* y_record, void* dy_record, void* workspace, size_t workspace_bytes,
+                         catseg_stream_t stream);
+
 /* catseg_dwgrad3_f16x2 on producer-written planes of BOTH operands (csrc/dwgrad3_pl.hip): dw[o][ky][kx][c] = sum_px dy[px][o] x[px + tap][c]
  * for the trunk widths 48 / 96 / 192 / 384 (autograd of F.conv2d, models/HRNetv2.py:22-65); workspace = catseg_dwgrad3_pl_workspace bytes
  * (slabs of partial sums, added in a fixed order: deterministic) */

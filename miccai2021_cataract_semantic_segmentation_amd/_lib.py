@@ -68,6 +68,9 @@ _SIGS = {
     "catseg_bn_backward_pre_planes": (I, [P, I, P, I, P, P, P, I, L, I, P, P, P, P, P, P, P, SZ, P]),
     "catseg_bn_backward_h2_workspace": (SZ, [L, I]),
     "catseg_bn_backward_h2": (I, [P, I, P, I, P, I, P, P, P, L, I, I, P, P, P, P, P, P, P, P, P, SZ, P]),
+    "catseg_head_fwd": (I, [P, I, P, P, P, P, P, I, L, I, P, I, I, P]),
+    "catseg_head_backward_workspace": (SZ, [L, I]),
+    "catseg_head_backward": (I, [P, I, P, I, P, P, P, P, I, L, I, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
     "catseg_maxpool2x2_fwd": (I, [P, I, P, I, P, I, I, I, I, P]),
     "catseg_maxpool2x2_bwd": (I, [P, I, P, P, I, I, I, I, I, P]),
     "catseg_bias_rows": (I, [P, P, I, L, I, P]),

@@ -1,0 +1,389 @@
+// The K-class classifier of a segmentation head fused with the BatchNorm + ReLU in front of it (round 6).
+//
+//   y [rows][C]  --BatchNorm (batch statistics) + ReLU-->  z  --1 x 1 convolution, bias-->  logits [rows][K],   K <= 32, C <= 512
+//
+// (models/OCR.py:72-74, 97 of the reference: interm_prediction_head[1..4] and conv_bn_dropout[1..2] + conv_out.)  z has ONE consumer, the
+// classifier.  The separate passes moved it five times through HBM per training step (535 MB at 8 x 136 x 240 x 512): written by the
+// BatchNorm apply, read by the classifier, read again by its backward-weight, and its gradient written by the classifier's backward-data and
+// read by both passes of the BatchNorm backward.  Here z and dz exist in registers only:
+//   hf_fwd_kernel        logits = relu(bn(y)) Wh^T + bh                                     reads y once
+//   hf_bwd_kernel<false> dz = dlogits Wh recomputed per tile; the BatchNorm's sums of (dz masked) and (dz masked) xhat, dWh = dlogits^T z as
+//                        per-block slabs, dbh, max|g|, max|y|                                reads y once (+ the 128-byte dlogits rows)
+//   hf_bwd_kernel<true>  dz recomputed again; dy = gamma invstd (g - mean(g) - xhat mean(g xhat)) written ONLY as the blocked fp16 x 2
+//                        planes of the head layers' kernels (what bn_bwd_apply_h2_kernel writes)  reads y once, writes the planes
+// All products are exact fp32 MFMA chains (v_mfma_f32_32x32x2_f32): 2 x 512 x 32 flops per pixel and pass = 55 us of matrix time per pass at
+// 8 x 136 x 240 pixels, below the 110 us the pass needs for its 535 MB.  Operand layouts (lane = 32 h + l31):
+//   A[i = l31][k = h],  B[k = h][j = l31],  D[i = (r & 3) + 8 (r >> 2) + 4 h][j = l31] in accumulator register r
+// and the reduction index may be permuted freely as long as A and B agree -- so a lane's 16 accumulator values (16 rows of one channel) ARE
+// its B operands of the backward-weight product over those rows, no transposition.
+// Included by norm.hip inside its anonymous namespace.
+#ifndef CATSEG_HEADFUSE_H
+#define CATSEG_HEADFUSE_H
+#include <type_traits>
+
+typedef float hf_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned hf_u32x4 __attribute__((ext_vector_type(4)));
+#define HF_ROW(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))
+
+// ---- forward.  Block = 4 waves; a wave owns 32 pixel rows at a time and walks their C channels in chunks of 32 (lane (l31, h): row l31,
+// channels c0 + 16 h .. + 15 = 64 contiguous bytes, three chunks of loads in flight under a chunk's 16 MFMAs).  Wh lives in LDS as
+// [channel][33] (lane l31 reads class l31 of 16 channels: conflict-free), the BatchNorm constants as [3][C].
+__global__ __launch_bounds__(256, 2) void hf_fwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ mean,
+                                                        const float* __restrict__ scale, const float* __restrict__ beta,
+                                                        const float* __restrict__ wh, const float* __restrict__ bh, int K, long long rows, int C,
+                                                        float* __restrict__ out, int ldo, int zero_to) {
+  extern __shared__ __attribute__((aligned(16))) float hf_sm[];
+  float* Wl = hf_sm;             // [C][33]
+  float* cst = hf_sm + C * 33;   // mean[C], scale[C], beta[C]   (C % 32 == 0: 16-byte aligned)
+  for (int k = 0; k < 32; ++k)
+    for (int c = threadIdx.x; c < C; c += 256) Wl[c * 33 + k] = k < K ? wh[(long long)k * C + c] : 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    cst[c] = mean[c];
+    cst[C + c] = scale[c];
+    cst[2 * C + c] = beta[c];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const long long ngroups = (rows + 31) >> 5;
+  const float bias = (bh != nullptr && l31 < K) ? bh[l31] : 0.f;
+  for (long long g = (long long)blockIdx.x * 4 + wave; g < ngroups; g += (long long)gridDim.x * 4) {
+    const long long row0 = g << 5;
+    long long row = row0 + l31;
+    if (row >= rows) row = rows - 1;   // (a clamped row's products land in accumulator rows that are not stored)
+    const float* yp = y + row * ldy + 16 * h;
+    hf_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // ring of four chunk buffers: the loads of chunk c + 3 are issued in front of the MFMAs of chunk c (16 MFMAs = 0.4 us: one chunk of
+    // distance did not cover an HBM round trip)
+    f32x4 ring[4][4];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (32 * u < C) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ring[u][q] = ld4(yp + 32 * u + 4 * q);
+      }
+    for (int c0 = 0; c0 < C; c0 += 128) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cc = c0 + 32 * u;
+        if (cc < C) {
+          if (cc + 96 < C) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ring[(u + 3) & 3][q] = ld4(yp + cc + 96 + 4 * q);
+          }
+          const float* cm = cst + cc + 16 * h;
+          const float* wl = Wl + (cc + 16 * h) * 33 + l31;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 m4 = *(const f32x4*)(cm + 4 * q), s4 = *(const f32x4*)(cm + C + 4 * q), b4 = *(const f32x4*)(cm + 2 * C + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float z = fmaxf(__builtin_fmaf(ring[u][q][e] - m4[e], s4[e], b4[e]), 0.f);   // = bn_affine + ReLU
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z, wl[(4 * q + e) * 33], acc, 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long ro = row0 + HF_ROW(r, h);
+      const float v = acc[r];
+      if (ro < rows) {
+        if (l31 < K) out[ro * ldo + l31] = v + bias;
+        else if (l31 < zero_to) out[ro * ldo + l31] = 0.f;
+      }
+    }
+  }
+}
+
+// ---- backward.  Block = NW waves; a wave owns NT 32-channel tiles (block (x, y): channels from 32 NT NW y) whose Wh fragments and BatchNorm
+// constants stay in registers, the block walks 32-row chunks blockIdx.x, + gridDim.x, ...  NT = 1, NW = 4: two blocks per CU, the grid sized to be
+// resident at once; the y rows of chunk i + 1 load into a second register set from the top of chunk i (a whole chunk of work covers the round
+// trip: with the loads half a chunk ahead the passes ran 288 / 251 us at 8 x 136 x 240 x 512, each phase's latency exposed).
+struct HfBwdArgs {
+  const float* dl; int lddl;        // gradient of the logits [rows][lddl], lddl >= 32
+  const float* y; int ldy;
+  const float* stats;               // mean[C], invstd[C]
+  const float* gamma; const float* beta;
+  const float* wh; int K;           // [K][C]
+  long long rows; int C;
+  // first pass
+  float* part;                      // [gridDim.x][2][C]: sum g, sum g xhat (bn_bwd_finalize_kernel's layout)
+  float* dws;                       // [gridDim.x][32][C]: slabs of dWh
+  float* dbs;                       // [gridDim.x][32]: slabs of dbh
+  unsigned* g_rec; unsigned* y_rec; // amax records: max|g|, max|y|
+  // second pass
+  const float* coef;                // mean(g)[C], mean(g xhat)[C]
+  unsigned char* planes; long long plane_bytes;
+  const unsigned* dy_rec; unsigned* scale;
+  float* colpart;                   // [gridDim.x][C]: column sums of dy (gradient of a bias in front of the BatchNorm), or null
+};
+
+template <bool APPLY, int NT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void hf_bwd_kernel(const HfBwdArgs p) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int cw = ((int)blockIdx.y * NW + wave) * 32 * NT;
+  const bool wlive = cw < p.C;
+  const int C = p.C, K = p.K, ldy = p.ldy;
+  const long long rows = p.rows;
+  // the chunk's logits gradient [32 rows][32 classes] (rows past the end and classes past K zeroed), double-buffered: every wave reads it in
+  // two layouts (rows on l31 for the dz product, classes on l31 for the dWh product); row stride 36 floats
+  __shared__ __attribute__((aligned(16))) float dlS[2][32 * 36];
+  // (second pass) a tile of 32 rows x 32 channels leaves through its wave's LDS region as four 1 KB pieces (plane, 16-channel chunk), each
+  // contiguous in the blocked planes [2][C / 16][rows][16].  Piece stride 1056 bytes: (plane, chunk, h) map onto eight distinct groups of 8 banks.
+  __shared__ __attribute__((aligned(16))) unsigned char hf_stage[APPLY ? NW : 1][APPLY ? 4 * 1056 : 16];
+  unsigned gm = 0, ym = 0;
+  float mean_[NT], inv_[NT], sc_[NT], be_[NT], c0_[NT], c1_[NT];
+  float W[NT][16];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ch = (wlive ? cw : 0) + 32 * t + l31;
+    mean_[t] = p.stats[ch];
+    inv_[t] = p.stats[C + ch];
+    sc_[t] = p.gamma[ch] * inv_[t];      // scale exactly as bn_finalize_kernel stored it
+    be_[t] = p.beta[ch];
+    c0_[t] = APPLY ? p.coef[ch] : 0.f;
+    c1_[t] = APPLY ? p.coef[C + ch] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) W[t][j] = (16 * h + j < K) ? p.wh[(long long)(16 * h + j) * C + ch] : 0.f;
+  }
+  float sg[NT], sgx[NT], csum[NT], dbl = 0.f;
+  hf_f32x16 accW[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) sg[t] = sgx[t] = csum[t] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accW[t][r] = 0.f;
+  float sc2 = 1.f;
+  if constexpr (APPLY) sc2 = __builtin_ldexpf(1.f, cs_plane_exponent(p.dy_rec[CS_REC_BOUND]));
+  const long long nchunks = (rows + 31) >> 5;
+  // staging of a chunk's dl: threads 0 .. 255 hold 16 bytes each (row = tid >> 3, classes 4 (tid & 7) ..)
+  const int srow = threadIdx.x >> 3, scls = (threadIdx.x & 7) * 4;
+  auto fetch_dl = [&](long long ck) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const long long r = (ck << 5) + srow;
+    if (threadIdx.x < 256 && ck < nchunks && r < rows) {
+      v = ld4(p.dl + r * p.lddl + scls);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (scls + e < K) ? v[e] : 0.f;
+    }
+    return v;
+  };
+  // this lane's 16 rows (accumulator layout) of channel tile t of a chunk: four wave-uniform bases + four per-lane offsets computed once (the
+  // last, ragged chunk clamps its rows to the last one: they are masked where they are used)
+  float Ya[NT][16], Yb[NT][16];      // two register sets: the loads of chunk i + 1 are issued at the top of chunk i
+  int yoff[4];      // rows (r & 3) + 4 h; the 8 (r >> 2) rows ride in the uniform base
+#pragma unroll
+  for (int r = 0; r < 4; ++r) yoff[r] = (r + 4 * h) * ldy + l31;
+  const int cbase = wlive ? cw : 0;
+  auto load_y = [&](float (&Y)[NT][16], int t, long long ck) {
+    const long long row0 = ck << 5;
+    const float* yb = p.y + row0 * ldy + cbase + 32 * t;
+    if (row0 + 32 <= rows) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[t][r] = (yb + (r >> 2) * 8 * ldy)[yoff[r & 3]];
+    } else {
+      const int last = (int)(rows - 1 - row0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[t][r] = yb[min(HF_ROW(r, h), last) * ldy + l31];
+    }
+  };
+  // per channel: dy = sc g - (k0 + (y - mean) k1) with k0 = sc mean(g), k1 = sc invstd mean(g xhat)  (two FMAs per element)
+  float k0_[NT], k1_[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    k0_[t] = sc_[t] * c0_[t];
+    k1_[t] = sc_[t] * inv_[t] * c1_[t];
+  }
+  float gmf = 0.f, ymf = 0.f;
+  const unsigned psel = (l31 & 1) ? 0x03020706u : 0x05040100u;      // v_perm selectors of the plane pairing below
+  unsigned char* const st = hf_stage[APPLY ? wave : 0];
+  unsigned char* const wp = st + (2 * (l31 & 1) + (l31 >> 4)) * 1056 + ((l31 & 15) >> 1) * 4;
+  typedef _Float16 hf_h2 __attribute__((ext_vector_type(2)));
+
+  long long ck = blockIdx.x;
+  if (ck < nchunks) {
+    const f32x4 v = fetch_dl(ck);
+    if (threadIdx.x < 256) *(f32x4*)(&dlS[0][srow * 36 + scls]) = v;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) load_y(Ya, t, ck);
+  }
+  __syncthreads();
+  auto iteration = [&](float (&Y)[NT][16], float (&Yn)[NT][16], const long long ck, const int buf) {
+    const long long row0 = ck << 5;
+    const bool full = row0 + 32 <= rows;
+    const long long nk = ck + gridDim.x;
+    const bool more = nk < nchunks;
+    const f32x4 nd = fetch_dl(nk);        // (in flight under this chunk's work)
+    if (more) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) load_y(Yn, t, nk);
+    }
+    __builtin_amdgcn_sched_barrier(0);    // (the round trips start here, not where the scheduler finds room)
+    const float* ds = dlS[buf];
+    if constexpr (!APPLY) {
+      if (wave == 0 && blockIdx.y == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dbl += ds[HF_ROW(r, h) * 36 + l31];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      hf_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      {
+        // A of the dz product: dl[row l31][classes 16 h + j]
+        const float* ap = ds + l31 * 36 + 16 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 a4 = *(const f32x4*)(ap + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], W[t][4 * q + e], acc, 0, 0, 0);
+        }
+      }
+      // the per-element arithmetic, once for full chunks (no row predicate) and once for the ragged last one
+      auto elements = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        float zr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = FULL || row0 + HF_ROW(r, h) < rows;
+          const float yy = Y[t][r];
+          const float d = yy - mean_[t];
+          const float z = __builtin_fmaf(d, sc_[t], be_[t]);      // = bn_affine: the forward's expression
+          const bool on = FULL ? (z > 0.f) : ((z > 0.f) && ok);
+          const float a = acc[r];
+          const float g = on ? a : 0.f;
+          if constexpr (!APPLY) {
+            sg[t] += g;
+            sgx[t] = __builtin_fmaf(g, d * inv_[t], sgx[t]);
+            gmf = fmaxf(gmf, fabsf(g));
+            ymf = fmaxf(ymf, FULL ? fabsf(yy) : (ok ? fabsf(yy) : 0.f));
+            zr[r] = FULL ? fmaxf(z, 0.f) : (on ? z : 0.f);
+          } else {
+            float o = __builtin_fmaf(g, sc_[t], -__builtin_fmaf(d, k1_[t], k0_[t]));
+            if constexpr (!FULL) o = ok ? o : 0.f;
+            csum[t] += o;
+            const float xs = o * sc2;
+            const _Float16 hh = (_Float16)xs;
+            const hf_h2 own2 = {hh, (_Float16)(xs - (float)hh)};
+            const unsigned own = __builtin_bit_cast(unsigned, own2);
+            // an even lane pairs its high half with its neighbour's and writes the high plane's dword, an odd lane the low plane's
+            const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xF, 0xF, false);   // lane ^ 1
+            *(unsigned*)(wp + HF_ROW(r, h) * 32) = __builtin_amdgcn_perm(other, own, psel);
+          }
+        }
+        if constexpr (!APPLY) {
+          // A of the dWh product: dl[row (j, h)][class l31]; B = this lane's 16 normalised values
+#pragma unroll
+          for (int j = 0; j < 16; ++j) accW[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[HF_ROW(j, h) * 36 + l31], zr[j], accW[t], 0, 0, 0);
+        }
+      };
+      if (full) elements(std::true_type{});
+      else elements(std::false_type{});
+      if constexpr (APPLY) {
+        if (wlive) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+          const int row = lane >> 1, half = lane & 1;
+          unsigned char* op = p.planes + ((((long long)(cw >> 4) + 2 * t) * rows + row0 + row) << 5) + half * 16;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const hf_u32x4 v = *(const hf_u32x4*)(st + q * 1056 + lane * 16);
+            if (full || row0 + row < rows) *(hf_u32x4*)(op + (q >> 1) * p.plane_bytes + (q & 1) * (rows << 5)) = v;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+    if (threadIdx.x < 256) *(f32x4*)(&dlS[buf ^ 1][srow * 36 + scls]) = nd;
+    __syncthreads();      // (the other buffer: every wave finished reading it one barrier ago)
+  };
+  while (ck < nchunks) {
+    iteration(Ya, Yb, ck, 0);
+    ck += gridDim.x;
+    if (ck >= nchunks) break;
+    iteration(Yb, Ya, ck, 1);
+    ck += gridDim.x;
+  }
+  gm = __float_as_uint(gmf);
+  ym = __float_as_uint(ymf);
+  // ---- what the block leaves: the two halves of a wave hold different rows of the same channels
+  if (wlive) {
+    if constexpr (!APPLY) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int ch = cw + 32 * t + l31;
+        const float s0 = sg[t] + __shfl_xor(sg[t], 32, 64), s1 = sgx[t] + __shfl_xor(sgx[t], 32, 64);
+        if (h == 0) {
+          p.part[((long long)blockIdx.x * 2) * C + ch] = s0;
+          p.part[((long long)blockIdx.x * 2 + 1) * C + ch] = s1;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = accW[t][r];
+          p.dws[((long long)blockIdx.x * 32 + HF_ROW(r, h)) * C + ch] = v;
+        }
+      }
+      if (wave == 0 && blockIdx.y == 0) {
+        const float d = dbl + __shfl_xor(dbl, 32, 64);
+        if (h == 0) p.dbs[(long long)blockIdx.x * 32 + l31] = d;
+      }
+    } else if (p.colpart != nullptr) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float s = csum[t] + __shfl_xor(csum[t], 32, 64);
+        if (h == 0) p.colpart[(long long)blockIdx.x * C + cw + 32 * t + l31] = s;
+      }
+    }
+  }
+  if constexpr (!APPLY) {
+    if (!wlive) gm = ym = 0;      // (an idle wave computed on wave 0's channels: its sums are dropped, its maxima must be too)
+    cs_amax_commit(gm, p.g_rec);
+    __syncthreads();              // (cs_amax_commit's LDS words are still being read by thread 0 for the first record)
+    cs_amax_commit(ym, p.y_rec);
+  } else {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+      const unsigned bound = p.dy_rec[CS_REC_BOUND];
+      p.scale[0] = bound;
+      ((int*)p.scale)[1] = cs_plane_exponent(bound);
+    }
+  }
+}
+
+// dWh[k][c] = sum over the blocks' slabs, dbh[k] likewise.  Block = 64 outputs x 4 slab groups (slabs b = group mod 4), eight independent
+// chains per thread, the groups combined through LDS: every sum in a fixed order
+__global__ __launch_bounds__(256) void hf_reduce_kernel(const float* __restrict__ dws, const float* __restrict__ dbs, int nb, int K, int C,
+                                                        float* __restrict__ dwh, float* __restrict__ dbh) {
+  __shared__ float red[4][64];
+  const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  const bool isw = i < K * C;
+  const int j = i - K * C;                       // (behind the weight: the K bias sums)
+  const bool isb = !isw && dbh != nullptr && j < K;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (isw || isb) {
+    const int k = isw ? i / C : 0, c = isw ? i - k * C : 0;
+    const float* s = isw ? dws + (long long)k * C + c : dbs + j;
+    const long long step = isw ? 32ll * C : 32ll;
+    for (int b0 = grp; b0 < nb; b0 += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (b0 + 4 * u < nb) a[u] += s[(long long)(b0 + 4 * u) * step];
+    }
+  }
+  red[grp][o] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (grp == 0) {
+    const float v = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    if (isw) dwh[i] = v;
+    else if (isb) dbh[j] = v;
+  }
+}
+#endif

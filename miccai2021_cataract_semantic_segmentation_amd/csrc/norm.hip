@@ -640,6 +640,8 @@ int grid_for(long long total) {
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
+#include "headfuse.h"
+
 }  // namespace
 
 // eval-mode BatchNorm folded into the preceding convolution: w'[o,:] = w[o,:] * g[o]/sqrt(rv[o]+eps),
@@ -1033,6 +1035,81 @@ extern "C" int catseg_bn_backward_planes_mask(const float* dz, int lddz, const v
   hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3((int)(tiles > 8192 ? 8192 : tiles)), dim3(256), 0, st, dz, lddz, (const float*)nullptr, 0, y, ldy,
                      stats, gamma, (const float*)nullptr, (const float*)coef, rows, C, 1, (unsigned char*)dy_planes, (unsigned*)dy_record, dres, lddres,
                      dres_accumulate, (const unsigned char*)mask);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// ---- the K-class classifier fused with the BatchNorm + ReLU in front of it (csrc/headfuse.h).
+// Forward: logits[rows][ldl] = relu((y - mean) * scale + beta) Wh^T + bh, columns [K, zero_to) zeroed; Wh [K][C] is the 1 x 1 convolution's
+// weight (models/OCR.py:74,97), mean / scale what catseg_bn_finalize left.  z is never written.
+extern "C" int catseg_head_fwd(const float* y, int ldy, const float* mean, const float* scale, const float* beta, const float* wh, const float* bh,
+                               int K, long long rows, int C, float* logits, int ldl, int zero_to, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C >= 32 && C % 32 == 0 && C <= 512 && K >= 1 && K <= 32 && ldy % 4 == 0 && ldy >= C && ldl >= K && zero_to <= ldl &&
+                 zero_to <= 32, "head forward: C a multiple of 32 up to 512, K <= 32, ld of y a multiple of 4");
+  CS_REQUIRE(y && mean && scale && beta && wh && logits && cs_aligned16(y), "head forward: pointers / alignment");
+  const size_t lds = (size_t)(C * 33 + 3 * C) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)hf_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (512 * 33 + 3 * 512) * 4) != hipSuccess) {
+      catseg_set_error("head forward: cannot raise the dynamic LDS limit");
+      return CATSEG_EHIP;
+    }
+    attr_set = true;
+  }
+  const long long groups = (rows + 31) / 32;
+  const long long want = (groups + 3) / 4;
+  hipLaunchKernelGGL(hf_fwd_kernel, dim3((int)(want < 512 ? want : 512)), dim3(256), lds, (hipStream_t)stream, y, ldy, mean, scale, beta, wh, bh, K,
+                     rows, C, logits, ldl, zero_to);
+  CS_LAUNCH_CHECK();
+  return CATSEG_OK;
+}
+
+// Backward of the same: from the gradient of the logits dl [rows][lddl] (lddl >= 32) to
+//   dy_planes / dy_scale   the gradient of y as the blocked fp16 x 2 planes of catseg_bn_backward_h2 (same records: g / y / dy_record zeroed)
+//   dgamma, dbeta          of the BatchNorm;  dbias (may be null): column sums of dy
+//   dwh [K][C], dbh [K]    of the classifier (written, not accumulated; dbh may be null)
+// row blocks of the backward launches: x (C / 128) channel blocks of 4 waves = 512 blocks, two per CU, all resident
+static int head_blocks(int C) { return 512 / ((C + 127) / 128); }
+extern "C" size_t catseg_head_backward_workspace(long long rows, int C) {
+  const size_t hb = (size_t)head_blocks(C);
+  return catseg_bn_workspace(rows, C) + cs_align_up(hb * C * 4, 256) + cs_align_up(hb * 32 * C * 4, 256) + cs_align_up(hb * 32 * 4, 256);
+}
+extern "C" int catseg_head_backward(const float* dl, int lddl, const float* y, int ldy, const float* stats, const float* gamma, const float* beta,
+                                    const float* wh, int K, long long rows, int C, void* dy_planes, void* dy_scale, float* dgamma, float* dbeta,
+                                    float* dbias, float* dwh, float* dbh, void* g_record, void* y_record, void* dy_record, void* workspace,
+                                    size_t workspace_bytes, catseg_stream_t stream) {
+  CS_REQUIRE(rows > 0 && C >= 64 && C % 64 == 0 && C <= 512 && K >= 1 && K <= 32 && lddl >= 32 && lddl % 4 == 0 && ldy >= C,
+             "head backward: C a multiple of 64 up to 512, K <= 32, ld of the logits gradient >= 32 and a multiple of 4");
+  CS_REQUIRE(dl && y && stats && gamma && beta && wh && dy_planes && dy_scale && dwh && g_record && y_record && dy_record && cs_aligned16(dl) &&
+                 cs_aligned16(dy_planes) && (((uintptr_t)dy_scale) & 7) == 0, "head backward: pointers / alignment");
+  CS_REQUIRE(rows * C * 4 < (1ll << 32) - 64, "head backward: the two planes must stay below 4 GB");
+  if (workspace_bytes < catseg_head_backward_workspace(rows, C) || !workspace) {
+    catseg_set_error("head backward: workspace too small");
+    return CATSEG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* coef = part + (size_t)kMaxRowBlocks * 3 * ((C + 3) & ~3);
+  char* w = (char*)workspace + catseg_bn_workspace(rows, C);
+  float* colpart = (float*)w;
+  const size_t hb = (size_t)head_blocks(C);
+  w += cs_align_up(hb * C * 4, 256);
+  float* dws = (float*)w;
+  w += cs_align_up(hb * 32 * C * 4, 256);
+  float* dbs = (float*)w;
+  const long long chunks = (rows + 31) / 32;
+  const int nb = (int)(chunks < (long long)hb ? chunks : (long long)hb);
+  HfBwdArgs a;
+  a.dl = dl; a.lddl = lddl; a.y = y; a.ldy = ldy; a.stats = stats; a.gamma = gamma; a.beta = beta; a.wh = wh; a.K = K; a.rows = rows; a.C = C;
+  a.part = part; a.dws = dws; a.dbs = dbs; a.g_rec = (unsigned*)g_record; a.y_rec = (unsigned*)y_record;
+  a.coef = coef; a.planes = (unsigned char*)dy_planes; a.plane_bytes = rows * C * 2; a.dy_rec = (const unsigned*)dy_record;
+  a.scale = (unsigned*)dy_scale; a.colpart = dbias ? colpart : nullptr;
+  hipLaunchKernelGGL((hf_bwd_kernel<false, 1, 4>), dim3(nb, (C + 127) / 128), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(1024), 0, st, (const float*)part, nb, rows, C, dgamma, dbeta, coef,
+                     (const unsigned*)a.g_rec, (const unsigned*)a.y_rec, stats, gamma, (unsigned*)dy_record);
+  hipLaunchKernelGGL(hf_reduce_kernel, dim3((K * C + K + 63) / 64), dim3(256), 0, st, (const float*)dws, (const float*)dbs, nb, K, C, dwh, dbh);
+  hipLaunchKernelGGL((hf_bwd_kernel<true, 1, 4>), dim3(nb, (C + 127) / 128), dim3(256), 0, st, a);
+  if (dbias) hipLaunchKernelGGL(colsum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)colpart, nb, C, dbias);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }

@@ -385,9 +385,42 @@ FUSE_BN_STATS = True  # training forward: BatchNorm batch statistics from the co
 FUSE_EVAL_BN = True   # eval-mode forward: fold BatchNorm into the conv and fuse bias/residual/ReLU into its epilogue
 
 
-def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=True, private_in=False, sole_conv_out=False):
+def _fused_head(cx, x, x_in, y, stats, scale, conv, bn, head, need_dx, pad_to):
+    """BatchNorm + ReLU + the K-class 1 x 1 classifier `head` behind the head convolution `conv` whose output y (and batch statistics) exist:
+    the normalised activation and its gradient are never written (ops.head_fwd / ops.head_backward, csrc/headfuse.h); the convolution's
+    backward streams the blocked planes of dy as on conv_bn_act's head route."""
+    w, hw = conv.weight, head.weight
+    Cout, K = w.shape[0], hw.shape[0]
+    kh, kw = conv.kernel_size
+    s, p, d = conv.stride[0], conv.padding[0], conv.dilation[0]
+    cx.claim(hw, head.bias)
+    hb = head.bias.data if head.bias is not None else None
+    logits = ops.head_fwd(y, stats[:Cout], scale, bn.bias.data, hw.data, hb, K, max(pad_to, (K + 3) // 4 * 4))
+
+    def bwd():
+        dl = cx.take(logits)
+        if dl is None:
+            return
+        dyp, dysc = ops.head_backward(dl, y, stats, bn.weight.data, bn.bias.data, hw.data, cx.pgrad(hw),
+                                      cx.pgrad(head.bias) if head.bias is not None else None, cx.pgrad(bn.weight), cx.pgrad(bn.bias),
+                                      cx.pgrad(conv.bias) if conv.bias is not None else None)
+        del dl
+        cx.done(hw, head.bias)
+        ops.conv_bwd_weight_h2(x_in, dyp, dysc, Cout, cx.pgrad(w), kh, kw, s, p, d)
+        if need_dx:
+            dx, accx = cx.dest(x)
+            ops.conv_bwd_data_h2(dyp, dysc, w.data, tuple(x.shape), Cout, kh, kw, p, d, dx, accx)
+        cx.done(bn.weight, bn.bias, w, conv.bias)
+    cx.push(bwd)
+    return logits
+
+
+def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=True, private_in=False, sole_conv_out=False, head=None, z_tap=None):
     """conv -> BatchNorm (batch stats in training) -> (+residual) -> (ReLU).  x NHWC (or the raw
     NCHW image for the stem).  Returns z (NHWC).
+    head: a 1 x 1 classifier convolution that is the ONLY consumer of z -- the call then returns conv_bias(z, head), and in a recorded training
+    pass on the head layers' route BatchNorm, ReLU and classifier run fused (_fused_head: z is never written); z_tap names z for the diagnostic
+    taps where it exists.
     private_in: the caller states that x is the output of the preceding conv_bn_act (ReLU, no residual) and has NO other consumer
     (the first half of a BasicBlock).  The backward-data kernel of this layer may then run the first pass of that BatchNorm's
     backward in its epilogue (ops.conv_bwd_data(bn_src=...)).
@@ -425,7 +458,10 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
         # the convolution epilogue — one kernel per layer, no separate normalisation pass over HBM
         per_out = wk.numel() // Cout
         wf, bf = ops.fold_bn(wk, bias, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps, Cout, per_out)
-        return ops.conv_fwd_fused(x_in, wf, bf, residual, relu, Cout, kh, kw, s, p, d, out=out, stem4=conv.stem, groups=conv.groups)
+        zf = ops.conv_fwd_fused(x_in, wf, bf, residual, relu, Cout, kh, kw, s, p, d, out=out, stem4=conv.stem, groups=conv.groups)
+        if z_tap is not None:
+            tap(z_tap, zf)
+        return zf if head is None else conv_bias(cx, zf, head)
     if cx.train:
         # batch statistics: per-tile partial sums come out of the convolution's epilogue (no separate pass over y)
         if stem3:
@@ -455,6 +491,11 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
         stats = None
         mean = bn.running_mean
         scale = ops.bn_eval_scale(bn.weight.data, bn.running_var, bn.eps)
+    if (head is not None and cx.train and cx.record and TAPS is None and zrec is None and residual is None and relu and out is None
+            and not conv.stem and not pad3 and partials is not None and head.kernel_size == (1, 1) and head.stride == (1, 1)
+            and head.padding == (0, 0) and head.groups == 1 and ops.head_fuse_ok(y, head.weight.shape[0])
+            and ops.h2_dy_route(x_in, y, w.data, kh, kw, s, p, d, conv.groups, need_dx)):
+        return _fused_head(cx, x, x_in, y, stats, scale, conv, bn, head, need_dx, 32)
     z = ops.bn_apply(y, mean, scale, bn.bias.data, residual, relu, out=out, planes_rec=zrec,
                      planes_only=zrec is not None and sole_conv_out and relu and residual is None,
                      want_mask=cx.record and cx.train)       # (a residual block's output: its ReLU mask as bits for the backward pass)
@@ -535,7 +576,9 @@ def conv_bn_act(cx, x, conv, bn, relu=True, residual=None, out=None, need_dx=Tru
                         cx.bn_pre[id(x)] = r[1]
             cx.done(bn.weight, bn.bias, w, conv.bias)
         cx.push(bwd)
-    return z
+    if z_tap is not None:
+        tap(z_tap, z)
+    return z if head is None else conv_bias(cx, z, head)
 
 
 def conv_bias(cx, x, conv, pad_to=32):

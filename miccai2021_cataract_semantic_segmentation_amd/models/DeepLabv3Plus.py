@@ -64,8 +64,7 @@ class Decoder(nn.Module):
         x2 = bilinear(cx, a, H, W, True, out=cat[..., c0:c1])
         concat_views(cx, cat, [(x1, 0, c0), (x2, c0, c1)])
         y = conv_bn_act(cx, cat, self.conv_3x3_1, self.conv_3x3_1_bn)
-        y = conv_bn_act(cx, y, self.conv_3x3_2, self.conv_3x3_2_bn)
-        return conv_bias(cx, y, self.conv_out)
+        return conv_bn_act(cx, y, self.conv_3x3_2, self.conv_3x3_2_bn, head=self.conv_out)
 
 
 class DeepLabv3Plus(EngineNet):

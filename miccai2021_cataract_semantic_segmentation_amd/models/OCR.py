@@ -5,7 +5,7 @@ import torch
 from torch import nn
 
 from .. import engine, ops
-from ..engine import (BatchNorm2d, Conv2d, EngineNet, bilinear, image_hw, concat_views, conv_bias, conv_bn_act,
+from ..engine import (BatchNorm2d, Conv2d, EngineNet, bilinear, image_hw, concat_views, conv_bn_act,
                       object_attention_core, spatial_gather)
 from ..utils import num_classes
 from .backbone import ResNetBackbone, load_pretrained_trunk
@@ -46,12 +46,13 @@ class SpatialOCR_Module(nn.Module):
                                              BatchNorm2d(out_channels), self.relu, nn.Dropout2d(dropout))
         self.in_channels = in_channels
 
-    def run(self, cx, cat, feats, proxy, K):
-        """cat: [B,H,W,2C] buffer whose upper half already holds feats (torch.cat([context, feats], 1))"""
+    def run(self, cx, cat, feats, proxy, K, head=None):
+        """cat: [B,H,W,2C] buffer whose upper half already holds feats (torch.cat([context, feats], 1)); head: the classifier that is the only
+        consumer of the module's output (then returned: its logits)"""
         C = self.in_channels
         context = self.object_context_block.run(cx, feats, proxy, K, out=cat[..., :C])
         concat_views(cx, cat, [(context, 0, C), (feats, C, 2 * C)])
-        return engine.tap("ocr_out", conv_bn_act(cx, cat, self.conv_bn_dropout[0], self.conv_bn_dropout[1]))
+        return conv_bn_act(cx, cat, self.conv_bn_dropout[0], self.conv_bn_dropout[1], head=head, z_tap="ocr_out")
 
 
 class SpatialGatherModule(nn.Module):
@@ -128,14 +129,13 @@ class OCRNet(EngineNet):
             low, high = f["low"], f["high"]
         hd = self.interm_prediction_head
         engine.tap("concat", low)
-        interm = engine.tap("interm_lowres", conv_bias(cx, conv_bn_act(cx, low, hd[0], hd[1]), hd[4]))
+        interm = engine.tap("interm_lowres", conv_bn_act(cx, low, hd[0], hd[1], head=hd[4]))
         B, h, w, _ = high.shape
         cat = torch.empty((B, h, w, 1024), dtype=torch.float32, device=x.device)
         feats = conv_bn_act(cx, high, self.conv_high_map[0], self.conv_high_map[1], out=cat[..., 512:])
         engine.tap("feats", feats)
         proxy = spatial_gather(cx, feats, interm, K)
-        o = self.spatial_ocr_head.run(cx, cat, feats, proxy, K)
-        logits = conv_bias(cx, o, self.conv_out)
+        logits = self.spatial_ocr_head.run(cx, cat, feats, proxy, K, head=self.conv_out)
         engine.tap("logits_lowres", logits)
         up = bilinear(cx, logits, H, W, True)
         if self.get_intermediate:

@@ -1418,6 +1418,45 @@ def bn_backward_h2(dz, y, stats, gamma, relu, dgamma, dbeta, beta, dbias=None):
     return blk, scale
 
 
+HEAD_FUSE = _plan.get("head_fuse")
+
+
+def head_fuse_ok(y, K):
+    """the classifier behind a head's BatchNorm + ReLU runs fused with it (csrc/headfuse.h): C % 64 == 0 up to 512 channels, at most 32 classes"""
+    C = y.shape[-1]
+    return bool(HEAD_FUSE and y.is_cuda and y.dim() == 4 and C % 64 == 0 and C <= 512 and 1 <= K <= 32 and ld_of(y) % 4 == 0
+                and 4 * rows_of(y) * C < B3_PLANE_LIMIT)
+
+
+def head_fwd(y, mean, scale, beta, wh, bh, K, ld):
+    """logits [B, H, W, K] (pixel stride ld, zero padded) = relu(bn(y)) wh^T + bh; the normalised activation is not written"""
+    B, H, W, C = y.shape
+    buf = torch.empty((B, H, W, ld), dtype=torch.float32, device=y.device)
+    rows = rows_of(y)
+    with _Timed("hbm:head_fwd", 4.0 * y.numel()):
+        check(lib.catseg_head_fwd(ptr(y), ld_of(y), ptr(mean), ptr(scale), ptr(beta), ptr(wh), ptr(bh), K, rows, C, ptr(buf), ld, min(ld, 32),
+                                  stream()))
+    return buf[..., :K] if ld != K else buf
+
+
+def head_backward(dl, y, stats, gamma, beta, wh, dwh, dbh, dgamma, dbeta, dbias=None):
+    """backward of head_fwd: (blocked planes of dy, their scale record) as bn_backward_h2 returns them; dwh / dbh / dgamma / dbeta / dbias written"""
+    C, rows, K = y.shape[-1], rows_of(y), wh.shape[0]
+    if ld_of(dl) < 32 or ld_of(dl) % 4:        # (a caller's dense gradient: the kernels read 128-byte rows)
+        padded = new_act(dl.shape[0], dl.shape[1], dl.shape[2], K, dl.device, ld=32, zero=True)
+        padded.copy_(dl)
+        dl = padded
+    blk = torch.empty((2, C // 16, rows, 16), dtype=torch.int16, device=y.device)
+    scale = torch.empty(2, dtype=torch.int32, device=y.device)
+    ws = workspace(lib.catseg_head_backward_workspace(rows, C), y.device)
+    grec, yrec, dyrec = new_amax(y.device), new_amax(y.device), new_amax(y.device)
+    with _Timed("hbm:head_backward", 4.0 * y.numel() * 3):
+        check(lib.catseg_head_backward(ptr(dl), ld_of(dl), ptr(y), ld_of(y), ptr(stats), ptr(gamma), ptr(beta), ptr(wh), K, rows, C, ptr(blk),
+                                       ptr(scale), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(dwh), ptr(dbh), ptr(grec), ptr(yrec), ptr(dyrec),
+                                       ptr(ws), ws.numel(), stream()))
+    return blk, scale
+
+
 def conv_bwd_weight_h2(x, dyp, dysc, Cout, dw, kh, kw, stride, pad, dil):
     """backward-weight from the blocked planes of dy (bn_backward_h2) and of x (kept from the forward pass, or split now)"""
     Cin = x.shape[-1]
