@@ -100,8 +100,9 @@ __global__ __launch_bounds__(256, 2) void hf_fwd_kernel(const float* __restrict_
 
 // ---- backward.  Block = NW waves; a wave owns NT 32-channel tiles (block (x, y): channels from 32 NT NW y) whose Wh fragments and BatchNorm
 // constants stay in registers, the block walks 32-row chunks blockIdx.x, + gridDim.x, ...  NT = 1, NW = 4: two blocks per CU, the grid sized to be
-// resident at once; the y rows of chunk i + 1 load into a second register set from the top of chunk i (a whole chunk of work covers the round
-// trip: with the loads half a chunk ahead the passes ran 288 / 251 us at 8 x 136 x 240 x 512, each phase's latency exposed).
+// resident at once; the y rows and the dl rows of chunk i + 1 load into a second register set from the top of chunk i and are waited for at
+// its end.  At 8 x 136 x 240 x 512: second pass 205 us = 5.2 TB/s of (y read + planes written); first pass 247 us (its 32 fp32 MFMAs per
+// 32 x 32 tile are 125 us of matrix time; 2 waves per SIMD keep the pipe half busy).
 struct HfBwdArgs {
   const float* dl; int lddl;        // gradient of the logits [rows][lddl], lddl >= 32
   const float* y; int ldy;
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(NW * 64, 2) void hf_bwd_kernel(const HfBwdArgs p) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) W[t][j] = (16 * h + j < K) ? p.wh[(long long)(16 * h + j) * C + ch] : 0.f;
   }
-  float sg[NT], sgx[NT], csum[NT], dbl = 0.f;
+  float sg[NT], sgx[NT], csum[NT];
+  f32x4 dbl4 = {0.f, 0.f, 0.f, 0.f};      // (first pass) the staging thread's share of dbh: its row of every chunk, four classes
   hf_f32x16 accW[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) sg[t] = sgx[t] = csum[t] = 0.f;
@@ -163,34 +165,35 @@ __global__ __launch_bounds__(NW * 64, 2) void hf_bwd_kernel(const HfBwdArgs p) {
   const long long nchunks = (rows + 31) >> 5;
   // staging of a chunk's dl: threads 0 .. 255 hold 16 bytes each (row = tid >> 3, classes 4 (tid & 7) ..)
   const int srow = threadIdx.x >> 3, scls = (threadIdx.x & 7) * 4;
-  auto fetch_dl = [&](long long ck) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const long long r = (ck << 5) + srow;
-    if (threadIdx.x < 256 && ck < nchunks && r < rows) {
-      v = ld4(p.dl + r * p.lddl + scls);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (scls + e < K) ? v[e] : 0.f;
-    }
-    return v;
+  // every vector-memory access of the loop goes through a buffer resource and is issued unconditionally (rows past the end: out of range =
+  // zeros read, nothing written): with no branch around a load or a store the compiler's s_waitcnt counts are exact -- the next chunk's rows
+  // are waited for with the plane stores still in flight (a conditional store behind them made every wait a vmcnt(0): one full store round
+  // trip per chunk)
+  const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)p.dl, (short)0, (int)(unsigned)(rows * p.lddl * 4), 0x00020000);
+  const unsigned dl_off = (unsigned)(srow * p.lddl + scls) * 4u, dl_step = 32u * (unsigned)p.lddl * 4u;
+  auto fetch_dl = [&](long long ck) {       // (raw: the classes past K are zeroed where the value is written to LDS)
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, dl_off + (unsigned)ck * dl_step, 0, 0));
   };
-  // this lane's 16 rows (accumulator layout) of channel tile t of a chunk: four wave-uniform bases + four per-lane offsets computed once (the
-  // last, ragged chunk clamps its rows to the last one: they are masked where they are used)
-  float Ya[NT][16], Yb[NT][16];      // two register sets: the loads of chunk i + 1 are issued at the top of chunk i
-  int yoff[4];      // rows (r & 3) + 4 h; the 8 (r >> 2) rows ride in the uniform base
+  auto stage_dl = [&](int buf, f32x4 v) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) yoff[r] = (r + 4 * h) * ldy + l31;
+    for (int e = 0; e < 4; ++e) v[e] = (scls + e < K) ? v[e] : 0.f;
+    if constexpr (!APPLY) dbl4 += v;
+    if (threadIdx.x < 256) *(f32x4*)(&dlS[buf][srow * 36 + scls]) = v;
+  };
+  // this lane's 16 rows (accumulator layout) of channel tile t of a chunk: rows (r & 3) + 4 h in four per-lane byte offsets, the chunk and the
+  // 8 (r >> 2) rows in a wave-uniform term
+  float Y[NT][16];
   const int cbase = wlive ? cw : 0;
-  auto load_y = [&](float (&Y)[NT][16], int t, long long ck) {
-    const long long row0 = ck << 5;
-    const float* yb = p.y + row0 * ldy + cbase + 32 * t;
-    if (row0 + 32 <= rows) {
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + cbase), (short)0, (int)(unsigned)((rows * ldy - cbase) * 4), 0x00020000);
+  unsigned yoff[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Y[t][r] = (yb + (r >> 2) * 8 * ldy)[yoff[r & 3]];
-    } else {
-      const int last = (int)(rows - 1 - row0);
+  for (int r = 0; r < 4; ++r) yoff[r] = (unsigned)((r + 4 * h) * ldy + l31) * 4u;
+  const unsigned y_step = 32u * (unsigned)ldy * 4u, y_oct = 8u * (unsigned)ldy * 4u;
+  auto load_y = [&](float (&Yd)[NT][16], int t, long long ck) {
+    const unsigned base = (unsigned)ck * y_step + 128u * t;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Y[t][r] = yb[min(HF_ROW(r, h), last) * ldy + l31];
-    }
+    for (int r = 0; r < 16; ++r)
+      Yd[t][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsY, yoff[r & 3] + (base + (r >> 2) * y_oct), 0, 0));
   };
   // per channel: dy = sc g - (k0 + (y - mean) k1) with k0 = sc mean(g), k1 = sc invstd mean(g xhat)  (two FMAs per element)
   float k0_[NT], k1_[NT];
@@ -204,33 +207,36 @@ __global__ __launch_bounds__(NW * 64, 2) void hf_bwd_kernel(const HfBwdArgs p) {
   unsigned char* const st = hf_stage[APPLY ? wave : 0];
   unsigned char* const wp = st + (2 * (l31 & 1) + (l31 >> 4)) * 1056 + ((l31 & 15) >> 1) * 4;
   typedef _Float16 hf_h2 __attribute__((ext_vector_type(2)));
+  // one resource per (tile, plane, 16-channel chunk) piece of this wave's channels: rows x 32 bytes, a row past the end is out of range
+  __amdgpu_buffer_rsrc_t rsP[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      rsP[t][q] = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(APPLY ? p.planes + (q >> 1) * p.plane_bytes + (((long long)(cbase >> 4) + 2 * t + (q & 1)) * rows << 5) : (unsigned char*)nullptr), (short)0,
+          (int)(unsigned)((APPLY && wlive) ? rows * 32 : 0), 0x00020000);      // (a wave without channels: empty, its stores are dropped)
 
   long long ck = blockIdx.x;
   if (ck < nchunks) {
-    const f32x4 v = fetch_dl(ck);
-    if (threadIdx.x < 256) *(f32x4*)(&dlS[0][srow * 36 + scls]) = v;
+    stage_dl(0, fetch_dl(ck));
 #pragma unroll
-    for (int t = 0; t < NT; ++t) load_y(Ya, t, ck);
+    for (int t = 0; t < NT; ++t) load_y(Y, t, ck);
   }
   __syncthreads();
-  auto iteration = [&](float (&Y)[NT][16], float (&Yn)[NT][16], const long long ck, const int buf) {
+  int buf = 0;
+  for (; ck < nchunks; ck += gridDim.x) {
     const long long row0 = ck << 5;
     const bool full = row0 + 32 <= rows;
     const long long nk = ck + gridDim.x;
     const bool more = nk < nchunks;
-    const f32x4 nd = fetch_dl(nk);        // (in flight under this chunk's work)
-    if (more) {
+    // the next chunk's dl and y rows start their round trips here, into a second register set; they are waited for at the END of this chunk
+    const f32x4 nd = fetch_dl(nk);
+    float Yn[NT][16];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) load_y(Yn, t, nk);
-    }
+    for (int t = 0; t < NT; ++t) load_y(Yn, t, nk);      // (past the last chunk: out of range, zeros)
     __builtin_amdgcn_sched_barrier(0);    // (the round trips start here, not where the scheduler finds room)
     const float* ds = dlS[buf];
-    if constexpr (!APPLY) {
-      if (wave == 0 && blockIdx.y == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dbl += ds[HF_ROW(r, h) * 36 + l31];
-      }
-    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       hf_f32x16 acc;
@@ -286,31 +292,30 @@ __global__ __launch_bounds__(NW * 64, 2) void hf_bwd_kernel(const HfBwdArgs p) {
       };
       if (full) elements(std::true_type{});
       else elements(std::false_type{});
-      if constexpr (APPLY) {
-        if (wlive) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_wave_barrier();
-          const int row = lane >> 1, half = lane & 1;
-          unsigned char* op = p.planes + ((((long long)(cw >> 4) + 2 * t) * rows + row0 + row) << 5) + half * 16;
+      if constexpr (APPLY) {       // (no branch around the stores: see rsD)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const hf_u32x4 v = *(const hf_u32x4*)(st + q * 1056 + lane * 16);
-            if (full || row0 + row < rows) *(hf_u32x4*)(op + (q >> 1) * p.plane_bytes + (q & 1) * (rows << 5)) = v;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_wave_barrier();
+        for (int q = 0; q < 4; ++q) {
+          const hf_u32x4 v = *(const hf_u32x4*)(st + q * 1056 + lane * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsP[t][q], (unsigned)lane * 16u + (unsigned)row0 * 32u, 0, 0);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
       }
     }
-    if (threadIdx.x < 256) *(f32x4*)(&dlS[buf ^ 1][srow * 36 + scls]) = nd;
-    __syncthreads();      // (the other buffer: every wave finished reading it one barrier ago)
-  };
-  while (ck < nchunks) {
-    iteration(Ya, Yb, ck, 0);
-    ck += gridDim.x;
-    if (ck >= nchunks) break;
-    iteration(Yb, Ya, ck, 1);
-    ck += gridDim.x;
+    __builtin_amdgcn_sched_barrier(0);    // (nothing below moves up into the chunk's work: the copies would drag the loads' wait with them)
+    stage_dl(buf ^ 1, nd);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[t][r] = Yn[t][r];
+    // the other buffer: every wave finished reading it one barrier ago.  LDS-only barrier (__syncthreads() also drains the vector-memory
+    // counter: the plane stores)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    buf ^= 1;
   }
   gm = __float_as_uint(gmf);
   ym = __float_as_uint(ymf);
@@ -331,10 +336,6 @@ __global__ __launch_bounds__(NW * 64, 2) void hf_bwd_kernel(const HfBwdArgs p) {
           p.dws[((long long)blockIdx.x * 32 + HF_ROW(r, h)) * C + ch] = v;
         }
       }
-      if (wave == 0 && blockIdx.y == 0) {
-        const float d = dbl + __shfl_xor(dbl, 32, 64);
-        if (h == 0) p.dbs[(long long)blockIdx.x * 32 + l31] = d;
-      }
     } else if (p.colpart != nullptr) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -344,6 +345,17 @@ __global__ __launch_bounds__(NW * 64, 2) void hf_bwd_kernel(const HfBwdArgs p) {
     }
   }
   if constexpr (!APPLY) {
+    if (blockIdx.y == 0 && NW == 4) {
+      // dbh slab of this block: the 32 staging rows of each class, summed in row order (the staged values past the last chunk are zeros)
+      __syncthreads();
+      *(f32x4*)(&dlS[0][srow * 36 + scls]) = dbl4;
+      __syncthreads();
+      if (threadIdx.x < 32) {
+        float d = 0.f;
+        for (int r = 0; r < 32; ++r) d += dlS[0][r * 36 + threadIdx.x];
+        p.dbs[(long long)blockIdx.x * 32 + threadIdx.x] = d;
+      }
+    }
     if (!wlive) gm = ym = 0;      // (an idle wave computed on wave 0's channels: its sums are dropped, its maxima must be too)
     cs_amax_commit(gm, p.g_rec);
     __syncthreads();              // (cs_amax_commit's LDS words are still being read by thread 0 for the first record)

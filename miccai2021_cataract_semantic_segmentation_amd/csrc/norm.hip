@@ -1082,7 +1082,8 @@ extern "C" int catseg_head_backward(const float* dl, int lddl, const float* y, i
              "head backward: C a multiple of 64 up to 512, K <= 32, ld of the logits gradient >= 32 and a multiple of 4");
   CS_REQUIRE(dl && y && stats && gamma && beta && wh && dy_planes && dy_scale && dwh && g_record && y_record && dy_record && cs_aligned16(dl) &&
                  cs_aligned16(dy_planes) && (((uintptr_t)dy_scale) & 7) == 0, "head backward: pointers / alignment");
-  CS_REQUIRE(rows * C * 4 < (1ll << 32) - 64, "head backward: the two planes must stay below 4 GB");
+  CS_REQUIRE(rows * C * 4 < (1ll << 32) - 64 && (rows + 32 * 512) * (long long)ldy * 4 < (1ll << 32) && (rows + 32 * 512) * (long long)lddl * 4 < (1ll << 32),
+             "head backward: planes and operands must stay below 4 GB (32-bit buffer offsets)");
   if (workspace_bytes < catseg_head_backward_workspace(rows, C) || !workspace) {
     catseg_set_error("head backward: workspace too small");
     return CATSEG_EWORKSPACE;
