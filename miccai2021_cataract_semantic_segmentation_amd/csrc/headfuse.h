@@ -25,10 +25,11 @@ typedef float hf_f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned hf_u32x4 __attribute__((ext_vector_type(4)));
 #define HF_ROW(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))
 
-// ---- forward.  Block = 4 waves; a wave owns 32 pixel rows at a time and walks their C channels in chunks of 32 (lane (l31, h): row l31,
+// ---- forward.  Block = kHfFwdWaves waves; a wave owns 32 pixel rows at a time and walks their C channels in chunks of 32 (lane (l31, h): row l31,
 // channels c0 + 16 h .. + 15 = 64 contiguous bytes, three chunks of loads in flight under a chunk's 16 MFMAs).  Wh lives in LDS as
 // [channel][33] (lane l31 reads class l31 of 16 channels: conflict-free), the BatchNorm constants as [3][C].
-__global__ __launch_bounds__(256, 2) void hf_fwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ mean,
+constexpr int kHfFwdWaves = 4;      // waves per block: two blocks per CU (67.6 + 6 KB of LDS each); six waves per block measured 207 against 158 us
+__global__ __launch_bounds__(kHfFwdWaves * 64, 2) void hf_fwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ mean,
                                                         const float* __restrict__ scale, const float* __restrict__ beta,
                                                         const float* __restrict__ wh, const float* __restrict__ bh, int K, long long rows, int C,
                                                         float* __restrict__ out, int ldo, int zero_to) {
@@ -36,8 +37,8 @@ __global__ __launch_bounds__(256, 2) void hf_fwd_kernel(const float* __restrict_
   float* Wl = hf_sm;             // [C][33]
   float* cst = hf_sm + C * 33;   // mean[C], scale[C], beta[C]   (C % 32 == 0: 16-byte aligned)
   for (int k = 0; k < 32; ++k)
-    for (int c = threadIdx.x; c < C; c += 256) Wl[c * 33 + k] = k < K ? wh[(long long)k * C + c] : 0.f;
-  for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += kHfFwdWaves * 64) Wl[c * 33 + k] = k < K ? wh[(long long)k * C + c] : 0.f;
+  for (int c = threadIdx.x; c < C; c += kHfFwdWaves * 64) {
     cst[c] = mean[c];
     cst[C + c] = scale[c];
     cst[2 * C + c] = beta[c];
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256, 2) void hf_fwd_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
   const long long ngroups = (rows + 31) >> 5;
   const float bias = (bh != nullptr && l31 < K) ? bh[l31] : 0.f;
-  for (long long g = (long long)blockIdx.x * 4 + wave; g < ngroups; g += (long long)gridDim.x * 4) {
+  for (long long g = (long long)blockIdx.x * kHfFwdWaves + wave; g < ngroups; g += (long long)gridDim.x * kHfFwdWaves) {
     const long long row0 = g << 5;
     long long row = row0 + l31;
     if (row >= rows) row = rows - 1;   // (a clamped row's products land in accumulator rows that are not stored)
@@ -239,39 +240,55 @@ __global__ __launch_bounds__(NW * 64, 2) void hf_bwd_kernel(const HfBwdArgs p) {
     const float* ds = dlS[buf];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      hf_f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      {
-        // A of the dz product: dl[row l31][classes 16 h + j]
-        const float* ap = ds + l31 * 36 + 16 * h;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 a4 = *(const f32x4*)(ap + 4 * q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], W[t][4 * q + e], acc, 0, 0, 0);
-        }
-      }
-      // the per-element arithmetic, once for full chunks (no row predicate) and once for the ragged last one
+      // the tile's arithmetic, once for full chunks (no row predicate) and once for the ragged last one
       auto elements = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
-        float zr[16];
+        hf_f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool ok = FULL || row0 + HF_ROW(r, h) < rows;
-          const float yy = Y[t][r];
-          const float d = yy - mean_[t];
-          const float z = __builtin_fmaf(d, sc_[t], be_[t]);      // = bn_affine: the forward's expression
-          const bool on = FULL ? (z > 0.f) : ((z > 0.f) && ok);
-          const float a = acc[r];
-          const float g = on ? a : 0.f;
-          if constexpr (!APPLY) {
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // A of the dz product: dl[row l31][classes 16 h + j]
+        const float* ap = ds + l31 * 36 + 16 * h;
+        f32x4 a4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a4[q] = *(const f32x4*)(ap + 4 * q);
+        if constexpr (!APPLY) {
+          // A of the dWh product: dl[row (j, h)][class l31], all sixteen reads in front of the products (issued one by one inside the chain,
+          // each product waited for its own LDS round trip); B = this lane's 16 normalised values, which do not depend on dz -- the two
+          // products are independent chains and alternate on the matrix pipe
+          float A2[16], zr[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) A2[j] = ds[HF_ROW(j, h) * 36 + l31];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float z = __builtin_fmaf(Y[t][r] - mean_[t], sc_[t], be_[t]);      // = bn_affine: the forward's expression
+            zr[r] = FULL ? fmaxf(z, 0.f) : ((z > 0.f && row0 + HF_ROW(r, h) < rows) ? z : 0.f);
+          }
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j >> 2][j & 3], W[t][j], acc, 0, 0, 0);
+            accW[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2[j], zr[j], accW[t], 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float yy = Y[t][r];
+            const float a = acc[r];
+            const float g = zr[r] > 0.f ? a : 0.f;       // (zr > 0 <=> the element passed the ReLU and its row exists)
             sg[t] += g;
-            sgx[t] = __builtin_fmaf(g, d * inv_[t], sgx[t]);
+            sgx[t] = __builtin_fmaf(g, (yy - mean_[t]) * inv_[t], sgx[t]);
             gmf = fmaxf(gmf, fabsf(g));
-            ymf = fmaxf(ymf, FULL ? fabsf(yy) : (ok ? fabsf(yy) : 0.f));
-            zr[r] = FULL ? fmaxf(z, 0.f) : (on ? z : 0.f);
-          } else {
+            ymf = fmaxf(ymf, FULL ? fabsf(yy) : (row0 + HF_ROW(r, h) < rows ? fabsf(yy) : 0.f));
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j >> 2][j & 3], W[t][j], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool ok = FULL || row0 + HF_ROW(r, h) < rows;
+            const float d = Y[t][r] - mean_[t];
+            const float z = __builtin_fmaf(d, sc_[t], be_[t]);      // = bn_affine: the forward's expression
+            const bool on = FULL ? (z > 0.f) : ((z > 0.f) && ok);
+            const float a = acc[r];
+            const float g = on ? a : 0.f;
             float o = __builtin_fmaf(g, sc_[t], -__builtin_fmaf(d, k1_[t], k0_[t]));
             if constexpr (!FULL) o = ok ? o : 0.f;
             csum[t] += o;
@@ -283,11 +300,6 @@ __global__ __launch_bounds__(NW * 64, 2) void hf_bwd_kernel(const HfBwdArgs p) {
             const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xF, 0xF, false);   // lane ^ 1
             *(unsigned*)(wp + HF_ROW(r, h) * 32) = __builtin_amdgcn_perm(other, own, psel);
           }
-        }
-        if constexpr (!APPLY) {
-          // A of the dWh product: dl[row (j, h)][class l31]; B = this lane's 16 normalised values
-#pragma unroll
-          for (int j = 0; j < 16; ++j) accW[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[HF_ROW(j, h) * 36 + l31], zr[j], accW[t], 0, 0, 0);
         }
       };
       if (full) elements(std::true_type{});

@@ -1057,8 +1057,8 @@ extern "C" int catseg_head_fwd(const float* y, int ldy, const float* mean, const
     attr_set = true;
   }
   const long long groups = (rows + 31) / 32;
-  const long long want = (groups + 3) / 4;
-  hipLaunchKernelGGL(hf_fwd_kernel, dim3((int)(want < 512 ? want : 512)), dim3(256), lds, (hipStream_t)stream, y, ldy, mean, scale, beta, wh, bh, K,
+  const long long want = (groups + kHfFwdWaves - 1) / kHfFwdWaves;
+  hipLaunchKernelGGL(hf_fwd_kernel, dim3((int)(want < 512 ? want : 512)), dim3(kHfFwdWaves * 64), lds, (hipStream_t)stream, y, ldy, mean, scale, beta, wh, bh, K,
                      rows, C, logits, ldl, zero_to);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;

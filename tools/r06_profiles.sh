@@ -41,3 +41,5 @@ bash "$R/tools/pmc_dconv3.sh" $TAG/sq_dconv3_pl_96 plfwd 8,68,120,96 > /dev/null
 bash "$R/tools/pmc_dconv3.sh" $TAG/sq_dconv3_h2_48 h2fwd 8,136,240,48 > /dev/null 2>&1
 bash "$R/tools/pmc_dconv3.sh" $TAG/sq_dwgrad3_pl_96 plwgrad 8,68,120,96 > /dev/null 2>&1
 tail -c 400 "$O"/bench_ocrnet_hrnet48.json
+bash "$R/tools/pmc_headfuse.sh" $TAG/sq_headfuse > /dev/null 2>&1
+python3 "$R/tools/time_headfuse.py" > "$O/time_headfuse.txt" 2>&1
