@@ -119,7 +119,15 @@ def test_ocrnet_hrnet48_fullres_train_step_vs_oracle(plan):
             "backbone.stage4.1.branches.3.2.conv2.weight", "backbone.stage4.2.branches.0.3.conv1.weight",
             "backbone.stage3.0.fuse_layers.2.0.0.0.weight", "backbone.stage4.0.fuse_layers.0.3.0.weight",
             "backbone.stage2.0.branches.0.2.bn1.weight", "conv_high_map.0.weight", "interm_prediction_head.3.weight",
-            "ocr_distri_head.object_context_block.f_pixel.0.weight", "final_prediction_head.weight"]
+            "ocr_distri_head.object_context_block.f_pixel.0.weight", "final_prediction_head.weight",
+            # round 6: both class heads run fused with the BatchNorm in front of them (csrc/headfuse.h): the classifier, the BatchNorm and the
+            # convolution in front of it, each against the oracle's autograd
+            "interm_prediction_head.4.weight", "interm_prediction_head.4.bias", "interm_prediction_head.1.weight", "interm_prediction_head.1.bias",
+            "interm_prediction_head.0.weight", "conv_out.weight", "conv_out.bias", "spatial_ocr_head.conv_bn_dropout.1.weight",
+            "spatial_ocr_head.conv_bn_dropout.1.bias", "spatial_ocr_head.conv_bn_dropout.0.weight",
+            "spatial_ocr_head.object_context_block.f_up.0.weight"]
+    if ops.HEAD_FUSE:
+        assert {"hbm:head_fwd", "hbm:head_backward"} <= kinds, "the class heads of the bench model did not take the fused route"
     have = dict(model.named_parameters())
     _grad_subset_check("OCRNet-HRNet-W48 full resolution", model, S, [k for k in keys if k in have and k in S])
 
