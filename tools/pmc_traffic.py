@@ -18,6 +18,8 @@ def group(name):
     m = re.search(r"igemm_f32_kernel<(\d)", name)
     if m:
         return LAY[m.group(1)]
+    if "hf_fwd_kernel" in name or "hf_bwd_kernel" in name or "hf_reduce_kernel" in name:
+        return "head"           # the class heads fused with the BatchNorm in front of them (round 6, csrc/headfuse.h): forward, both backward passes
     if "p1t_kernel" in name or "p1t_reduce" in name:
         return "wgrad_p1"       # pointwise backward-weight + its slab sum (round 5, csrc/pconv1.hip)
     if "p1_kernel" in name:
