@@ -961,7 +961,9 @@ class EngineNet(nn.Module):
         if ops.P1 and ops._trunk_h2() and self.training:
             banks.append(self._p1_bank())
         banks = [b for b in banks if b]
-        if banks:
+        ops.h2_weight_images_begin(self.__dict__.setdefault("_h2w_images", {}))
+        heads = self.training and ops.H2W_BANK and ops._h2w_bank
+        if banks or heads:
             if PREP_ASYNC and x.is_cuda and torch.cuda.is_current_stream_capturing():
                 main = torch.cuda.current_stream(x.device)
                 side = prep_stream(x.device)
@@ -969,6 +971,8 @@ class EngineNet(nn.Module):
                 with torch.cuda.stream(side):
                     for b in banks:
                         b.refresh()
+                    if heads:
+                        ops.h2_weight_images_refresh()      # (the head layers' images: in line, in front of their GEMMs, in the launch loop)
                     ev = torch.cuda.Event()
                     ev.record(side)
                 ops.images_pending(ev, main)

@@ -1970,22 +1970,69 @@ def split2h_blocked(x):
     return blk, scale
 
 
+# Weight images of the head layers (forward: blocked planes; backward-data: the transposed bank's).  Each was amax + split launched in line, in
+# front of its GEMM on the strictly serial head path (~55 us with the launch gaps, six times per step).  Round 6: a layer that took this route
+# once keeps its two image buffers, and while a step is being captured into a hipGraph EngineNet._run refreshes them all on the weight-image
+# side stream beside stem + stage 1 (h2_weight_images_refresh: the same hand-over as the trunk's banks, ops.images_ready); everywhere else the
+# images are made in line as before.
+H2W_BANK = _plan.get("h2w_bank")
+_h2w_bank = None      # the running network's bank (EngineNet._run sets it: the buffers live as long as the network):
+                      # (data_ptr, shape, transposed) -> {"w": weights, "planes", "scale", "fresh": made for the CURRENT step by the refresh}
+
+
+def _h2w_entry(w, transposed):
+    O, I, kh, kw = w.shape
+    key = (w.data_ptr(), tuple(w.shape), transposed)
+    e = _h2w_bank.get(key) if _h2w_bank is not None else None
+    if e is None:
+        rows = kh * kw * ((O + 15) // 16) if transposed else kh * kw * I // 16
+        e = {"w": w, "planes": torch.empty((2, rows, I if transposed else O, 16), dtype=torch.int16, device=w.device),
+             "scale": torch.empty(2, dtype=torch.int32, device=w.device), "fresh": False}
+        if H2W_BANK and _h2w_bank is not None and len(_h2w_bank) < 64:
+            _h2w_bank[key] = e
+    return e
+
+
+def _h2w_launch(e, transposed):
+    w = e["w"]
+    O, I, kh, kw = w.shape
+    fn = lib.catseg_split2h_weight_t_blocked if transposed else lib.catseg_split2h_weight_blocked
+    check(fn(ptr(w), O, kh * kw, I, ptr(e["planes"]), ptr(e["scale"]), stream()))
+
+
+def h2_weight_images_begin(bank):
+    """a network's pass starts: its bank becomes the current one, nothing in it is valid for this step yet"""
+    global _h2w_bank
+    _h2w_bank = bank
+    for e in bank.values():
+        e["fresh"] = False
+
+
+def h2_weight_images_refresh():
+    """(on the weight-image side stream) both images of every head layer seen so far, for the step that starts now"""
+    for (_, _, transposed), e in _h2w_bank.items():
+        _h2w_launch(e, transposed)
+        e["fresh"] = True
+
+
 def split2h_weight_blocked(w):
     """[O, I, kh, kw] weights (physical OHWI, I % 16 == 0) -> (fp16 planes [2, kh*kw*I/16, O, 16], scale record): forward operand"""
-    O, I, kh, kw = w.shape
-    planes = torch.empty((2, kh * kw * I // 16, O, 16), dtype=torch.int16, device=w.device)
-    scale = torch.empty(2, dtype=torch.int32, device=w.device)
-    check(lib.catseg_split2h_weight_blocked(ptr(w), O, kh * kw, I, ptr(planes), ptr(scale), stream()))
-    return planes, scale
+    e = _h2w_entry(w, False)
+    if e["fresh"]:
+        images_ready()
+    else:
+        _h2w_launch(e, False)
+    return e["planes"], e["scale"]
 
 
 def split2h_weight_t_blocked(w):
     """OHWI weights -> (fp16 planes of the transposed bank [2, taps*roundup(O,16)/16, Cin, 16], scale record): backward-data operand"""
-    O, Cin, kh, kw = w.shape
-    planes = torch.empty((2, kh * kw * ((O + 15) // 16), Cin, 16), dtype=torch.int16, device=w.device)
-    scale = torch.empty(2, dtype=torch.int32, device=w.device)
-    check(lib.catseg_split2h_weight_t_blocked(ptr(w), O, kh * kw, Cin, ptr(planes), ptr(scale), stream()))
-    return planes, scale
+    e = _h2w_entry(w, True)
+    if e["fresh"]:
+        images_ready()
+    else:
+        _h2w_launch(e, True)
+    return e["planes"], e["scale"]
 
 
 def split3_weight_blocked(w):

@@ -58,6 +58,7 @@ FIELDS = {
     "concat_planes": (True, _bool, "ops:CONCAT_PLANES", "HRNet head input written only as blocked f16x2 planes"),
     "head_dy_planes": (True, _bool, "ops:HEAD_DY_PLANES", "BatchNorm backward of the head layers writes dy only as blocked planes"),
     "head_fuse": (True, _bool, "ops:HEAD_FUSE", "the K-class classifier behind a head's BatchNorm + ReLU fused with it (csrc/headfuse.h): the normalised activation and its gradient are never written"),
+    "h2w_bank": (True, _bool, "ops:H2W_BANK", "the head layers' weight images keep their buffers and are refreshed on the weight-image side stream at the start of a captured step (in line otherwise)"),
     # ---- launch-shape knobs of the library (include/catseg_debug.h; 0 = the library's default)
     "wg_blocks": (0, int, None, "blocks of the direct backward-weight kernel csrc/dwgrad3_b3.hip"),
     "dc_blocks": (0, int, None, "persistent blocks of the direct 3x3 kernel csrc/dconv3_b3.hip"),
