@@ -858,23 +858,27 @@ __global__ __launch_bounds__(512) void p1t_kernel(const P1TArgs p) {
       }
 }
 
-// dw[o][c] = sum over slabs, fixed order (four independent chains)
+// dw[o][c] = sum over slabs, fixed order.  Block = 64 outputs x 4 slab groups (group g takes slabs g, g + 4, ...), eight independent load chains
+// per thread, the groups merged through LDS: the 256 slabs of a 64 x 256 layer were 64 dependent rounds of four loads (19 us, latency-bound;
+// 54 launches per HRNet-W48 step), now 8 rounds
 __global__ __launch_bounds__(256) void p1t_reduce_kernel(const float* __restrict__ slabs, int nslabs, int Mtot, int Ntot, int M, int N, float* __restrict__ dw) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * N) return;
-  const int o = i / N, c = i - o * N;
-  const float* s = slabs + (long long)o * Ntot + c;
-  const long long stride = (long long)Mtot * Ntot;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int k = 0;
-  for (; k + 3 < nslabs; k += 4) {
-    a0 += s[(long long)k * stride];
-    a1 += s[(long long)(k + 1) * stride];
-    a2 += s[(long long)(k + 2) * stride];
-    a3 += s[(long long)(k + 3) * stride];
+  __shared__ float red[4][64];
+  const int t = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + t;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < M * N) {
+    const int o = i / N, c = i - o * N;
+    const float* s = slabs + (long long)o * Ntot + c;
+    const long long stride = (long long)Mtot * Ntot;
+    for (int k0 = grp; k0 < nslabs; k0 += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + 4 * u < nslabs) a[u] += s[(long long)(k0 + 4 * u) * stride];
+    }
   }
-  for (; k < nslabs; ++k) a0 += s[(long long)k * stride];
-  dw[i] = (a0 + a1) + (a2 + a3);
+  red[grp][t] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (grp == 0 && i < M * N) dw[i] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
 
 struct P1TPlan { int kind, MP, NP; };
@@ -1003,7 +1007,7 @@ extern "C" int catseg_pconv1_wgrad(long long P, int Cout, int Cin, const float* 
   a.dy_bytes = (unsigned long long)P * lddy * 4ull; a.x_bytes = (unsigned long long)P * ldx * 4ull;
   hipStream_t st = (hipStream_t)stream;
   p1t_dispatch(a, g, false, st);
-  hipLaunchKernelGGL(p1t_reduce_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, st, (const float*)workspace, g.blocks, g.Mtot, g.Ntot, Cout, Cin, dw);
+  hipLaunchKernelGGL(p1t_reduce_kernel, dim3((Cout * Cin + 63) / 64), dim3(256), 0, st, (const float*)workspace, g.blocks, g.Mtot, g.Ntot, Cout, Cin, dw);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
@@ -1172,7 +1176,7 @@ extern "C" int catseg_gconv_bwd_weight(const catseg_conv_desc* d, const float* d
   a.geo = 1; a.Cin = d->Cin; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.Hi = d->H; a.Wi = d->W; a.Ho = d->Ho; a.Wo = d->Wo;
   hipStream_t st = (hipStream_t)stream;
   p1t_dispatch(a, g, true, st);
-  hipLaunchKernelGGL(p1t_reduce_kernel, dim3((d->Cout * N + 255) / 256), dim3(256), 0, st, (const float*)workspace, g.blocks, g.Mtot, g.Ntot, d->Cout, N, dw);
+  hipLaunchKernelGGL(p1t_reduce_kernel, dim3((d->Cout * N + 63) / 64), dim3(256), 0, st, (const float*)workspace, g.blocks, g.Mtot, g.Ntot, d->Cout, N, dw);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
