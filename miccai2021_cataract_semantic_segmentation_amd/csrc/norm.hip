@@ -585,20 +585,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
   }
 }
 
-// out[c] = sum over the partial rows part[0 .. nparts)[c], four independent chains combined in a fixed order (csrc/igemm.hip: colsum_final_kernel)
-__global__ void colsum_rows_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int i = 0;
-  for (; i + 3 < nparts; i += 4) {
-    s0 += part[(long long)i * C + c];
-    s1 += part[(long long)(i + 1) * C + c];
-    s2 += part[(long long)(i + 2) * C + c];
-    s3 += part[(long long)(i + 3) * C + c];
+// out[c] = sum over the partial rows part[0 .. nparts)[c] in a fixed order: block = 64 channels x 4 row groups (group g takes rows g, g + 4, ...),
+// eight independent chains per thread, the groups merged through LDS (256 rows were 64 dependent rounds of four loads: 30 us)
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int t = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + t;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    for (int i0 = grp; i0 < nparts; i0 += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + 4 * u < nparts) a[u] += part[(long long)(i0 + 4 * u) * C + c];
+    }
   }
-  for (; i < nparts; ++i) s0 += part[(long long)i * C + c];
-  out[c] = (s0 + s1) + (s2 + s3);
+  red[grp][t] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (grp == 0 && c < C) out[c] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z,
@@ -946,7 +949,7 @@ extern "C" int catseg_bn_backward_h2(const float* dz, int lddz, const float* z, 
   hipLaunchKernelGGL(bn_bwd_apply_h2_kernel, dim3(gx, C / 64), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, stats, gamma, beta, (const float*)coef, rows,
                      C, relu, (unsigned char*)dy_planes, (long long)rows * C * 2, (const unsigned*)dy_rec, (unsigned*)dy_scale,
                      dbias ? colpart : (float*)nullptr);
-  if (dbias) hipLaunchKernelGGL(colsum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)colpart, gx, C, dbias);
+  if (dbias) hipLaunchKernelGGL(colsum_rows_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)colpart, gx, C, dbias);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
@@ -1110,7 +1113,7 @@ extern "C" int catseg_head_backward(const float* dl, int lddl, const float* y, i
                      (const unsigned*)a.g_rec, (const unsigned*)a.y_rec, stats, gamma, (unsigned*)dy_record);
   hipLaunchKernelGGL(hf_reduce_kernel, dim3((K * C + K + 63) / 64), dim3(256), 0, st, (const float*)dws, (const float*)dbs, nb, K, C, dwh, dbh);
   hipLaunchKernelGGL((hf_bwd_kernel<true, 1, 4>), dim3(nb, (C + 127) / 128), dim3(256), 0, st, a);
-  if (dbias) hipLaunchKernelGGL(colsum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)colpart, nb, C, dbias);
+  if (dbias) hipLaunchKernelGGL(colsum_rows_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)colpart, nb, C, dbias);
   CS_LAUNCH_CHECK();
   return CATSEG_OK;
 }
