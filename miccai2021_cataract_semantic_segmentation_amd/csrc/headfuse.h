@@ -396,11 +396,15 @@ __global__ __launch_bounds__(256) void hf_reduce_kernel(const float* __restrict_
     const int k = isw ? i / C : 0, c = isw ? i - k * C : 0;
     const float* s = isw ? dws + (long long)k * C + c : dbs + j;
     const long long step = isw ? 32ll * C : 32ll;
-    for (int b0 = grp; b0 < nb; b0 += 32) {
+    int b0 = grp;
+    for (; b0 + 28 < nb; b0 += 32) {      // (eight UNCONDITIONAL loads in flight)
+      float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (b0 + 4 * u < nb) a[u] += s[(long long)(b0 + 4 * u) * step];
+      for (int u = 0; u < 8; ++u) v[u] = s[(long long)(b0 + 4 * u) * step];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += v[u];
     }
+    for (; b0 < nb; b0 += 4) a[0] += s[(long long)b0 * step];
   }
   red[grp][o] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();

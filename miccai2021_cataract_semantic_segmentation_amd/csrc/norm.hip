@@ -593,11 +593,15 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restric
   const int c = blockIdx.x * 64 + t;
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < C) {
-    for (int i0 = grp; i0 < nparts; i0 += 32) {
+    int i0 = grp;
+    for (; i0 + 28 < nparts; i0 += 32) {      // (eight UNCONDITIONAL loads in flight)
+      float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (i0 + 4 * u < nparts) a[u] += part[(long long)(i0 + 4 * u) * C + c];
+      for (int u = 0; u < 8; ++u) v[u] = part[(long long)(i0 + 4 * u) * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += v[u];
     }
+    for (; i0 < nparts; i0 += 4) a[0] += part[(long long)i0 * C + c];
   }
   red[grp][t] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();

@@ -870,11 +870,15 @@ __global__ __launch_bounds__(256) void p1t_reduce_kernel(const float* __restrict
     const int o = i / N, c = i - o * N;
     const float* s = slabs + (long long)o * Ntot + c;
     const long long stride = (long long)Mtot * Ntot;
-    for (int k0 = grp; k0 < nslabs; k0 += 32) {
+    int k0 = grp;
+    for (; k0 + 28 < nslabs; k0 += 32) {      // (eight UNCONDITIONAL loads: a predicate around each one serialises their round trips)
+      float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (k0 + 4 * u < nslabs) a[u] += s[(long long)(k0 + 4 * u) * stride];
+      for (int u = 0; u < 8; ++u) v[u] = s[(long long)(k0 + 4 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += v[u];
     }
+    for (; k0 < nslabs; k0 += 4) a[0] += s[(long long)k0 * stride];
   }
   red[grp][t] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
