@@ -114,30 +114,37 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     }
   }
   if (live) {
-    auto one = [&](int b, double& s0, double& s1) {
-      const float* o = part + ((long long)b * 3) * C;
-      const bool last = b == nrb - 1;
-      double nb = last ? n_last : n_full, inv = last ? inv_last : inv_full;
-      // the count and the partial row are fetched TOGETHER (the row of an empty tile -- a wave of csrc/dconv3_pl.hip whose pixel rows all
-      // lie below the image -- is allocated but never written: whatever it holds is discarded by the selects below, never multiplied in)
-      const int cnt = counts ? counts[b] : 1;   // per-block row counts (2-D pixel tiles with ragged edges: csrc/dconv3_b3.hip)
-      const double K = o[c], t1 = o[C + c], t2 = o[2 * C + c];
-      if (counts) {
-        nb = (double)cnt;
-        inv = 1.0 / (cnt > 0 ? nb : 1.0);
-      }
-      const double mb = K + t1 * inv;
-      const double u0 = nb * mb, u1 = (t2 - t1 * t1 * inv) + nb * mb * mb;
-      s0 += cnt > 0 ? u0 : 0.0;
-      s1 += cnt > 0 ? u1 : 0.0;
-    };
-    // four independent load chains per round, ALSO in the last, ragged round (a serial tail of up to three dependent L2 round trips was
-    // most of these launches' 10 us)
+    // four independent load chains per round.  Every load is UNCONDITIONAL (a chain past the end re-reads the last row and is discarded by a
+    // select): with a branch around each chain's loads the compiler waited for one chain before it issued the next -- four dependent L2 round
+    // trips per round (the disassembly showed load, s_waitcnt vmcnt(0), load, ...), most of these launches' 8 us (round 6)
     for (int b = rl; b < nrb; b += 1024) {
-      one(b, a0[0], a1[0]);
-      if (b + 256 < nrb) one(b + 256, a0[1], a1[1]);
-      if (b + 512 < nrb) one(b + 512, a0[2], a1[2]);
-      if (b + 768 < nrb) one(b + 768, a0[3], a1[3]);
+      int cnt[4];
+      float K[4], t1[4], t2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int bb = min(b + 256 * u, nrb - 1);
+        const float* o = part + ((long long)bb * 3) * C;
+        // the count and the partial row are fetched TOGETHER (the row of an empty tile -- a wave of csrc/dconv3_pl.hip whose pixel rows all
+        // lie below the image -- is allocated but never written: whatever it holds is discarded by the selects below, never multiplied in)
+        cnt[u] = counts ? counts[bb] : 1;   // per-block row counts (2-D pixel tiles with ragged edges: csrc/dconv3_b3.hip)
+        K[u] = o[c]; t1[u] = o[C + c]; t2[u] = o[2 * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int bb = b + 256 * u;
+        const bool last = bb == nrb - 1;
+        double nb = last ? n_last : n_full, inv = last ? inv_last : inv_full;
+        if (counts) {
+          nb = (double)cnt[u];
+          inv = 1.0 / (cnt[u] > 0 ? nb : 1.0);
+        }
+        const double dK = K[u], d1 = t1[u], d2 = t2[u];
+        const double mb = dK + d1 * inv;
+        const double u0 = nb * mb, u1 = (d2 - d1 * d1 * inv) + nb * mb * mb;
+        const bool use = bb < nrb && cnt[u] > 0;
+        a0[u] += use ? u0 : 0.0;
+        a1[u] += use ? u1 : 0.0;
+      }
     }
   }
   // merge over the 256 row lanes in a fixed order (deterministic): the 16 row lanes of a wave by lane shuffles (lane = 4 row lane + channel),
@@ -404,13 +411,20 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
   if (live)
     for (int b = rl; b < nrb; b += 1024) {
+      // UNCONDITIONAL loads (a chain past the end re-reads the last row, a select discards it): see bn_finalize_kernel
+      float v0[4], v1[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (b + 256 * u < nrb) {
-          const float* o = part + ((long long)(b + 256 * u) * 2) * C;
-          a0[u] += o[c];
-          a1[u] += o[C + c];
-        }
+      for (int u = 0; u < 4; ++u) {
+        const float* o = part + ((long long)min(b + 256 * u, nrb - 1) * 2) * C;
+        v0[u] = o[c];
+        v1[u] = o[C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool use = b + 256 * u < nrb;
+        a0[u] += use ? (double)v0[u] : 0.0;
+        a1[u] += use ? (double)v1[u] : 0.0;
+      }
     }
   double sg = (a0[0] + a0[1]) + (a0[2] + a0[3]), sgx = (a1[0] + a1[1]) + (a1[2] + a1[3]);
   // the 16 row lanes of a wave by lane shuffles (lane = 4 row lane + channel), the 16 waves through LDS (fixed order)
